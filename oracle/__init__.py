@@ -1,0 +1,18 @@
+"""CPU oracle for the Moonshine encoder-decoder hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker / CPU baseline.  The shipped path
+(``moonshine_amd`` -> ``libmoonshine.so`` -> HIP kernels) never calls into it
+and has no CPU fallback.
+
+Parity pinning: the reference hot path executes inside ONNX Runtime 1.23.2 on
+``.ort`` graphs that are not in the checkout, and the
+reference's own tests hold no numeric golden vectors for this path
+(SURVEY.md section 8c).  The float definition the reference itself names as its
+oracle is HuggingFace ``transformers`` ``modeling_moonshine.py`` (reference
+``docs/models/accuracy.md:14-19``, ``scripts/eval-librispeech.py:434-477``).
+This restatement is pinned against outputs of that implementation generated in
+the build container by ``tests/golden/make_golden.py`` and committed under
+``tests/golden/`` (see ``tests/test_oracle_golden.py``).
+"""

@@ -1,0 +1,207 @@
+"""Restatement of the reference's host-side byte/integer work on the hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Pure Python / numpy; each function
+cites the reference lines it follows.  Bit-exact parity is required of the C++
+host code against these (tests/test_host_parity.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+SPACE = "▁".encode("utf-8")  # sentencepiece word-boundary marker
+
+
+# --- tokenizer.bin ---------------------------------------------------------
+def encode_tokenizer_bin(tokens: list[bytes]) -> bytes:
+    """Length-prefixed byte strings.  reference core/bin-tokenizer/bin-tokenizer.cpp:46-66
+    (reader) and scripts/convert_tokenizer.py:29-48 (writer): length < 128 is one
+    byte; otherwise first = (len % 128) + 128, second = len // 128; a zero byte is
+    an empty entry."""
+    out = bytearray()
+    for t in tokens:
+        n = len(t)
+        if n == 0:
+            out.append(0)
+        elif n < 128:
+            out.append(n)
+        else:
+            assert n < 128 * 256
+            out.append((n % 128) + 128)
+            out.append(n // 128)
+        out += t
+    return bytes(out)
+
+
+def decode_tokenizer_bin(blob: bytes) -> list[bytes]:
+    """reference core/bin-tokenizer/bin-tokenizer.cpp:46-66."""
+    toks: list[bytes] = []
+    i = 0
+    while i < len(blob):
+        first = blob[i]
+        i += 1
+        if first == 0:
+            toks.append(b"")
+            continue
+        if first < 128:
+            n = first
+        else:
+            second = blob[i]
+            i += 1
+            n = second * 128 + first - 128
+        if i + n > len(blob):
+            raise ValueError("truncated tokenizer.bin")
+        toks.append(blob[i : i + n])
+        i += n
+    if not toks:
+        raise ValueError("no tokens")
+    return toks
+
+
+def synthetic_vocab(vocab: int) -> list[bytes]:
+    """ids 0,1,2 = <unk>,<s>,</s>; then 256 byte fallbacks ``<0xNN>``; then word
+    pieces (layout of the shipped vocabularies,
+    reference core/bin-tokenizer/bin-tokenizer-test.cpp:12-25).  Pieces are
+    deterministic: every 3rd one starts a new word; a few are long (>127 bytes)
+    or carry multi-byte / deliberately broken UTF-8 to exercise the 2-byte
+    length prefix and sanitize_text."""
+    toks = [b"<unk>", b"<s>", b"</s>"]
+    toks += [("<0x%02X>" % b).encode() for b in range(256)]
+    letters = b"abcdefghijklmnopqrstuvwxyz"
+    i = 0
+    while len(toks) < vocab:
+        k = len(toks)
+        n = 1 + (k * 7) % 5
+        body = bytes(letters[(k * 31 + j * 17) % 26] for j in range(n))
+        if k % 3 == 0:
+            body = SPACE + body
+        if k % 997 == 0:
+            body = body * 40                      # > 127 bytes: 2-byte length prefix
+        elif k % 1013 == 0:
+            body = "é中".encode("utf-8") + body  # valid multi-byte
+        elif k % 1021 == 0:
+            body = b"\xe4\xb8" + body             # truncated 3-byte sequence
+        elif k % 1031 == 0:
+            body = b"\x9f" + body                 # stray continuation byte
+        toks.append(body)
+        i += 1
+    return toks[:vocab]
+
+
+def write_synthetic_tokenizer(path: str, vocab: int) -> list[bytes]:
+    toks = synthetic_vocab(vocab)
+    with open(path, "wb") as f:
+        f.write(encode_tokenizer_bin(toks))
+    return toks
+
+
+def tokens_to_text(vocab: list[bytes], tokens) -> bytes:
+    """reference core/bin-tokenizer/bin-tokenizer.cpp:406-426: concatenate token
+    bytes, skip ``<...>`` specials (len > 2), replace the space marker, trim."""
+    out = bytearray()
+    for t in tokens:
+        b = vocab[int(t)]
+        if len(b) == 0:
+            raise ValueError(f"Invalid token {t}")
+        if len(b) > 2 and b[:1] == b"<" and b[-1:] == b">":
+            continue
+        out += b
+    res = bytes(out).replace(SPACE, b" ")
+    # trim(): reference core/moonshine-utils/string-utils.cpp:21-29, default
+    # whitespace set " \t" (string-utils.h:12)
+    return res.strip(b" \t")
+
+
+def sanitize_text(text: bytes) -> bytes:
+    """reference core/transcriber.cpp:1489-1543: replace each byte that does not
+    start a structurally valid UTF-8 sequence by '?'."""
+    out = bytearray()
+    i = 0
+    n = len(text)
+
+    def cont(j):
+        return (text[j] & 0xC0) == 0x80
+
+    while i < n:
+        c = text[i]
+        rem = n - i
+        if c < 0x80:
+            out.append(c)
+            i += 1
+        elif (c & 0xE0) == 0xC0:
+            if rem < 2 or not cont(i + 1):
+                out.append(0x3F)
+                i += 1
+            else:
+                out += text[i : i + 2]
+                i += 2
+        elif (c & 0xF0) == 0xE0:
+            if rem < 3 or not cont(i + 1) or not cont(i + 2):
+                out.append(0x3F)
+                i += 1
+            else:
+                out += text[i : i + 3]
+                i += 3
+        elif (c & 0xF8) == 0xF0:
+            if rem < 4 or not cont(i + 1) or not cont(i + 2) or not cont(i + 3):
+                out.append(0x3F)
+                i += 1
+            else:
+                out += text[i : i + 4]
+                i += 4
+        else:
+            out.append(0x3F)
+            i += 1
+    return bytes(out)
+
+
+# --- VAD segmentation with the Silero model bypassed -----------------------
+def vad_segments_threshold0(
+    n_samples: int,
+    hop: int = 512,
+    look_behind: int = 8192,
+    max_segment_samples: int = 240000,
+) -> list[tuple[int, int, bool]]:
+    """Segment boundaries (start_sample, end_sample, is_complete) produced by the
+    reference VAD when ``vad_threshold == 0`` (no Silero call), for one
+    ``transcribe_without_streaming`` call on 16 kHz audio.
+
+    Follows reference core/voice-activity-detector.cpp:69-96 (whole hops only,
+    remainder dropped), :125-199 (threshold 0 => probability 1, multiplied by the
+    max-length fade factor (len - fade)/fade once len > fade; voice iff p > 0)
+    and :62-67 (stop() closes the open segment).  The first voiced hop starts
+    the segment from the look-behind buffer (:171-179)."""
+    segs: list[tuple[int, int, bool]] = []
+    fade = (max_segment_samples * 2) // 3
+    processed = 0
+    prev_voice = False
+    cur_start = 0
+    cur_len = 0
+    n_hops = n_samples // hop
+    for _ in range(n_hops):
+        processed += hop
+        p = 1.0
+        if max_segment_samples and cur_len > fade:
+            p = p * (np.float32(cur_len - fade) / np.float32(fade))
+        voice = p > 0.0
+        if voice and not prev_voice:
+            lb = min(look_behind, processed)
+            cur_len = lb
+            cur_start = processed - lb
+        elif (not voice) and prev_voice:
+            cur_len += hop
+            segs.append((cur_start, cur_start + cur_len, True))
+            cur_len = 0
+        elif voice and prev_voice:
+            cur_len += hop
+        prev_voice = voice
+    if prev_voice:
+        segs.append((cur_start, cur_start + cur_len, True))
+    return segs
+
+
+def max_decode_len(n_samples: int, max_tokens_per_second: float = 6.5) -> int:
+    """reference core/moonshine-model.cpp:347-349 (float32 arithmetic)."""
+    dur = np.float32(n_samples) / np.float32(16000.0)
+    return int(math.ceil(float(np.float32(dur * np.float32(max_tokens_per_second)))))
