@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Moonshine-base throughput benchmark on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (conv stem + 8-layer encoder + cross-K/V + 65-step greedy decode,
+EOS ignored so the work is weight-independent) over one batch of synthetic 10 s / 16 kHz clips that are
+already resident in HBM.  Utterances are sharded across ranks (weak scaling: --batch clips per GPU);
+the only collective is the gather of token ids.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel group (by HIP-event time on the engine's stream): algorithmic
+                flops or bytes per launch / average launch time, against the MI355X peak.
+  cpu_baseline  the numpy oracle ("port") timed on this box's host cores on a bounded sample.
+  latency_ms    p50 end-to-end latency of a single 10 s clip (batch 1), encode / decode split.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 10.0
+CLIP_SAMPLES = 160000
+PEAK_TFLOPS_BF16 = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--decode-steps", type=int, default=65, help="forced decode steps (ceil(10 s * 6.5 tok/s))")
+    ap.add_argument("--arch", default="base")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=3)
+    return ap.parse_args()
+
+
+def roofline_entry(p):
+    """p: one profile group -> dict with achieved rate against the bound its arithmetic intensity implies."""
+    ms_per = p["ms"] / max(p["launches"], 1)
+    flops_per = p["flops"] / max(p["launches"], 1)
+    bytes_per = p["bytes"] / max(p["launches"], 1)
+    intensity = flops_per / bytes_per if bytes_per > 0 else float("inf")
+    ridge = PEAK_TFLOPS_BF16 * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if flops_per > 0 and intensity >= ridge:
+        ach = flops_per / (ms_per * 1e-3) / 1e12
+        return {"kernel": p["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS_BF16, 4), "traffic": None, "ms_per_launch": round(ms_per, 5),
+                "launches_per_step": p["launches"], "algorithmic_flops_per_launch": flops_per}
+    ach = bytes_per / (ms_per * 1e-3) / 1e9 if bytes_per > 0 else 0.0
+    return {"kernel": p["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "ms_per_launch": round(ms_per, 5),
+            "launches_per_step": p["launches"], "algorithmic_bytes_per_launch": bytes_per}
+
+
+def main():
+    args = parse()
+    import torch
+
+    from moonshine_amd.hip_api import Engine
+    from moonshine_amd.synth import ARCHS, make_audio, make_weights, save_safetensors
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = ARCHS[args.arch]
+    eng = Engine(local_rank)
+    with tempfile.TemporaryDirectory() as d:
+        w = make_weights(cfg, 0)
+        path = os.path.join(d, "model.safetensors")
+        save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
+        eng.load_weights_file(path)
+
+    # this rank's shard of the utterance list, resident in HBM before the timed region
+    B = args.batch
+    first = rank * B
+    host = np.stack([make_audio(first + i, CLIP_SAMPLES) for i in range(B)])
+    audio = torch.from_numpy(host).to(dev)
+    torch.cuda.synchronize()
+    ptrs = [(audio[i].data_ptr(), CLIP_SAMPLES) for i in range(B)]
+    tok_stride = args.decode_steps + 1
+
+    def step():
+        toks = eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)
+        if dist is not None:  # gather of the ids: the only collective on the path
+            t = torch.tensor(toks, dtype=torch.int32, device=dev)
+            out = torch.empty((world, B, tok_stride), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(out, t)
+        return toks
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert all(len(t) == tok_stride for t in toks)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * CLIP_SECONDS * args.steps / elapsed
+
+    # ---- per-kernel-group HIP-event times over one more step (eager decode while profiling) ----
+    eng.profile_reset()
+    eng.profile_enable(True)
+    eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)
+    prof = eng.profile()
+    eng.profile_enable(False)
+    prof = [p for p in prof if p["launches"] > 0]
+    kernels = sorted((roofline_entry(p) | {"total_ms": round(p["ms"], 3)} for p in prof), key=lambda r: -r["total_ms"])
+    dominant = dict(kernels[0])
+    prof_total = sum(p["ms"] for p in prof)
+
+    # ---- batch-1 latency (p50), encode / decode split ----
+    latency = None
+    if not args.no_latency:
+        one = [ptrs[0]]
+        for _ in range(3):
+            eng.transcribe_tokens(device_ptrs=one, forced_steps=args.decode_steps)
+        tot, enc_t, dec_t = [], [], []
+        for _ in range(20):
+            a = time.perf_counter()
+            eng.encode(device_ptrs=one)
+            eng.synchronize()
+            b = time.perf_counter()
+            eng.decode(forced_steps=args.decode_steps)
+            c = time.perf_counter()
+            tot.append((c - a) * 1e3)
+            enc_t.append((b - a) * 1e3)
+            dec_t.append((c - b) * 1e3)
+        latency = {"batch": 1, "p50_total": round(statistics.median(tot), 3), "p50_encode": round(statistics.median(enc_t), 3),
+                   "p50_decode": round(statistics.median(dec_t), 3), "decode_steps": args.decode_steps, "runs": 20}
+
+    # ---- CPU baseline: the numpy oracle on this box's host cores (rank 0, N = 1 only) ----
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import moonshine_ref as ref  # checker / baseline only, never on the GPU path
+
+        n_clips = args.cpu_clips
+        ref.transcribe_tokens(w, cfg, host[0][:32000], ignore_eos=True)  # warm BLAS threads
+        t0 = time.perf_counter()
+        for i in range(n_clips):
+            enc = ref.encoder_forward(w, cfg, host[i])
+            ref.greedy_decode(w, cfg, enc, args.decode_steps, ignore_eos=True)
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": os.cpu_count(),
+               "kind": "port", "sample": f"{n_clips} clips x 10 s, {args.decode_steps} forced decode steps, batch 1, "
+               f"numpy fp32 oracle (multi-threaded BLAS), {dt:.1f} s of CPU time"}
+
+    line = {
+        "metric": "audio-seconds/sec (RTF^-1), Moonshine-base 10 s @ 16 kHz clips",
+        "value": round(value, 1),
+        "unit": "audio-seconds/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (white-noise clips sigma 0.1; fan-in-scaled random weights with HF tensor names; EOS ignored, "
+                f"{args.decode_steps} decode steps forced)",
+        "config": {"workload": f"Moonshine-{args.arch}, batch={B} x 10 s clips per GPU, encoder + {args.decode_steps}-step greedy decode, "
+                               "inputs resident in HBM", "clips_per_gpu": B, "global_batch": world * B, "decode_steps": args.decode_steps,
+                   "parallelism": f"utterance-sharded dp{world}"},
+        "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
+            "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"], "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3)},
+        "cpu_baseline": cpu,
+        "latency_ms": latency,
+        "kernels": kernels,
+        "profiled_step_ms": round(prof_total, 3),
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+/* moonshine_hip.h -- thin C ABI over the MI355X (gfx950) Moonshine engine.
+ *
+ * This is the seam that replaces the reference's ONNX Runtime glue: where the reference's
+ * MoonshineModel creates two ORT sessions and calls OrtApi::Run per token
+ * (reference core/moonshine-model.cpp:145-161 load, :270-274 encoder Run, :443-447 decoder Run,
+ * core/ort-utils/ort-utils.cpp:37-81 session creation, :256-288 ort_run), the MI355X build calls the
+ * functions below.  Plain C types only (pointers, sizes, int status); no C++ or torch types cross it.
+ * Every function returns 0 on success and a negative msh_status on failure; the message for the last
+ * failure on an engine is available from msh_last_error().  There is no CPU fallback: msh_create fails
+ * when no HIP device is present.
+ *
+ * Threading: calls on one engine must be serialised by the caller (the Transcriber above holds the
+ * same mutex the reference holds around MoonshineModel::transcribe, core/transcriber.cpp:1078).
+ */
+#ifndef MOONSHINE_HIP_H
+#define MOONSHINE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSH_EXPORT __attribute__((visibility("default")))
+
+typedef struct msh_engine msh_engine;
+
+enum msh_status {
+  MSH_OK = 0,
+  MSH_ERR_UNKNOWN = -1,
+  MSH_ERR_INVALID_ARGUMENT = -3,
+  MSH_ERR_NO_DEVICE = -10,
+  MSH_ERR_HIP = -11,
+};
+
+typedef struct msh_model_info {
+  int32_t hidden, ffn, enc_layers, dec_layers, heads, head_dim, vocab, bos, eos;
+  char arch[16];
+} msh_model_info;
+
+typedef struct msh_profile_entry {
+  char name[48];
+  double ms;         /* summed HIP-event time of this kernel group */
+  uint64_t launches;
+  double flops;      /* algorithmic flops summed over the launches */
+  double bytes;      /* algorithmic HBM bytes summed over the launches */
+} msh_profile_entry;
+
+/* Library / device queries (msh_device_count never fails: 0 when no GPU or no driver). */
+MSH_EXPORT int32_t msh_device_count(void);
+MSH_EXPORT const char* msh_version(void);
+
+/* Engine life cycle.  Replaces MoonshineModel::MoonshineModel / ~MoonshineModel
+ * (reference core/moonshine-model.cpp:82-143). */
+MSH_EXPORT int32_t msh_create(int32_t device, msh_engine** out);
+MSH_EXPORT void msh_destroy(msh_engine* e);
+MSH_EXPORT const char* msh_last_error(const msh_engine* e);
+
+/* Weights: a safetensors blob with HuggingFace Moonshine tensor names.  model_arch: 0 tiny, 1 base
+ * (MOONSHINE_MODEL_ARCH_*), -1 = take the dimensions from the file.  Replaces MoonshineModel::load /
+ * load_from_memory (reference core/moonshine-model.cpp:145-161, :163-186). */
+MSH_EXPORT int32_t msh_load_weights_file(msh_engine* e, const char* safetensors_path, int32_t model_arch);
+MSH_EXPORT int32_t msh_load_weights_memory(msh_engine* e, const void* data, uint64_t size, int32_t model_arch);
+MSH_EXPORT int32_t msh_model_info_get(const msh_engine* e, msh_model_info* out);
+
+/* Encoder (+ cross-attention K/V projection) over a batch of 16 kHz mono float clips.
+ * pcm[i] points to n_samples[i] floats in host memory, or in device memory when pcm_on_device != 0.
+ * Replaces the encoder ORT_RUN of reference core/moonshine-model.cpp:245-290, batched. */
+MSH_EXPORT int32_t msh_encode(msh_engine* e, const float* const* pcm, const uint64_t* n_samples, uint32_t count,
+                              int32_t pcm_on_device, float max_tokens_per_second);
+
+/* Greedy decode of the batch encoded last.  Replaces the decode loop of reference
+ * core/moonshine-model.cpp:380-517 (BOS start, first-max argmax, stop on EOS or after
+ * ceil(duration * max_tokens_per_second) steps), run in lock-step over the batch.
+ *   forced_steps <  0 : reference semantics.
+ *   forced_steps >= 0 : ignore EOS, run exactly forced_steps steps (benchmarks, parity tests).
+ *   teacher           : optional [count][teacher_stride] ids (row starts with BOS) fed instead of the
+ *                       argmax of the previous step (teacher forcing for logit parity).
+ *   logits_out        : optional [logit_steps][count][vocab] fp32, logits of the first logit_steps steps.
+ *   tokens_out        : [count][tokens_stride] ids incl. BOS (and EOS when emitted), -1 padded;
+ *                       tokens_stride >= steps + 1 where steps = forced_steps or msh_max_decode_steps().
+ *   counts_out        : [count] number of valid ids per clip. */
+MSH_EXPORT int32_t msh_decode(msh_engine* e, int32_t forced_steps, const int32_t* teacher, int32_t teacher_stride,
+                              float* logits_out, int32_t logit_steps, int32_t* tokens_out, int32_t* counts_out,
+                              int32_t tokens_stride);
+
+/* encode + decode in one call: the batched equivalent of MoonshineModel::transcribe up to, not
+ * including, detokenisation (reference core/moonshine-model.cpp:216-563). */
+MSH_EXPORT int32_t msh_transcribe_tokens(msh_engine* e, const float* const* pcm, const uint64_t* n_samples,
+                                         uint32_t count, int32_t pcm_on_device, float max_tokens_per_second,
+                                         int32_t forced_steps, int32_t* tokens_out, int32_t* counts_out,
+                                         int32_t tokens_stride);
+
+/* Batch introspection after msh_encode. */
+MSH_EXPORT int32_t msh_max_decode_steps(const msh_engine* e);           /* max over clips of the step budget */
+MSH_EXPORT int32_t msh_clip_frames(const msh_engine* e, uint32_t clip); /* encoder frames T of a clip */
+/* fp32 copy of last_hidden_state [T][hidden] of one clip; needs msh_set_keep_encoder_output(e, 1)
+ * before msh_encode (test / debugging hook: the reference keeps it for word alignment,
+ * core/moonshine-model.cpp:292-302). */
+MSH_EXPORT int32_t msh_set_keep_encoder_output(msh_engine* e, int32_t keep);
+MSH_EXPORT int32_t msh_get_encoder_output(msh_engine* e, uint32_t clip, float* out);
+
+/* Per-kernel-group timing with HIP events on the engine's stream (the role of the reference's
+ * log_ort_run option, core/ort-utils/ort-utils.cpp:256-288).  While enabled the decode step runs
+ * eagerly instead of from its hipGraph. */
+MSH_EXPORT int32_t msh_profile_enable(msh_engine* e, int32_t on);
+MSH_EXPORT int32_t msh_profile_reset(msh_engine* e);
+MSH_EXPORT int32_t msh_profile_count(msh_engine* e);
+MSH_EXPORT int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_entry* out);
+
+MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOONSHINE_HIP_H */

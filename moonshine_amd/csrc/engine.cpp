@@ -1,0 +1,680 @@
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <stdlib.h>
+
+#include <algorithm>
+
+namespace msh {
+
+// ------------------------------------------------------------------------------------------------
+bool DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap && p != nullptr) return false;
+  size_t want = bytes + bytes / 8 + 256;  // a little slack so ragged batches do not thrash
+  void* np = nullptr;
+  MSH_HIP(hipMalloc(&np, want));
+  MSH_HIP(hipMemset(np, 0, want));
+  if (p) MSH_HIP(hipFree(p));
+  p = np;
+  cap = want;
+  return true;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+Engine::Engine(int device) : device_(device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    throw HipError("no HIP device available: the MI355X engine has no CPU fallback (" +
+                   std::string(hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= n) throw HipError("invalid device index " + std::to_string(device));
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  const char* ng = getenv("MSH_NO_GRAPH");
+  if (ng != nullptr && ng[0] == '1') use_graph_ = false;
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (step_graph_) (void)hipGraphExecDestroy(step_graph_);
+  for (hipEvent_t ev : event_pool_) (void)hipEventDestroy(ev);
+  for (auto& r : prof_pending_) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (void* p : weight_allocs_) (void)hipFree(p);
+  DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x1n_, &x2_, &H_,
+                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &KT_, &VT_, &dH_, &dq_, &dao_, &dz_,
+                    &logits_, &cacheK_, &cacheV_, &tokens_, &counts_, &finished_, &scalars_, &teacher_};
+  for (DevBuf* b : bufs) b->release();
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::synchronize() {
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::upload(const std::vector<float>& src, float** dst) {
+  void* p = nullptr;
+  MSH_HIP(hipMalloc(&p, src.size() * sizeof(float)));
+  weight_allocs_.push_back(p);
+  MSH_HIP(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<float*>(p);
+}
+
+void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
+  std::vector<bf16_t> tmp(src.size());
+  for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
+  void* p = nullptr;
+  MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  weight_allocs_.push_back(p);
+  MSH_HIP(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<bf16_t*>(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weights.  Tensor names / shapes: HuggingFace MoonshineForConditionalGeneration state_dict
+// (transformers modeling_moonshine.py:520-540 stem, :265-274 attention, :74-75 / :89-90 MLPs,
+// :836-850 tied head).  Layout changes made here, once, at load:
+//   conv1  [D,1,127]   -> [D][128] (tap 127 = 0)                  GEMM over the raw sample stream, lda = 64
+//   conv2  [2D,D,7]    -> [2D][7][D]  (tap-major, channel-minor)  matches the channels-last window
+//   conv3  [D,2D,3]    -> [D][3][2D]
+//   q,k,v  3 x [D,D]   -> [3D][D] fused
+//   cross k,v of all decoder layers -> [L*2D][D] (one GEMM per batch)
+//   decoder fc1 [2F,D] -> rows interleaved (value_j, gate_j) so SwiGLU pairs sit in one lane
+// ------------------------------------------------------------------------------------------------
+void Engine::load_weights(const SafeTensors& st, int expect_arch) {
+  MSH_HIP(hipSetDevice(device_));
+  if (loaded_) throw std::runtime_error("weights already loaded");
+  ModelConfig c;
+  const StTensor& c1 = st.get("model.encoder.conv1.weight");
+  if (c1.shape.size() != 3 || c1.shape[1] != 1 || c1.shape[2] != 127)
+    throw std::runtime_error("conv1.weight has unexpected shape");
+  c.hidden = (int)c1.shape[0];
+  c.ffn = (int)st.get("model.encoder.layers.0.mlp.fc1.weight").shape[0];
+  c.vocab = (int)st.get("model.decoder.embed_tokens.weight").shape[0];
+  while (st.has("model.encoder.layers." + std::to_string(c.enc_layers) + ".mlp.fc1.weight")) ++c.enc_layers;
+  while (st.has("model.decoder.layers." + std::to_string(c.dec_layers) + ".mlp.fc1.weight")) ++c.dec_layers;
+  auto md = st.metadata;
+  c.arch = md.count("arch") ? md["arch"] : (c.hidden == 288 ? "tiny" : c.hidden == 416 ? "base" : "custom");
+  c.heads = md.count("heads") ? std::stoi(md["heads"]) : (c.arch == "micro" ? 4 : 8);
+  if (expect_arch == 0 && c.hidden != 288)
+    throw std::runtime_error("model_arch TINY requested but weights have hidden size " + std::to_string(c.hidden));
+  if (expect_arch == 1 && c.hidden != 416)
+    throw std::runtime_error("model_arch BASE requested but weights have hidden size " + std::to_string(c.hidden));
+  const int D = c.hidden, F = c.ffn, V = c.vocab, dh = D / c.heads;
+  if (D % 32 != 0 || D % c.heads != 0 || dh % 4 != 0 || dh > 64 || (dh != 52 && dh != 36 && dh != 16))
+    throw std::runtime_error("unsupported model dimensions (hidden " + std::to_string(D) + ", heads " +
+                             std::to_string(c.heads) + ")");
+  if (F % 32 != 0 || V % 4 != 0) throw std::runtime_error("unsupported ffn / vocab size");
+  cfg_ = c;
+
+  auto expect_shape = [&](const std::string& name, std::vector<int64_t> shape) {
+    if (st.get(name).shape != shape) throw std::runtime_error("unexpected shape for " + name);
+  };
+
+  {  // conv stem
+    std::vector<float> w = st.to_f32("model.encoder.conv1.weight"), r((size_t)D * 128, 0.f);
+    for (int n = 0; n < D; ++n)
+      for (int k = 0; k < 127; ++k) r[(size_t)n * 128 + k] = w[(size_t)n * 127 + k];
+    upload_bf16(r, &conv1_w_);
+    expect_shape("model.encoder.conv2.weight", {2 * D, D, 7});
+    w = st.to_f32("model.encoder.conv2.weight");
+    r.assign((size_t)2 * D * 7 * D, 0.f);
+    for (int n = 0; n < 2 * D; ++n)
+      for (int ch = 0; ch < D; ++ch)
+        for (int k = 0; k < 7; ++k) r[((size_t)n * 7 + k) * D + ch] = w[((size_t)n * D + ch) * 7 + k];
+    upload_bf16(r, &conv2_w_);
+    expect_shape("model.encoder.conv3.weight", {D, 2 * D, 3});
+    w = st.to_f32("model.encoder.conv3.weight");
+    r.assign((size_t)D * 3 * 2 * D, 0.f);
+    for (int n = 0; n < D; ++n)
+      for (int ch = 0; ch < 2 * D; ++ch)
+        for (int k = 0; k < 3; ++k) r[((size_t)n * 3 + k) * 2 * D + ch] = w[((size_t)n * 2 * D + ch) * 3 + k];
+    upload_bf16(r, &conv3_w_);
+    upload(st.to_f32("model.encoder.conv2.bias"), &conv2_b_);
+    upload(st.to_f32("model.encoder.conv3.bias"), &conv3_b_);
+    upload(st.to_f32("model.encoder.groupnorm.weight"), &gn_w_);
+    upload(st.to_f32("model.encoder.groupnorm.bias"), &gn_b_);
+    upload(st.to_f32("model.encoder.layer_norm.weight"), &enc_ln_);
+  }
+  auto fuse = [&](std::initializer_list<std::string> names) {
+    std::vector<float> out;
+    for (const std::string& n : names) {
+      expect_shape(n, {D, D});
+      std::vector<float> w = st.to_f32(n);
+      out.insert(out.end(), w.begin(), w.end());
+    }
+    return out;
+  };
+  enc_.resize(c.enc_layers);
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
+    EncLayerW& L = enc_[l];
+    upload_bf16(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
+                &L.wqkv);
+    upload_bf16(fuse({p + "self_attn.o_proj.weight"}), &L.wo);
+    expect_shape(p + "mlp.fc1.weight", {F, D});
+    expect_shape(p + "mlp.fc2.weight", {D, F});
+    upload_bf16(st.to_f32(p + "mlp.fc1.weight"), &L.fc1);
+    upload_bf16(st.to_f32(p + "mlp.fc2.weight"), &L.fc2);
+    upload(st.to_f32(p + "mlp.fc1.bias"), &L.b1);
+    upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
+    upload(st.to_f32(p + "input_layernorm.weight"), &L.ln1);
+    upload(st.to_f32(p + "post_attention_layernorm.weight"), &L.ln2);
+  }
+  {
+    expect_shape("model.decoder.embed_tokens.weight", {V, D});
+    std::vector<float> e = st.to_f32("model.decoder.embed_tokens.weight");
+    upload(e, &embed_f32_);
+    upload_bf16(e, &embed_bf16_);  // tied LM head (configuration_moonshine.py:103)
+    upload(st.to_f32("model.decoder.norm.weight"), &dec_ln_);
+  }
+  dec_.resize(c.dec_layers);
+  std::vector<float> cross;
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
+    DecLayerW& L = dec_[l];
+    upload_bf16(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
+                &L.wqkv);
+    upload_bf16(fuse({p + "self_attn.o_proj.weight"}), &L.wo);
+    upload_bf16(fuse({p + "encoder_attn.q_proj.weight"}), &L.wq_c);
+    upload_bf16(fuse({p + "encoder_attn.o_proj.weight"}), &L.wo_c);
+    std::vector<float> kv = fuse({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"});
+    cross.insert(cross.end(), kv.begin(), kv.end());
+    expect_shape(p + "mlp.fc1.weight", {2 * F, D});
+    expect_shape(p + "mlp.fc2.weight", {D, F});
+    std::vector<float> w = st.to_f32(p + "mlp.fc1.weight"), b = st.to_f32(p + "mlp.fc1.bias");
+    std::vector<float> wi((size_t)2 * F * D), bi((size_t)2 * F);
+    for (int j = 0; j < F; ++j) {  // first half = value, second half = gate (modeling_moonshine.py:92-96)
+      memcpy(&wi[(size_t)(2 * j) * D], &w[(size_t)j * D], D * sizeof(float));
+      memcpy(&wi[(size_t)(2 * j + 1) * D], &w[(size_t)(F + j) * D], D * sizeof(float));
+      bi[2 * j] = b[j];
+      bi[2 * j + 1] = b[F + j];
+    }
+    upload_bf16(wi, &L.fc1);
+    upload(bi, &L.b1);
+    upload_bf16(st.to_f32(p + "mlp.fc2.weight"), &L.fc2);
+    upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
+    upload(st.to_f32(p + "input_layernorm.weight"), &L.ln1);
+    upload(st.to_f32(p + "post_attention_layernorm.weight"), &L.ln2);
+    upload(st.to_f32(p + "final_layernorm.weight"), &L.ln3);
+  }
+  upload_bf16(cross, &cross_kv_w_);
+
+  // RoPE tables in fp32, computed the way the float definition does (modeling_moonshine.py:132-154):
+  // inv_freq = 1 / theta^(2j/dim), angle = pos * inv_freq, then cos / sin.
+  rope_max_pos_ = 8192;
+  const int rp = cfg_.rot_pairs(), dim = rp * 2;
+  std::vector<float> cs((size_t)rope_max_pos_ * rp), sn((size_t)rope_max_pos_ * rp);
+  for (int j = 0; j < rp; ++j) {
+    const float inv = 1.0f / powf(cfg_.rope_theta, (float)(2 * j) / (float)dim);
+    for (int pos = 0; pos < rope_max_pos_; ++pos) {
+      const float a = (float)pos * inv;
+      cs[(size_t)pos * rp + j] = cosf(a);
+      sn[(size_t)pos * rp + j] = sinf(a);
+    }
+  }
+  upload(cs, &rope_cos_);
+  upload(sn, &rope_sin_);
+  loaded_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Profiling scopes (HIP events on the engine stream)
+// ------------------------------------------------------------------------------------------------
+hipEvent_t Engine::get_event() {
+  if (!event_pool_.empty()) {
+    hipEvent_t e = event_pool_.back();
+    event_pool_.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  MSH_HIP(hipEventCreate(&e));
+  return e;
+}
+
+struct Engine::ProfScope {
+  Engine* e;
+  int idx = -1;
+  hipEvent_t a{}, b{};
+  ProfScope(Engine* eng, const char* name, double flops, double bytes) : e(eng) {
+    if (!e->prof_on_) return;
+    auto it = e->prof_idx_.find(name);
+    if (it == e->prof_idx_.end()) {
+      idx = (int)e->prof_.size();
+      e->prof_idx_[name] = idx;
+      ProfEntry pe;
+      pe.name = name;
+      e->prof_.push_back(pe);
+    } else {
+      idx = it->second;
+    }
+    e->prof_[idx].flops += flops;
+    e->prof_[idx].bytes += bytes;
+    e->prof_[idx].launches += 1;
+    a = e->get_event();
+    b = e->get_event();
+    MSH_HIP(hipEventRecord(a, e->stream_));
+  }
+  ~ProfScope() {
+    if (idx < 0) return;
+    (void)hipEventRecord(b, e->stream_);
+    e->prof_pending_.push_back({idx, a, b});
+  }
+};
+
+void Engine::prof_flush() {
+  if (prof_pending_.empty()) return;
+  MSH_HIP(hipStreamSynchronize(stream_));
+  for (auto& r : prof_pending_) {
+    float ms = 0.f;
+    MSH_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    prof_[r.idx].ms += ms;
+    event_pool_.push_back(r.a);
+    event_pool_.push_back(r.b);
+  }
+  prof_pending_.clear();
+}
+
+void Engine::profile_enable(bool on) {
+  prof_flush();
+  prof_on_ = on;
+}
+void Engine::profile_reset() {
+  prof_flush();
+  prof_.clear();
+  prof_idx_.clear();
+}
+std::vector<ProfEntry> Engine::profile_get() {
+  prof_flush();
+  return prof_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch planning
+// ------------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void Engine::plan_batch(const uint64_t* n_samples, uint32_t count, float mtps) {
+  if (count == 0) throw std::invalid_argument("empty batch");
+  clips_h_.assign(count, ClipMeta{});
+  long row = 0, kv = 0;
+  max_rows_ = 0;
+  max_steps_ = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint64_t n = n_samples[i];
+    if (n > (1u << 30)) throw std::invalid_argument("clip too long");
+    ClipMeta& c = clips_h_[i];
+    // conv length formula: transformers modeling_moonshine.py:500-508
+    const int L1 = n >= 127 ? (int)((n - 127) / 64 + 1) : 0;
+    const int L2 = L1 >= 7 ? (L1 - 7) / 3 + 1 : 0;
+    const int T = L2 >= 3 ? (L2 - 3) / 2 + 1 : 0;
+    if (T < 1) throw std::invalid_argument("clip " + std::to_string(i) + " is too short (" + std::to_string(n) +
+                                           " samples): the conv stem needs at least 895");
+    c.n_samples = (int)n;
+    c.L1 = L1;
+    c.L2 = L2;
+    c.T = T;
+    // rows: the clip's slot in every stream.  conv1 consumes samples [0, 64*L1 + 63) from a slot of
+    // 384*rows samples; conv2/conv3 need 2*rows >= L2 and rows >= T.
+    int rows = std::max({(64 * L1 + 63 + 383) / 384, (L2 + 1) / 2, T});
+    c.rows = round_up(rows, 4);
+    c.row_start = (int)row;
+    c.Tk = round_up(T, 8);
+    c.kv_start = (int)kv;
+    // step budget: reference core/moonshine-model.cpp:347-349 (float arithmetic)
+    const float dur = (float)n / 16000.0f;
+    c.max_len = (int)ceilf(dur * mtps);
+    if (c.max_len < 1) c.max_len = 1;
+    row += c.rows;
+    kv += c.Tk;
+    max_rows_ = std::max(max_rows_, c.rows);
+    max_steps_ = std::max(max_steps_, c.max_len);
+    if (T > rope_max_pos_) throw std::invalid_argument("clip too long for the RoPE table");
+  }
+  if (row > (1L << 24)) throw std::invalid_argument("batch too large");
+  R_ = row;
+  kv_keys_ = kv;
+  n_clips_ = count;
+}
+
+// ------------------------------------------------------------------------------------------------
+void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t count, bool on_device, float mtps) {
+  MSH_HIP(hipSetDevice(device_));
+  if (!loaded_) throw std::runtime_error("no weights loaded");
+  encoded_ = false;
+  plan_batch(n_samples, count, mtps);
+  const int D = cfg_.hidden, F = cfg_.ffn, L = cfg_.dec_layers;
+  const long R = R_;
+  bool moved = false;
+  moved |= clips_d_.reserve(count * sizeof(ClipMeta));
+  moved |= clip_ptrs_d_.reserve(count * sizeof(float*));
+  moved |= audio_bf16_.reserve((384 * R + 512) * sizeof(bf16_t));
+  moved |= row_pos_.reserve(R * sizeof(int));
+  moved |= row_clip_.reserve(R * sizeof(int));
+  moved |= x1_.reserve((6 * R + 16) * D * sizeof(float));
+  moved |= x1n_.reserve((6 * R + 16) * D * sizeof(bf16_t));
+  moved |= x2_.reserve((2 * R + 8) * 2 * D * sizeof(bf16_t));
+  moved |= H_.reserve(R * D * sizeof(float));
+  moved |= Y_.reserve(R * D * sizeof(bf16_t));
+  moved |= QKV_.reserve(R * 3 * D * sizeof(bf16_t));
+  moved |= AO_.reserve(R * D * sizeof(bf16_t));
+  moved |= Z_.reserve(R * F * sizeof(bf16_t));
+  moved |= ENC_.reserve(R * D * sizeof(bf16_t));
+  if (keep_enc_f32_) moved |= ENC32_.reserve(R * D * sizeof(float));
+  moved |= gn_part_.reserve((size_t)count * 64 * sizeof(float2));
+  moved |= gn_stats_.reserve(count * sizeof(float2));
+  moved |= KT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
+  moved |= VT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
+  if (moved) ++ws_gen_;
+
+  // clip pointers: stage host PCM into one device buffer, or use the caller's device pointers
+  std::vector<const float*> ptrs(count);
+  if (on_device) {
+    for (uint32_t i = 0; i < count; ++i) ptrs[i] = pcm[i];
+  } else {
+    size_t total = 0;
+    for (uint32_t i = 0; i < count; ++i) total += (n_samples[i] + 3) & ~size_t(3);
+    pcm_stage_.reserve(total * sizeof(float));
+    size_t off = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+      float* dst = pcm_stage_.as<float>() + off;
+      MSH_HIP(hipMemcpyAsync(dst, pcm[i], n_samples[i] * sizeof(float), hipMemcpyHostToDevice, stream_));
+      ptrs[i] = dst;
+      off += (n_samples[i] + 3) & ~size_t(3);
+    }
+  }
+  MSH_HIP(hipMemcpyAsync(clips_d_.p, clips_h_.data(), count * sizeof(ClipMeta), hipMemcpyHostToDevice, stream_));
+  MSH_HIP(hipMemcpyAsync(clip_ptrs_d_.p, ptrs.data(), count * sizeof(float*), hipMemcpyHostToDevice, stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));  // `ptrs` / `clips_h_` staging is on the host stack
+  run_encoder();
+  prof_flush();
+  encoded_ = true;
+}
+
+void Engine::run_encoder() {
+  const int D = cfg_.hidden, F = cfg_.ffn, Hh = cfg_.heads, L = cfg_.dec_layers;
+  const int R = (int)R_;
+  const ClipMeta* clips = clips_d_.as<ClipMeta>();
+  hipStream_t s = stream_;
+  // algorithmic work (valid frames only) for the profiler
+  double sL1 = 0, sL2 = 0, sT = 0, sT2 = 0, sN = 0;
+  for (const ClipMeta& c : clips_h_) {
+    sL1 += c.L1;
+    sL2 += c.L2;
+    sT += c.T;
+    sT2 += (double)c.T * c.T;
+    sN += c.n_samples;
+  }
+  RopeParams rp{rope_cos_, rope_sin_, cfg_.rot_pairs(), cfg_.head_dim(), D};
+
+  {
+    ProfScope p(this, "pack_audio", 0, sN * 4 + 384.0 * R * 2);
+    pack_audio(clip_ptrs_d_.as<const float*>(), clips, (int)n_clips_, audio_bf16_.as<bf16_t>(), 0, s);
+    build_row_meta(clips, (int)n_clips_, row_pos_.as<int>(), row_clip_.as<int>(), s);
+  }
+  {  // conv1 (k127, s64, no bias) + tanh: GEMM over the sample stream, row t = samples [64t, 64t+128)
+    ProfScope p(this, "conv1_tanh_gemm", 2.0 * sL1 * D * 127, sN * 2 + sL1 * D * 4);
+    gemm_tanh_f32(audio_bf16_.as<bf16_t>(), 64, conv1_w_, 6 * R, D, 128, x1_.as<float>(), s);
+  }
+  {
+    ProfScope p(this, "groupnorm", 0, sL1 * D * (4 + 4 + 2));
+    groupnorm_stats(x1_.as<float>(), clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
+    groupnorm_apply(x1_.as<float>(), gn_stats_.as<float2>(), row_clip_.as<int>(), gn_w_, gn_b_, 6L * R, D,
+                    x1n_.as<bf16_t>(), s);
+  }
+  {  // conv2 (k7, s3) + GELU: window of 7 channels-last frames is contiguous -> lda = 3D, K = 7D
+    ProfScope p(this, "conv2_gelu_gemm", 2.0 * sL2 * 2 * D * 7 * D, sL1 * D * 2 + sL2 * 2 * D * 2);
+    gemm_bias_gelu_bf16(x1n_.as<bf16_t>(), 3L * D, conv2_w_, conv2_b_, 2 * R, 2 * D, 7 * D, x2_.as<bf16_t>(), s);
+  }
+  {  // conv3 (k3, s2) + GELU -> residual stream H [R, D] fp32
+    ProfScope p(this, "conv3_gelu_gemm", 2.0 * sT * D * 6 * D, sL2 * 2 * D * 2 + sT * D * 4);
+    gemm_bias_gelu_f32(x2_.as<bf16_t>(), 4L * D, conv3_w_, conv3_b_, R, D, 6 * D, H_.as<float>(), s);
+  }
+  for (int l = 0; l < cfg_.enc_layers; ++l) {
+    const EncLayerW& W = enc_[l];
+    {
+      ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+      layernorm_bf16(H_.as<float>(), W.ln1, R, D, Y_.as<bf16_t>(), nullptr, s);
+    }
+    {
+      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 3 * D, sT * D * 2 * 4);
+      gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 3 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
+    }
+    {
+      ProfScope p(this, "enc_attention", 4.0 * sT2 * D, sT * D * 2 * 4);
+      enc_attention(QKV_.as<bf16_t>(), AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
+    }
+    {
+      ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));
+      gemm_resid_f32(AO_.as<bf16_t>(), D, W.wo, nullptr, R, D, D, H_.as<float>(), s);
+    }
+    {
+      ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+      layernorm_bf16(H_.as<float>(), W.ln2, R, D, Y_.as<bf16_t>(), nullptr, s);
+    }
+    {
+      ProfScope p(this, "enc_fc1_gelu_gemm", 2.0 * sT * D * F, sT * (D + F) * 2);
+      gemm_bias_gelu_bf16(Y_.as<bf16_t>(), D, W.fc1, W.b1, R, F, D, Z_.as<bf16_t>(), s);
+    }
+    {
+      ProfScope p(this, "enc_fc2_gemm", 2.0 * sT * D * F, sT * (F * 2 + D * 8));
+      gemm_resid_f32(Z_.as<bf16_t>(), F, W.fc2, W.b2, R, D, F, H_.as<float>(), s);
+    }
+  }
+  {
+    ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+    layernorm_bf16(H_.as<float>(), enc_ln_, R, D, ENC_.as<bf16_t>(), keep_enc_f32_ ? ENC32_.as<float>() : nullptr, s);
+  }
+  {  // cross-attention K/V of all decoder layers in one GEMM, written as K^T / V^T for the decode stream
+    ProfScope p(this, "cross_kv_gemm", 2.0 * sT * D * 2 * D * L, sT * D * 2 + sT * D * 2.0 * L * 2);
+    gemm_cross_kv(ENC_.as<bf16_t>(), D, cross_kv_w_, R, L * 2 * D, D, row_clip_.as<int>(), clips, D,
+                  (long)D * kv_keys_, KT_.as<bf16_t>(), VT_.as<bf16_t>(), s);
+  }
+}
+
+void Engine::get_encoder_output(uint32_t clip, float* out) {
+  MSH_HIP(hipSetDevice(device_));
+  if (!encoded_ || !keep_enc_f32_) throw std::runtime_error("encoder output not available (enable keep_encoder_f32)");
+  const ClipMeta& c = clips_h_.at(clip);
+  MSH_HIP(hipStreamSynchronize(stream_));
+  MSH_HIP(hipMemcpy(out, ENC32_.as<float>() + (long)c.row_start * cfg_.hidden,
+                    (size_t)c.T * cfg_.hidden * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode
+// ------------------------------------------------------------------------------------------------
+void Engine::decode_step_enqueue(int M) {
+  const int D = cfg_.hidden, F = cfg_.ffn, Hh = cfg_.heads, V = cfg_.vocab, dh = cfg_.head_dim();
+  hipStream_t s = stream_;
+  RopeParams rp{rope_cos_, rope_sin_, cfg_.rot_pairs(), dh, D};
+  int32_t* sc = scalars_.as<int32_t>();
+  int32_t* pos = sc;  // [0] = pos, [1] = n_active
+  float* dH = dH_.as<float>();
+  float* dq = dq_.as<float>();
+  bf16_t* dao = dao_.as<bf16_t>();
+  bf16_t* dz = dz_.as<bf16_t>();
+  const ClipMeta* clips = clips_d_.as<ClipMeta>();
+  const size_t cache_layer = (size_t)M * Hh * Smax_ * dh;
+  double sT = 0;
+  for (const ClipMeta& c : clips_h_) sT += c.T;
+  const double w_dd = 2.0 * D * D;  // bytes of a [D, D] bf16 weight
+  for (int l = 0; l < cfg_.dec_layers; ++l) {
+    const DecLayerW& W = dec_[l];
+    bf16_t* cK = cacheK_.as<bf16_t>() + l * cache_layer;
+    bf16_t* cV = cacheV_.as<bf16_t>() + l * cache_layer;
+    {
+      ProfScope p(this, "dec_qkv_gemm", 2.0 * M * D * 3 * D, 3 * w_dd + M * D * 4.0 * 2);
+      dec_gemm_qkv(dH, W.ln1, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
+    }
+    {
+      ProfScope p(this, "dec_self_attention", 0, 0);
+      dec_self_attention(dq, cK, cV, pos, M, D, Hh, Smax_, dao, s);
+    }
+    {
+      ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
+      dec_gemm_resid(dao, D, W.wo, nullptr, M, D, D, dH, s);
+    }
+    {
+      ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
+      dec_gemm_ln_f32(dH, W.ln2, W.wq_c, M, D, D, dq, s);
+    }
+    {
+      ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
+      dec_cross_attention(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
+                          clips, M, D, Hh, dao, s);
+    }
+    {
+      ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
+      dec_gemm_resid(dao, D, W.wo_c, nullptr, M, D, D, dH, s);
+    }
+    {
+      ProfScope p(this, "dec_fc1_swiglu_gemm", 2.0 * M * D * 2 * F, 2.0 * 2 * F * D + M * (D * 4.0 + F * 2.0));
+      dec_gemm_ln_swiglu(dH, W.ln3, W.fc1, W.b1, M, F, D, dz, s);
+    }
+    {
+      ProfScope p(this, "dec_fc2_resid_gemm", 2.0 * M * D * F, 2.0 * F * D + M * (F * 2.0 + D * 8.0));
+      dec_gemm_resid(dz, F, W.fc2, W.b2, M, D, F, dH, s);
+    }
+  }
+  {
+    ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
+    dec_gemm_logits(dH, dec_ln_, embed_bf16_, M, V, D, logits_.as<float>(), s);
+  }
+}
+
+int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride, float* logits_out,
+                   int max_logit_steps, int32_t* tokens_out, int32_t* counts_out, int tokens_stride) {
+  MSH_HIP(hipSetDevice(device_));
+  if (!encoded_) throw std::runtime_error("decode() called before encode()");
+  const int M = (int)n_clips_, D = cfg_.hidden, F = cfg_.ffn, V = cfg_.vocab, Hh = cfg_.heads, dh = cfg_.head_dim();
+  const bool forced = forced_steps >= 0;
+  const int steps = forced ? forced_steps : max_steps_;
+  if (steps < 1) throw std::invalid_argument("decode: need at least one step");
+  if (steps > 504) throw std::invalid_argument("decode: step budget above 504 tokens is not supported");
+  const int stride = steps + 1;
+  if (tokens_out != nullptr && tokens_stride < stride)
+    throw std::invalid_argument("decode: tokens_stride " + std::to_string(tokens_stride) + " < steps+1 = " +
+                                std::to_string(stride));
+  if (teacher != nullptr && teacher_stride < 1) throw std::invalid_argument("decode: bad teacher stride");
+  Smax_ = round_up(steps, 8);
+
+  bool moved = false;
+  moved |= dH_.reserve((size_t)M * D * sizeof(float));
+  moved |= dq_.reserve((size_t)M * D * sizeof(float));
+  moved |= dao_.reserve((size_t)M * D * sizeof(bf16_t));
+  moved |= dz_.reserve((size_t)M * F * sizeof(bf16_t));
+  moved |= logits_.reserve((size_t)M * V * sizeof(float));
+  moved |= cacheK_.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
+  moved |= cacheV_.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
+  moved |= tokens_.reserve((size_t)M * stride * sizeof(int32_t));
+  moved |= counts_.reserve((size_t)M * sizeof(int32_t));
+  moved |= finished_.reserve((size_t)M * sizeof(int32_t));
+  moved |= scalars_.reserve(16 * sizeof(int32_t));
+  if (teacher) moved |= teacher_.reserve((size_t)M * stride * sizeof(int32_t));
+  if (moved) ++ws_gen_;
+
+  if (forced) {  // fixed step count, EOS ignored (benchmark / parity mode)
+    std::vector<ClipMeta> tmp = clips_h_;
+    for (ClipMeta& c : tmp) c.max_len = steps;
+    MSH_HIP(hipMemcpyAsync(clips_d_.p, tmp.data(), tmp.size() * sizeof(ClipMeta), hipMemcpyHostToDevice, stream_));
+    MSH_HIP(hipStreamSynchronize(stream_));
+  } else {
+    MSH_HIP(hipMemcpyAsync(clips_d_.p, clips_h_.data(), clips_h_.size() * sizeof(ClipMeta), hipMemcpyHostToDevice,
+                           stream_));
+    MSH_HIP(hipStreamSynchronize(stream_));
+  }
+  if (teacher) {
+    std::vector<int32_t> t((size_t)M * stride, 0);
+    for (int b = 0; b < M; ++b)
+      for (int i = 0; i < stride && i < teacher_stride; ++i) t[(size_t)b * stride + i] = teacher[(size_t)b * teacher_stride + i];
+    MSH_HIP(hipMemcpy(teacher_.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+
+  DecodeState st{};
+  st.tokens = tokens_.as<int32_t>();
+  st.counts = counts_.as<int32_t>();
+  st.finished = finished_.as<int32_t>();
+  st.pos = scalars_.as<int32_t>();
+  st.n_active = scalars_.as<int32_t>() + 1;
+  st.forced = teacher ? teacher_.as<int32_t>() : nullptr;
+  st.stride = stride;
+  st.eos = cfg_.eos;
+  st.ignore_eos = forced ? 1 : 0;
+  const ClipMeta* clips = clips_d_.as<ClipMeta>();
+
+  decode_begin(M, st, cfg_.bos, embed_f32_, D, dH_.as<float>(), stream_);
+
+  // One decode step = 8 kernels per layer + head + bookkeeping; captured once into a hipGraph and
+  // replayed (everything step-dependent -- position, ids, masks -- lives in device memory).
+  const bool graph_ok = use_graph_ && !prof_on_ && logits_out == nullptr;
+  // everything baked into the captured kernel arguments
+  const std::string key = std::to_string(M) + ":" + std::to_string(ws_gen_) + ":" + std::to_string(Smax_) + ":" +
+                          std::to_string(stride) + ":" + std::to_string(st.ignore_eos) + ":" +
+                          std::to_string(teacher != nullptr);
+  if (graph_ok && (step_graph_ == nullptr || graph_key_ != key)) {
+    if (step_graph_) {
+      MSH_HIP(hipGraphExecDestroy(step_graph_));
+      step_graph_ = nullptr;
+    }
+    hipGraph_t g = nullptr;
+    MSH_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    decode_step_enqueue(M);
+    decode_advance(logits_.as<float>(), M, V, clips, st, embed_f32_, D, dH_.as<float>(), stream_);
+    MSH_HIP(hipStreamEndCapture(stream_, &g));
+    MSH_HIP(hipGraphInstantiate(&step_graph_, g, nullptr, nullptr, 0));
+    MSH_HIP(hipGraphDestroy(g));
+    graph_key_ = key;
+  }
+
+  int steps_run = 0;
+  int32_t n_active_h = M;
+  for (int i = 0; i < steps; ++i) {
+    if (graph_ok) {
+      MSH_HIP(hipGraphLaunch(step_graph_, stream_));
+    } else {
+      decode_step_enqueue(M);
+      if (logits_out != nullptr && i < max_logit_steps)
+        MSH_HIP(hipMemcpyAsync(logits_out + (size_t)i * M * V, logits_.p, (size_t)M * V * sizeof(float),
+                               hipMemcpyDeviceToHost, stream_));
+      ProfScope p(this, "dec_argmax_advance", 0, (double)M * V * 4);
+      decode_advance(logits_.as<float>(), M, V, clips, st, embed_f32_, D, dH_.as<float>(), stream_);
+    }
+    ++steps_run;
+    if (!forced && ((i & 7) == 7) && i + 1 < steps) {
+      MSH_HIP(hipMemcpyAsync(&n_active_h, st.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+      MSH_HIP(hipStreamSynchronize(stream_));
+      if (n_active_h <= 0) break;
+    }
+  }
+  if (tokens_out != nullptr || counts_out != nullptr) {
+    std::vector<int32_t> tk((size_t)M * stride), cn(M);
+    MSH_HIP(hipMemcpyAsync(tk.data(), tokens_.p, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    MSH_HIP(hipMemcpyAsync(cn.data(), counts_.p, cn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    MSH_HIP(hipStreamSynchronize(stream_));
+    for (int b = 0; b < M; ++b) {
+      if (counts_out) counts_out[b] = cn[b];
+      if (tokens_out) {
+        for (int i = 0; i < tokens_stride; ++i)
+          tokens_out[(size_t)b * tokens_stride + i] = i < cn[b] ? tk[(size_t)b * stride + i] : -1;
+      }
+    }
+  } else {
+    MSH_HIP(hipStreamSynchronize(stream_));
+  }
+  prof_flush();
+  return steps_run;
+}
+
+}  // namespace msh

@@ -1,0 +1,147 @@
+// MI355X Moonshine engine: weights resident in HBM, batched encoder, lock-step batched greedy decoder.
+// This is the device-side replacement for the reference's ORT sessions
+// (reference core/moonshine-model.cpp:216-563 + core/ort-utils/): host code above it only sees
+// "PCM clips in, token ids out".
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "safetensors.h"
+
+namespace msh {
+
+struct ModelConfig {
+  std::string arch;
+  int hidden = 0, ffn = 0, enc_layers = 0, dec_layers = 0, heads = 0, vocab = 0;
+  int bos = 1, eos = 2;  // reference core/moonshine-model.cpp:56-57
+  float rope_theta = 10000.f;
+  float partial_rotary = 0.9f;
+  int head_dim() const { return hidden / heads; }
+  int rot_pairs() const { return (int)(head_dim() * partial_rotary) / 2; }
+};
+
+// A device allocation that only ever grows.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t bytes);  // returns true if reallocated (contents lost, zero-filled)
+  void release();
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct EncLayerW {
+  float *ln1, *ln2, *b1, *b2;
+  bf16_t *wqkv, *wo, *fc1, *fc2;
+};
+struct DecLayerW {
+  float *ln1, *ln2, *ln3, *b1, *b2;
+  bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;
+};
+
+struct ProfEntry {
+  std::string name;
+  double ms = 0;
+  uint64_t launches = 0;
+  double flops = 0;  // algorithmic flops over all launches
+  double bytes = 0;  // algorithmic HBM bytes over all launches
+};
+
+class Engine {
+ public:
+  explicit Engine(int device);
+  ~Engine();
+
+  void load_weights(const SafeTensors& st, int expect_arch /* -1 any, 0 tiny, 1 base */);
+  const ModelConfig& config() const { return cfg_; }
+  bool loaded() const { return loaded_; }
+
+  // Encoder + cross-K/V projection for a batch of clips.  pcm[i] is a host pointer unless on_device.
+  void encode(const float* const* pcm, const uint64_t* n_samples, uint32_t count, bool on_device,
+              float max_tokens_per_second);
+  // Lock-step greedy decode of the encoded batch.  forced_steps < 0: stop on EOS / per-clip budget
+  // (reference loop); >= 0: ignore EOS and run exactly that many steps.  teacher (optional,
+  // [count][teacher_stride], row starts with BOS) feeds given ids instead of the argmax.
+  // logits_out (optional) receives [steps][count][V] fp32.  Returns the number of steps run.
+  int decode(int forced_steps, const int32_t* teacher, int teacher_stride, float* logits_out, int max_logit_steps,
+             int32_t* tokens_out, int32_t* counts_out, int tokens_stride);
+
+  uint32_t batch_count() const { return n_clips_; }
+  int clip_frames(uint32_t clip) const { return clips_h_.at(clip).T; }
+  int max_decode_len() const { return max_steps_; }
+  void get_encoder_output(uint32_t clip, float* out);  // [T][D] fp32 (needs keep_encoder_f32)
+  void set_keep_encoder_f32(bool v) { keep_enc_f32_ = v; }
+
+  // per-kernel-group timing with HIP events on the engine stream
+  void profile_enable(bool on);
+  void profile_reset();
+  std::vector<ProfEntry> profile_get();
+
+  hipStream_t stream() const { return stream_; }
+  void synchronize();
+
+ private:
+  struct ProfScope;
+  void plan_batch(const uint64_t* n_samples, uint32_t count, float max_tokens_per_second);
+  void run_encoder();
+  void decode_step_enqueue(int M);
+  void upload(const std::vector<float>& src, float** dst);
+  void upload_bf16(const std::vector<float>& src, bf16_t** dst);
+
+  int device_;
+  hipStream_t stream_ = nullptr;
+  ModelConfig cfg_;
+  bool loaded_ = false;
+  std::vector<void*> weight_allocs_;
+
+  // weights
+  bf16_t *conv1_w_ = nullptr, *conv2_w_ = nullptr, *conv3_w_ = nullptr;
+  float *conv2_b_ = nullptr, *conv3_b_ = nullptr, *gn_w_ = nullptr, *gn_b_ = nullptr, *enc_ln_ = nullptr;
+  std::vector<EncLayerW> enc_;
+  std::vector<DecLayerW> dec_;
+  bf16_t *embed_bf16_ = nullptr, *cross_kv_w_ = nullptr;
+  float *embed_f32_ = nullptr, *dec_ln_ = nullptr;
+  float *rope_cos_ = nullptr, *rope_sin_ = nullptr;
+  int rope_max_pos_ = 0;
+
+  // current batch
+  uint32_t n_clips_ = 0;
+  std::vector<ClipMeta> clips_h_;
+  long R_ = 0;        // packed rows
+  long kv_keys_ = 0;  // sum of Tk
+  int max_rows_ = 0, max_steps_ = 0;
+  bool encoded_ = false, keep_enc_f32_ = false;
+
+  // workspace (grow-only)
+  DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x1n_, x2_, H_, Y_, QKV_, AO_, Z_,
+      ENC_, ENC32_, gn_part_, gn_stats_, KT_, VT_;
+  DevBuf dH_, dq_, dao_, dz_, logits_, cacheK_, cacheV_, tokens_, counts_, finished_, scalars_, teacher_;
+  int Smax_ = 0;
+
+  // decode-step graph cache (invalidated when any buffer it references moves)
+  hipGraphExec_t step_graph_ = nullptr;
+  std::string graph_key_;
+  uint64_t ws_gen_ = 0;
+  bool use_graph_ = true;
+
+  // profiling
+  bool prof_on_ = false;
+  struct ProfRec {
+    int idx;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfEntry> prof_;
+  std::map<std::string, int> prof_idx_;
+  std::vector<ProfRec> prof_pending_;
+  std::vector<hipEvent_t> event_pool_;
+  hipEvent_t get_event();
+  void prof_flush();
+};
+
+}  // namespace msh

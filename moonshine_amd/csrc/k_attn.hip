@@ -1,0 +1,368 @@
+// Attention kernels for gfx950.
+//
+//  enc_attention        non-causal MHA over the packed encoder stream (flash-style: 64-key blocks staged
+//                       through LDS, online softmax in fp32, bf16 MFMA 16x16x32 for QK^T and PV).
+//                       Both products are computed transposed (S^T = K Q^T, O^T = V^T P^T) so that the
+//                       query index is the MFMA column (lane & 15) everywhere: softmax statistics, the
+//                       P fragment and the O accumulator all live in the same lane, no cross-lane moves
+//                       other than two xor-shuffles for the row max.
+//  dec_self_attention   one wave per (clip, head): <= Smax cached keys, latency-bound, plain VALU.
+//  dec_cross_attention  one wave per (clip, head) streaming K^T / V^T ([dh][Tk] bf16, keys contiguous)
+//                       with 16-byte loads: the HBM-bound kernel that dominates batched decode
+//                       (5.5 MB per clip per step at Moonshine-base).
+#include "kernels.h"
+
+namespace msh {
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ------------------------------------------------------------------------------------------------
+// Encoder attention
+// ------------------------------------------------------------------------------------------------
+constexpr int KB = 64;        // keys per LDS block
+constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: conflict-free ds_read_b64)
+
+template <int DH>
+__global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __restrict__ qkv,
+                                                            bf16_t* __restrict__ out,
+                                                            const ClipMeta* __restrict__ clips, int D) {
+  static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
+  constexpr int PIECES = DH / 4;  // 8-byte pieces per K/V row
+  __shared__ __attribute__((aligned(16))) uint2 Ks[KB * 16];        // [key][8 x 16 B], chunk ^= (key>>1)&7
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VT_LD];    // [d][key]
+
+  const ClipMeta cm = clips[blockIdx.z];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= cm.rows) return;
+  const int h = blockIdx.y;
+  const int T = cm.T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const long ld = 3L * D;
+  const bf16_t* base = qkv + (long)cm.row_start * ld + h * DH;
+
+  // zero the head-dim padding once (never overwritten by the staging loop)
+  for (int p = tid; p < KB * 16; p += 256) {
+    const int key = p >> 4, piece = p & 15;
+    if (piece >= PIECES) Ks[(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = make_uint2(0u, 0u);
+  }
+  for (int p = tid; p < (64 - DH) * VT_LD; p += 256) Vt[DH * VT_LD + p] = 0;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds q row (li), d = s*32 + kg*8 .. +8
+  int qrow = q0 + wave * 16 + li;
+  const int qrow_ld = qrow < cm.rows ? qrow : cm.rows - 1;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int d = s * 32 + kg * 8;
+    uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+    if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
+    if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
+    uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    qf[s] = *reinterpret_cast<bf16x8*>(&t);
+  }
+
+  const float c = rsqrtf((float)DH) * kLog2e;  // scores are compared / exponentiated in the exp2 domain
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (T + KB - 1) / KB;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();  // previous block fully consumed (also orders the padding zero-fill)
+    for (int p = tid; p < KB * PIECES; p += 256) {
+      const int key = p / PIECES, piece = p - key * PIECES;
+      const int t = kb * KB + key;
+      uint2 kv = make_uint2(0u, 0u), vv = make_uint2(0u, 0u);
+      if (t < T) {
+        const bf16_t* r = base + (long)t * ld + piece * 4;
+        kv = *reinterpret_cast<const uint2*>(r + D);
+        vv = *reinterpret_cast<const uint2*>(r + 2 * D);
+      }
+      Ks[(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = kv;
+      bf16_t* vd = Vt + (piece * 4) * VT_LD + key;
+      vd[0] = (bf16_t)(vv.x & 0xffffu);
+      vd[VT_LD] = (bf16_t)(vv.x >> 16);
+      vd[2 * VT_LD] = (bf16_t)(vv.y & 0xffffu);
+      vd[3 * VT_LD] = (bf16_t)(vv.y >> 16);
+    }
+    __syncthreads();
+
+    // S^T tiles: rows = keys, cols = queries.  st[kt][r] = score(q = li, key = kb*64 + kt*16 + kg*4 + r)
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int key = kt * 16 + li;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint4 t = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&t), qf[s], a, 0, 0, 0);
+      }
+      st[kt] = a;
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = kb * KB + kt * 16 + kg * 4 + r;
+        st[kt][r] = t < T ? st[kt][r] * c : -INFINITY;
+        mloc = fmaxf(mloc, st[kt][r]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+        psum += st[kt][r];
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+
+    // O^T += V^T P^T.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 pt;
+      pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
+      pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
+      pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+      pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+      const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pt);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if (dt * 16 >= DH) continue;
+        const bf16_t* vr = Vt + (dt * 16 + li) * VT_LD + ks * 32 + kg * 4;
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
+        uint4 vt = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vt), pf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_run;
+  if (qrow < cm.rows) {
+    const bool valid = qrow < T;
+    bf16_t* orow = out + (long)(cm.row_start + qrow) * D + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int d = dt * 16 + kg * 4;
+      if (d < DH) {
+        uint2 w = make_uint2(0u, 0u);
+        if (valid) {
+          w.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+          w.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+        }
+        *reinterpret_cast<uint2*>(orow + d) = w;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode self-attention: one wave per (clip, head)
+// ------------------------------------------------------------------------------------------------
+constexpr int SELF_SMAX = 512;
+
+template <int DH>
+__global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __restrict__ q,
+                                                                 const bf16_t* __restrict__ cacheK,
+                                                                 const bf16_t* __restrict__ cacheV,
+                                                                 const int* __restrict__ pos_ptr, int M, int D,
+                                                                 int heads, int Smax, bf16_t* __restrict__ out) {
+  __shared__ float sc[4][SELF_SMAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= M * heads) return;
+  const int b = pair / heads, h = pair - b * heads;
+  const int S = *pos_ptr + 1;
+  const float* qp = q + (long)b * D + h * DH;
+  const bf16_t* kp = cacheK + (long)pair * Smax * DH;
+  const bf16_t* vp = cacheV + (long)pair * Smax * DH;
+  const float c = rsqrtf((float)DH) * kLog2e;
+
+  float qreg[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    float4 t = *reinterpret_cast<const float4*>(qp + d);
+    qreg[d] = t.x; qreg[d + 1] = t.y; qreg[d + 2] = t.z; qreg[d + 3] = t.w;
+  }
+  float mloc = -INFINITY;
+  for (int s = lane; s < S; s += 64) {
+    const bf16_t* kr = kp + (long)s * DH;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      uint2 u = *reinterpret_cast<const uint2*>(kr + d);
+      acc += qreg[d] * bf_lo(u.x) + qreg[d + 1] * bf_hi(u.x) + qreg[d + 2] * bf_lo(u.y) + qreg[d + 3] * bf_hi(u.y);
+    }
+    acc *= c;
+    sc[wave][s] = acc;
+    mloc = fmaxf(mloc, acc);
+  }
+  const float mx = wave_max(mloc);
+  float lsum = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float p = __builtin_amdgcn_exp2f(sc[wave][s] - mx);
+    sc[wave][s] = p;
+    lsum += p;
+  }
+  lsum = wave_sum(lsum);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DH) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += sc[wave][s] * bf16_to_f32(vp[(long)s * DH + lane]);
+    out[(long)b * D + h * DH + lane] = f32_to_bf16(acc / lsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode cross-attention: one wave per (clip, head), K^T / V^T streamed with 16-byte loads
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void dec_cross_attention_kernel(const float* __restrict__ q,
+                                                                  const bf16_t* __restrict__ KT,
+                                                                  const bf16_t* __restrict__ VT,
+                                                                  const ClipMeta* __restrict__ clips, int M, int D,
+                                                                  int heads, bf16_t* __restrict__ out) {
+  __shared__ float red[4][DH][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= M * heads) return;
+  const int b = pair / heads, h = pair - b * heads;
+  const ClipMeta cm = clips[b];
+  const int T = cm.T, Tk = cm.Tk;
+  const float* qp = q + (long)b * D + h * DH;
+  const long off = (long)cm.kv_start * D + (long)(h * DH) * Tk;
+  const bf16_t* kt = KT + off;
+  const bf16_t* vt = VT + off;
+  const float c = rsqrtf((float)DH) * kLog2e;
+
+  float opart[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) opart[d] = 0.f;
+  float m_run = -INFINITY, l_part = 0.f;
+
+  for (int k0 = 0; k0 < Tk; k0 += 512) {
+    const int key = k0 + lane * 8;
+    const bool in = key < Tk;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (in) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        const uint4 u = *reinterpret_cast<const uint4*>(kt + (long)d * Tk + key);
+        const float qd = qp[d];
+        s[0] += qd * bf_lo(u.x); s[1] += qd * bf_hi(u.x);
+        s[2] += qd * bf_lo(u.y); s[3] += qd * bf_hi(u.y);
+        s[4] += qd * bf_lo(u.z); s[5] += qd * bf_hi(u.z);
+        s[6] += qd * bf_lo(u.w); s[7] += qd * bf_hi(u.w);
+      }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] = (in && key + e < T) ? s[e] * c : -INFINITY;
+      mloc = fmaxf(mloc, s[e]);
+    }
+    mloc = wave_max(mloc);
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
+      psum += s[e];
+    }
+    l_part = l_part * alpha + psum;
+    if (in) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        const uint4 u = *reinterpret_cast<const uint4*>(vt + (long)d * Tk + key);
+        const float part = s[0] * bf_lo(u.x) + s[1] * bf_hi(u.x) + s[2] * bf_lo(u.y) + s[3] * bf_hi(u.y) +
+                           s[4] * bf_lo(u.z) + s[5] * bf_hi(u.z) + s[6] * bf_lo(u.w) + s[7] * bf_hi(u.w);
+        opart[d] = opart[d] * alpha + part;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) opart[d] *= alpha;
+    }
+  }
+  const float l = wave_sum(l_part);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) red[wave][d][lane] = opart[d];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DH) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
+    out[(long)b * D + h * DH + lane] = f32_to_bf16(acc / l);
+  }
+}
+
+}  // namespace
+
+void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows, int D, int heads,
+                   hipStream_t s) {
+  const int dh = D / heads;
+  dim3 grid((max_rows + 63) / 64, heads, n_clips);
+  switch (dh) {
+    case 52: hipLaunchKernelGGL(enc_attention_kernel<52>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
+    case 36: hipLaunchKernelGGL(enc_attention_kernel<36>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
+    case 16: hipLaunchKernelGGL(enc_attention_kernel<16>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
+    default: throw std::runtime_error("enc_attention: unsupported head_dim " + std::to_string(dh));
+  }
+}
+
+void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
+                        int heads, int Smax, bf16_t* out, hipStream_t s) {
+  const int dh = D / heads;
+  if (Smax > SELF_SMAX) throw std::runtime_error("dec_self_attention: Smax > 512");
+  dim3 grid((M * heads + 3) / 4);
+  switch (dh) {
+    case 52: hipLaunchKernelGGL(dec_self_attention_kernel<52>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    case 36: hipLaunchKernelGGL(dec_self_attention_kernel<36>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    case 16: hipLaunchKernelGGL(dec_self_attention_kernel<16>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    default: throw std::runtime_error("dec_self_attention: unsupported head_dim " + std::to_string(dh));
+  }
+}
+
+void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
+                         int heads, bf16_t* out, hipStream_t s) {
+  const int dh = D / heads;
+  dim3 grid((M * heads + 3) / 4);
+  switch (dh) {
+    case 52: hipLaunchKernelGGL(dec_cross_attention_kernel<52>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
+    case 36: hipLaunchKernelGGL(dec_cross_attention_kernel<36>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
+    case 16: hipLaunchKernelGGL(dec_cross_attention_kernel<16>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
+    default: throw std::runtime_error("dec_cross_attention: unsupported head_dim " + std::to_string(dh));
+  }
+}
+
+}  // namespace msh

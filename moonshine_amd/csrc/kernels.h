@@ -1,0 +1,102 @@
+// Launch wrappers for the hand-written gfx950 kernels.  Every function enqueues on
+// `stream` and returns immediately; shapes are in elements.
+#pragma once
+
+#include "msh_common.h"
+
+namespace msh {
+
+// RoPE parameters shared by encoder and decoder epilogues
+// (interleaved pairs on the first 2*rot_pairs dims of each head,
+//  transformers modeling_moonshine.py:196-240).
+struct RopeParams {
+  const float* cos;  // [max_pos][rot_pairs]
+  const float* sin;
+  int rot_pairs;
+  int head_dim;
+  int hidden;  // D = heads * head_dim
+};
+
+// ---------------- tiled MFMA GEMM (large M): C = A[M,K](lda) * W[N,K]^T ----------------
+// conv1: out_f32[M,N] = tanh(acc)
+void gemm_tanh_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
+// out_bf16[M,N] = gelu(acc + bias)
+void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
+                         bf16_t* out, hipStream_t s);
+// out_f32[M,N] = gelu(acc + bias)
+void gemm_bias_gelu_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
+                        float* out, hipStream_t s);
+// encoder QKV: out_bf16[M,3D] = rope(acc) (q,k parts), position from row_pos[m] (junk rows: pos<0 -> 0)
+void gemm_qkv_rope_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_pos,
+                        RopeParams rp, bf16_t* out, hipStream_t s);
+// H_f32[M,N] += acc (+ bias if non-null)
+void gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                    hipStream_t s);
+// cross K/V for all decoder layers at once: W = [L*2*D, D]; writes K^T / V^T
+// ([L][clip][D][Tk] bf16, zero for t >= T) -- the layout the decode kernel streams.
+void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
+                   const ClipMeta* clips, int D, long layer_stride, bf16_t* KT, bf16_t* VT, hipStream_t s);
+
+// ---------------- fragment-direct MFMA GEMM (decode, M = batch) ----------------
+// q/k/v for one decoder layer from LN(H): q_f32[M,D] (rope), k (rope) / v appended to the
+// self cache [M][H][Smax][dh] at position *pos_ptr.
+void dec_gemm_qkv(const float* H, const float* gamma, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp,
+                  float* q, bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s);
+// out_f32[M,N] = LN(H) * W^T
+void dec_gemm_ln_f32(const float* H, const float* gamma, const bf16_t* W, int M, int N, int D, float* out,
+                     hipStream_t s);
+// z_bf16[M,F] = silu(gate) * value of (LN(H) * W^T + bias); W/bias rows interleaved (value_j, gate_j)
+void dec_gemm_ln_swiglu(const float* H, const float* gamma, const bf16_t* W, const float* bias, int M, int F, int D,
+                        bf16_t* z, hipStream_t s);
+// H_f32[M,N] += A_bf16[M,K] * W^T (+ bias)
+void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                    hipStream_t s);
+// logits_f32[M,V] = LN(H) * E^T
+void dec_gemm_logits(const float* H, const float* gamma, const bf16_t* E, int M, int V, int D, float* logits,
+                     hipStream_t s);
+
+// ---------------- attention ----------------
+// encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
+void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,
+                   hipStream_t s);
+// decode self-attention: q [M,D] f32, cache [M][H][Smax][dh] bf16, keys 0..*pos_ptr -> out [M,D] bf16
+void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
+                        int heads, int Smax, bf16_t* out, hipStream_t s);
+// decode cross-attention: q [M,D] f32, K^T/V^T of one layer -> out [M,D] bf16
+void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
+                         int heads, bf16_t* out, hipStream_t s);
+
+// ---------------- elementwise / reductions ----------------
+// pack fp32 clips into the bf16 conv1 input stream (clip b at 384*row_start samples)
+void pack_audio(const float* const* clip_ptrs, const ClipMeta* clips, int n_clips, bf16_t* out, long out_elems,
+                hipStream_t s);
+// row_pos[m] = frame index within its clip (or -1 for padding rows), row_clip[m] = clip id
+void build_row_meta(const ClipMeta* clips, int n_clips, int* row_pos, int* row_clip, hipStream_t s);
+// GroupNorm(1 group) statistics per clip over the valid [L1, D] block of x1 (fp32) -> stats[b] = {mean, rstd}
+void groupnorm_stats(const float* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
+                     hipStream_t s);
+// x1n_bf16 = (x1 - mean_b) * rstd_b * gamma[c] + beta[c]
+// (rows6 = 6 * R conv1 rows; row r6 belongs to the clip of stream row r6 / 6)
+void groupnorm_apply(const float* x1, const float2* stats, const int* row_clip, const float* gamma, const float* beta,
+                     long rows6, int D, bf16_t* out, hipStream_t s);
+// y_bf16[r,:] = LayerNorm(x[r,:]) * gamma   (no bias, eps 1e-5); optional fp32 copy
+void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t* y, float* y_f32, hipStream_t s);
+// decode bookkeeping after the logits of one step: first-max argmax per row, EOS / budget
+// masks, token append, next-input embedding, position advance.
+struct DecodeState {
+  int32_t* tokens;      // [M][stride]; tokens[b][0] = BOS
+  int32_t* counts;      // [M] number of tokens written (incl. BOS)
+  int32_t* finished;    // [M]
+  int32_t* pos;         // [1] current decode position (= number of steps done)
+  int32_t* n_active;    // [1] clips still decoding
+  const int32_t* forced;  // nullable [M][stride]: teacher-forced inputs for step i+1 at [b][i+1]
+  int32_t stride;
+  int32_t eos;
+  int32_t ignore_eos;
+};
+void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, DecodeState st, const float* embed_f32,
+                    int D, float* H, hipStream_t s);
+// H[b,:] = embed[BOS]; counters reset
+void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D, float* H, hipStream_t s);
+
+}  // namespace msh

@@ -1,0 +1,72 @@
+// Shared declarations for the MI355X Moonshine engine (device side).
+// gfx950 only: 64-wide wavefronts, bf16 MFMA 16x16x32, fp32 accumulate.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace msh {
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define MSH_HIP(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      throw ::msh::HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + \
+                            __FILE__ + ":" + std::to_string(__LINE__) + ")");               \
+    }                                                                                        \
+  } while (0)
+
+// ---- bf16 <-> fp32 (round-to-nearest-even), usable on host and device ----
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.f = f;
+  if ((v.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((v.u >> 16) | 0x40);  // quiet NaN
+  uint32_t lsb = (v.u >> 16) & 1u;
+  v.u += 0x7fffu + lsb;
+  return (bf16_t)(v.u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.u = ((uint32_t)h) << 16;
+  return v.f;
+}
+
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- per-batch clip geometry, shared by host planner and kernels ----
+// Rows of the packed encoder stream: clip b owns rows [row_start, row_start + rows)
+// of every [*, D] activation; conv2 output rows are 2x, conv1 output rows 6x that
+// (so the strided conv-as-GEMM views have one uniform row stride over the batch).
+struct ClipMeta {
+  int32_t row_start;  // first row in the [R, D] stream
+  int32_t rows;       // R_b (multiple of 4): padded frame count
+  int32_t T;          // valid encoder frames (conv3 length)
+  int32_t L1;         // valid conv1 frames
+  int32_t L2;         // valid conv2 frames
+  int32_t n_samples;  // audio samples fed to the model
+  int32_t kv_start;   // offset (in keys) of this clip in the cross K^T/V^T buffers
+  int32_t Tk;         // padded key count (multiple of 8) of the cross K^T/V^T rows
+  int32_t max_len;    // decode step budget: ceil(n/16000 * max_tokens_per_second)
+  int32_t pad_;
+};
+
+}  // namespace msh

@@ -10,28 +10,11 @@ import math
 
 import numpy as np
 
-SPACE = "▁".encode("utf-8")  # sentencepiece word-boundary marker
+SPACE = "\u2581".encode("utf-8")  # sentencepiece word-boundary marker
 
 
 # --- tokenizer.bin ---------------------------------------------------------
-def encode_tokenizer_bin(tokens: list[bytes]) -> bytes:
-    """Length-prefixed byte strings.  reference core/bin-tokenizer/bin-tokenizer.cpp:46-66
-    (reader) and scripts/convert_tokenizer.py:29-48 (writer): length < 128 is one
-    byte; otherwise first = (len % 128) + 128, second = len // 128; a zero byte is
-    an empty entry."""
-    out = bytearray()
-    for t in tokens:
-        n = len(t)
-        if n == 0:
-            out.append(0)
-        elif n < 128:
-            out.append(n)
-        else:
-            assert n < 128 * 256
-            out.append((n % 128) + 128)
-            out.append(n // 128)
-        out += t
-    return bytes(out)
+from moonshine_amd.synth import encode_tokenizer_bin, synthetic_vocab, write_synthetic_tokenizer  # noqa: E402,F401
 
 
 def decode_tokenizer_bin(blob: bytes) -> list[bytes]:
@@ -56,43 +39,6 @@ def decode_tokenizer_bin(blob: bytes) -> list[bytes]:
         i += n
     if not toks:
         raise ValueError("no tokens")
-    return toks
-
-
-def synthetic_vocab(vocab: int) -> list[bytes]:
-    """ids 0,1,2 = <unk>,<s>,</s>; then 256 byte fallbacks ``<0xNN>``; then word
-    pieces (layout of the shipped vocabularies,
-    reference core/bin-tokenizer/bin-tokenizer-test.cpp:12-25).  Pieces are
-    deterministic: every 3rd one starts a new word; a few are long (>127 bytes)
-    or carry multi-byte / deliberately broken UTF-8 to exercise the 2-byte
-    length prefix and sanitize_text."""
-    toks = [b"<unk>", b"<s>", b"</s>"]
-    toks += [("<0x%02X>" % b).encode() for b in range(256)]
-    letters = b"abcdefghijklmnopqrstuvwxyz"
-    i = 0
-    while len(toks) < vocab:
-        k = len(toks)
-        n = 1 + (k * 7) % 5
-        body = bytes(letters[(k * 31 + j * 17) % 26] for j in range(n))
-        if k % 3 == 0:
-            body = SPACE + body
-        if k % 997 == 0:
-            body = body * 40                      # > 127 bytes: 2-byte length prefix
-        elif k % 1013 == 0:
-            body = "é中".encode("utf-8") + body  # valid multi-byte
-        elif k % 1021 == 0:
-            body = b"\xe4\xb8" + body             # truncated 3-byte sequence
-        elif k % 1031 == 0:
-            body = b"\x9f" + body                 # stray continuation byte
-        toks.append(body)
-        i += 1
-    return toks[:vocab]
-
-
-def write_synthetic_tokenizer(path: str, vocab: int) -> list[bytes]:
-    toks = synthetic_vocab(vocab)
-    with open(path, "wb") as f:
-        f.write(encode_tokenizer_bin(toks))
     return toks
 
 

@@ -1,193 +1,12 @@
-"""Synthetic Moonshine weights (HF tensor names) + a minimal safetensors reader/writer.
-
-TEST INFRASTRUCTURE (see oracle/__init__.py).
-
-The reference's shipped weights are int8 ``.ort`` flatbuffers fetched from a CDN
-(reference ``core/moonshine-model-catalog.cpp:86-113``) and the float
-checkpoints live on the HuggingFace hub; neither is on disk and there is no
-network.  Tests and benchmarks therefore run on deterministic synthetic weights
-that use the HuggingFace state_dict names and shapes
-(``transformers/models/moonshine/modeling_moonshine.py:520-540, 265-274, 74-75,
-89-90, 836-850``) so a real ``UsefulSensors/moonshine-base`` checkpoint drops in
-unchanged.
-
-Weight distribution "fanin-v1": matrices ~ N(0, gain/sqrt(fan_in)) so that
-activations, attention scores and logits are O(1) (a 0.02-std init makes every
-softmax nearly uniform and hides masking / scaling bugs); biases ~ N(0, 0.1);
-norm scales ~ 1 + 0.1 N(0,1).  Every tensor has its own PCG64 stream keyed by
-(seed, tensor index), so generation is order-independent and reproducible on
-any machine.
-"""
-from __future__ import annotations
-
-import json
-import struct
-from dataclasses import dataclass
-
-import numpy as np
-
-
-@dataclass(frozen=True)
-class ArchConfig:
-    """Dimensions of a non-streaming Moonshine model.
-
-    base / tiny follow reference ``core/moonshine-model.cpp:41-54`` and
-    ``configuration_moonshine.py:80-112``; ``micro`` is a test-only shrink.
-    """
-
-    name: str
-    hidden: int          # D
-    ffn: int             # F (encoder fc1 out; decoder fc1 out is 2F)
-    enc_layers: int
-    dec_layers: int
-    heads: int
-    vocab: int = 32768
-    bos: int = 1         # reference core/moonshine-model.cpp:56
-    eos: int = 2         # reference core/moonshine-model.cpp:57
-    rope_theta: float = 10000.0
-    partial_rotary: float = 0.9
-
-    @property
-    def head_dim(self) -> int:
-        return self.hidden // self.heads
-
-    @property
-    def rotary_dim(self) -> int:
-        # modeling_moonshine.py:132-134  dim = int(head_dim * partial_rotary_factor)
-        return int(self.head_dim * self.partial_rotary)
-
-
-ARCHS = {
-    "tiny": ArchConfig("tiny", 288, 1152, 6, 6, 8),
-    "base": ArchConfig("base", 416, 1664, 8, 8, 8),
-    # test-only: small enough that the pure-numpy oracle runs in milliseconds
-    "micro": ArchConfig("micro", 64, 256, 2, 2, 4, vocab=512),
-}
-
-
-def tensor_specs(cfg: ArchConfig):
-    """(name, shape, kind, fan_in) in HF state_dict order. kind in
-    {matrix, bias, scale, conv1}."""
-    D, F, V = cfg.hidden, cfg.ffn, cfg.vocab
-    specs = [
-        ("model.encoder.conv1.weight", (D, 1, 127), "conv1", 127),
-        ("model.encoder.conv2.weight", (2 * D, D, 7), "matrix", 7 * D),
-        ("model.encoder.conv2.bias", (2 * D,), "bias", 0),
-        ("model.encoder.conv3.weight", (D, 2 * D, 3), "matrix", 6 * D),
-        ("model.encoder.conv3.bias", (D,), "bias", 0),
-        ("model.encoder.groupnorm.weight", (D,), "scale", 0),
-        ("model.encoder.groupnorm.bias", (D,), "bias", 0),
-    ]
-    for l in range(cfg.enc_layers):
-        p = f"model.encoder.layers.{l}."
-        for n in ("q", "k", "v", "o"):
-            specs.append((p + f"self_attn.{n}_proj.weight", (D, D), "matrix", D))
-        specs += [
-            (p + "mlp.fc1.weight", (F, D), "matrix", D),
-            (p + "mlp.fc1.bias", (F,), "bias", 0),
-            (p + "mlp.fc2.weight", (D, F), "matrix", F),
-            (p + "mlp.fc2.bias", (D,), "bias", 0),
-            (p + "input_layernorm.weight", (D,), "scale", 0),
-            (p + "post_attention_layernorm.weight", (D,), "scale", 0),
-        ]
-    specs.append(("model.encoder.layer_norm.weight", (D,), "scale", 0))
-    specs.append(("model.decoder.embed_tokens.weight", (V, D), "matrix", D))
-    for l in range(cfg.dec_layers):
-        p = f"model.decoder.layers.{l}."
-        for a in ("self_attn", "encoder_attn"):
-            for n in ("q", "k", "v", "o"):
-                specs.append((p + f"{a}.{n}_proj.weight", (D, D), "matrix", D))
-        specs += [
-            (p + "mlp.fc1.weight", (2 * F, D), "matrix", D),
-            (p + "mlp.fc1.bias", (2 * F,), "bias", 0),
-            (p + "mlp.fc2.weight", (D, F), "matrix", F),
-            (p + "mlp.fc2.bias", (D,), "bias", 0),
-            (p + "input_layernorm.weight", (D,), "scale", 0),
-            (p + "post_attention_layernorm.weight", (D,), "scale", 0),
-            (p + "final_layernorm.weight", (D,), "scale", 0),
-        ]
-    specs.append(("model.decoder.norm.weight", (D,), "scale", 0))
-    return specs
-
-
-def make_weights(cfg: ArchConfig, seed: int = 0) -> dict[str, np.ndarray]:
-    """Deterministic synthetic fp32 weights, HF names. ``proj_out.weight`` is
-    tied to the embedding (configuration_moonshine.py:103) and is not stored."""
-    out: dict[str, np.ndarray] = {}
-    for idx, (name, shape, kind, fan_in) in enumerate(tensor_specs(cfg)):
-        rng = np.random.Generator(np.random.PCG64([seed, idx]))
-        x = rng.standard_normal(shape, dtype=np.float32)
-        if kind == "matrix":
-            x *= np.float32(1.0 / np.sqrt(fan_in))
-        elif kind == "conv1":
-            x *= np.float32(3.0 / np.sqrt(fan_in))
-        elif kind == "bias":
-            x *= np.float32(0.1)
-        elif kind == "scale":
-            x = np.float32(1.0) + np.float32(0.1) * x
-        out[name] = np.ascontiguousarray(x, dtype=np.float32)
-    return out
-
-
-def make_audio(index: int, n_samples: int = 160000) -> np.ndarray:
-    """Synthetic clip ``index``: white noise sigma 0.1 clipped to [-1, 1]
-    (BASELINE.md section 3 / SURVEY.md section 8d)."""
-    x = np.random.default_rng(1234 + index).standard_normal(n_samples).astype(np.float32) * np.float32(0.1)
-    return np.clip(x, -1.0, 1.0).astype(np.float32)
-
-
-# ---------------------------------------------------------------------------
-# safetensors (https://github.com/huggingface/safetensors format v0.x):
-#   u64 little-endian header length | JSON header | raw little-endian tensor bytes
-# ---------------------------------------------------------------------------
-_DT = {"F32": np.float32, "F16": np.float16, "I64": np.int64, "I32": np.int32}
-
-
-def save_safetensors(path: str, tensors: dict[str, np.ndarray], metadata: dict[str, str] | None = None) -> None:
-    header: dict = {}
-    if metadata:
-        header["__metadata__"] = {str(k): str(v) for k, v in metadata.items()}
-    off = 0
-    for name, arr in tensors.items():
-        assert arr.dtype == np.float32, name
-        nbytes = arr.size * 4
-        header[name] = {"dtype": "F32", "shape": list(arr.shape), "data_offsets": [off, off + nbytes]}
-        off += nbytes
-    hj = json.dumps(header, separators=(",", ":")).encode()
-    hj += b" " * ((8 - len(hj) % 8) % 8)
-    with open(path, "wb") as f:
-        f.write(struct.pack("<Q", len(hj)))
-        f.write(hj)
-        for arr in tensors.values():
-            f.write(np.ascontiguousarray(arr).tobytes())
-
-
-def load_safetensors(path: str) -> tuple[dict[str, np.ndarray], dict[str, str]]:
-    with open(path, "rb") as f:
-        (n,) = struct.unpack("<Q", f.read(8))
-        header = json.loads(f.read(n))
-        blob = f.read()
-    meta = header.pop("__metadata__", {})
-    out = {}
-    for name, info in header.items():
-        s, e = info["data_offsets"]
-        out[name] = np.frombuffer(blob[s:e], dtype=_DT[info["dtype"]]).reshape(info["shape"]).copy()
-    return out, meta
-
-
-def write_model_dir(path: str, cfg: ArchConfig, seed: int = 0, weights: dict[str, np.ndarray] | None = None) -> dict[str, np.ndarray]:
-    """Write ``model.safetensors`` + ``tokenizer.bin`` -- the model directory
-    contract of the MI355X engine."""
-    import os
-
-    from .host_ref import write_synthetic_tokenizer
-
-    os.makedirs(path, exist_ok=True)
-    w = weights if weights is not None else make_weights(cfg, seed)
-    save_safetensors(
-        os.path.join(path, "model.safetensors"),
-        w,
-        {"arch": cfg.name, "format": "moonshine-hf-f32", "seed": str(seed)},
-    )
-    write_synthetic_tokenizer(os.path.join(path, "tokenizer.bin"), cfg.vocab)
-    return w
+"""Re-export of the synthetic data generators (they hold no model arithmetic and live in the
+package so that bench.py's GPU leg does not import oracle/).  TEST INFRASTRUCTURE."""
+from moonshine_amd.synth import (  # noqa: F401
+    ARCHS,
+    ArchConfig,
+    load_safetensors,
+    make_audio,
+    make_weights,
+    save_safetensors,
+    tensor_specs,
+    write_model_dir,
+)

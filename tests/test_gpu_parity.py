@@ -1,0 +1,251 @@
+"""GPU parity: the HIP path (through the C ABI of include/moonshine_hip.h) against the CPU oracle
+and the committed HF golden vectors.  Run on the MI355X box with `pytest -m gpu`.
+
+Stated tolerances (bf16 GEMM operands, fp32 accumulate / softmax / norms):
+  encoder last_hidden_state : rel-RMS <= 1e-2, max-abs <= 6e-2   (values are O(1) after the final LN)
+  logits                    : max-abs <= 5e-2 over the compared entries
+  greedy ids                : identical wherever the oracle's top-1 margin exceeds 0.1
+Integer / control behaviour (EOS stop, step budget, token lists, batch independence) is bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import moonshine_ref as ref
+from oracle.host_ref import max_decode_len
+from oracle.weights import ARCHS, make_audio, make_weights, save_safetensors
+
+pytestmark = pytest.mark.gpu
+
+ENC_RELRMS = 1e-2
+ENC_MAXABS = 6e-2
+LOGIT_MAXABS = 5e-2
+MARGIN = 0.1
+
+
+def _engine(tmp_path_factory, arch, seed=0, weights=None):
+    from moonshine_amd.hip_api import Engine
+
+    cfg = ARCHS[arch]
+    w = weights if weights is not None else make_weights(cfg, seed)
+    d = tmp_path_factory.mktemp(f"w_{arch}_{seed}")
+    path = os.path.join(d, "model.safetensors")
+    save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
+    e = Engine(0)
+    e.load_weights_file(path)
+    os.remove(path)
+    return e, w, cfg
+
+
+@pytest.fixture(scope="module")
+def micro(tmp_path_factory):
+    return _engine(tmp_path_factory, "micro", 0)
+
+
+@pytest.fixture(scope="module")
+def base(tmp_path_factory):
+    return _engine(tmp_path_factory, "base", 0)
+
+
+def _enc_check(got, want):
+    err = got - want
+    relrms = float(np.sqrt((err**2).mean()) / np.sqrt((want**2).mean()))
+    maxabs = float(np.abs(err).max())
+    assert relrms <= ENC_RELRMS, (relrms, maxabs)
+    assert maxabs <= ENC_MAXABS, (relrms, maxabs)
+    return relrms, maxabs
+
+
+def test_model_info(micro, base):
+    e, _, cfg = base
+    mi = e.info()
+    assert (mi.hidden, mi.ffn, mi.enc_layers, mi.dec_layers, mi.heads, mi.head_dim, mi.vocab) == (416, 1664, 8, 8, 8, 52, 32768)
+    assert (mi.bos, mi.eos) == (1, 2)
+    assert micro[0].info().head_dim == 16
+
+
+def test_micro_encoder_ragged_batch(micro):
+    e, w, cfg = micro
+    lens = [16000, 23789, 9000, 895, 40000]
+    clips = [make_audio(10 + i, n) for i, n in enumerate(lens)]
+    e.set_keep_encoder_output(True)
+    e.encode(clips)
+    outs = []
+    for i, c in enumerate(clips):
+        got = e.encoder_output(i)
+        want = ref.encoder_forward(w, cfg, c)
+        assert got.shape == want.shape == (ref.conv_out_lengths(lens[i])[2], cfg.hidden)
+        _enc_check(got, want)
+        outs.append(got)
+    # batch independence: a clip encoded alone gives bit-identical frames
+    for i in (1, 3):
+        e.encode([clips[i]])
+        np.testing.assert_array_equal(e.encoder_output(0), outs[i])
+
+
+def test_micro_too_short_clip_is_an_error(micro):
+    from moonshine_amd.hip_api import MshError
+
+    e, _, _ = micro
+    with pytest.raises(MshError) as ei:
+        e.encode([np.zeros(600, np.float32)])
+    assert ei.value.code == -3
+
+
+def _teacher_logit_check(e, w, cfg, clips, steps):
+    """Teacher-force the oracle's own greedy ids through the GPU decoder; compare logits + argmax."""
+    encs = [ref.encoder_forward(w, cfg, c) for c in clips]
+    gold = []
+    gold_logits = []
+    for enc in encs:
+        toks, lg = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, return_logits=True)
+        gold.append(toks)
+        gold_logits.append(lg)
+    teacher = np.asarray(gold, np.int32)
+    e.encode(clips)
+    toks, logits = e.decode(forced_steps=steps, teacher=teacher, want_logits=steps)
+    flips = 0
+    worst = 0.0
+    for b in range(len(clips)):
+        for i in range(steps):
+            g = gold_logits[b][i]
+            d = float(np.abs(logits[i, b] - g).max())
+            worst = max(worst, d)
+            top2 = np.partition(g, -2)[-2:]
+            margin = float(top2[1] - top2[0])
+            if margin > MARGIN:
+                assert toks[b][i + 1] == gold[b][i + 1], (b, i, margin)
+            elif toks[b][i + 1] != gold[b][i + 1]:
+                flips += 1
+    assert worst <= LOGIT_MAXABS, worst
+    return worst, flips
+
+
+def test_micro_decode_logits_teacher_forced(micro):
+    e, w, cfg = micro
+    clips = [make_audio(20 + i, n) for i, n in enumerate([16000, 30000, 12345])]
+    _teacher_logit_check(e, w, cfg, clips, 12)
+
+
+def test_micro_greedy_free_running(micro):
+    e, w, cfg = micro
+    clips = [make_audio(30 + i, 16000 + 1000 * i) for i in range(6)]
+    got = e.transcribe_tokens(clips, forced_steps=7)
+    for c, g in zip(clips, got):
+        enc = ref.encoder_forward(w, cfg, c)
+        toks, lg = ref.greedy_decode(w, cfg, enc, 7, ignore_eos=True, return_logits=True)
+        # compare up to the first step whose oracle margin is within the stated tolerance
+        for i in range(7):
+            top2 = np.partition(lg[i], -2)[-2:]
+            if top2[1] - top2[0] <= MARGIN:
+                break
+            assert g[i + 1] == toks[i + 1]
+        assert g[0] == cfg.bos and len(g) == 8
+
+
+def eos_test_weights():
+    """micro weights whose greedy sequences hit EOS mid-sequence for some clips and run to the step
+    budget for others, with clear (> 0.15) oracle margins on 5 of the 8 clips (found by a CPU search
+    with the oracle): seed 39, tied embedding x2, vocabulary rows 412 <-> EOS swapped."""
+    cfg = ARCHS["micro"]
+    w = dict(make_weights(cfg, 39))
+    E = w["model.decoder.embed_tokens.weight"] * np.float32(2.0)
+    E[[412, cfg.eos]] = E[[cfg.eos, 412]]
+    w["model.decoder.embed_tokens.weight"] = np.ascontiguousarray(E)
+    lens = [16000, 48000, 20000, 32000, 9000, 64000, 24000, 40000]
+    clips = [make_audio(40 + i, n) for i, n in enumerate(lens)]
+    return cfg, w, lens, clips
+
+
+def test_micro_eos_and_budget_semantics(tmp_path_factory):
+    """EOS stop / per-clip step budget (reference core/moonshine-model.cpp:347-349, 380-517): token lists
+    must equal the oracle loop exactly, including where each clip stops."""
+    cfg, w, lens, clips = eos_test_weights()
+    e, w, cfg = _engine(tmp_path_factory, "micro", 39, w)
+    got = e.transcribe_tokens(clips)  # reference semantics: EOS + budget
+    n_mid_eos = n_budget = compared = 0
+    for c, g, n in zip(clips, got, lens):
+        enc = ref.encoder_forward(w, cfg, c)
+        budget = max_decode_len(n)
+        toks, lg = ref.greedy_decode(w, cfg, enc, budget, return_logits=True)
+        margins = [float(np.diff(np.partition(l, -2)[-2:])[0]) for l in lg]
+        assert len(g) <= budget + 1
+        if min(margins) > MARGIN:  # unambiguous clip: must match exactly, including where it stops
+            assert g == toks, (n, g, toks)
+            compared += 1
+            n_mid_eos += int(toks[-1] == cfg.eos and len(toks) > 2)
+            n_budget += int(toks[-1] != cfg.eos and len(toks) == budget + 1)
+        else:
+            k = next(i for i, m in enumerate(margins) if m <= MARGIN)
+            assert g[: k + 1] == toks[: k + 1]
+    assert compared >= 4 and n_mid_eos >= 1 and n_budget >= 1, (compared, n_mid_eos, n_budget)
+
+
+@pytest.mark.parametrize("case", ["base_10s", "base_vadtrunc"])
+def test_base_against_hf_golden(base, case, golden_dir):
+    e, w, cfg = base
+    g = np.load(os.path.join(golden_dir, f"golden_{case}.npz"))
+    audio = make_audio(int(g["clip"]), int(g["n_samples"]))
+    e.set_keep_encoder_output(True)
+    e.encode([audio])
+    enc = e.encoder_output(0)
+    rows = g["enc_rows"]
+    _enc_check(enc[rows], g["enc"])
+    gold = g["tokens"].astype(np.int32)
+    steps = len(gold) - 1
+    toks, logits = e.decode(forced_steps=steps, teacher=gold[None, :], want_logits=steps)
+    for i in range(steps):
+        idx, val = g["logit_idx"][i], g["logit_val"][i]
+        assert float(np.abs(logits[i, 0][idx] - val).max()) <= LOGIT_MAXABS
+        if val[0] - val[1] > MARGIN:
+            assert toks[0][i + 1] == gold[i + 1]
+
+
+def test_tiny_against_hf_golden(tmp_path_factory, golden_dir):
+    e, w, cfg = _engine(tmp_path_factory, "tiny", 0)
+    g = np.load(os.path.join(golden_dir, "golden_tiny_2s.npz"))
+    audio = make_audio(int(g["clip"]), int(g["n_samples"]))
+    e.set_keep_encoder_output(True)
+    e.encode([audio])
+    _enc_check(e.encoder_output(0)[g["enc_rows"]], g["enc"])
+    gold = g["tokens"].astype(np.int32)
+    steps = len(gold) - 1
+    toks, logits = e.decode(forced_steps=steps, teacher=gold[None, :], want_logits=steps)
+    for i in range(steps):
+        assert float(np.abs(logits[i, 0][g["logit_idx"][i]] - g["logit_val"][i]).max()) <= LOGIT_MAXABS
+
+
+def test_base_ragged_batch_vs_oracle(base):
+    e, w, cfg = base
+    lens = [160000, 48000, 159744, 100000]
+    clips = [make_audio(50 + i, n) for i, n in enumerate(lens)]
+    e.set_keep_encoder_output(True)
+    e.encode(clips)
+    for i in (1, 3):
+        _enc_check(e.encoder_output(i), ref.encoder_forward(w, cfg, clips[i]))
+    _teacher_logit_check(e, w, cfg, [clips[1]], 8)
+
+
+def test_base_full_size_batch_properties(base):
+    """Size-independent properties at a benchmark-sized batch (32 x 10 s, 65 forced steps):
+    run-to-run determinism, permutation invariance, and batch == single-clip ids."""
+    e, w, cfg = base
+    n = 32
+    clips = [make_audio(100 + i, 160000) for i in range(n)]
+    a = e.transcribe_tokens(clips, forced_steps=65)
+    b = e.transcribe_tokens(clips, forced_steps=65)
+    assert a == b
+    assert all(len(t) == 66 and t[0] == cfg.bos for t in a)
+    perm = np.random.default_rng(0).permutation(n)
+    c = e.transcribe_tokens([clips[j] for j in perm], forced_steps=65)
+    for k, j in enumerate(perm):
+        assert c[k] == a[j]
+    single = e.transcribe_tokens([clips[5]], forced_steps=65)
+    assert single[0] == a[5]
+    # reference semantics on the same batch: every list is a prefix-compatible, EOS-terminated or
+    # budget-limited version of the forced run
+    d = e.transcribe_tokens(clips)
+    for t_forced, t_ref in zip(a, d):
+        assert t_ref == t_forced[: len(t_ref)]
+        assert len(t_ref) == 66 or t_ref[-1] == cfg.eos
