@@ -55,7 +55,9 @@ def roofline_entry(p):
     bytes_per = p["bytes"] / max(p["launches"], 1)
     intensity = flops_per / bytes_per if bytes_per > 0 else float("inf")
     ridge = PEAK_TFLOPS_BF16 * 1e12 / (PEAK_HBM_GBS * 1e9)
-    if flops_per > 0 and intensity >= ridge:
+    # the LDS-tiled GEMMs / attention are matrix-core work by construction; everything else is a stream
+    mfma_kernel = p["name"].startswith(("conv", "enc_")) and p["name"].endswith(("_gemm", "attention")) or p["name"] == "cross_kv_gemm"
+    if flops_per > 0 and (mfma_kernel or intensity >= ridge):
         ach = flops_per / (ms_per * 1e-3) / 1e12
         return {"kernel": p["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS_BF16, 4), "traffic": None, "ms_per_launch": round(ms_per, 5),

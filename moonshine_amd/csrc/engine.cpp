@@ -39,12 +39,15 @@ Engine::Engine(int device) : device_(device) {
   MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   const char* ng = getenv("MSH_NO_GRAPH");
   if (ng != nullptr && ng[0] == '1') use_graph_ = false;
+  const char* dg = getenv("MSH_DEC_GROUPS");
+  if (dg != nullptr) dec_groups_ = atoi(dg);
 }
 
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  if (step_graph_) (void)hipGraphExecDestroy(step_graph_);
+  groups_.clear();
+  if (enc_done_) (void)hipEventDestroy(enc_done_);
   for (hipEvent_t ev : event_pool_) (void)hipEventDestroy(ev);
   for (auto& r : prof_pending_) {
     (void)hipEventDestroy(r.a);
@@ -52,8 +55,7 @@ Engine::~Engine() {
   }
   for (void* p : weight_allocs_) (void)hipFree(p);
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x1n_, &x2_, &H_,
-                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &KT_, &VT_, &dH_, &dq_, &dao_, &dz_,
-                    &logits_, &cacheK_, &cacheV_, &tokens_, &counts_, &finished_, &scalars_, &teacher_};
+                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &KT_, &VT_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -494,26 +496,52 @@ void Engine::get_encoder_output(uint32_t clip, float* out) {
 
 // ------------------------------------------------------------------------------------------------
 // Decode
+//
+// The batch is decoded in lock-step, split into `groups` contiguous sub-batches that run on their own
+// HIP streams: a decode step is a chain of short, latency-bound kernels (fused LN+GEMMs, self-attention)
+// around one HBM-bound stream (cross-attention over K^T/V^T); with two or more independent chains in
+// flight the short kernels of one group fill the CUs while another group streams its cross K/V.
+// Each group's step (8 kernels per layer + LM head + bookkeeping) is captured once into a hipGraph and
+// replayed: everything step-dependent (position, ids, masks) lives in device memory.
 // ------------------------------------------------------------------------------------------------
-void Engine::decode_step_enqueue(int M) {
+struct Engine::DecodeGroup {
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int first = 0, M = 0;
+  DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher;
+  hipGraphExec_t graph = nullptr;
+  std::string key;
+  uint64_t gen = 0;
+  int32_t n_active_h = 0;
+  ~DecodeGroup() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+    DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher};
+    for (DevBuf* b : bufs) b->release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+void Engine::destroy_groups() { groups_.clear(); }
+
+void Engine::decode_step_enqueue(DecodeGroup& g) {
   const int D = cfg_.hidden, F = cfg_.ffn, Hh = cfg_.heads, V = cfg_.vocab, dh = cfg_.head_dim();
-  hipStream_t s = stream_;
+  const int M = g.M;
+  hipStream_t s = g.stream;
   RopeParams rp{rope_cos_, rope_sin_, cfg_.rot_pairs(), dh, D};
-  int32_t* sc = scalars_.as<int32_t>();
-  int32_t* pos = sc;  // [0] = pos, [1] = n_active
-  float* dH = dH_.as<float>();
-  float* dq = dq_.as<float>();
-  bf16_t* dao = dao_.as<bf16_t>();
-  bf16_t* dz = dz_.as<bf16_t>();
-  const ClipMeta* clips = clips_d_.as<ClipMeta>();
+  int32_t* pos = g.scalars.as<int32_t>();  // [0] = pos, [1] = n_active
+  float* dH = g.dH.as<float>();
+  float* dq = g.dq.as<float>();
+  bf16_t* dao = g.dao.as<bf16_t>();
+  bf16_t* dz = g.dz.as<bf16_t>();
+  const ClipMeta* clips = clips_d_.as<ClipMeta>() + g.first;
   const size_t cache_layer = (size_t)M * Hh * Smax_ * dh;
   double sT = 0;
-  for (const ClipMeta& c : clips_h_) sT += c.T;
+  for (int b = 0; b < M; ++b) sT += clips_h_[g.first + b].T;
   const double w_dd = 2.0 * D * D;  // bytes of a [D, D] bf16 weight
   for (int l = 0; l < cfg_.dec_layers; ++l) {
     const DecLayerW& W = dec_[l];
-    bf16_t* cK = cacheK_.as<bf16_t>() + l * cache_layer;
-    bf16_t* cV = cacheV_.as<bf16_t>() + l * cache_layer;
+    bf16_t* cK = g.cacheK.as<bf16_t>() + l * cache_layer;
+    bf16_t* cV = g.cacheV.as<bf16_t>() + l * cache_layer;
     {
       ProfScope p(this, "dec_qkv_gemm", 2.0 * M * D * 3 * D, 3 * w_dd + M * D * 4.0 * 2);
       dec_gemm_qkv(dH, W.ln1, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
@@ -548,9 +576,16 @@ void Engine::decode_step_enqueue(int M) {
       dec_gemm_resid(dz, F, W.fc2, W.b2, M, D, F, dH, s);
     }
   }
-  {
+  if (M >= 128) {  // batch large enough for the LDS-tiled MFMA kernel: final LN once, then [M,D] x [V,D]^T
+    {
+      ProfScope p(this, "dec_final_layernorm", 0, M * D * 6.0);
+      layernorm_bf16(dH, dec_ln_, M, D, g.dy.as<bf16_t>(), nullptr, s);
+    }
     ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
-    dec_gemm_logits(dH, dec_ln_, embed_bf16_, M, V, D, logits_.as<float>(), s);
+    gemm_logits_f32(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.logits.as<float>(), s);
+  } else {
+    ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
+    dec_gemm_logits(dH, dec_ln_, embed_bf16_, M, V, D, g.logits.as<float>(), s);
   }
 }
 
@@ -558,7 +593,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
                    int max_logit_steps, int32_t* tokens_out, int32_t* counts_out, int tokens_stride) {
   MSH_HIP(hipSetDevice(device_));
   if (!encoded_) throw std::runtime_error("decode() called before encode()");
-  const int M = (int)n_clips_, D = cfg_.hidden, F = cfg_.ffn, V = cfg_.vocab, Hh = cfg_.heads, dh = cfg_.head_dim();
+  const int Mtot = (int)n_clips_, D = cfg_.hidden, F = cfg_.ffn, V = cfg_.vocab, Hh = cfg_.heads, dh = cfg_.head_dim();
   const bool forced = forced_steps >= 0;
   const int steps = forced ? forced_steps : max_steps_;
   if (steps < 1) throw std::invalid_argument("decode: need at least one step");
@@ -570,108 +605,149 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
   if (teacher != nullptr && teacher_stride < 1) throw std::invalid_argument("decode: bad teacher stride");
   Smax_ = round_up(steps, 8);
 
-  bool moved = false;
-  moved |= dH_.reserve((size_t)M * D * sizeof(float));
-  moved |= dq_.reserve((size_t)M * D * sizeof(float));
-  moved |= dao_.reserve((size_t)M * D * sizeof(bf16_t));
-  moved |= dz_.reserve((size_t)M * F * sizeof(bf16_t));
-  moved |= logits_.reserve((size_t)M * V * sizeof(float));
-  moved |= cacheK_.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
-  moved |= cacheV_.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
-  moved |= tokens_.reserve((size_t)M * stride * sizeof(int32_t));
-  moved |= counts_.reserve((size_t)M * sizeof(int32_t));
-  moved |= finished_.reserve((size_t)M * sizeof(int32_t));
-  moved |= scalars_.reserve(16 * sizeof(int32_t));
-  if (teacher) moved |= teacher_.reserve((size_t)M * stride * sizeof(int32_t));
-  if (moved) ++ws_gen_;
+  // ---- groups ----
+  const bool eager = prof_on_ || logits_out != nullptr || !use_graph_;
+  int ngroups = 1;
+  if (!eager) {
+    ngroups = dec_groups_ > 0 ? dec_groups_ : (Mtot >= 192 ? 4 : (Mtot >= 64 ? 2 : 1));
+    if (ngroups > Mtot) ngroups = Mtot;
+  }
+  while ((int)groups_.size() < ngroups) {
+    std::unique_ptr<DecodeGroup> g(new DecodeGroup());
+    if (groups_.empty()) {
+      g->stream = stream_;
+    } else {
+      MSH_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+      g->own_stream = true;
+    }
+    groups_.push_back(std::move(g));
+  }
+  if (enc_done_ == nullptr) MSH_HIP(hipEventCreateWithFlags(&enc_done_, hipEventDisableTiming));
 
-  if (forced) {  // fixed step count, EOS ignored (benchmark / parity mode)
+  {  // clip metadata: the step budget is what decode_advance reads
     std::vector<ClipMeta> tmp = clips_h_;
-    for (ClipMeta& c : tmp) c.max_len = steps;
+    if (forced)
+      for (ClipMeta& c : tmp) c.max_len = steps;  // fixed step count, EOS ignored (benchmark / parity mode)
     MSH_HIP(hipMemcpyAsync(clips_d_.p, tmp.data(), tmp.size() * sizeof(ClipMeta), hipMemcpyHostToDevice, stream_));
     MSH_HIP(hipStreamSynchronize(stream_));
-  } else {
-    MSH_HIP(hipMemcpyAsync(clips_d_.p, clips_h_.data(), clips_h_.size() * sizeof(ClipMeta), hipMemcpyHostToDevice,
-                           stream_));
-    MSH_HIP(hipStreamSynchronize(stream_));
   }
-  if (teacher) {
-    std::vector<int32_t> t((size_t)M * stride, 0);
-    for (int b = 0; b < M; ++b)
-      for (int i = 0; i < stride && i < teacher_stride; ++i) t[(size_t)b * stride + i] = teacher[(size_t)b * teacher_stride + i];
-    MSH_HIP(hipMemcpy(teacher_.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
+  MSH_HIP(hipEventRecord(enc_done_, stream_));
 
-  DecodeState st{};
-  st.tokens = tokens_.as<int32_t>();
-  st.counts = counts_.as<int32_t>();
-  st.finished = finished_.as<int32_t>();
-  st.pos = scalars_.as<int32_t>();
-  st.n_active = scalars_.as<int32_t>() + 1;
-  st.forced = teacher ? teacher_.as<int32_t>() : nullptr;
-  st.stride = stride;
-  st.eos = cfg_.eos;
-  st.ignore_eos = forced ? 1 : 0;
-  const ClipMeta* clips = clips_d_.as<ClipMeta>();
-
-  decode_begin(M, st, cfg_.bos, embed_f32_, D, dH_.as<float>(), stream_);
-
-  // One decode step = 8 kernels per layer + head + bookkeeping; captured once into a hipGraph and
-  // replayed (everything step-dependent -- position, ids, masks -- lives in device memory).
-  const bool graph_ok = use_graph_ && !prof_on_ && logits_out == nullptr;
-  // everything baked into the captured kernel arguments
-  const std::string key = std::to_string(M) + ":" + std::to_string(ws_gen_) + ":" + std::to_string(Smax_) + ":" +
-                          std::to_string(stride) + ":" + std::to_string(st.ignore_eos) + ":" +
-                          std::to_string(teacher != nullptr);
-  if (graph_ok && (step_graph_ == nullptr || graph_key_ != key)) {
-    if (step_graph_) {
-      MSH_HIP(hipGraphExecDestroy(step_graph_));
-      step_graph_ = nullptr;
+  std::vector<DecodeState> states(ngroups);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    DecodeGroup& g = *groups_[gi];
+    g.first = (int)((long)Mtot * gi / ngroups);
+    g.M = (int)((long)Mtot * (gi + 1) / ngroups) - g.first;
+    const int M = g.M;
+    bool moved = false;
+    moved |= g.dH.reserve((size_t)M * D * sizeof(float));
+    moved |= g.dq.reserve((size_t)M * D * sizeof(float));
+    moved |= g.dao.reserve((size_t)M * D * sizeof(bf16_t));
+    moved |= g.dz.reserve((size_t)M * F * sizeof(bf16_t));
+    moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
+    moved |= g.logits.reserve((size_t)M * V * sizeof(float));
+    moved |= g.cacheK.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
+    moved |= g.cacheV.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
+    moved |= g.tokens.reserve((size_t)M * stride * sizeof(int32_t));
+    moved |= g.counts.reserve((size_t)M * sizeof(int32_t));
+    moved |= g.finished.reserve((size_t)M * sizeof(int32_t));
+    moved |= g.scalars.reserve(16 * sizeof(int32_t));
+    if (teacher) moved |= g.teacher.reserve((size_t)M * stride * sizeof(int32_t));
+    if (moved) ++g.gen;
+    if (teacher) {
+      std::vector<int32_t> t((size_t)M * stride, 0);
+      for (int b = 0; b < M; ++b)
+        for (int i = 0; i < stride && i < teacher_stride; ++i)
+          t[(size_t)b * stride + i] = teacher[(size_t)(g.first + b) * teacher_stride + i];
+      MSH_HIP(hipMemcpy(g.teacher.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    hipGraph_t g = nullptr;
-    MSH_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    decode_step_enqueue(M);
-    decode_advance(logits_.as<float>(), M, V, clips, st, embed_f32_, D, dH_.as<float>(), stream_);
-    MSH_HIP(hipStreamEndCapture(stream_, &g));
-    MSH_HIP(hipGraphInstantiate(&step_graph_, g, nullptr, nullptr, 0));
-    MSH_HIP(hipGraphDestroy(g));
-    graph_key_ = key;
+    DecodeState& st = states[gi];
+    st.tokens = g.tokens.as<int32_t>();
+    st.counts = g.counts.as<int32_t>();
+    st.finished = g.finished.as<int32_t>();
+    st.pos = g.scalars.as<int32_t>();
+    st.n_active = g.scalars.as<int32_t>() + 1;
+    st.forced = teacher ? g.teacher.as<int32_t>() : nullptr;
+    st.stride = stride;
+    st.eos = cfg_.eos;
+    st.ignore_eos = forced ? 1 : 0;
+    const ClipMeta* clips = clips_d_.as<ClipMeta>() + g.first;
+
+    if (g.own_stream) MSH_HIP(hipStreamWaitEvent(g.stream, enc_done_, 0));
+    decode_begin(M, st, cfg_.bos, embed_f32_, D, g.dH.as<float>(), g.stream);
+    if (!eager) {
+      // everything baked into the captured kernel arguments
+      const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(ws_gen_) + ":" +
+                              std::to_string(g.gen) + ":" + std::to_string(Smax_) + ":" + std::to_string(stride) + ":" +
+                              std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
+                              std::to_string(kv_keys_);
+      if (g.graph == nullptr || g.key != key) {
+        if (g.graph) {
+          MSH_HIP(hipGraphExecDestroy(g.graph));
+          g.graph = nullptr;
+        }
+        hipGraph_t gr = nullptr;
+        MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        decode_step_enqueue(g);
+        decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+        MSH_HIP(hipStreamEndCapture(g.stream, &gr));
+        MSH_HIP(hipGraphInstantiate(&g.graph, gr, nullptr, nullptr, 0));
+        MSH_HIP(hipGraphDestroy(gr));
+        g.key = key;
+      }
+    }
+    g.n_active_h = M;
   }
 
   int steps_run = 0;
-  int32_t n_active_h = M;
   for (int i = 0; i < steps; ++i) {
-    if (graph_ok) {
-      MSH_HIP(hipGraphLaunch(step_graph_, stream_));
-    } else {
-      decode_step_enqueue(M);
-      if (logits_out != nullptr && i < max_logit_steps)
-        MSH_HIP(hipMemcpyAsync(logits_out + (size_t)i * M * V, logits_.p, (size_t)M * V * sizeof(float),
-                               hipMemcpyDeviceToHost, stream_));
-      ProfScope p(this, "dec_argmax_advance", 0, (double)M * V * 4);
-      decode_advance(logits_.as<float>(), M, V, clips, st, embed_f32_, D, dH_.as<float>(), stream_);
+    for (int gi = 0; gi < ngroups; ++gi) {
+      DecodeGroup& g = *groups_[gi];
+      if (g.n_active_h <= 0) continue;
+      if (!eager) {
+        MSH_HIP(hipGraphLaunch(g.graph, g.stream));
+      } else {
+        decode_step_enqueue(g);
+        if (logits_out != nullptr && i < max_logit_steps)
+          MSH_HIP(hipMemcpyAsync(logits_out + (size_t)i * Mtot * V, g.logits.p, (size_t)Mtot * V * sizeof(float),
+                                 hipMemcpyDeviceToHost, g.stream));
+        ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * V * 4);
+        decode_advance(g.logits.as<float>(), g.M, V, clips_d_.as<ClipMeta>() + g.first, states[gi], embed_f32_, D,
+                       g.dH.as<float>(), g.stream);
+      }
     }
     ++steps_run;
     if (!forced && ((i & 7) == 7) && i + 1 < steps) {
-      MSH_HIP(hipMemcpyAsync(&n_active_h, st.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-      MSH_HIP(hipStreamSynchronize(stream_));
-      if (n_active_h <= 0) break;
+      int alive = 0;
+      for (int gi = 0; gi < ngroups; ++gi) {
+        DecodeGroup& g = *groups_[gi];
+        if (g.n_active_h <= 0) continue;
+        MSH_HIP(hipMemcpyAsync(&g.n_active_h, states[gi].n_active, sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+      }
+      for (int gi = 0; gi < ngroups; ++gi) {
+        MSH_HIP(hipStreamSynchronize(groups_[gi]->stream));
+        alive += groups_[gi]->n_active_h > 0 ? 1 : 0;
+      }
+      if (alive == 0) break;
     }
   }
-  if (tokens_out != nullptr || counts_out != nullptr) {
-    std::vector<int32_t> tk((size_t)M * stride), cn(M);
-    MSH_HIP(hipMemcpyAsync(tk.data(), tokens_.p, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    MSH_HIP(hipMemcpyAsync(cn.data(), counts_.p, cn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    MSH_HIP(hipStreamSynchronize(stream_));
-    for (int b = 0; b < M; ++b) {
-      if (counts_out) counts_out[b] = cn[b];
-      if (tokens_out) {
-        for (int i = 0; i < tokens_stride; ++i)
-          tokens_out[(size_t)b * tokens_stride + i] = i < cn[b] ? tk[(size_t)b * stride + i] : -1;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    DecodeGroup& g = *groups_[gi];
+    if (tokens_out != nullptr || counts_out != nullptr) {
+      std::vector<int32_t> tk((size_t)g.M * stride), cn(g.M);
+      MSH_HIP(hipMemcpyAsync(tk.data(), g.tokens.p, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+      MSH_HIP(hipMemcpyAsync(cn.data(), g.counts.p, cn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+      MSH_HIP(hipStreamSynchronize(g.stream));
+      for (int b = 0; b < g.M; ++b) {
+        const int gb = g.first + b;
+        if (counts_out) counts_out[gb] = cn[b];
+        if (tokens_out)
+          for (int i = 0; i < tokens_stride; ++i)
+            tokens_out[(size_t)gb * tokens_stride + i] = i < cn[b] ? tk[(size_t)b * stride + i] : -1;
       }
+    } else {
+      MSH_HIP(hipStreamSynchronize(g.stream));
     }
-  } else {
-    MSH_HIP(hipStreamSynchronize(stream_));
   }
   prof_flush();
   return steps_run;

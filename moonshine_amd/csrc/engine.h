@@ -88,9 +88,11 @@ class Engine {
 
  private:
   struct ProfScope;
+  struct DecodeGroup;
+  void destroy_groups();
   void plan_batch(const uint64_t* n_samples, uint32_t count, float max_tokens_per_second);
   void run_encoder();
-  void decode_step_enqueue(int M);
+  void decode_step_enqueue(DecodeGroup& g);
   void upload(const std::vector<float>& src, float** dst);
   void upload_bf16(const std::vector<float>& src, bf16_t** dst);
 
@@ -121,12 +123,12 @@ class Engine {
   // workspace (grow-only)
   DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x1n_, x2_, H_, Y_, QKV_, AO_, Z_,
       ENC_, ENC32_, gn_part_, gn_stats_, KT_, VT_;
-  DevBuf dH_, dq_, dao_, dz_, logits_, cacheK_, cacheV_, tokens_, counts_, finished_, scalars_, teacher_;
   int Smax_ = 0;
 
-  // decode-step graph cache (invalidated when any buffer it references moves)
-  hipGraphExec_t step_graph_ = nullptr;
-  std::string graph_key_;
+  // decode groups (own stream + buffers + captured step graph each); group 0 runs on stream_
+  std::vector<std::unique_ptr<DecodeGroup>> groups_;
+  hipEvent_t enc_done_ = nullptr;
+  int dec_groups_ = 0;  // 0 = auto (MSH_DEC_GROUPS overrides)
   uint64_t ws_gen_ = 0;
   bool use_graph_ = true;
 

@@ -1,0 +1,177 @@
+#include "host_text_vad.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "host_utils.h"
+
+namespace msh_host {
+
+// ---------------------------------------------------------------------------------------------
+BinTokenizer::BinTokenizer(const uint8_t* data, size_t size, const std::string& space_marker) : space_(space_marker) {
+  size_t i = 0;
+  while (i < size) {
+    const uint8_t first = data[i++];
+    if (first == 0) {  // empty entry
+      tokens_.emplace_back();
+      continue;
+    }
+    size_t n = first;
+    if (first >= 128) {  // two-byte length: first = (len % 128) + 128, second = len / 128
+      if (i >= size) throw std::runtime_error("tokenizer.bin: truncated length prefix");
+      n = (size_t)data[i++] * 128 + first - 128;
+    }
+    if (i + n > size) throw std::runtime_error("tokenizer.bin: truncated token bytes");
+    tokens_.emplace_back(reinterpret_cast<const char*>(data + i), n);
+    i += n;
+  }
+  if (tokens_.empty()) throw std::runtime_error("tokenizer.bin: no tokens found");
+}
+
+BinTokenizer* BinTokenizer::from_file(const std::string& path) {
+  std::vector<uint8_t> blob;
+  if (!read_file(path, &blob)) throw std::runtime_error("Failed to open tokenizer file at " + path);
+  return new BinTokenizer(blob.data(), blob.size());
+}
+
+std::string BinTokenizer::tokens_to_text(const int32_t* ids, size_t count, bool skip_specials) const {
+  std::string bytes;
+  for (size_t k = 0; k < count; ++k) {
+    const int32_t id = ids[k];
+    if (id < 0 || (size_t)id >= tokens_.size()) throw std::out_of_range("token id " + std::to_string(id) + " out of range");
+    const std::string& t = tokens_[id];
+    if (t.empty()) throw std::runtime_error("Invalid token " + std::to_string(id));
+    if (skip_specials && t.size() > 2 && t.front() == '<' && t.back() == '>') continue;
+    bytes += t;
+  }
+  return trim(replace_all(bytes, space_, " "));
+}
+
+// ---------------------------------------------------------------------------------------------
+std::string sanitize_utf8(const std::string& text) {
+  std::string out;
+  out.reserve(text.size());
+  const size_t n = text.size();
+  auto cont = [&](size_t j) { return (((uint8_t)text[j]) & 0xC0) == 0x80; };
+  size_t i = 0;
+  while (i < n) {
+    const uint8_t c = (uint8_t)text[i];
+    size_t need = 0;
+    if (c < 0x80) need = 1;
+    else if ((c & 0xE0) == 0xC0) need = 2;
+    else if ((c & 0xF0) == 0xE0) need = 3;
+    else if ((c & 0xF8) == 0xF0) need = 4;
+    bool ok = need != 0 && n - i >= need;
+    for (size_t k = 1; ok && k < need; ++k) ok = cont(i + k);
+    if (ok) {
+      out.append(text, i, need);
+      i += need;
+    } else {
+      out.push_back('?');
+      i += 1;
+    }
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+VoiceActivityDetector::VoiceActivityDetector(float threshold, int32_t /*window_size*/, int32_t hop_size,
+                                             size_t look_behind, size_t max_segment)
+    : threshold_(threshold), hop_(hop_size), look_behind_(look_behind), max_segment_(max_segment) {
+  if (threshold > 0.0f)
+    throw std::runtime_error(
+        "vad_threshold > 0 needs the Silero VAD model, which is not part of the MI355X build yet; "
+        "load the transcriber with the option vad_threshold=0 (segments are then split by length only)");
+  if (hop_size <= 0) throw std::runtime_error("vad_hop_size must be positive");
+  look_buf_.assign(look_behind_, 0.f);
+}
+
+void VoiceActivityDetector::start() {
+  active_ = true;
+  processed_ = 0;
+  segments_.clear();
+  cur_.clear();
+  remainder_.clear();
+  look_buf_.assign(look_behind_, 0.f);
+  prev_voice_ = false;
+}
+
+void VoiceActivityDetector::stop() {
+  active_ = false;
+  if (prev_voice_ && !segments_.empty()) {  // close the open segment as it stands (the sub-hop tail is dropped)
+    VadSegment& s = segments_.back();
+    s.audio = cur_;
+    s.end_time = (float)processed_ / kSampleRate;
+    s.is_complete = true;
+    s.just_updated = true;
+  }
+}
+
+void VoiceActivityDetector::process_audio(const float* audio, size_t count, int32_t sample_rate) {
+  if (!active_) return;
+  for (VadSegment& s : segments_) s.just_updated = false;
+  std::vector<float> in(audio, audio + count);
+  std::vector<float> buf = remainder_;
+  if (sample_rate == kSampleRate) {
+    buf.insert(buf.end(), in.begin(), in.end());
+  } else {
+    std::vector<float> r = resample(in, (float)sample_rate, (float)kSampleRate);
+    buf.insert(buf.end(), r.begin(), r.end());
+  }
+  size_t off = 0;
+  while (buf.size() - off >= (size_t)hop_) {
+    process_hop(buf.data() + off);
+    off += hop_;
+  }
+  remainder_.assign(buf.begin() + off, buf.end());
+}
+
+void VoiceActivityDetector::clear_completed_audio() {
+  for (VadSegment& s : segments_)
+    if (s.is_complete) std::vector<float>().swap(s.audio);
+}
+
+void VoiceActivityDetector::process_hop(const float* hop) {
+  processed_ += hop_;
+  // slide the look-behind window
+  if ((size_t)hop_ >= look_buf_.size()) {
+    std::copy(hop + hop_ - look_buf_.size(), hop + hop_, look_buf_.begin());
+  } else {
+    std::move(look_buf_.begin() + hop_, look_buf_.end(), look_buf_.begin());
+    std::copy(hop, hop + hop_, look_buf_.end() - hop_);
+  }
+  // threshold 0: probability 1, scaled by the max-length fade once the segment passes 2/3 of the cap
+  float p = 1.0f;
+  const size_t fade = (max_segment_ * 2) / 3;
+  if (max_segment_ && cur_.size() > fade) p = p * ((float)(cur_.size() - fade) / (float)fade);
+  const bool voice = p > threshold_;
+  const float now = (float)processed_ / kSampleRate;
+  if (voice && !prev_voice_) {
+    const size_t lb = std::min(look_behind_, processed_);
+    cur_.assign(look_buf_.end() - lb, look_buf_.end());
+    VadSegment s;
+    s.audio = cur_;
+    s.start_time = now - (float)cur_.size() / kSampleRate;
+    s.end_time = now;
+    s.just_updated = true;
+    segments_.push_back(std::move(s));
+  } else if (!voice && prev_voice_) {
+    cur_.insert(cur_.end(), hop, hop + hop_);
+    VadSegment& s = segments_.back();
+    s.audio = cur_;
+    s.end_time = now;
+    s.is_complete = true;
+    s.just_updated = true;
+    cur_.clear();  // (the reference's resize() of the look-behind buffer here is a no-op: it keeps its contents)
+  } else if (voice && prev_voice_) {
+    cur_.insert(cur_.end(), hop, hop + hop_);
+    VadSegment& s = segments_.back();
+    s.audio = cur_;
+    s.end_time = now;
+    s.is_complete = false;
+    s.just_updated = true;
+  }
+  prev_voice_ = voice;
+}
+
+}  // namespace msh_host

@@ -1,0 +1,63 @@
+// Host-side pre/post steps of the transcription path: tokenizer.bin reader (ids -> text), UTF-8 repair,
+// and the hop-based voice-activity segmenter.  Byte-exact with the reference for the paths it keeps.
+#pragma once
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace msh_host {
+
+// tokenizer.bin = concatenated length-prefixed byte strings, one per id
+// (reference core/bin-tokenizer/bin-tokenizer.cpp:46-66).
+class BinTokenizer {
+ public:
+  BinTokenizer(const uint8_t* data, size_t size, const std::string& space_marker = "\xE2\x96\x81");
+  static BinTokenizer* from_file(const std::string& path);
+  size_t vocab_size() const { return tokens_.size(); }
+  // ids -> text: concatenate, skip `<...>` specials, marker -> ' ', trim spaces/tabs
+  // (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).  Throws on an id with no bytes.
+  std::string tokens_to_text(const int32_t* ids, size_t count, bool skip_specials = true) const;
+
+ private:
+  std::vector<std::string> tokens_;
+  std::string space_;
+};
+
+// Replace every byte that does not start a structurally valid UTF-8 sequence by '?'
+// (reference core/transcriber.cpp:1489-1543).
+std::string sanitize_utf8(const std::string& text);
+
+struct VadSegment {
+  std::vector<float> audio;  // 16 kHz samples of the segment so far
+  float start_time = 0.f, end_time = 0.f;
+  bool is_complete = false, just_updated = false;
+};
+
+// Segmenter with the reference's state machine (reference core/voice-activity-detector.cpp:69-199):
+// whole hops only, look-behind on voice start, max-segment fade.  The speech probability itself comes
+// from Silero in the reference; this build only supports threshold == 0 ("always voice"), which is what
+// the reference's own evaluation / benchmark scripts use (scripts/eval-librispeech.py:381-388).
+class VoiceActivityDetector {
+ public:
+  VoiceActivityDetector(float threshold, int32_t window_size, int32_t hop_size, size_t look_behind, size_t max_segment);
+  void start();
+  void stop();
+  bool is_active() const { return active_; }
+  void process_audio(const float* audio, size_t count, int32_t sample_rate);
+  const std::vector<VadSegment>& segments() const { return segments_; }
+  void clear_completed_audio();
+
+ private:
+  void process_hop(const float* hop);
+  float threshold_;
+  int32_t hop_;
+  size_t look_behind_, max_segment_;
+  bool active_ = false, prev_voice_ = false;
+  size_t processed_ = 0;
+  std::vector<float> look_buf_, cur_, remainder_;
+  std::vector<VadSegment> segments_;
+};
+
+}  // namespace msh_host

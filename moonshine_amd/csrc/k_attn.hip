@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
                                                                  const int* __restrict__ pos_ptr, int M, int D,
                                                                  int heads, int Smax, bf16_t* __restrict__ out) {
   __shared__ float sc[4][SELF_SMAX];
+  __shared__ float4 red[4][64 / (DH / 4)][DH / 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + wave;
   if (pair >= M * heads) return;
@@ -233,10 +234,36 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
   }
   lsum = wave_sum(lsum);
   __builtin_amdgcn_wave_barrier();
-  if (lane < DH) {
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += sc[wave][s] * bf16_to_f32(vp[(long)s * DH + lane]);
-    out[(long)b * D + h * DH + lane] = f32_to_bf16(acc / lsum);
+  // PV: lane = (key group g, 8-byte piece of the head dim); group g walks keys g, g+G, ... with
+  // independent loads, then the G partial rows are summed through LDS in a fixed order.
+  constexpr int PIECES = DH / 4, G = 64 / PIECES;
+  const int g = lane / PIECES, piece = lane - g * PIECES;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+#pragma unroll 4
+    for (int s = g; s < S; s += G) {
+      const uint2 u = *reinterpret_cast<const uint2*>(vp + (long)s * DH + piece * 4);
+      const float p = sc[wave][s];
+      acc.x += p * bf_lo(u.x);
+      acc.y += p * bf_hi(u.x);
+      acc.z += p * bf_lo(u.y);
+      acc.w += p * bf_hi(u.y);
+    }
+    red[wave][g][piece] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < PIECES) {
+    float4 t = red[wave][0][lane];
+#pragma unroll
+    for (int k = 1; k < G; ++k) {
+      const float4 r = red[wave][k][lane];
+      t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+    }
+    const float inv = 1.0f / lsum;
+    uint2 o;
+    o.x = pack_bf16x2(t.x * inv, t.y * inv);
+    o.y = pack_bf16x2(t.z * inv, t.w * inv);
+    *reinterpret_cast<uint2*>(out + (long)b * D + h * DH + lane * 4) = o;
   }
 }
 

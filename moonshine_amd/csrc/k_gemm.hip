@@ -16,6 +16,8 @@
 // row = (l>>4)*4 + reg.  SWAP = true computes C^T tiles (W fragment as the A operand) so a lane
 // ends up with 4 consecutive n for one m (vector stores along n, RoPE / SwiGLU pairs in-lane);
 // SWAP = false gives 4 consecutive m for one n (used to write K^T / V^T along t).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace msh {
@@ -316,6 +318,167 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled kernel, LDS-DMA pipeline.  Same tile / fragment / epilogue structure as gemm_tiled_kernel, but
+// the k-slices travel HBM -> LDS with `global_load_lds_dwordx4` (no staging registers), NSTAGE buffers
+// deep with up to NSTAGE-1 slices in flight across the per-step barrier (counted vmcnt, raw s_barrier).
+// The DMA writes LDS lane-linearly (wave-uniform base + lane*16 B), so the XOR swizzle of the slot layout
+// is applied on the per-lane SOURCE address: a 1-KiB piece = 16 rows x 4 slots, lane l fills slot
+// (row = l>>2, pos = l&3) with global k-chunk pos ^ swz(row) -- still one 64-B segment per row.
+// The DMA is issued from inline asm: hipcc otherwise treats it as an LDS store that may alias the
+// fragment reads and drains vmcnt(0) before every ds_read (cdna_hip_programming.md section 5).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long)(lds_char_t*)(p); }
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi>
+__global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
+                                                             const bf16_t* __restrict__ W, int M, int N, int K,
+                                                             int ntn, int nblocks, Epi epi) {
+  constexpr int BM = 16 * NW * TM, BN = 16 * TN;
+  constexpr int PA = BM / 16, P = PA + TN;     // 1-KiB pieces per k-slice (A rows, then W rows)
+  constexpr int PMAX = (P + NW - 1) / NW;      // pieces per wave (waves take pieces w, w+NW, ...)
+  constexpr int STAGE_SLOTS = (BM + BN) * 4;   // 16-B slots per k-slice
+  __shared__ __attribute__((aligned(16))) uint4 lds[NSTAGE * STAGE_SLOTS];
+
+  const int bid = blockIdx.x;
+  const int q8 = nblocks >> 3, r8 = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+  const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int my_pieces = (P - wave + NW - 1) / NW;  // wave-uniform
+
+  // per-lane source pointers of this wave's pieces (k0 = 0)
+  const bf16_t* src[PMAX];
+  unsigned dst[PMAX];
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    const int p = wave + NW * i;
+    const int r = lane >> 2, pos = lane & 3;
+    if (p < PA) {
+      const int row = p * 16 + r;
+      int gm = m0 + row;
+      gm = gm < M ? gm : M - 1;
+      src[i] = A + (long)gm * lda + ((pos ^ swz(row)) << 3);
+    } else {
+      const int row = (p - PA) * 16 + r;
+      int gn = n0 + row;
+      gn = gn < N ? gn : N - 1;
+      src[i] = W + (long)gn * K + ((pos ^ swz(row)) << 3);
+    }
+    dst[i] = lds_base + (unsigned)p * 1024u;   // piece p starts at slot 64*p (A pieces first, then W)
+  }
+  auto issue = [&](int kt) {
+    const unsigned sb = (unsigned)(kt % NSTAGE) * (STAGE_SLOTS * 16u);
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i)
+      if (i < my_pieces) dma16(src[i] + (kt << 5), dst[i] + sb);
+  };
+  // wait until at most `stages` of this wave's k-slices are still in flight
+  auto wait_stages = [&](int stages) {
+    if (my_pieces == PMAX) {
+      if (stages >= 2) wait_vmcnt<2 * PMAX>();
+      else if (stages == 1) wait_vmcnt<PMAX>();
+      else wait_vmcnt<0>();
+    } else {
+      if (stages >= 2) wait_vmcnt<2 * (PMAX - 1)>();
+      else if (stages == 1) wait_vmcnt<PMAX - 1>();
+      else wait_vmcnt<0>();
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K >> 5;
+  constexpr int AHEAD = NSTAGE - 1;            // k-slices issued ahead of the one being consumed
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // slices kt+1 .. min(kt+AHEAD-1, nk-1) may stay in flight; AHEAD is 2 or 3
+    const int inflight = (kt + AHEAD - 1 < nk ? AHEAD - 1 : nk - 1 - kt);
+    wait_stages(inflight);
+    __builtin_amdgcn_s_barrier();              // every wave's pieces of slice kt have landed; slice kt-1 is consumed
+    if (kt + AHEAD < nk) issue(kt + AHEAD);
+    const uint4* st = lds + (kt % NSTAGE) * STAGE_SLOTS;
+    bf16x8 af[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wave * 16 * TM + i * 16 + li;
+      uint4 t = st[row * 4 + (kg ^ swz(row))];
+      af[i] = *reinterpret_cast<bf16x8*>(&t);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 16 + li;
+      uint4 t = st[BM * 4 + row * 4 + (kg ^ swz(row))];
+      bf16x8 bf = *reinterpret_cast<bf16x8*>(&t);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (SWAP)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  wait_vmcnt<0>();
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (SWAP) {
+        const int m = m0 + wave * 16 * TM + i * 16 + li, n = n0 + j * 16 + kg * 4;
+        if (m < M && n < N) epi.n4(m, n, acc[i][j]);
+      } else {
+        const int m = m0 + wave * 16 * TM + i * 16 + kg * 4, n = n0 + j * 16 + li;
+        if (m < M && n < N) epi.m4(m, n, acc[i][j]);
+      }
+    }
+  }
+}
+
+template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi>
+void launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  constexpr int BM = 16 * NW * TM, BN = 16 * TN;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  const int nblocks = ntm * ntn;
+  hipLaunchKernelGGL((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
+                     W, M, N, K, ntn, nblocks, epi);
+}
+
+// MSH_GEMM_MODE (debug / A-B switch): 0 = register-staged double buffer; 1 = LDS-DMA, 256x208 tile, 4 waves,
+// 4 stages (one workgroup per CU: measured ~2x slower than 2, nothing hides a wave's ds_read latency);
+// 2 = LDS-DMA, 128x208 tile, 4 waves, 3 stages, two workgroups per CU (default);
+// 3 = LDS-DMA, 256x208 tile, 8 waves (two per SIMD), 4 stages.
+inline int gemm_mode() {
+  static int mode = [] {
+    const char* e = getenv("MSH_GEMM_MODE");
+    return e ? atoi(e) : 2;
+  }();
+  return mode;
+}
+
 template <int TM, int TN, bool SWAP, class Epi>
 void launch_tiled_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
@@ -333,10 +496,19 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
   if ((K & 31) != 0 || (N & 3) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_tiled: unsupported shape");
   const bool big = (long)((M + 255) / 256) * ((N + 207) / 208) >= 512;
   if (N % 208 == 0) {
-    if (big)
-      launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
-    else
-      launch_tiled_cfg<2, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    const int mode = gemm_mode();
+    if (mode == 0) {
+      if (big)
+        launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+      else
+        launch_tiled_cfg<2, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    } else if (mode == 1 && big) {
+      launch_tiled_dma_cfg<4, 4, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    } else if (mode == 3 && big) {
+      launch_tiled_dma_cfg<8, 2, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    } else {
+      launch_tiled_dma_cfg<4, 2, 13, 3, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    }
   } else if (N % 144 == 0) {
     launch_tiled_cfg<2, 9, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
   } else {
@@ -345,119 +517,160 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fragment-direct kernel (decode)
+// Decode GEMM (M = batch rows): fragment-direct, split-K inside the workgroup.
+//
+// A workgroup owns one 16 x (16*TN) output tile; its 4 waves split the K loop (wave w takes the 32-wide
+// k-steps w, w+4, ...), each loading its MFMA fragments straight from global memory -- all loads of a
+// wave are independent and issued up front, so the kernel costs about one memory round trip instead of a
+// K/32-long dependent chain.  Partial tiles are summed through LDS in a fixed order (deterministic).
+// LN = true: A is the fp32 residual stream [M][K]; LayerNorm (no bias, eps 1e-5, exact two-pass) is
+// fused into the fragment build: row sums are combined across the 4 waves through LDS.
 // ------------------------------------------------------------------------------------------------
-// KS > 0: A is the fp32 residual [M][K = 32*KS]; the wave normalises its 16 rows (LayerNorm, no bias,
-// eps 1e-5, two-pass in registers) while building the bf16 A fragments.  KS == 0: A is bf16 [M][lda].
-template <int KS, int TN, class Epi>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const void* __restrict__ Aptr, long lda,
-                                                         const float* __restrict__ gamma,
-                                                         const bf16_t* __restrict__ W, int M, int N, int K,
-                                                         int n_tiles, int total_tiles, Epi epi) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= total_tiles) return;
-  const int m0 = (tile / n_tiles) * 16, n0 = (tile % n_tiles) * (16 * TN);
+template <int KS, int TN, bool LN, class Epi>
+__global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
+                                                       const float* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ W, int M, int N, int n_tiles,
+                                                       Epi epi) {
+  constexpr int K = 32 * KS;
+  constexpr int KW = (KS + 3) / 4;  // k-steps per wave (upper bound)
+  __shared__ __attribute__((aligned(16))) float4 part[4][TN][64];
+  __shared__ float stat[2][4][16];
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = (blockIdx.x / n_tiles) * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
   int gm = m0 + li;
   gm = gm < M ? gm : M - 1;
 
-  f32x4 acc[TN];
+  // ---- issue every load of this wave first ----
+  uint4 wreg[KW][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* wrow[TN];
+  for (int i = 0; i < KW; ++i) {
+    const int s = wave + 4 * i;
+    if (s < KS) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int gn = n0 + j * 16 + li;
-    gn = gn < N ? gn : N - 1;
-    wrow[j] = W + (long)gn * K + kg * 8;
+      for (int j = 0; j < TN; ++j) {
+        int gn = n0 + j * 16 + li;
+        gn = gn < N ? gn : N - 1;
+        wreg[i][j] = *reinterpret_cast<const uint4*>(W + (long)gn * K + s * 32 + kg * 8);
+      }
+    }
   }
-
-  if constexpr (KS > 0) {
+  bf16x8 afrag[KW];
+  if constexpr (LN) {
     const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
-    float xv[KS][8];
+    float xv[KW][8];
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float4 a = *reinterpret_cast<const float4*>(x + s * 32);
-      float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
-      xv[s][0] = a.x; xv[s][1] = a.y; xv[s][2] = a.z; xv[s][3] = a.w;
-      xv[s][4] = b.x; xv[s][5] = b.y; xv[s][6] = b.z; xv[s][7] = b.w;
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
+        const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
+        xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+        xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+        for (int e = 0; e < 8; ++e) sum += xv[i][e];
+      }
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float mean = sum / (float)K;
+    if (kg == 0) stat[0][wave][li] = sum;
+    __syncthreads();
+    const float mean = ((stat[0][0][li] + stat[0][1][li]) + (stat[0][2][li] + stat[0][3][li])) * (1.0f / (float)K);
     float sq = 0.f;
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int i = 0; i < KW; ++i) {
+      if (wave + 4 * i < KS) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = xv[s][e] - mean;
-        sq += d * d;
+        for (int e = 0; e < 8; ++e) {
+          const float d = xv[i][e] - mean;
+          sq += d * d;
+        }
       }
+    }
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq / (float)K + 1e-5f);
+    if (kg == 0) stat[1][wave][li] = sq;
+    __syncthreads();
+    const float var = ((stat[1][0][li] + stat[1][1][li]) + (stat[1][2][li] + stat[1][3][li])) * (1.0f / (float)K);
+    const float rstd = rsqrtf(var + 1e-5f);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float4 g0 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8);
-      float4 g1 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8 + 4);
-      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      uint4 t;
-      t.x = pack_bf16x2((xv[s][0] - mean) * rstd * g[0], (xv[s][1] - mean) * rstd * g[1]);
-      t.y = pack_bf16x2((xv[s][2] - mean) * rstd * g[2], (xv[s][3] - mean) * rstd * g[3]);
-      t.z = pack_bf16x2((xv[s][4] - mean) * rstd * g[4], (xv[s][5] - mean) * rstd * g[5]);
-      t.w = pack_bf16x2((xv[s][6] - mean) * rstd * g[6], (xv[s][7] - mean) * rstd * g[7]);
-      const bf16x8 af = *reinterpret_cast<bf16x8*>(&t);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        uint4 wv = *reinterpret_cast<const uint4*>(wrow[j] + s * 32);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), af, acc[j], 0, 0, 0);
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8);
+        const float4 g1 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8 + 4);
+        uint4 t;
+        t.x = pack_bf16x2((xv[i][0] - mean) * rstd * g0.x, (xv[i][1] - mean) * rstd * g0.y);
+        t.y = pack_bf16x2((xv[i][2] - mean) * rstd * g0.z, (xv[i][3] - mean) * rstd * g0.w);
+        t.z = pack_bf16x2((xv[i][4] - mean) * rstd * g1.x, (xv[i][5] - mean) * rstd * g1.y);
+        t.w = pack_bf16x2((xv[i][6] - mean) * rstd * g1.z, (xv[i][7] - mean) * rstd * g1.w);
+        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
       }
     }
   } else {
     const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
-    const int nk = K >> 5;
-#pragma unroll 4
-    for (int s = 0; s < nk; ++s) {
-      uint4 av = *reinterpret_cast<const uint4*>(a + s * 32);
-      const bf16x8 af = *reinterpret_cast<bf16x8*>(&av);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        uint4 wv = *reinterpret_cast<const uint4*>(wrow[j] + s * 32);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), af, acc[j], 0, 0, 0);
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        uint4 t = *reinterpret_cast<const uint4*>(a + s * 32);
+        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
       }
     }
   }
-  const int m = m0 + li;
+
+  f32x4 acc[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
+  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    if (wave + 4 * i < KS) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[i], acc[j], 0,
+                                                         0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) part[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  __syncthreads();
+  // waves 0..TN-1 (round-robin when TN > 4) finish one column tile each: fixed summation order
+  const int m = m0 + li;
+  for (int j = wave; j < TN; j += 4) {
+    const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
+    f32x4 v;
+    v[0] = (p0.x + p1.x) + (p2.x + p3.x);
+    v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+    v[2] = (p0.z + p1.z) + (p2.z + p3.z);
+    v[3] = (p0.w + p1.w) + (p2.w + p3.w);
     const int n = n0 + j * 16 + kg * 4;
-    if (m < M && n < N) epi.n4(m, n, acc[j]);
+    if (m < M && n < N) epi.n4(m, n, v);
   }
 }
 
-template <int KS, int TN, class Epi>
-void launch_small_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, int K, Epi epi,
-                      hipStream_t s) {
+template <int KS, int TN, bool LN, class Epi>
+void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
+                    hipStream_t s) {
   const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  const int total = m_tiles * n_tiles;
-  hipLaunchKernelGGL((gemm_small_kernel<KS, TN, Epi>), dim3((total + 3) / 4), dim3(256), 0, s, A, lda, gamma, W, M, N,
-                     K, n_tiles, total, epi);
+  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W, M,
+                     N, n_tiles, epi);
 }
 
-template <int TN, class Epi>
-void launch_small_ln(const float* H, const float* gamma, const bf16_t* W, int M, int N, int D, Epi epi,
-                     hipStream_t s) {
-  if ((N & 3) != 0) throw std::runtime_error("gemm_small: N must be a multiple of 4");
-  switch (D / 32) {
-    case 13: if (D == 416) return launch_small_cfg<13, TN, Epi>(H, D, gamma, W, M, N, D, epi, s); break;
-    case 9:  if (D == 288) return launch_small_cfg<9, TN, Epi>(H, D, gamma, W, M, N, D, epi, s); break;
-    case 2:  if (D == 64)  return launch_small_cfg<2, TN, Epi>(H, D, gamma, W, M, N, D, epi, s); break;
-    default: break;
+// K is a compile-time multiple of 32: D (LN-fused and attention-output GEMMs) or F (fc2)
+template <int TN, bool LN, class Epi>
+void launch_dec(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, int K, Epi epi,
+                hipStream_t s) {
+  if ((N & 3) != 0) throw std::runtime_error("gemm_dec: N must be a multiple of 4");
+  switch (K) {
+    case 416: return launch_dec_cfg<13, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 1664: return launch_dec_cfg<52, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 288: return launch_dec_cfg<9, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 1152: return launch_dec_cfg<36, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 64: return launch_dec_cfg<2, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 256: return launch_dec_cfg<8, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    default: throw std::runtime_error("gemm_dec: unsupported K " + std::to_string(K));
   }
-  throw std::runtime_error("gemm_small: unsupported hidden size " + std::to_string(D));
 }
 
 }  // namespace
@@ -489,27 +702,26 @@ void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int
 
 void dec_gemm_qkv(const float* H, const float* gamma, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp,
                   float* q, bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
-  launch_small_ln<2>(H, gamma, W, M, 3 * D, D, EpiDecQkv{q, cacheK, cacheV, pos_ptr, rp, Smax}, s);
+  launch_dec<2, true>(H, D, gamma, W, M, 3 * D, D, EpiDecQkv{q, cacheK, cacheV, pos_ptr, rp, Smax}, s);
 }
 void dec_gemm_ln_f32(const float* H, const float* gamma, const bf16_t* W, int M, int N, int D, float* out,
                      hipStream_t s) {
-  launch_small_ln<2>(H, gamma, W, M, N, D, EpiF32{out, N}, s);
+  launch_dec<2, true>(H, D, gamma, W, M, N, D, EpiF32{out, N}, s);
 }
 void dec_gemm_ln_swiglu(const float* H, const float* gamma, const bf16_t* W, const float* bias, int M, int F, int D,
                         bf16_t* z, hipStream_t s) {
-  launch_small_ln<2>(H, gamma, W, M, 2 * F, D, EpiSwiGLU{z, F, bias}, s);
+  launch_dec<2, true>(H, D, gamma, W, M, 2 * F, D, EpiSwiGLU{z, F, bias}, s);
 }
 void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                     hipStream_t s) {
-  if ((K & 31) != 0 || (N & 3) != 0) throw std::runtime_error("dec_gemm_resid: unsupported shape");
-  launch_small_cfg<0, 2>(A, lda, nullptr, W, M, N, K, EpiResidF32{H, N, bias}, s);
+  launch_dec<2, false>(A, lda, nullptr, W, M, N, K, EpiResidF32{H, N, bias}, s);
 }
 void dec_gemm_logits(const float* H, const float* gamma, const bf16_t* E, int M, int V, int D, float* logits,
                      hipStream_t s) {
-  if (M > 32)
-    launch_small_ln<8>(H, gamma, E, M, V, D, EpiF32{logits, V}, s);
-  else
-    launch_small_ln<2>(H, gamma, E, M, V, D, EpiF32{logits, V}, s);
+  launch_dec<4, true>(H, D, gamma, E, M, V, D, EpiF32{logits, V}, s);
+}
+void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
+  launch_tiled<true>(A, lda, W, M, N, K, EpiF32{out, N}, s);
 }
 
 }  // namespace msh

@@ -55,6 +55,9 @@ void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bia
 void dec_gemm_logits(const float* H, const float* gamma, const bf16_t* E, int M, int V, int D, float* logits,
                      hipStream_t s);
 
+// logits_f32[M,N] = A_bf16[M,K] * W^T with the tiled kernel (LM head at batch >= 128, after layernorm_bf16)
+void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,

@@ -249,3 +249,18 @@ def test_base_full_size_batch_properties(base):
     for t_forced, t_ref in zip(a, d):
         assert t_ref == t_forced[: len(t_ref)]
         assert len(t_ref) == 66 or t_ref[-1] == cfg.eos
+
+
+def test_decode_groups_match_single_stream(tmp_path_factory, monkeypatch, micro):
+    """The multi-stream decode split (MSH_DEC_GROUPS) must not change a single token: ragged micro batch,
+    reference EOS semantics, 3 uneven groups vs the default single group."""
+    cfg, w, lens, clips = eos_test_weights()
+    e1, _, _ = _engine(tmp_path_factory, "micro", 39, w)
+    want = e1.transcribe_tokens(clips)
+    monkeypatch.setenv("MSH_DEC_GROUPS", "3")
+    e3, _, _ = _engine(tmp_path_factory, "micro", 39, w)
+    got = e3.transcribe_tokens(clips)
+    assert got == want
+    forced = e3.transcribe_tokens(clips, forced_steps=9)
+    monkeypatch.delenv("MSH_DEC_GROUPS")
+    assert forced == e1.transcribe_tokens(clips, forced_steps=9)

@@ -18,8 +18,9 @@ timeout 1200 python bench.py "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/$
 tail -c 3000 gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
 echo "== rocprofv3"
 rm -rf gpurun_out/${TAG}_prof
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG} -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency > /tmp/prof_${TAG}.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o prof -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency > /tmp/prof_${TAG}.log 2>&1)
 tail -3 /tmp/prof_${TAG}.log
 mkdir -p gpurun_out/${TAG}_prof
-find /tmp/prof_${TAG} -name "*stats*" -exec cp {} gpurun_out/${TAG}_prof/ \; 2>/dev/null
+find /tmp/prof_${TAG} -name "*stats*.csv" -exec cp {} gpurun_out/${TAG}_prof/ \; 2>/dev/null
+find /tmp/prof_${TAG} | head -20
 ls -la gpurun_out/${TAG}_prof | head
