@@ -111,6 +111,20 @@ MSH_EXPORT int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_ent
 
 MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
 
+/* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
+ * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
+ * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).
+ *                           Returns the text length (excluding the terminating NUL), or a negative status;
+ *                           at most out_cap-1 bytes are written.
+ * msh_host_sanitize_utf8  : invalid UTF-8 bytes -> '?' (reference core/transcriber.cpp:1489-1543); same return rule.
+ * msh_host_resample       : box-filter down / linear up (reference core/resampler.cpp:5-86); returns the output
+ *                           sample count (call with out == NULL to size the buffer). */
+MSH_EXPORT int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const int32_t* ids,
+                                           uint64_t n_ids, char* out, uint64_t out_cap);
+MSH_EXPORT int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap);
+MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out,
+                                     uint64_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,318 @@
+// The exported moonshine_* C API (include/moonshine-c-api.h): handle map, option parsing and the
+// exception barrier, following the conventions of reference core/moonshine-c-api.cpp:74-80 (handle check),
+// :87-97 (option names lower-cased), :129-198 (recognised options; unknown names fail the load),
+// :200-216 (int32 handles into a process-global map), :439-446 (exceptions -> MOONSHINE_ERROR_UNKNOWN).
+#include "../../include/moonshine-c-api.h"
+#include "../../include/moonshine_hip.h"
+
+#include <inttypes.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_utils.h"
+#include "transcriber.h"
+
+using namespace msh_host;
+
+namespace {
+
+typedef std::vector<std::pair<std::string, std::string>> OptionList;
+bool g_log_api_calls = false;
+
+OptionList read_options(const moonshine_option_t* options, uint64_t count) {
+  OptionList out;
+  for (uint64_t i = 0; i < count; ++i) {
+    if (options[i].name == nullptr || options[i].value == nullptr) throw std::runtime_error("option with null name or value");
+    out.emplace_back(to_lower(options[i].name), options[i].value);
+  }
+  return out;
+}
+
+// Options the reference accepts for features this build does not have.  They are accepted when they
+// ask for the default (feature off) and refused otherwise, so a caller never silently loses a feature.
+void require_off(const std::string& name, const std::string& value) {
+  if (parse_bool(value))
+    throw std::runtime_error("option '" + name + "' needs a component that is not part of the MI355X build");
+}
+
+void apply_options(const OptionList& options, TranscriberOptions* o) {
+  for (const auto& kv : options) {
+    const std::string& k = kv.first;
+    const std::string& v = kv.second;
+    if (k == "log_api_calls") g_log_api_calls = parse_bool(v);
+    else if (k == "skip_transcription") o->model_source = TranscriberOptions::NONE;
+    else if (k == "transcription_interval") o->transcription_interval = parse_float(v);
+    else if (k == "vad_threshold") o->vad_threshold = parse_float(v);
+    else if (k == "vad_window_duration") o->vad_window_duration = parse_float(v);
+    else if (k == "vad_hop_size") o->vad_hop_size = parse_int32(v);
+    else if (k == "vad_look_behind_sample_count") o->vad_look_behind_sample_count = parse_size(v);
+    else if (k == "vad_max_segment_duration") o->vad_max_segment_duration = parse_float(v);
+    else if (k == "max_tokens_per_second") o->max_tokens_per_second = parse_float(v);
+    else if (k == "decode_incomplete_lines") o->decode_incomplete_lines = parse_bool(v);
+    else if (k == "return_audio_data") o->return_audio_data = parse_bool(v);
+    else if (k == "log_output_text") o->log_output_text = parse_bool(v);
+    else if (k == "log_ort_run") o->log_ort_run = parse_bool(v);
+    else if (k == "save_input_wav_path") o->save_input_wav_path = v;
+    else if (k == "device") o->device = parse_int32(v);
+    else if (k == "use_speculative_decoding") (void)parse_bool(v);  // streaming architectures only
+    else if (k == "word_timestamps" || k == "identify_speakers") require_off(k, v);
+    else if (k == "keyterms" || k == "context") {
+      if (!trim(v).empty()) throw std::runtime_error("option '" + k + "' only applies to the streaming architectures");
+    } else if (k == "keyterm_boost" || k == "context_max_terms" || k == "diarization_cluster_cadence" ||
+               k == "diarization_analyze_cadence" || k == "diarization_cluster_window_sec" ||
+               k == "diarization_model_dir" || k == "coreml_cache_dir") {
+      // tuning knobs of features that are off: nothing to do
+    } else if (k == "ort_providers" || k == "ort_provider") {
+      // there is no ONNX Runtime here; the only execution target is the MI355X
+    } else if (k == "spelling_model_path") {
+      if (!v.empty()) throw std::runtime_error("option 'spelling_model_path' needs the spelling model, not part of the MI355X build");
+    } else {
+      throw std::runtime_error("Unknown transcriber option: '" + k + "', value=" + v);
+    }
+  }
+}
+
+std::mutex g_map_mutex;
+std::map<int32_t, Transcriber*> g_transcribers;
+int32_t g_next_handle = 0;
+
+int32_t register_transcriber(Transcriber* t) {
+  std::lock_guard<std::mutex> lock(g_map_mutex);
+  const int32_t h = g_next_handle++;
+  g_transcribers[h] = t;
+  return h;
+}
+
+Transcriber* lookup(int32_t handle) {
+  std::lock_guard<std::mutex> lock(g_map_mutex);
+  auto it = g_transcribers.find(handle);
+  return (handle < 0 || it == g_transcribers.end()) ? nullptr : it->second;
+}
+
+template <class F>
+int32_t with_transcriber(int32_t handle, const char* what, F&& f) {
+  Transcriber* t = lookup(handle);
+  if (t == nullptr) {
+    MSH_LOGF("Moonshine transcriber handle is invalid: handle %d", handle);
+    return MOONSHINE_ERROR_INVALID_HANDLE;
+  }
+  try {
+    return f(t);
+  } catch (const std::exception& e) {
+    MSH_LOGF("Failed to %s: %s", what, e.what());
+    return MOONSHINE_ERROR_UNKNOWN;
+  }
+}
+
+int32_t load_common(TranscriberOptions& o, const moonshine_option_t* options, uint64_t options_count) {
+  try {
+    if (options_count > 0 && options == nullptr) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    apply_options(read_options(options, options_count), &o);
+    return register_transcriber(new Transcriber(o));
+  } catch (const std::exception& e) {
+    MSH_LOGF("Failed to load transcriber: %s", e.what());
+    return MOONSHINE_ERROR_UNKNOWN;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t moonshine_get_version(void) { return MOONSHINE_HEADER_VERSION; }
+
+const char* moonshine_error_to_string(int32_t error) {
+  switch (error) {
+    case MOONSHINE_ERROR_NONE: return "Success";
+    case MOONSHINE_ERROR_INVALID_HANDLE: return "Invalid handle";
+    case MOONSHINE_ERROR_INVALID_ARGUMENT: return "Invalid argument";
+    default: return "Unknown error";
+  }
+}
+
+void moonshine_free_buffer(void* ptr) { free(ptr); }
+
+const char* moonshine_transcript_to_string(const struct transcript_t* transcript) {
+  static std::string description;  // static buffer, like the reference (core/moonshine-c-api.cpp:560-562)
+  description = transcript == nullptr ? std::string("<null transcript>") : Transcriber::transcript_to_string(transcript);
+  return description.c_str();
+}
+
+int32_t moonshine_transcriber_set_keyterms(int32_t handle, const char* keyterms) {
+  return with_transcriber(handle, "set keyterms", [&](Transcriber*) -> int32_t {
+    if (keyterms == nullptr || trim(keyterms).empty()) return MOONSHINE_ERROR_NONE;  // turning biasing off is a no-op
+    throw std::runtime_error("keyterm biasing only applies to the streaming architectures");
+  });
+}
+
+int32_t moonshine_transcriber_set_context(int32_t handle, const char* context, int32_t /*max_terms*/) {
+  return with_transcriber(handle, "set context", [&](Transcriber*) -> int32_t {
+    if (context == nullptr || trim(context).empty()) return MOONSHINE_ERROR_NONE;
+    throw std::runtime_error("context biasing only applies to the streaming architectures");
+  });
+}
+
+int32_t moonshine_load_transcriber_from_files(const char* path, uint32_t model_arch, const moonshine_option_t* options,
+                                              uint64_t options_count, int32_t moonshine_version) {
+  if (g_log_api_calls)
+    MSH_LOGF("moonshine_load_transcriber_from_files(path=%s, model_arch=%u, options_count=%" PRIu64 ", version=%d)",
+             path ? path : "(null)", model_arch, options_count, moonshine_version);
+  TranscriberOptions o;
+  o.model_source = TranscriberOptions::FILES;
+  o.model_path = path ? path : "";
+  o.model_arch = model_arch;
+  return load_common(o, options, options_count);
+}
+
+int32_t moonshine_load_transcriber_from_memory(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, size_t,
+                                               const uint8_t*, size_t, uint32_t, const moonshine_option_t*, uint64_t,
+                                               int32_t moonshine_version) {
+  // The fixed encoder/decoder/tokenizer triple describes ORT graphs.  Callers built against >= 3.0.0 get the
+  // reference's answer (core/moonshine-c-api.cpp:313-320); older ones are told the same thing.
+  MSH_LOGF("moonshine_load_transcriber_from_memory() is not supported (caller version %d): use "
+           "moonshine_load_transcriber_from_memory_files() with model.safetensors + tokenizer.bin",
+           moonshine_version);
+  return MOONSHINE_ERROR_INVALID_ARGUMENT;
+}
+
+int32_t moonshine_load_transcriber_from_memory_files(const char** filenames, const uint8_t** memory,
+                                                     const uint64_t* memory_sizes, uint64_t file_count,
+                                                     uint32_t model_arch, const moonshine_option_t* options,
+                                                     uint64_t options_count, int32_t /*moonshine_version*/) {
+  if (file_count > 0 && (filenames == nullptr || memory == nullptr || memory_sizes == nullptr))
+    return MOONSHINE_ERROR_INVALID_ARGUMENT;
+  TranscriberOptions o;
+  o.model_source = TranscriberOptions::MEMORY_FILES;
+  o.model_arch = model_arch;
+  for (uint64_t i = 0; i < file_count; ++i) {
+    if (filenames[i] == nullptr) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    const std::string key(filenames[i]);
+    if (key != "model.safetensors" && key != "tokenizer.bin") {
+      MSH_LOGF("moonshine_load_transcriber_from_memory_files(): '%s' is not a model asset this loader recognizes. "
+               "Canonical filenames: model.safetensors, tokenizer.bin",
+               key.c_str());
+      return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    }
+    o.memory_files[key] = std::make_pair(memory[i], (size_t)memory_sizes[i]);
+  }
+  return load_common(o, options, options_count);
+}
+
+void moonshine_free_transcriber(int32_t handle) {
+  Transcriber* t = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_map_mutex);
+    auto it = g_transcribers.find(handle);
+    if (it == g_transcribers.end()) return;
+    t = it->second;
+    g_transcribers.erase(it);
+  }
+  delete t;
+}
+
+int32_t moonshine_transcribe_without_streaming(int32_t handle, float* audio_data, uint64_t audio_length,
+                                               int32_t sample_rate, uint32_t flags, struct transcript_t** out) {
+  if (g_log_api_calls)
+    MSH_LOGF("moonshine_transcribe_without_streaming(handle=%d, audio_length=%" PRIu64 ", sample_rate=%d, flags=%u)", handle,
+             audio_length, sample_rate, flags);
+  return with_transcriber(handle, "transcribe without streaming", [&](Transcriber* t) -> int32_t {
+    if (audio_data == nullptr && audio_length > 0) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    t->transcribe_without_streaming(audio_data, audio_length, sample_rate, flags, out);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_transcribe_batch_without_streaming(int32_t handle, const float* const* audio_data,
+                                                     const uint64_t* audio_lengths, uint64_t count, int32_t sample_rate,
+                                                     uint32_t flags, struct transcript_t** out_transcripts) {
+  return with_transcriber(handle, "transcribe batch", [&](Transcriber* t) -> int32_t {
+    if (count > 0 && (audio_data == nullptr || audio_lengths == nullptr || out_transcripts == nullptr))
+      return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < count; ++i)
+      if (audio_data[i] == nullptr && audio_lengths[i] > 0) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    t->transcribe_batch_without_streaming(audio_data, audio_lengths, count, sample_rate, flags, out_transcripts);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_create_stream(int32_t handle, uint32_t /*flags*/) {
+  return with_transcriber(handle, "create stream", [&](Transcriber* t) -> int32_t { return t->create_stream(); });
+}
+
+int32_t moonshine_free_stream(int32_t handle, int32_t stream) {
+  return with_transcriber(handle, "free stream", [&](Transcriber* t) -> int32_t {
+    t->free_stream(stream);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_start_stream(int32_t handle, int32_t stream) {
+  return with_transcriber(handle, "start stream", [&](Transcriber* t) -> int32_t {
+    t->start_stream(stream);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_stop_stream(int32_t handle, int32_t stream) {
+  return with_transcriber(handle, "stop stream", [&](Transcriber* t) -> int32_t {
+    t->stop_stream(stream);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_transcribe_add_audio_to_stream(int32_t handle, int32_t stream, const float* new_audio_data,
+                                                 uint64_t audio_length, int32_t sample_rate, uint32_t /*flags*/) {
+  return with_transcriber(handle, "add audio to stream", [&](Transcriber* t) -> int32_t {
+    if (new_audio_data == nullptr && audio_length > 0) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    t->add_audio_to_stream(stream, new_audio_data, audio_length, sample_rate);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+int32_t moonshine_transcribe_stream(int32_t handle, int32_t stream, uint32_t flags, struct transcript_t** out) {
+  return with_transcriber(handle, "transcribe stream", [&](Transcriber* t) -> int32_t {
+    t->transcribe_stream(stream, flags, out);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
+// ---- host helpers (include/moonshine_hip.h) ----
+static int64_t copy_out(const std::string& r, char* out, uint64_t cap) {
+  if (out != nullptr && cap > 0) {
+    const size_t n = r.size() < cap - 1 ? r.size() : (size_t)cap - 1;
+    memcpy(out, r.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)r.size();
+}
+
+int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const int32_t* ids, uint64_t n_ids,
+                                char* out, uint64_t out_cap) {
+  try {
+    BinTokenizer tok(tokenizer_bin, (size_t)tokenizer_size);
+    return copy_out(tok.tokens_to_text(ids, (size_t)n_ids), out, out_cap);
+  } catch (const std::exception& e) {
+    MSH_LOGF("tokens_to_text failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap) {
+  if (text == nullptr && n > 0) return MSH_ERR_INVALID_ARGUMENT;
+  return copy_out(sanitize_utf8(std::string(text ? text : "", (size_t)n)), out, out_cap);
+}
+
+int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out, uint64_t out_cap) {
+  if (in == nullptr && n > 0) return MSH_ERR_INVALID_ARGUMENT;
+  std::vector<float> r = resample(std::vector<float>(in, in + n), in_rate, out_rate);
+  if (out != nullptr) memcpy(out, r.data(), sizeof(float) * (r.size() < out_cap ? r.size() : (size_t)out_cap));
+  return (int64_t)r.size();
+}
+
+}  // extern "C"

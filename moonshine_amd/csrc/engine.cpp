@@ -609,7 +609,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
   const bool eager = prof_on_ || logits_out != nullptr || !use_graph_;
   int ngroups = 1;
   if (!eager) {
-    ngroups = dec_groups_ > 0 ? dec_groups_ : (Mtot >= 192 ? 4 : (Mtot >= 64 ? 2 : 1));
+    ngroups = dec_groups_ > 0 ? dec_groups_ : 1;  // measured: extra streams only add per-kernel fixed cost
     if (ngroups > Mtot) ngroups = Mtot;
   }
   while ((int)groups_.size() < ngroups) {

@@ -16,6 +16,7 @@ namespace msh {
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -268,53 +269,78 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decode cross-attention: one wave per (clip, head), K^T / V^T streamed with 16-byte loads
+// Decode cross-attention: one workgroup per (clip, head); its 4 waves split the head dim.
+//
+// K^T / V^T are [dh][Tk] bf16 (keys contiguous).  Lane l owns keys 8l..8l+7 of a 512-key chunk and
+// streams 16 B per row; wave w covers rows d in [w*dh/4, (w+1)*dh/4): partial q.k sums are combined
+// through LDS (fixed order), every wave then runs the same fp32 online softmax and accumulates its own
+// dh/4 output dims, reduced across lanes at the end.  Each wave issues 2*dh/4 independent 16-B loads per
+// chunk -- short enough to be latency-friendly at batch 1 and, with 4x more waves in flight than a
+// one-wave-per-head layout, enough bytes in flight to stream at HBM rate at batch 256.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void dec_cross_attention_kernel(const float* __restrict__ q,
+__global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float* __restrict__ q,
                                                                   const bf16_t* __restrict__ KT,
                                                                   const bf16_t* __restrict__ VT,
-                                                                  const ClipMeta* __restrict__ clips, int M, int D,
+                                                                  const ClipMeta* __restrict__ clips, int D,
                                                                   int heads, bf16_t* __restrict__ out) {
-  __shared__ float red[4][DH][65];
+  constexpr int DQ = DH / 4;
+  __shared__ float sp[4][512];
+  __shared__ float red[4][DQ][65];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int pair = blockIdx.x * 4 + wave;
-  if (pair >= M * heads) return;
-  const int b = pair / heads, h = pair - b * heads;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const ClipMeta cm = clips[b];
   const int T = cm.T, Tk = cm.Tk;
-  const float* qp = q + (long)b * D + h * DH;
-  const long off = (long)cm.kv_start * D + (long)(h * DH) * Tk;
-  const bf16_t* kt = KT + off;
-  const bf16_t* vt = VT + off;
+  const float* qp = q + (long)b * D + h * DH + wave * DQ;
+  const long off = (long)cm.kv_start * D + (long)(h * DH + wave * DQ) * Tk;
+  // buffer descriptors over this wave's dh/4 rows: row d sits at scalar offset d*Tk*2, the lane's keys at
+  // one shared 32-bit vector offset -> no per-row 64-bit addresses in VGPRs; reads past the last row return 0
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(KT + off), 0, DQ * Tk * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VT + off), 0, DQ * Tk * 2, 0x00020000);
   const float c = rsqrtf((float)DH) * kLog2e;
 
-  float opart[DH];
+  float qd[DQ];
 #pragma unroll
-  for (int d = 0; d < DH; ++d) opart[d] = 0.f;
+  for (int d = 0; d < DQ; ++d) qd[d] = qp[d];
+  float opart[DQ];
+#pragma unroll
+  for (int d = 0; d < DQ; ++d) opart[d] = 0.f;
   float m_run = -INFINITY, l_part = 0.f;
 
+#pragma unroll 1
   for (int k0 = 0; k0 < Tk; k0 += 512) {
     const int key = k0 + lane * 8;
     const bool in = key < Tk;
+    u32x4 kr[DQ], vr[DQ];
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Tk * 2, 0);
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    if (in) {
+    {
 #pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        const uint4 u = *reinterpret_cast<const uint4*>(kt + (long)d * Tk + key);
-        const float qd = qp[d];
-        s[0] += qd * bf_lo(u.x); s[1] += qd * bf_hi(u.x);
-        s[2] += qd * bf_lo(u.y); s[3] += qd * bf_hi(u.y);
-        s[4] += qd * bf_lo(u.z); s[5] += qd * bf_hi(u.z);
-        s[6] += qd * bf_lo(u.w); s[7] += qd * bf_hi(u.w);
+      for (int d = 0; d < DQ; ++d) {
+        const u32x4 u = kr[d];
+        s[0] += qd[d] * bf_lo(u.x); s[1] += qd[d] * bf_hi(u.x);
+        s[2] += qd[d] * bf_lo(u.y); s[3] += qd[d] * bf_hi(u.y);
+        s[4] += qd[d] * bf_lo(u.z); s[5] += qd[d] * bf_hi(u.z);
+        s[6] += qd[d] * bf_lo(u.w); s[7] += qd[d] * bf_hi(u.w);
       }
     }
+    // the V rows are requested only now (K registers are dead): they fly during the score exchange
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) vr[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Tk * 2, 0);
+    if (k0 > 0) __syncthreads();  // previous chunk's partial scores fully consumed
+    *reinterpret_cast<float4*>(&sp[wave][lane * 8]) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(&sp[wave][lane * 8 + 4]) = make_float4(s[4], s[5], s[6], s[7]);
+    __syncthreads();
     float mloc = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      s[e] = (in && key + e < T) ? s[e] * c : -INFINITY;
+      const int i = lane * 8 + e;
+      const float t = (sp[0][i] + sp[1][i]) + (sp[2][i] + sp[3][i]);
+      s[e] = (in && key + e < T) ? t * c : -INFINITY;
       mloc = fmaxf(mloc, s[e]);
     }
     mloc = wave_max(mloc);
@@ -328,28 +354,25 @@ __global__ __launch_bounds__(256) void dec_cross_attention_kernel(const float* _
       psum += s[e];
     }
     l_part = l_part * alpha + psum;
-    if (in) {
+    {
 #pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        const uint4 u = *reinterpret_cast<const uint4*>(vt + (long)d * Tk + key);
+      for (int d = 0; d < DQ; ++d) {
+        const u32x4 u = vr[d];
         const float part = s[0] * bf_lo(u.x) + s[1] * bf_hi(u.x) + s[2] * bf_lo(u.y) + s[3] * bf_hi(u.y) +
                            s[4] * bf_lo(u.z) + s[5] * bf_hi(u.z) + s[6] * bf_lo(u.w) + s[7] * bf_hi(u.w);
         opart[d] = opart[d] * alpha + part;
       }
-    } else {
-#pragma unroll
-      for (int d = 0; d < DH; ++d) opart[d] *= alpha;
     }
   }
   const float l = wave_sum(l_part);
 #pragma unroll
-  for (int d = 0; d < DH; ++d) red[wave][d][lane] = opart[d];
+  for (int d = 0; d < DQ; ++d) red[wave][d][lane] = opart[d];
   __builtin_amdgcn_wave_barrier();
-  if (lane < DH) {
+  if (lane < DQ) {
     float acc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
-    out[(long)b * D + h * DH + lane] = f32_to_bf16(acc / l);
+    out[(long)b * D + h * DH + wave * DQ + lane] = f32_to_bf16(acc / l);
   }
 }
 
@@ -383,11 +406,11 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                          int heads, bf16_t* out, hipStream_t s) {
   const int dh = D / heads;
-  dim3 grid((M * heads + 3) / 4);
+  dim3 grid(M * heads);
   switch (dh) {
-    case 52: hipLaunchKernelGGL(dec_cross_attention_kernel<52>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
-    case 36: hipLaunchKernelGGL(dec_cross_attention_kernel<36>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
-    case 16: hipLaunchKernelGGL(dec_cross_attention_kernel<16>, grid, dim3(256), 0, s, q, KT, VT, clips, M, D, heads, out); break;
+    case 52: hipLaunchKernelGGL(dec_cross_attention_kernel<52>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
+    case 36: hipLaunchKernelGGL(dec_cross_attention_kernel<36>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
+    case 16: hipLaunchKernelGGL(dec_cross_attention_kernel<16>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
     default: throw std::runtime_error("dec_cross_attention: unsupported head_dim " + std::to_string(dh));
   }
 }

@@ -23,7 +23,23 @@
 namespace msh {
 namespace {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output rounding): one v_exp,
+// one v_rcp and a degree-5 Horner chain instead of libm's branchy erff (which cost as much as the
+// K = 416 main loop in the fc1 epilogue).
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly (e^{2x} -> inf gives 1, -> 0 gives -1)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -33,7 +49,7 @@ struct EpiTanhF32 {
   float* out;
   long ldc;
   __device__ void n4(int m, int n, f32x4 v) const {
-    float4 o = make_float4(tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3]));
+    float4 o = make_float4(tanh_fast(v[0]), tanh_fast(v[1]), tanh_fast(v[2]), tanh_fast(v[3]));
     *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
   }
 };
@@ -101,6 +117,20 @@ struct EpiResidF32 {
   float* H;
   long ldc;
   const float* bias;  // nullable
+  // decode path: the old residual value and the bias are fetched before the GEMM, not after it
+  struct Pre {
+    float4 h, b;
+  };
+  __device__ Pre pre(int m, int n) const {
+    Pre p;
+    p.h = *reinterpret_cast<const float4*>(H + (long)m * ldc + n);
+    p.b = bias != nullptr ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    *reinterpret_cast<float4*>(H + (long)m * ldc + n) =
+        make_float4(p.h.x + p.b.x + v[0], p.h.y + p.b.y + v[1], p.h.z + p.b.z + v[2], p.h.w + p.b.w + v[3]);
+  }
   __device__ void n4(int m, int n, f32x4 v) const {
     float4* p = reinterpret_cast<float4*>(H + (long)m * ldc + n);
     float4 h = *p;
@@ -154,6 +184,48 @@ struct EpiDecQkv {
   const int* pos_ptr;
   RopeParams rp;
   int Smax;
+  struct Pre {
+    int pos;
+    float c0, s0, c1, s1;
+  };
+  __device__ Pre pre(int /*m*/, int n) const {
+    Pre p;
+    p.pos = *pos_ptr;
+    const int d = (n % rp.hidden) % rp.head_dim, j0 = d >> 1;
+    p.c0 = p.c1 = 1.f;
+    p.s0 = p.s1 = 0.f;
+    if (n < 2 * rp.hidden) {  // q / k: rotation factors of the lane's two pairs (identity beyond rot_pairs)
+      if (j0 < rp.rot_pairs) {
+        p.c0 = rp.cos[(long)p.pos * rp.rot_pairs + j0];
+        p.s0 = rp.sin[(long)p.pos * rp.rot_pairs + j0];
+      }
+      if (j0 + 1 < rp.rot_pairs) {
+        p.c1 = rp.cos[(long)p.pos * rp.rot_pairs + j0 + 1];
+        p.s1 = rp.sin[(long)p.pos * rp.rot_pairs + j0 + 1];
+      }
+    }
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    const int D = rp.hidden, dh = rp.head_dim;
+    const int which = n / D;
+    const int c = n - which * D;
+    const int h = c / dh, d = c - h * dh;
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    v[0] = x0 * p.c0 - x1 * p.s0;
+    v[1] = x1 * p.c0 + x0 * p.s0;
+    v[2] = x2 * p.c1 - x3 * p.s1;
+    v[3] = x3 * p.c1 + x2 * p.s1;
+    if (which == 0) {
+      *reinterpret_cast<float4*>(q + (long)m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      bf16_t* dst = (which == 1 ? cacheK : cacheV) + (((long)m * (D / dh) + h) * Smax + p.pos) * dh + d;
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst) = o;
+    }
+  }
   __device__ void n4(int m, int n, f32x4 v) const {
     const int D = rp.hidden, dh = rp.head_dim;
     const int pos = *pos_ptr;
@@ -176,6 +248,9 @@ struct EpiDecQkv {
 struct EpiF32 {
   float* out;
   long ldc;
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
   __device__ void n4(int m, int n, f32x4 v) const {
     *reinterpret_cast<float4*>(out + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -186,6 +261,15 @@ struct EpiSwiGLU {
   bf16_t* z;
   long ldz;  // F
   const float* bias;
+  struct Pre {
+    float4 b;
+  };
+  __device__ Pre pre(int, int n) const { return Pre{*reinterpret_cast<const float4*>(bias + n)}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    const float val0 = v[0] + p.b.x, gate0 = v[1] + p.b.y, val1 = v[2] + p.b.z, gate1 = v[3] + p.b.w;
+    uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
+    *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
+  }
   __device__ void n4(int m, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     const float val0 = v[0] + b.x, gate0 = v[1] + b.y, val1 = v[2] + b.z, gate1 = v[3] + b.w;
@@ -420,24 +504,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
     __builtin_amdgcn_s_barrier();              // every wave's pieces of slice kt have landed; slice kt-1 is consumed
     if (kt + AHEAD < nk) issue(kt + AHEAD);
     const uint4* st = lds + (kt % NSTAGE) * STAGE_SLOTS;
-    bf16x8 af[TM];
+    // all fragment reads of the k-slice are issued before the first MFMA: one LDS latency per slice
+    // instead of one per column tile (the two waves of a SIMD then cover each other's read phase)
+    uint4 afr[TM], bfr[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wave * 16 * TM + i * 16 + li;
-      uint4 t = st[row * 4 + (kg ^ swz(row))];
-      af[i] = *reinterpret_cast<bf16x8*>(&t);
+      afr[i] = st[row * 4 + (kg ^ swz(row))];
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = j * 16 + li;
-      uint4 t = st[BM * 4 + row * 4 + (kg ^ swz(row))];
-      bf16x8 bf = *reinterpret_cast<bf16x8*>(&t);
+      bfr[j] = st[BM * 4 + row * 4 + (kg ^ swz(row))];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (SWAP)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&bfr[j]),
+                                                               *reinterpret_cast<bf16x8*>(&afr[i]), acc[i][j], 0, 0, 0);
         else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&afr[i]),
+                                                               *reinterpret_cast<bf16x8*>(&bfr[j]), acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -495,7 +585,7 @@ template <bool SWAP, class Epi>
 void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((K & 31) != 0 || (N & 3) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_tiled: unsupported shape");
   const bool big = (long)((M + 255) / 256) * ((N + 207) / 208) >= 512;
-  if (N % 208 == 0) {
+  if (N % 208 == 0 || (N % 144 != 0 && N >= 416)) {  // ragged last column tile (e.g. the 32768-wide LM head) is predicated
     const int mode = gemm_mode();
     if (mode == 0) {
       if (big)
@@ -555,10 +645,32 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
       }
     }
   }
+  // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors): fetched now so
+  // that the kernel has ONE memory round trip on its critical path, not one per dependent stage
+  constexpr int NE = (TN + 3) / 4;
+  typename Epi::Pre epre[NE];
+  {
+    const int m = m0 + li;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int j = wave + 4 * e;
+      const int n = n0 + j * 16 + kg * 4;
+      if (j < TN && m < M && n < N) epre[e] = epi.pre(m, n);
+    }
+  }
   bf16x8 afrag[KW];
   if constexpr (LN) {
     const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
     float xv[KW][8];
+    float4 gam[KW][2];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        gam[i][0] = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8);
+        gam[i][1] = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8 + 4);
+      }
+    }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < KW; ++i) {
@@ -598,8 +710,7 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
     for (int i = 0; i < KW; ++i) {
       const int s = wave + 4 * i;
       if (s < KS) {
-        const float4 g0 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8);
-        const float4 g1 = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8 + 4);
+        const float4 g0 = gam[i][0], g1 = gam[i][1];
         uint4 t;
         t.x = pack_bf16x2((xv[i][0] - mean) * rstd * g0.x, (xv[i][1] - mean) * rstd * g0.y);
         t.y = pack_bf16x2((xv[i][2] - mean) * rstd * g0.z, (xv[i][3] - mean) * rstd * g0.w);
@@ -637,15 +748,19 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
   __syncthreads();
   // waves 0..TN-1 (round-robin when TN > 4) finish one column tile each: fixed summation order
   const int m = m0 + li;
-  for (int j = wave; j < TN; j += 4) {
-    const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
-    f32x4 v;
-    v[0] = (p0.x + p1.x) + (p2.x + p3.x);
-    v[1] = (p0.y + p1.y) + (p2.y + p3.y);
-    v[2] = (p0.z + p1.z) + (p2.z + p3.z);
-    v[3] = (p0.w + p1.w) + (p2.w + p3.w);
-    const int n = n0 + j * 16 + kg * 4;
-    if (m < M && n < N) epi.n4(m, n, v);
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int j = wave + 4 * e;
+    if (j < TN) {
+      const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
+      f32x4 v;
+      v[0] = (p0.x + p1.x) + (p2.x + p3.x);
+      v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+      v[2] = (p0.z + p1.z) + (p2.z + p3.z);
+      v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+      const int n = n0 + j * 16 + kg * 4;
+      if (m < M && n < N) epi.n4p(m, n, v, epre[e]);
+    }
   }
 }
 

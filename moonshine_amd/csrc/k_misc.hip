@@ -171,12 +171,12 @@ __global__ void decode_begin_kernel(int M, DecodeState st, int bos, const float*
 // One block per clip: first-max argmax (strict '>' scan order, ties -> lowest index, the rule of
 // reference core/ort-utils/moonshine-tensor-view.cpp:222-236), then the loop bookkeeping of
 // reference core/moonshine-model.cpp:511-516 (append, stop on EOS / step budget, next input id).
-__global__ __launch_bounds__(256) void decode_advance_kernel(const float* __restrict__ logits, int V,
+__global__ __launch_bounds__(1024) void decode_advance_kernel(const float* __restrict__ logits, int V,
                                                              const ClipMeta* __restrict__ clips, DecodeState st,
                                                              const float* __restrict__ embed, int D,
                                                              float* __restrict__ H) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
+  __shared__ float bv[16];
+  __shared__ int bi[16];
   __shared__ int next_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
   const bool done = st.finished[b] != 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const float* __rest
     const float4* lp = reinterpret_cast<const float4*>(logits + (long)b * V);
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    for (int i = tid; i < (V >> 2); i += 256) {
+    for (int i = tid; i < (V >> 2); i += 1024) {
       const float4 v = lp[i];
       const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const float* __rest
     }
     __syncthreads();
     if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
+      for (int w = 1; w < 16; ++w)
         if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
           best = bv[w];
           besti = bi[w];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const float* __rest
     }
     __syncthreads();
     const int nt = next_tok;
-    for (int d = tid; d < D; d += 256) H[(long)b * D + d] = embed[(long)nt * D + d];
+    for (int d = tid; d < D; d += 1024) H[(long)b * D + d] = embed[(long)nt * D + d];
   }
   if (b == 0 && tid == 0) *st.pos += 1;
 }
@@ -281,7 +281,7 @@ void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D,
 
 void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, DecodeState st, const float* embed_f32,
                     int D, float* H, hipStream_t s) {
-  hipLaunchKernelGGL(decode_advance_kernel, dim3(M), dim3(256), 0, s, logits, V, clips, st, embed_f32, D, H);
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(M), dim3(1024), 0, s, logits, V, clips, st, embed_f32, D, H);
 }
 
 }  // namespace msh

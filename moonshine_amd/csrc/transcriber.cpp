@@ -1,0 +1,458 @@
+#include "transcriber.h"
+
+#include <math.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <random>
+#include <stdexcept>
+
+#include "host_utils.h"
+
+namespace msh_host {
+
+// ------------------------------------------------------------------------------------------------
+// MoonshineModel
+// ------------------------------------------------------------------------------------------------
+MoonshineModel::MoonshineModel(bool log_run, float mtps, int device) : max_tokens_per_second(mtps), log_ort_run(log_run) {
+  const int32_t rc = msh_create(device, &engine);
+  if (rc != MSH_OK) {
+    const std::string why = msh_last_error(nullptr);
+    throw std::runtime_error("cannot create the MI355X engine (status " + std::to_string(rc) + "): " + why);
+  }
+}
+
+MoonshineModel::~MoonshineModel() {
+  msh_destroy(engine);
+  delete tokenizer;
+}
+
+std::string MoonshineModel::error() const { return msh_last_error(engine); }
+
+int MoonshineModel::load(const char* weights_path, const char* tokenizer_path, int32_t model_type) {
+  if (weights_path == nullptr || tokenizer_path == nullptr) return 1;
+  if (msh_load_weights_file(engine, weights_path, model_type) != MSH_OK) {
+    MSH_LOGF("Failed to load weights from '%s': %s", weights_path, error().c_str());
+    return 1;
+  }
+  tokenizer = BinTokenizer::from_file(tokenizer_path);
+  return 0;
+}
+
+int MoonshineModel::load_from_memory(const uint8_t* weights, size_t weights_size, const uint8_t* tokenizer_data,
+                                     size_t tokenizer_size, int32_t model_type) {
+  if (weights == nullptr || tokenizer_data == nullptr) return 1;
+  if (msh_load_weights_memory(engine, weights, weights_size, model_type) != MSH_OK) {
+    MSH_LOGF("Failed to load weights from memory: %s", error().c_str());
+    return 1;
+  }
+  tokenizer = new BinTokenizer(tokenizer_data, tokenizer_size);
+  return 0;
+}
+
+int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, const std::vector<size_t>& n_samples,
+                                     std::vector<std::string>* out_texts) {
+  std::lock_guard<std::mutex> lock(processing_mutex);
+  const uint32_t count = (uint32_t)audio.size();
+  out_texts->assign(count, std::string());
+  if (count == 0) return 0;
+  std::vector<uint64_t> lens(n_samples.begin(), n_samples.end());
+  if (log_ort_run) {
+    msh_profile_reset(engine);
+    msh_profile_enable(engine, 1);
+  }
+  if (msh_encode(engine, audio.data(), lens.data(), count, 0, max_tokens_per_second) != MSH_OK) {
+    MSH_LOGF("encoder failed: %s", error().c_str());
+    return 1;
+  }
+  const int32_t steps = msh_max_decode_steps(engine);
+  const int32_t stride = steps + 1;
+  std::vector<int32_t> tokens((size_t)count * stride), counts(count);
+  if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, tokens.data(), counts.data(), stride) != MSH_OK) {
+    MSH_LOGF("decoder failed: %s", error().c_str());
+    return 1;
+  }
+  if (log_ort_run) {
+    const int32_t n = msh_profile_count(engine);
+    for (int32_t i = 0; i < n; ++i) {
+      msh_profile_entry pe;
+      if (msh_profile_get(engine, i, &pe) == MSH_OK)
+        MSH_LOGF("kernel group %-24s %8.3f ms over %llu launches", pe.name, pe.ms, (unsigned long long)pe.launches);
+    }
+    msh_profile_enable(engine, 0);
+  }
+  for (uint32_t i = 0; i < count; ++i)
+    (*out_texts)[i] = tokenizer->tokens_to_text(tokens.data() + (size_t)i * stride, (size_t)counts[i]);
+  return 0;
+}
+
+int MoonshineModel::transcribe(const float* audio, size_t n, char** out_text) {
+  *out_text = nullptr;
+  if (audio == nullptr || n == 0) {
+    MSH_LOGF("Audio data is nullptr or empty");
+    return 1;
+  }
+  std::vector<std::string> texts;
+  const int rc = transcribe_batch({audio}, {n}, &texts);
+  if (rc != 0) return rc;
+  last_result = texts[0];
+  *out_text = const_cast<char*>(last_result.c_str());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TranscriptOutput
+// ------------------------------------------------------------------------------------------------
+void TranscriptOutput::clear_update_flags() {
+  std::lock_guard<std::mutex> lock(mutex);
+  for (uint64_t id : order) {
+    TranscriberLine& l = lines.at(id);
+    l.just_updated = l.is_new = l.has_text_changed = false;
+  }
+  for (transcript_line_t& l : c_lines) l.is_updated = l.has_text_changed = l.is_new = l.have_speakers_changed = 0;
+}
+
+void TranscriptOutput::add_or_update(TranscriberLine& line) {
+  auto it = lines.find(line.id);
+  if (it != lines.end()) {
+    line.is_new = false;
+    const TranscriberLine& old = it->second;
+    line.has_text_changed = (old.has_text != line.has_text) || (old.has_text && line.has_text && old.text != line.text);
+  } else {
+    line.is_new = true;
+    line.has_text_changed = line.has_text;
+  }
+  lines[line.id] = line;
+}
+
+void TranscriptOutput::rebuild() {
+  std::lock_guard<std::mutex> lock(mutex);
+  c_lines.clear();
+  for (uint64_t id : order) {
+    const TranscriberLine& l = lines[id];
+    transcript_line_t c{};
+    c.text = l.has_text ? l.text.c_str() : nullptr;
+    c.audio_data = l.audio.empty() ? nullptr : l.audio.data();
+    c.audio_data_count = l.audio.size();
+    c.start_time = l.start_time;
+    c.duration = l.duration;
+    c.id = l.id;
+    c.is_complete = l.is_complete;
+    c.is_updated = l.just_updated;
+    c.is_new = l.is_new;
+    c.has_text_changed = l.has_text_changed;
+    c.last_transcription_latency_ms = l.latency_ms;
+    c_lines.push_back(c);
+  }
+  transcript.lines = c_lines.data();
+  transcript.line_count = c_lines.size();
+}
+
+void TranscriptOutput::mark_all_complete() {
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    for (uint64_t id : order) {
+      TranscriberLine& l = lines[id];
+      if (!l.is_complete) {
+        l.is_complete = true;
+        l.just_updated = true;
+      }
+    }
+  }
+  rebuild();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Transcriber
+// ------------------------------------------------------------------------------------------------
+namespace {
+bool is_streaming_arch(uint32_t a) { return a >= MOONSHINE_MODEL_ARCH_TINY_STREAMING && a <= MOONSHINE_MODEL_ARCH_MEDIUM_STREAMING; }
+const char* kWeightsName = "model.safetensors";
+const char* kTokenizerName = "tokenizer.bin";
+bool is_dir_or_file(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0;
+}
+}  // namespace
+
+Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
+  std::random_device rd;  // random 64-bit base for line ids (reference core/transcriber.cpp:112-117)
+  next_line_id_ = ((uint64_t)rd() << 32) | (uint64_t)rd();
+  if (opt_.model_source == TranscriberOptions::NONE) return;
+  if (opt_.model_arch > MOONSHINE_MODEL_ARCH_MEDIUM_STREAMING)
+    throw std::runtime_error("Invalid model architecture: " + std::to_string(opt_.model_arch));
+  if (is_streaming_arch(opt_.model_arch))
+    throw std::runtime_error("streaming model architectures (arch " + std::to_string(opt_.model_arch) +
+                             ") are not supported by the MI355X build yet; use MOONSHINE_MODEL_ARCH_TINY or _BASE");
+  model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
+  if (opt_.model_source == TranscriberOptions::FILES) {
+    if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
+    if (!is_dir_or_file(opt_.model_path))
+      throw std::runtime_error("Model directory does not exist at path '" + opt_.model_path + "'");
+    const std::string tok = join_path(opt_.model_path, kTokenizerName);
+    if (!file_exists(tok)) throw std::runtime_error("Required tokenizer file does not exist at path '" + tok + "'");
+    const std::string wts = join_path(opt_.model_path, kWeightsName);
+    if (!file_exists(wts)) {
+      if (file_exists(join_path(opt_.model_path, "encoder_model.ort")))
+        throw std::runtime_error("'" + opt_.model_path +
+                                 "' holds ONNX Runtime .ort graphs; the MI355X build loads model.safetensors "
+                                 "(HuggingFace Moonshine tensor names) -- see INTEGRATION.md");
+      throw std::runtime_error("Required model file does not exist at path '" + wts + "'");
+    }
+    if (model_->load(wts.c_str(), tok.c_str(), (int32_t)opt_.model_arch) != 0)
+      throw std::runtime_error("Failed to load model from '" + opt_.model_path + "': " + model_->error());
+  } else {
+    auto get = [&](const char* name, std::vector<uint8_t>* owned, const uint8_t** p, size_t* n) {
+      auto it = opt_.memory_files.find(name);
+      if (it == opt_.memory_files.end()) throw std::runtime_error(std::string("Required model asset missing: ") + name);
+      if (it->second.first != nullptr && it->second.second > 0) {
+        *p = it->second.first;
+        *n = it->second.second;
+      } else {  // no buffer: the key is a path
+        if (!read_file(name, owned)) throw std::runtime_error(std::string("cannot read ") + name);
+        *p = owned->data();
+        *n = owned->size();
+      }
+    };
+    std::vector<uint8_t> o1, o2;
+    const uint8_t *w = nullptr, *t = nullptr;
+    size_t wn = 0, tn = 0;
+    get(kWeightsName, &o1, &w, &wn);
+    get(kTokenizerName, &o2, &t, &tn);
+    if (model_->load_from_memory(w, wn, t, tn, (int32_t)opt_.model_arch) != 0)
+      throw std::runtime_error("Failed to load model from memory: " + model_->error());
+  }
+}
+
+Transcriber::~Transcriber() {}
+
+TranscriberStream* Transcriber::new_stream(int32_t id) {
+  const int32_t window = (int32_t)ceilf((opt_.vad_window_duration * kSampleRate) / opt_.vad_hop_size);
+  const size_t max_seg = (size_t)roundf(opt_.vad_max_segment_duration * kSampleRate);
+  TranscriberStream* s = new TranscriberStream();
+  s->vad.reset(new VoiceActivityDetector(opt_.vad_threshold, window, opt_.vad_hop_size, opt_.vad_look_behind_sample_count,
+                                         max_seg));
+  s->id = id;
+  return s;
+}
+
+TranscriberStream* Transcriber::find_stream(int32_t id) {
+  std::lock_guard<std::mutex> lock(streams_mutex_);
+  auto it = streams_.find(id);
+  if (it == streams_.end())
+    throw std::runtime_error("Stream with ID " + std::to_string(id) + " not found in " + std::to_string(streams_.size()) +
+                             " streams");
+  return it->second.get();
+}
+
+void Transcriber::save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush) {
+  if (opt_.save_input_wav_path.empty()) return;
+  const size_t before = s->saved_input.size() / kSampleRate;
+  if (audio != nullptr) {
+    s->saved_input.insert(s->saved_input.end(), audio, audio + n);
+    s->saved_rate = rate;
+  }
+  if (flush || s->saved_input.size() / kSampleRate != before) {
+    mkdir(opt_.save_input_wav_path.c_str(), 0755);
+    const std::string name = s->id == -1 ? "input_batch.wav" : "input_" + std::to_string(s->id) + ".wav";
+    save_wav(join_path(opt_.save_input_wav_path, name), s->saved_input.data(), s->saved_input.size(), s->saved_rate);
+  }
+}
+
+// The per-segment loop of reference core/transcriber.cpp:989-1148, with every model call of the pass
+// gathered into one GPU batch.
+void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& streams,
+                                       const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs) {
+  struct Job {
+    size_t stream, segment;
+  };
+  std::vector<Job> jobs;
+  std::vector<const float*> ptrs;
+  std::vector<size_t> lens;
+  for (size_t si = 0; si < streams.size(); ++si) {
+    streams[si]->out.clear_update_flags();
+    for (size_t gi = 0; gi < segments[si].size(); ++gi) {
+      const VadSegment& seg = segments[si][gi];
+      if (!seg.just_updated || model_ == nullptr) continue;
+      if (!seg.is_complete && !opt_.decode_incomplete_lines) continue;
+      if (seg.audio.size() < 895) continue;  // shorter than the conv stem's receptive field: empty text
+      jobs.push_back({si, gi});
+      ptrs.push_back(seg.audio.data());
+      lens.push_back(seg.audio.size());
+    }
+  }
+  std::vector<std::string> texts;
+  uint32_t latency_ms = 0;
+  if (!jobs.empty()) {
+    std::lock_guard<std::mutex> lock(model_mutex_);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (model_->transcribe_batch(ptrs, lens, &texts) != 0) throw std::runtime_error("Failed to transcribe: " + model_->error());
+    latency_ms = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+  size_t job = 0;
+  for (size_t si = 0; si < streams.size(); ++si) {
+    TranscriberStream* s = streams[si];
+    for (size_t gi = 0; gi < segments[si].size(); ++gi) {
+      const VadSegment& seg = segments[si][gi];
+      if (!seg.just_updated) continue;
+      std::lock_guard<std::mutex> lock(s->out.mutex);
+      TranscriberLine line;
+      line.start_time = seg.start_time;
+      line.duration = seg.end_time - seg.start_time;
+      line.is_complete = seg.is_complete;
+      line.just_updated = true;
+      if (gi >= s->out.order.size()) s->out.order.push_back(next_line_id_.fetch_add(1));
+      line.id = s->out.order.at(gi);
+      if (model_ != nullptr) {
+        line.has_text = true;
+        if (job < jobs.size() && jobs[job].stream == si && jobs[job].segment == gi) {
+          if (opt_.log_output_text) MSH_LOGF("Transcribed text: '%s'", texts[job].c_str());
+          line.text = sanitize_utf8(texts[job]);
+          line.latency_ms = latency_ms;
+          ++job;
+        }
+      }
+      if (opt_.return_audio_data) line.audio = seg.audio;
+      s->out.add_or_update(line);
+    }
+    if (!s->vad->is_active()) s->out.mark_all_complete();
+    s->out.rebuild();
+    if (outs != nullptr && outs[si] == nullptr) outs[si] = &s->out.transcript;
+  }
+}
+
+void Transcriber::transcribe_without_streaming(const float* audio, uint64_t n, int32_t sample_rate, uint32_t /*flags*/,
+                                               transcript_t** out) {
+  std::lock_guard<std::mutex> lock(batch_mutex_);
+  if (!batch_stream_) batch_stream_.reset(new_stream(-1));
+  TranscriberStream* s = batch_stream_.get();
+  save_input(s, audio, n, sample_rate, true);
+  std::vector<std::vector<VadSegment>> segs(1);
+  {
+    std::lock_guard<std::mutex> vl(s->vad_mutex);
+    s->vad->start();
+    {
+      std::lock_guard<std::mutex> ol(s->out.mutex);
+      s->out.lines.clear();
+      s->out.order.clear();
+    }
+    s->vad->process_audio(audio, (size_t)n, sample_rate);
+    s->vad->stop();
+    segs[0] = s->vad->segments();
+  }
+  transcript_t* one = nullptr;
+  update_from_segments({s}, segs, &one);
+  if (out != nullptr) *out = one;
+}
+
+void Transcriber::transcribe_batch_without_streaming(const float* const* audio, const uint64_t* n, uint64_t count,
+                                                     int32_t sample_rate, uint32_t /*flags*/, transcript_t** out) {
+  std::lock_guard<std::mutex> lock(batch_mutex_);
+  batch_streams_.clear();
+  std::vector<TranscriberStream*> streams;
+  std::vector<std::vector<VadSegment>> segs(count);
+  for (uint64_t i = 0; i < count; ++i) {
+    batch_streams_.emplace_back(new_stream(-1));
+    TranscriberStream* s = batch_streams_.back().get();
+    s->vad->start();
+    s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
+    s->vad->stop();
+    segs[i] = s->vad->segments();
+    streams.push_back(s);
+  }
+  std::vector<transcript_t*> outs(count, nullptr);
+  update_from_segments(streams, segs, outs.data());
+  if (out != nullptr)
+    for (uint64_t i = 0; i < count; ++i) out[i] = outs[i];
+}
+
+int32_t Transcriber::create_stream() {
+  std::lock_guard<std::mutex> lock(streams_mutex_);
+  const int32_t id = next_stream_id_++;
+  streams_[id].reset(new_stream(id));
+  return id;
+}
+
+void Transcriber::free_stream(int32_t id) {
+  std::lock_guard<std::mutex> lock(streams_mutex_);
+  streams_.erase(id);
+}
+
+void Transcriber::start_stream(int32_t id) {
+  TranscriberStream* s = find_stream(id);
+  std::lock_guard<std::mutex> ol(s->out.mutex);
+  s->out.lines.clear();
+  s->out.order.clear();
+  s->out.transcript.lines = nullptr;  // earlier pointers handed to the client are invalid from here on
+  s->out.transcript.line_count = 0;
+  s->vad->start();
+}
+
+void Transcriber::stop_stream(int32_t id) {
+  TranscriberStream* s = find_stream(id);
+  s->vad->stop();
+  save_input(s, nullptr, 0, 0, true);
+}
+
+void Transcriber::add_audio_to_stream(int32_t id, const float* audio, uint64_t n, int32_t sample_rate) {
+  TranscriberStream* s = find_stream(id);
+  if (!s->vad->is_active())
+    throw std::runtime_error("Adding new audio for stream with ID " + std::to_string(id) +
+                             " but VAD is not active. Did you call start_stream()?");
+  save_input(s, audio, n, sample_rate, false);
+  std::vector<float> in(audio, audio + n);
+  std::vector<float> r = resample(in, (float)sample_rate, (float)kSampleRate);
+  s->new_audio.insert(s->new_audio.end(), r.begin(), r.end());
+}
+
+// reference core/transcriber.cpp:775-891: only re-run the model when enough new audio has arrived
+// (or on FORCE_UPDATE); otherwise hand back the cached transcript with cleared update flags.
+void Transcriber::transcribe_stream(int32_t id, uint32_t flags, transcript_t** out) {
+  TranscriberStream* s = find_stream(id);
+  const size_t n = s->new_audio.size();
+  const bool has_new = n > 0;
+  const bool long_enough = (float)n / (float)kSampleRate >= opt_.transcription_interval;
+  const bool force = (flags & MOONSHINE_FLAG_FORCE_UPDATE) != 0;
+  if (!((long_enough || force) && has_new)) {
+    s->out.clear_update_flags();
+    if (!s->vad->is_active()) s->out.mark_all_complete();
+    if (out != nullptr) *out = &s->out.transcript;
+    return;
+  }
+  std::vector<std::vector<VadSegment>> segs(1);
+  {
+    std::lock_guard<std::mutex> vl(s->vad_mutex);
+    s->vad->process_audio(s->new_audio.data(), n, kSampleRate);
+    for (const VadSegment& seg : s->vad->segments()) {
+      VadSegment c;
+      c.start_time = seg.start_time;
+      c.end_time = seg.end_time;
+      c.is_complete = seg.is_complete;
+      c.just_updated = seg.just_updated;
+      if (seg.just_updated) c.audio = seg.audio;
+      segs[0].push_back(std::move(c));
+    }
+  }
+  s->new_audio.clear();
+  transcript_t* one = nullptr;
+  update_from_segments({s}, segs, &one);
+  if (out != nullptr) *out = one;
+  if (!opt_.return_audio_data) {
+    std::lock_guard<std::mutex> vl(s->vad_mutex);
+    s->vad->clear_completed_audio();
+  }
+}
+
+std::string Transcriber::transcript_to_string(const transcript_t* t) {
+  std::string r = std::to_string(t->line_count) + " lines\n";
+  for (uint64_t i = 0; i < t->line_count; ++i) {
+    char buf[32];
+    snprintf(buf, sizeof(buf), "%.1fs: ", t->lines[i].start_time);
+    r += buf;
+    r += t->lines[i].text == nullptr ? "<null>" : t->lines[i].text;
+    r += "\n";
+  }
+  return r;
+}
+
+}  // namespace msh_host

@@ -1,0 +1,136 @@
+// Host orchestration above the HIP engine: the MoonshineModel / Transcriber pair of the reference,
+// re-implemented for the MI355X build.
+//
+//   MoonshineModel  mirrors reference core/moonshine-model.h:17-108 (load, load_from_memory, transcribe) --
+//                   the struct the reference's Transcriber drives -- but runs on the engine of
+//                   include/moonshine_hip.h instead of two ORT sessions, and adds transcribe_batch.
+//   Transcriber     mirrors reference core/transcriber.h:231-366 for the offline architectures: VAD
+//                   segmentation -> model call per just-updated segment -> transcript_t assembly, with
+//                   the same line / flag / ownership semantics (core/transcriber.cpp:656-696, 775-891,
+//                   989-1148, 1648-1726).  Segments of one call are decoded as ONE GPU batch.
+#pragma once
+
+#include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/moonshine-c-api.h"
+#include "../../include/moonshine_hip.h"
+#include "host_text_vad.h"
+
+namespace msh_host {
+
+struct MoonshineModel {
+  msh_engine* engine = nullptr;
+  BinTokenizer* tokenizer = nullptr;
+  std::mutex processing_mutex;
+  float max_tokens_per_second = 6.5f;  // reference core/moonshine-model.h:49
+  bool log_ort_run = false;            // here: print per-kernel-group timings after each call
+  std::string last_result;
+
+  MoonshineModel(bool log_ort_run, float max_tokens_per_second, int device);
+  ~MoonshineModel();
+  // model_type: MOONSHINE_MODEL_ARCH_TINY / _BASE.  Both return 0 on success (reference convention).
+  int load(const char* weights_path, const char* tokenizer_path, int32_t model_type);
+  int load_from_memory(const uint8_t* weights, size_t weights_size, const uint8_t* tokenizer_data,
+                       size_t tokenizer_size, int32_t model_type);
+  // One clip -> text; *out_text points into last_result and is valid until the next call
+  // (reference core/moonshine-model.cpp:216-563).
+  int transcribe(const float* audio, size_t n_samples, char** out_text);
+  // Many clips -> texts in one GPU batch (no reference counterpart).
+  int transcribe_batch(const std::vector<const float*>& audio, const std::vector<size_t>& n_samples,
+                       std::vector<std::string>* out_texts);
+  std::string error() const;
+};
+
+struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields this build honours)
+  enum ModelSource { FILES, MEMORY_FILES, NONE };
+  ModelSource model_source = FILES;
+  std::string model_path;
+  uint32_t model_arch = (uint32_t)-1;
+  std::map<std::string, std::pair<const uint8_t*, size_t>> memory_files;  // name -> client buffer
+  float transcription_interval = 0.5f;
+  float vad_threshold = 0.5f;
+  float vad_window_duration = 0.5f;
+  int32_t vad_hop_size = 512;
+  size_t vad_look_behind_sample_count = 8192;
+  float vad_max_segment_duration = 15.0f;
+  float max_tokens_per_second = 6.5f;
+  bool decode_incomplete_lines = true;
+  bool return_audio_data = true;
+  bool log_output_text = false;
+  bool log_ort_run = false;
+  std::string save_input_wav_path;
+  int device = 0;
+};
+
+struct TranscriberLine {
+  bool has_text = false;
+  std::string text;
+  std::vector<float> audio;
+  float start_time = 0.f, duration = 0.f;
+  bool is_complete = false, just_updated = false, is_new = false, has_text_changed = false;
+  uint64_t id = 0;
+  uint32_t latency_ms = 0;
+};
+
+struct TranscriptOutput {
+  std::map<uint64_t, TranscriberLine> lines;
+  std::vector<uint64_t> order;
+  std::vector<transcript_line_t> c_lines;
+  transcript_t transcript{nullptr, 0};
+  std::mutex mutex;
+  void clear_update_flags();
+  void mark_all_complete();
+  void add_or_update(TranscriberLine& line);
+  void rebuild();
+};
+
+struct TranscriberStream {
+  std::unique_ptr<VoiceActivityDetector> vad;
+  std::mutex vad_mutex;
+  TranscriptOutput out;
+  std::vector<float> new_audio;
+  std::vector<float> saved_input;
+  int32_t saved_rate = 0;
+  int32_t id = -1;
+};
+
+class Transcriber {
+ public:
+  explicit Transcriber(const TranscriberOptions& options);
+  ~Transcriber();
+  void transcribe_without_streaming(const float* audio, uint64_t n, int32_t sample_rate, uint32_t flags,
+                                    transcript_t** out);
+  void transcribe_batch_without_streaming(const float* const* audio, const uint64_t* n, uint64_t count,
+                                          int32_t sample_rate, uint32_t flags, transcript_t** out);
+  int32_t create_stream();
+  void free_stream(int32_t id);
+  void start_stream(int32_t id);
+  void stop_stream(int32_t id);
+  void add_audio_to_stream(int32_t id, const float* audio, uint64_t n, int32_t sample_rate);
+  void transcribe_stream(int32_t id, uint32_t flags, transcript_t** out);
+  static std::string transcript_to_string(const transcript_t* t);
+
+ private:
+  TranscriberStream* new_stream(int32_t id);
+  TranscriberStream* find_stream(int32_t id);
+  // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs
+  void update_from_segments(const std::vector<TranscriberStream*>& streams,
+                            const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs);
+  void save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush);
+
+  TranscriberOptions opt_;
+  std::unique_ptr<MoonshineModel> model_;
+  std::mutex model_mutex_, batch_mutex_, streams_mutex_;
+  std::unique_ptr<TranscriberStream> batch_stream_;
+  std::vector<std::unique_ptr<TranscriberStream>> batch_streams_;  // one per clip of the last batch call
+  std::map<int32_t, std::unique_ptr<TranscriberStream>> streams_;
+  std::atomic<uint64_t> next_line_id_;
+  int32_t next_stream_id_ = 1;
+};
+
+}  // namespace msh_host

@@ -65,6 +65,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_profile_count": (i32, [vp]),
         "msh_profile_get": (i32, [vp, i32, P(ProfileEntry)]),
         "msh_synchronize": (i32, [vp]),
+        "msh_host_tokens_to_text": (C.c_int64, [vp, u64, vp, u64, vp, u64]),
+        "msh_host_sanitize_utf8": (C.c_int64, [vp, u64, vp, u64]),
+        "msh_host_resample": (C.c_int64, [vp, u64, f32, f32, vp, u64]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -80,6 +83,7 @@ DECLARED_SYMBOLS = [
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize",
+    "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample",
 ]
 
 

@@ -151,3 +151,35 @@ def max_decode_len(n_samples: int, max_tokens_per_second: float = 6.5) -> int:
     """reference core/moonshine-model.cpp:347-349 (float32 arithmetic)."""
     dur = np.float32(n_samples) / np.float32(16000.0)
     return int(math.ceil(float(np.float32(dur * np.float32(max_tokens_per_second)))))
+
+
+def resample_ref(audio: np.ndarray, in_rate: float, out_rate: float) -> np.ndarray:
+    """reference core/resampler.cpp:5-86 in float32: identity at equal rates; box average over
+    [floor(i*r), floor((i+1)*r)] (inclusive, clamped) when decimating; linear interpolation with the last
+    sample held when interpolating.  Output length = trunc(n * out_rate / in_rate) in float arithmetic."""
+    audio = np.asarray(audio, np.float32)
+    if in_rate == out_rate:
+        return audio.copy()
+    n_in = audio.shape[0]
+    n_out = int(np.float32(np.float32(n_in) * np.float32(out_rate)) / np.float32(in_rate))
+    ratio = np.float32(in_rate) / np.float32(out_rate)
+    out = np.zeros(n_out, np.float32)
+    if in_rate > out_rate:
+        for i in range(n_out):
+            lo = int(np.float32(i) * ratio)
+            hi = min(int(np.float32(i + 1) * ratio), n_in - 1)
+            acc = np.float32(0.0)
+            for j in range(lo, hi + 1):
+                acc = np.float32(acc + audio[j])
+            cnt = hi - lo + 1
+            out[i] = acc / np.float32(cnt) if cnt > 0 else 0.0
+    else:
+        for i in range(n_out):
+            pos = np.float32(i) * ratio
+            idx = int(pos)
+            frac = np.float32(pos - np.float32(idx))
+            if idx >= n_in - 1:
+                out[i] = audio[n_in - 1]
+            else:
+                out[i] = np.float32(audio[idx] + frac * np.float32(audio[idx + 1] - audio[idx]))
+    return out

@@ -1,0 +1,134 @@
+"""GPU tests through the public C API (include/moonshine-c-api.h): the full drop-in path
+VAD -> batched HIP encoder/decoder -> detokenise -> sanitize -> transcript_t, on the tiny architecture with
+synthetic weights.  Host-side glue is compared bit-exactly with the oracle's restatement applied to the
+engine's own token ids; the numerics of those ids are covered by tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from moonshine_amd import api
+from moonshine_amd.synth import ARCHS, make_audio, synthetic_vocab, write_model_dir
+from oracle import host_ref
+from oracle import moonshine_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("tiny_model"))
+    w = write_model_dir(d, ARCHS["tiny"], seed=3)
+    return d, w
+
+
+@pytest.fixture(scope="module")
+def tiny(tiny_dir):
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0"})
+    yield t
+    t.close()
+
+
+def _expected_text(engine, vocab, segment):
+    toks = engine.transcribe_tokens([segment])[0]
+    return host_ref.sanitize_text(host_ref.tokens_to_text(vocab, toks)), toks
+
+
+@pytest.fixture(scope="module")
+def engine(tiny_dir):
+    from moonshine_amd.hip_api import Engine
+
+    e = Engine(0)
+    e.load_weights_file(os.path.join(tiny_dir[0], "model.safetensors"), 0)
+    return e
+
+
+def test_transcribe_without_streaming_end_to_end(tiny, tiny_dir, engine):
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    n = 48000 + 300  # not a multiple of the 512-sample hop: the tail is dropped before the model sees it
+    audio = make_audio(7, n)
+    lines = tiny.transcribe_without_streaming(audio)
+    assert len(lines) == 1
+    l = lines[0]
+    seg = audio[: (n // 512) * 512]
+    want, toks = _expected_text(engine, vocab, seg)
+    assert l.text_bytes == want and len(want) > 0
+    assert l.is_complete and l.is_new and l.is_updated and l.has_text_changed
+    np.testing.assert_array_equal(l.audio_data, seg)
+    assert abs(l.duration - len(seg) / 16000) < 1e-6 and l.start_time == 0.0
+    # the ids behind that text agree with the oracle's greedy loop wherever the oracle is unambiguous
+    cfg, w = ARCHS["tiny"], tiny_dir[1]
+    enc = ref.encoder_forward(w, cfg, seg)
+    otoks, lg = ref.greedy_decode(w, cfg, enc, host_ref.max_decode_len(len(seg)), return_logits=True)
+    for i in range(min(len(otoks), len(toks)) - 1):
+        top2 = np.partition(lg[i], -2)[-2:]
+        if top2[1] - top2[0] <= 0.1:
+            break
+        assert toks[i + 1] == otoks[i + 1]
+    # second call on the same transcriber: previous transcript is replaced, ids move on
+    again = tiny.transcribe_without_streaming(audio)
+    assert again[0].text_bytes == want and again[0].line_id != l.line_id
+
+
+def test_batch_call_equals_single_calls(tiny):
+    clips = [make_audio(20 + i, n) for i, n in enumerate([16000, 52000, 30000, 899, 600, 80000])]
+    single = [tiny.transcribe_without_streaming(c) for c in clips]
+    batch = tiny.transcribe_batch_without_streaming(clips)
+    assert len(batch) == len(clips)
+    for s, b in zip(single, batch):
+        assert [l.text_bytes for l in s] == [l.text_bytes for l in b]
+        assert [l.duration for l in s] == [l.duration for l in b]
+    # a segment shorter than the conv stem's receptive field (600 -> 512 samples) yields an empty line
+    assert batch[4][0].text_bytes == b""
+
+
+def test_other_sample_rate_goes_through_the_resampler(tiny, engine):
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    x = make_audio(31, 72000)  # pretend 24 kHz
+    lines = tiny.transcribe_without_streaming(x, sample_rate=24000)
+    r = host_ref.resample_ref(x, 24000, 16000)
+    seg = r[: (len(r) // 512) * 512]
+    want, _ = _expected_text(engine, vocab, seg)
+    assert lines[0].text_bytes == want
+
+
+def test_memory_files_loader_and_arch_check(tiny_dir, tiny):
+    d = tiny_dir[0]
+    files = {"model.safetensors": open(os.path.join(d, "model.safetensors"), "rb").read(), "tokenizer.bin": open(os.path.join(d, "tokenizer.bin"), "rb").read()}
+    t = api.Transcriber.from_memory_files(files, api.ARCH_TINY, {"vad_threshold": "0"})
+    audio = make_audio(40, 32000)
+    assert t.transcribe_without_streaming(audio)[0].text_bytes == tiny.transcribe_without_streaming(audio)[0].text_bytes
+    t.close()
+    with pytest.raises(api.MoonshineError):  # tiny weights requested as BASE
+        api.Transcriber(d, api.ARCH_BASE, {"vad_threshold": "0"})
+    with pytest.raises(api.MoonshineError):  # unrecognised asset name
+        api.Transcriber.from_memory_files({"encoder_model.ort": b"x"}, api.ARCH_TINY, {"vad_threshold": "0"})
+
+
+def test_stream_api_with_offline_model(tiny):
+    """Streams work with the offline architectures too (every update re-transcribes the open segment,
+    reference transcriber.cpp:1078-1081): the final text equals the one-shot call on the same audio."""
+    audio = make_audio(50, 16000 * 3)
+    s = tiny.create_stream()
+    tiny.start_stream(s)
+    texts = []
+    for i in range(0, len(audio), 12000):
+        tiny.add_audio(s, audio[i : i + 12000])
+        lines = tiny.transcribe_stream(s)
+        assert len(lines) == 1
+        texts.append(lines[0].text_bytes)
+        assert not lines[0].is_complete
+    tiny.stop_stream(s)
+    final = tiny.transcribe_stream(s)
+    assert final[0].is_complete
+    oneshot = tiny.transcribe_without_streaming(audio)
+    assert final[0].text_bytes == oneshot[0].text_bytes == texts[-1]
+    tiny.free_stream(s)
+
+
+def test_log_ort_run_option_reports_kernel_groups(tiny_dir, capfd):
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "log_ort_run": "true"})
+    t.transcribe_without_streaming(make_audio(60, 16000))
+    err = capfd.readouterr().err
+    assert "dec_cross_attention" in err and "enc_attention" in err
+    t.close()

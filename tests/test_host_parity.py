@@ -1,0 +1,219 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, struct layouts match
+the reference ABI, and the host-side byte / integer work (tokenizer, UTF-8 repair, resampler, VAD
+segmentation, option parsing, handle / error rules, stream flags) is bit-exact with the oracle
+restatement of the reference (oracle/host_ref.py)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from moonshine_amd import api
+from moonshine_amd.hip_api import LIB_PATH, load_library
+from oracle import host_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(LIB_PATH)
+    declared = []
+    for h in sorted(os.listdir(INCLUDE)):
+        txt = open(os.path.join(INCLUDE, h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"#define[^\n]*", "", txt)
+        declared += re.findall(r"(?:MSH_EXPORT|MOONSHINE_EXPORT)[^;(]*?\b(\w+)\s*\(", txt)
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert set(api.C_API_SYMBOLS) <= set(declared)
+
+
+def test_struct_layout_matches_reference_abi(tmp_path):
+    """sizeof / offsetof of the public structs as gcc sees include/moonshine-c-api.h must equal the
+    ctypes mirror (which pins the sizes the reference binding pins: 24 / 40 / 88 / 16)."""
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "moonshine-c-api.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu %zu\\n", sizeof(struct transcript_word_t), sizeof(struct speaker_span_t), sizeof(struct transcript_line_t), sizeof(struct transcript_t), sizeof(struct moonshine_option_t));\n'
+        'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", offsetof(struct transcript_line_t, audio_data_count), offsetof(struct transcript_line_t, start_time), offsetof(struct transcript_line_t, id), offsetof(struct transcript_line_t, is_complete), offsetof(struct transcript_line_t, speaker_spans), offsetof(struct transcript_line_t, last_transcription_latency_ms), offsetof(struct transcript_line_t, words), offsetof(struct transcript_line_t, word_count));\n'
+        "return 0;}\n"
+    )
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", INCLUDE, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert [int(x) for x in out[0].split()] == [24, 40, 88, 16, 16]
+    L = api.TranscriptLineC
+    want = [getattr(L, f).offset for f in ("audio_data_count", "start_time", "id", "is_complete", "speaker_spans", "last_transcription_latency_ms", "words", "word_count")]
+    assert [int(x) for x in out[1].split()] == want
+
+
+def _tok_text(blob: bytes, ids) -> bytes:
+    lib = load_library()
+    ids = np.asarray(ids, np.int32)
+    buf = C.create_string_buffer(1 << 16)
+    n = lib.msh_host_tokens_to_text(blob, len(blob), ids.ctypes.data, len(ids), buf, len(buf))
+    assert n >= 0
+    return buf.raw[:n]
+
+
+def test_tokenizer_and_sanitize_bit_exact():
+    vocab = host_ref.synthetic_vocab(4096)
+    blob = host_ref.encode_tokenizer_bin(vocab)
+    assert host_ref.decode_tokenizer_bin(blob) == vocab
+    rng = np.random.default_rng(0)
+    lib = load_library()
+    special = [0, 1, 2, 3, 258, 997, 1013, 1021, 1031, 1994, 2026, 2042, 3063]  # <..> specials, long / multi-byte / broken pieces
+    for trial in range(200):
+        n = int(rng.integers(0, 40))
+        ids = rng.integers(0, 4096, n).tolist() + [special[trial % len(special)]]
+        rng.shuffle(ids)
+        want = host_ref.tokens_to_text(vocab, ids)
+        got = _tok_text(blob, ids)
+        assert got == want
+        buf = C.create_string_buffer(len(got) + 8)
+        m = lib.msh_host_sanitize_utf8(got, len(got), buf, len(buf))
+        assert buf.raw[:m] == host_ref.sanitize_text(want)
+    # random byte strings through the sanitizer, including truncated sequences at the very end
+    for trial in range(300):
+        raw = bytes(rng.integers(0, 256, int(rng.integers(0, 24))).tolist())
+        raw = raw.replace(b"\x00", b"\x01")  # the reference operates on a C string
+        buf = C.create_string_buffer(len(raw) + 8)
+        m = lib.msh_host_sanitize_utf8(raw, len(raw), buf, len(buf))
+        assert buf.raw[:m] == host_ref.sanitize_text(raw), raw
+    # an empty entry is an invalid token (reference throws): negative status
+    bad = host_ref.encode_tokenizer_bin([b"<unk>", b"", b"ab"])
+    ids = np.asarray([2, 1], np.int32)
+    buf = C.create_string_buffer(64)
+    assert lib.msh_host_tokens_to_text(bad, len(bad), ids.ctypes.data, 2, buf, 64) < 0
+    assert lib.msh_host_tokens_to_text(b"", 0, ids.ctypes.data, 2, buf, 64) < 0
+
+
+@pytest.mark.parametrize("in_rate,out_rate,n", [(48000, 16000, 4801), (44100, 16000, 3000), (24000, 16000, 777), (8000, 16000, 500), (11025, 16000, 333), (16000, 16000, 100)])
+def test_resampler_bit_exact(in_rate, out_rate, n):
+    lib = load_library()
+    x = np.random.default_rng(n).standard_normal(n).astype(np.float32)
+    want = host_ref.resample_ref(x, in_rate, out_rate)
+    m = lib.msh_host_resample(x.ctypes.data, n, in_rate, out_rate, None, 0)
+    assert m == want.shape[0]
+    out = np.zeros(m, np.float32)
+    lib.msh_host_resample(x.ctypes.data, n, in_rate, out_rate, out.ctypes.data, m)
+    np.testing.assert_array_equal(out, want)
+
+
+def _load_skip(options=None):
+    opts = {"skip_transcription": "true", "vad_threshold": "0"}
+    opts.update(options or {})
+    return api.Transcriber("", api.ARCH_BASE, opts)
+
+
+@pytest.mark.parametrize("n", [160000, 159414, 511, 512, 16000 * 31 + 7, 600])
+def test_vad_threshold0_segments_match_reference_rules(n):
+    """Hop truncation / look-behind / never-split behaviour through the public API
+    with no model loaded: text is NULL, audio is the hop-truncated clip."""
+    t = _load_skip()
+    x = np.random.default_rng(n).standard_normal(n).astype(np.float32) * 0.1
+    lines = t.transcribe_without_streaming(x)
+    want = host_ref.vad_segments_threshold0(n)
+    assert len(lines) == len(want)
+    for l, (s, e, complete) in zip(lines, want):
+        assert l.text is None and l.is_complete == complete and l.is_new and l.is_updated
+        np.testing.assert_array_equal(l.audio_data, x[s:e])
+        assert abs(l.start_time - s / 16000) < 1e-6 and abs(l.duration - (e - s) / 16000) < 1e-6
+    t.close()
+
+
+def test_vad_other_sample_rate_and_options():
+    t = _load_skip({"vad_max_segment_duration": "5", "return_audio_data": "false"})
+    x = np.random.default_rng(1).standard_normal(48000 * 3).astype(np.float32) * 0.1
+    lines = t.transcribe_without_streaming(x, sample_rate=48000)
+    want = host_ref.vad_segments_threshold0(48000, max_segment_samples=80000)
+    assert len(lines) == len(want) == 1
+    assert lines[0].audio_data is None  # return_audio_data=false
+    assert abs(lines[0].duration - (want[0][1] - want[0][0]) / 16000) < 1e-6
+    t.close()
+
+
+def test_option_parsing_and_error_rules():
+    lib = api.lib()
+    assert lib.moonshine_get_version() == 30000
+    assert lib.moonshine_error_to_string(0) == b"Success"
+    assert lib.moonshine_error_to_string(-2) == b"Invalid handle"
+    assert lib.moonshine_error_to_string(-3) == b"Invalid argument"
+    assert lib.moonshine_error_to_string(-77) == b"Unknown error"
+    with pytest.raises(api.MoonshineError) as e:  # unknown option names fail the load (reference c-api.cpp:193-196)
+        _load_skip({"no_such_option": "1"})
+    assert e.value.code == -1
+    with pytest.raises(api.MoonshineError):  # bools accept only true/false/1/0
+        _load_skip({"return_audio_data": "yes"})
+    with pytest.raises(api.MoonshineError):  # Silero is not part of this build: must fail loudly, not fall back
+        api.Transcriber("", api.ARCH_BASE, {"skip_transcription": "true", "vad_threshold": "0.5"}).transcribe_without_streaming(np.zeros(1000, np.float32))
+    t = _load_skip({"VAD_HOP_SIZE": "256", "Log_Api_Calls": "false"})  # names are case-insensitive
+    assert len(t.transcribe_without_streaming(np.zeros(1024, np.float32))) == 1
+    out = C.POINTER(api.TranscriptC)()
+    assert lib.moonshine_transcribe_without_streaming(12345, None, 0, 16000, 0, C.byref(out)) == -2
+    assert lib.moonshine_transcribe_without_streaming(-1, None, 0, 16000, 0, C.byref(out)) == -2
+    assert lib.moonshine_create_stream(9999, 0) == -2
+    assert lib.moonshine_transcriber_set_keyterms(t.handle, b"") == 0
+    assert lib.moonshine_transcriber_set_keyterms(t.handle, b"Kubernetes") == -1
+    assert lib.moonshine_load_transcriber_from_memory(None, 0, None, 0, None, 0, None, 0, 1, None, 0, 30000) == -3
+    t.close()
+    t.close()  # double free is harmless
+    lib.moonshine_free_transcriber(4242)
+
+
+def test_loading_a_model_without_a_gpu_fails_loudly(tmp_path):
+    """There is no CPU fallback: on a box without an MI355X a real model load returns an error."""
+    load = load_library()
+    if load.msh_device_count() > 0:
+        pytest.skip("GPU present")
+    (tmp_path / "tokenizer.bin").write_bytes(host_ref.encode_tokenizer_bin(host_ref.synthetic_vocab(300)))
+    (tmp_path / "model.safetensors").write_bytes(b"\x02\x00\x00\x00\x00\x00\x00\x00{}")
+    with pytest.raises(api.MoonshineError) as e:
+        api.Transcriber(str(tmp_path), api.ARCH_BASE, {"vad_threshold": "0"})
+    assert e.value.code == -1
+    with pytest.raises(api.MoonshineError):  # .ort-only directory: clear refusal
+        (tmp_path / "encoder_model.ort").write_bytes(b"x")
+        os.remove(tmp_path / "model.safetensors")
+        api.Transcriber(str(tmp_path), api.ARCH_BASE, {"vad_threshold": "0"})
+    with pytest.raises(api.MoonshineError):
+        api.Transcriber(str(tmp_path / "missing"), api.ARCH_BASE, {"vad_threshold": "0"})
+    with pytest.raises(api.MoonshineError):  # streaming architectures are a later row
+        api.Transcriber(str(tmp_path), 5, {"vad_threshold": "0"})
+
+
+def test_stream_flag_semantics_without_model():
+    """Line bookkeeping of the stream API (reference transcriber.cpp:775-891, 1648-1726 and the guarantees of
+    moonshine-c-api.h:159-200): lines are only added, ids are stable, only new audio >= the interval (or
+    FORCE_UPDATE) triggers an update, stop marks the open line complete."""
+    t = _load_skip({"transcription_interval": "0.5"})
+    s = t.create_stream()
+    with pytest.raises(api.MoonshineError):
+        t.add_audio(s, np.zeros(100, np.float32))  # not started
+    t.start_stream(s)
+    x = np.random.default_rng(3).standard_normal(16000 * 2).astype(np.float32) * 0.1
+    t.add_audio(s, x[:4000])
+    assert t.transcribe_stream(s) == []  # 0.25 s < interval: cached (empty) transcript
+    lines = t.transcribe_stream(s, api.FLAG_FORCE_UPDATE)
+    assert len(lines) == 1 and lines[0].is_new and lines[0].is_updated and not lines[0].is_complete
+    first_id = lines[0].line_id
+    np.testing.assert_array_equal(lines[0].audio_data, x[:3584])  # 7 whole hops
+    t.add_audio(s, x[4000:16000])
+    lines = t.transcribe_stream(s)
+    assert len(lines) == 1 and lines[0].line_id == first_id and not lines[0].is_new and lines[0].is_updated
+    assert lines[0].audio_data.shape[0] == (16000 // 512) * 512
+    lines = t.transcribe_stream(s)  # nothing new: flags cleared
+    assert not lines[0].is_updated and not lines[0].is_new
+    t.stop_stream(s)
+    lines = t.transcribe_stream(s)
+    assert lines[0].is_complete and lines[0].line_id == first_id
+    t.start_stream(s)  # restarting clears the transcript
+    assert t.transcribe_stream(s) == []
+    t.free_stream(s)
+    with pytest.raises(api.MoonshineError):
+        t.transcribe_stream(s)
+    t.close()
