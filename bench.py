@@ -75,47 +75,38 @@ def main():
     from moonshine_amd.hip_api import Engine
     from moonshine_amd.synth import ARCHS, make_audio, make_weights, save_safetensors
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from moonshine_amd import dist as msd
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rank, world = msd.init_from_env("nccl", dev)  # "nccl" is RCCL on ROCm
+    dist = torch.distributed if world > 1 else None
 
     cfg = ARCHS[args.arch]
     eng = Engine(local_rank)
-    with tempfile.TemporaryDirectory() as d:
+    with tempfile.TemporaryDirectory() as d:  # weights are replicated: every rank loads the same file
         w = make_weights(cfg, 0)
         path = os.path.join(d, "model.safetensors")
         save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
         eng.load_weights_file(path)
 
-    # this rank's shard of the utterance list, resident in HBM before the timed region
+    # Utterance sharding: rank 0 owns the clip list and scatters it once (RCCL over xGMI); from then on
+    # every rank's shard is resident in its own HBM, which is where the timed region starts.
     B = args.batch
-    first = rank * B
-    host = np.stack([make_audio(first + i, CLIP_SAMPLES) for i in range(B)])
-    audio = torch.from_numpy(host).to(dev)
+    host = np.stack([make_audio(i, CLIP_SAMPLES) for i in range(world * B)]) if rank == 0 else None
+    audio, lens = msd.scatter_clips(list(host) if rank == 0 else None, world, rank, dev)
+    assert audio.shape[0] == B and all(n == CLIP_SAMPLES for n in lens)
     torch.cuda.synchronize()
     ptrs = [(audio[i].data_ptr(), CLIP_SAMPLES) for i in range(B)]
     tok_stride = args.decode_steps + 1
 
     def step():
         toks = eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)
-        if dist is not None:  # gather of the ids: the only collective on the path
-            t = torch.tensor(toks, dtype=torch.int32, device=dev)
-            out = torch.empty((world, B, tok_stride), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(out, t)
-        return toks
+        # gather of the ids: the only collective on the path
+        return msd.gather_tokens(toks, world * B, world, rank, dev)
 
     for _ in range(args.warmup):
         step()
@@ -129,12 +120,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert all(len(t) == tok_stride for t in toks)
+    elapsed = msd.max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert len(toks) == world * B and all(len(t) == tok_stride for t in toks)
 
     if rank != 0:
         if dist is not None:
