@@ -110,6 +110,9 @@ MSH_EXPORT int32_t msh_profile_count(msh_engine* e);
 MSH_EXPORT int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_entry* out);
 
 MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
+/* Developer hook: ms per launch of one tiled-GEMM configuration on synthetic operands (tools/gemm_microbench.py). */
+MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
+                                          int32_t iters);
 
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----

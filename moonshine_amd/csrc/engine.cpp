@@ -179,17 +179,31 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     std::vector<float> e = st.to_f32("model.decoder.embed_tokens.weight");
     upload(e, &embed_f32_);
     upload_bf16(e, &embed_bf16_);  // tied LM head (configuration_moonshine.py:103)
-    upload(st.to_f32("model.decoder.norm.weight"), &dec_ln_);
+    std::vector<float> g = st.to_f32("model.decoder.norm.weight");
+    upload(g, &dec_ln_);
+    // copy of the head with the final LayerNorm scale folded in, for the LN-fused small-batch head GEMM
+    for (int v = 0; v < V; ++v)
+      for (int d = 0; d < D; ++d) e[(size_t)v * D + d] *= g[d];
+    upload_bf16(e, &embed_head_folded_);
   }
   dec_.resize(c.dec_layers);
   std::vector<float> cross;
   for (int l = 0; l < c.dec_layers; ++l) {
     const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
     DecLayerW& L = dec_[l];
-    upload_bf16(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
+    // the decode GEMMs fuse LayerNorm into their A operand and expect its scale inside the weights:
+    // LN(x) * W^T = ((x - mu) * rstd) * (W * diag(gamma))^T
+    auto fold = [&](std::vector<float> w, const std::string& ln_name, int rows) {
+      const std::vector<float> gam = st.to_f32(ln_name);
+      for (int r = 0; r < rows; ++r)
+        for (int d = 0; d < D; ++d) w[(size_t)r * D + d] *= gam[d];
+      return w;
+    };
+    upload_bf16(fold(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
+                     p + "input_layernorm.weight", 3 * D),
                 &L.wqkv);
     upload_bf16(fuse({p + "self_attn.o_proj.weight"}), &L.wo);
-    upload_bf16(fuse({p + "encoder_attn.q_proj.weight"}), &L.wq_c);
+    upload_bf16(fold(fuse({p + "encoder_attn.q_proj.weight"}), p + "post_attention_layernorm.weight", D), &L.wq_c);
     upload_bf16(fuse({p + "encoder_attn.o_proj.weight"}), &L.wo_c);
     std::vector<float> kv = fuse({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"});
     cross.insert(cross.end(), kv.begin(), kv.end());
@@ -203,7 +217,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       bi[2 * j] = b[j];
       bi[2 * j + 1] = b[F + j];
     }
-    upload_bf16(wi, &L.fc1);
+    upload_bf16(fold(wi, p + "final_layernorm.weight", 2 * F), &L.fc1);
     upload(bi, &L.b1);
     upload_bf16(st.to_f32(p + "mlp.fc2.weight"), &L.fc2);
     upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
@@ -544,7 +558,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
     bf16_t* cV = g.cacheV.as<bf16_t>() + l * cache_layer;
     {
       ProfScope p(this, "dec_qkv_gemm", 2.0 * M * D * 3 * D, 3 * w_dd + M * D * 4.0 * 2);
-      dec_gemm_qkv(dH, W.ln1, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
+      dec_gemm_qkv(dH, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
     }
     {
       ProfScope p(this, "dec_self_attention", 0, 0);
@@ -556,7 +570,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
     }
     {
       ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
-      dec_gemm_ln_f32(dH, W.ln2, W.wq_c, M, D, D, dq, s);
+      dec_gemm_ln_f32(dH, W.wq_c, M, D, D, dq, s);
     }
     {
       ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
@@ -569,7 +583,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
     }
     {
       ProfScope p(this, "dec_fc1_swiglu_gemm", 2.0 * M * D * 2 * F, 2.0 * 2 * F * D + M * (D * 4.0 + F * 2.0));
-      dec_gemm_ln_swiglu(dH, W.ln3, W.fc1, W.b1, M, F, D, dz, s);
+      dec_gemm_ln_swiglu(dH, W.fc1, W.b1, M, F, D, dz, s);
     }
     {
       ProfScope p(this, "dec_fc2_resid_gemm", 2.0 * M * D * F, 2.0 * F * D + M * (F * 2.0 + D * 8.0));
@@ -585,7 +599,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
     gemm_logits_f32(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.logits.as<float>(), s);
   } else {
     ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
-    dec_gemm_logits(dH, dec_ln_, embed_bf16_, M, V, D, g.logits.as<float>(), s);
+    dec_gemm_logits(dH, embed_head_folded_, M, V, D, g.logits.as<float>(), s);
   }
 }
 

@@ -107,7 +107,7 @@ class Engine {
   float *conv2_b_ = nullptr, *conv3_b_ = nullptr, *gn_w_ = nullptr, *gn_b_ = nullptr, *enc_ln_ = nullptr;
   std::vector<EncLayerW> enc_;
   std::vector<DecLayerW> dec_;
-  bf16_t *embed_bf16_ = nullptr, *cross_kv_w_ = nullptr;
+  bf16_t *embed_bf16_ = nullptr, *embed_head_folded_ = nullptr, *cross_kv_w_ = nullptr;
   float *embed_f32_ = nullptr, *dec_ln_ = nullptr;
   float *rope_cos_ = nullptr, *rope_sin_ = nullptr;
   int rope_max_pos_ = 0;

@@ -1,0 +1,286 @@
+// Shared pieces of the gfx950 GEMM kernels: fast activations, epilogue functors, LDS-DMA helpers.
+// Included by k_gemm.hip (tiled encoder GEMMs) and k_gemm_dec.hip (decode GEMMs); everything is
+// internal-linkage (anonymous namespace) device code.
+#pragma once
+
+#include "kernels.h"
+
+namespace msh {
+namespace {
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output rounding): one v_exp,
+// one v_rcp and a degree-5 Horner chain instead of libm's branchy erff (which cost as much as the
+// K = 416 main loop in the fc1 epilogue).
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly (e^{2x} -> inf gives 1, -> 0 gives -1)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  n4(m, n, v): v[i] = C[m][n+i].   m4(m, n, v): v[i] = C[m+i][n].
+// ------------------------------------------------------------------------------------------------
+struct EpiTanhF32 {
+  float* out;
+  long ldc;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    float4 o = make_float4(tanh_fast(v[0]), tanh_fast(v[1]), tanh_fast(v[2]), tanh_fast(v[3]));
+    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
+  }
+};
+
+struct EpiBiasGeluBf16 {
+  bf16_t* out;
+  long ldc;
+  const float* bias;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    uint2 o;
+    o.x = pack_bf16x2(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y));
+    o.y = pack_bf16x2(gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+  }
+};
+
+struct EpiBiasGeluF32 {
+  float* out;
+  long ldc;
+  const float* bias;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    float4 o = make_float4(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
+  }
+};
+
+// rotate the two (even, odd) pairs held in v for head-dim offsets d, d+2
+__device__ __forceinline__ void rope4(f32x4& v, int d, int pos, const RopeParams& rp) {
+  const int j0 = d >> 1;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int j = j0 + p;
+    if (j < rp.rot_pairs) {
+      const float c = rp.cos[(long)pos * rp.rot_pairs + j];
+      const float s = rp.sin[(long)pos * rp.rot_pairs + j];
+      const float x0 = v[2 * p], x1 = v[2 * p + 1];
+      v[2 * p] = x0 * c - x1 * s;
+      v[2 * p + 1] = x1 * c + x0 * s;
+    }
+  }
+}
+
+struct EpiQkvRopeBf16 {
+  bf16_t* out;
+  long ldc;
+  const int* row_pos;
+  RopeParams rp;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
+      int pos = row_pos[m];
+      pos = pos < 0 ? 0 : pos;
+      const int d = (n % rp.hidden) % rp.head_dim;
+      rope4(v, d, pos, rp);
+    }
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+  }
+};
+
+struct EpiResidF32 {
+  float* H;
+  long ldc;
+  const float* bias;  // nullable
+  // decode path: the old residual value and the bias are fetched before the GEMM, not after it
+  struct Pre {
+    float4 h, b;
+  };
+  __device__ Pre pre(int m, int n) const {
+    Pre p;
+    p.h = *reinterpret_cast<const float4*>(H + (long)m * ldc + n);
+    p.b = bias != nullptr ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    *reinterpret_cast<float4*>(H + (long)m * ldc + n) =
+        make_float4(p.h.x + p.b.x + v[0], p.h.y + p.b.y + v[1], p.h.z + p.b.z + v[2], p.h.w + p.b.w + v[3]);
+  }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    float4* p = reinterpret_cast<float4*>(H + (long)m * ldc + n);
+    float4 h = *p;
+    if (bias != nullptr) {
+      float4 b = *reinterpret_cast<const float4*>(bias + n);
+      h.x += b.x;
+      h.y += b.y;
+      h.z += b.z;
+      h.w += b.w;
+    }
+    h.x += v[0];
+    h.y += v[1];
+    h.z += v[2];
+    h.w += v[3];
+    *p = h;
+  }
+};
+
+// cross K/V, all decoder layers in one GEMM: n = layer*2D + which*D + c  ->  K^T/V^T[layer][clip][c][t]
+struct EpiCrossKV {
+  bf16_t* KT;
+  bf16_t* VT;
+  const int* row_clip;
+  const ClipMeta* clips;
+  int D;
+  long layer_stride;  // elements per layer = D * sum(Tk)
+  __device__ void m4(int m, int n, f32x4 v) const {
+    const int b = row_clip[m];
+    const ClipMeta cm = clips[b];
+    const int t = m - cm.row_start;
+    if (t >= cm.Tk) return;  // Tk is a multiple of 8 and t of 4: the group is all in or all out
+    const int layer = n / (2 * D);
+    const int r = n - layer * 2 * D;
+    const int which = r / D;
+    const int c = r - which * D;
+    bf16_t* base = (which ? VT : KT) + layer * layer_stride + (long)cm.kv_start * D + (long)c * cm.Tk + t;
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (t + i < cm.T) ? v[i] : 0.0f;  // padding keys are exact zeros
+    uint2 o;
+    o.x = pack_bf16x2(x[0], x[1]);
+    o.y = pack_bf16x2(x[2], x[3]);
+    *reinterpret_cast<uint2*>(base) = o;
+  }
+};
+
+struct EpiDecQkv {
+  float* q;         // [M][D]
+  bf16_t* cacheK;   // [M][H][Smax][dh]
+  bf16_t* cacheV;
+  const int* pos_ptr;
+  RopeParams rp;
+  int Smax;
+  struct Pre {
+    int pos;
+    float c0, s0, c1, s1;
+  };
+  __device__ Pre pre(int /*m*/, int n) const {
+    Pre p;
+    p.pos = *pos_ptr;
+    const int d = (n % rp.hidden) % rp.head_dim, j0 = d >> 1;
+    p.c0 = p.c1 = 1.f;
+    p.s0 = p.s1 = 0.f;
+    if (n < 2 * rp.hidden) {  // q / k: rotation factors of the lane's two pairs (identity beyond rot_pairs)
+      if (j0 < rp.rot_pairs) {
+        p.c0 = rp.cos[(long)p.pos * rp.rot_pairs + j0];
+        p.s0 = rp.sin[(long)p.pos * rp.rot_pairs + j0];
+      }
+      if (j0 + 1 < rp.rot_pairs) {
+        p.c1 = rp.cos[(long)p.pos * rp.rot_pairs + j0 + 1];
+        p.s1 = rp.sin[(long)p.pos * rp.rot_pairs + j0 + 1];
+      }
+    }
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    const int D = rp.hidden, dh = rp.head_dim;
+    const int which = n / D;
+    const int c = n - which * D;
+    const int h = c / dh, d = c - h * dh;
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    v[0] = x0 * p.c0 - x1 * p.s0;
+    v[1] = x1 * p.c0 + x0 * p.s0;
+    v[2] = x2 * p.c1 - x3 * p.s1;
+    v[3] = x3 * p.c1 + x2 * p.s1;
+    if (which == 0) {
+      *reinterpret_cast<float4*>(q + (long)m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      bf16_t* dst = (which == 1 ? cacheK : cacheV) + (((long)m * (D / dh) + h) * Smax + p.pos) * dh + d;
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst) = o;
+    }
+  }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    const int D = rp.hidden, dh = rp.head_dim;
+    const int pos = *pos_ptr;
+    const int which = n / D;
+    const int c = n - which * D;
+    const int h = c / dh, d = c - h * dh;
+    if (which < 2) rope4(v, d, pos, rp);
+    if (which == 0) {
+      *reinterpret_cast<float4*>(q + (long)m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      bf16_t* dst = (which == 1 ? cacheK : cacheV) + (((long)m * (D / dh) + h) * Smax + pos) * dh + d;
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst) = o;
+    }
+  }
+};
+
+struct EpiF32 {
+  float* out;
+  long ldc;
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// rows of W / bias interleaved as (value_j, gate_j): modeling_moonshine.py:92-96 chunk order
+struct EpiSwiGLU {
+  bf16_t* z;
+  long ldz;  // F
+  const float* bias;
+  struct Pre {
+    float4 b;
+  };
+  __device__ Pre pre(int, int n) const { return Pre{*reinterpret_cast<const float4*>(bias + n)}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    const float val0 = v[0] + p.b.x, gate0 = v[1] + p.b.y, val1 = v[2] + p.b.z, gate1 = v[3] + p.b.w;
+    uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
+    *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
+  }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    const float val0 = v[0] + b.x, gate0 = v[1] + b.y, val1 = v[2] + b.z, gate1 = v[3] + b.w;
+    uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
+    *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
+  }
+};
+
+// XOR swizzle of the 16-B k-chunk position inside a 64-B row of an LDS k-slice (conflict-free
+// ds_read_b128 fragment reads for the lane groups of gfx950; verified: SQ_LDS_BANK_CONFLICT = 0)
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long)(lds_char_t*)(p); }
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+}  // namespace msh

@@ -17,6 +17,13 @@ namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// cache-policy bits of the buffer-load aux operand: 2 = nt (non-temporal).  The cross K^T/V^T stream
+// (1.4 GB per decode step at batch 256) is read exactly once per step; marking it streaming keeps it from
+// evicting the 77 MB of decoder weights that every step re-reads (MI355X_MICROARCH.md, row nt-weights).
+#ifndef MSH_CROSS_KV_AUX
+#define MSH_CROSS_KV_AUX 2
+#endif
+constexpr int kStreamAux = MSH_CROSS_KV_AUX;
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -88,6 +95,10 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     for (int p = tid; p < KB * PIECES; p += 256) {
       const int key = p / PIECES, piece = p - key * PIECES;
       const int t = kb * KB + key;
+      // V is transposed on the way into LDS with 2-byte stores.  The piece-major lane mapping keeps the
+      // global reads coalesced (104 contiguous bytes per key) at the price of LDS write conflicts (a
+      // wave's 13 pieces of one key land on two banks); a key-major mapping removed the conflicts but
+      // measured 35 % slower overall (uncoalesced row reads), so this stays.
       uint2 kv = make_uint2(0u, 0u), vv = make_uint2(0u, 0u);
       if (t < T) {
         const bf16_t* r = base + (long)t * ld + piece * 4;
@@ -213,6 +224,19 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
     float4 t = *reinterpret_cast<const float4*>(qp + d);
     qreg[d] = t.x; qreg[d + 1] = t.y; qreg[d + 2] = t.z; qreg[d + 3] = t.w;
   }
+  // PV mapping: lane = (key group g, 8-byte piece of the head dim).  The first NPRE V rows of each group
+  // (enough for the 66 keys of a 10 s clip) are requested now, so they arrive during the score phase
+  // instead of adding a third dependent memory round trip after the softmax.
+  constexpr int PIECES = DH / 4, G = 64 / PIECES, NPRE = 17;
+  const int g = lane / PIECES, piece = lane - g * PIECES;
+  uint2 vpre[NPRE];
+  if (g < G) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int s = g + G * i;
+      vpre[i] = s < S ? *reinterpret_cast<const uint2*>(vp + (long)s * DH + piece * 4) : make_uint2(0u, 0u);
+    }
+  }
   float mloc = -INFINITY;
   for (int s = lane; s < S; s += 64) {
     const bf16_t* kr = kp + (long)s * DH;
@@ -237,12 +261,22 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
   __builtin_amdgcn_wave_barrier();
   // PV: lane = (key group g, 8-byte piece of the head dim); group g walks keys g, g+G, ... with
   // independent loads, then the G partial rows are summed through LDS in a fixed order.
-  constexpr int PIECES = DH / 4, G = 64 / PIECES;
-  const int g = lane / PIECES, piece = lane - g * PIECES;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g < G) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int s = g + G * i;
+      if (s < S) {
+        const uint2 u = vpre[i];
+        const float p = sc[wave][s];
+        acc.x += p * bf_lo(u.x);
+        acc.y += p * bf_hi(u.x);
+        acc.z += p * bf_lo(u.y);
+        acc.w += p * bf_hi(u.y);
+      }
+    }
 #pragma unroll 4
-    for (int s = g; s < S; s += G) {
+    for (int s = g + G * NPRE; s < S; s += G) {
       const uint2 u = *reinterpret_cast<const uint2*>(vp + (long)s * DH + piece * 4);
       const float p = sc[wave][s];
       acc.x += p * bf_lo(u.x);
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
     const bool in = key < Tk;
     u32x4 kr[DQ], vr[DQ];
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Tk * 2, 0);
+    for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Tk * 2, kStreamAux);
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
@@ -330,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
     // the V rows are requested only now (K registers are dead): they fly during the score exchange
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) vr[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Tk * 2, 0);
+    for (int d = 0; d < DQ; ++d) vr[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Tk * 2, kStreamAux);
     if (k0 > 0) __syncthreads();  // previous chunk's partial scores fully consumed
     *reinterpret_cast<float4*>(&sp[wave][lane * 8]) = make_float4(s[0], s[1], s[2], s[3]);
     *reinterpret_cast<float4*>(&sp[wave][lane * 8 + 4]) = make_float4(s[4], s[5], s[6], s[7]);

@@ -18,270 +18,14 @@
 // SWAP = false gives 4 consecutive m for one n (used to write K^T / V^T along t).
 #include <stdlib.h>
 
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace msh {
 namespace {
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output rounding): one v_exp,
-// one v_rcp and a degree-5 Horner chain instead of libm's branchy erff (which cost as much as the
-// K = 416 main loop in the fc1 epilogue).
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float e = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(e, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-// tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly (e^{2x} -> inf gives 1, -> 0 gives -1)
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-
-// ------------------------------------------------------------------------------------------------
-// Epilogues.  n4(m, n, v): v[i] = C[m][n+i].   m4(m, n, v): v[i] = C[m+i][n].
-// ------------------------------------------------------------------------------------------------
-struct EpiTanhF32 {
-  float* out;
-  long ldc;
-  __device__ void n4(int m, int n, f32x4 v) const {
-    float4 o = make_float4(tanh_fast(v[0]), tanh_fast(v[1]), tanh_fast(v[2]), tanh_fast(v[3]));
-    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
-  }
-};
-
-struct EpiBiasGeluBf16 {
-  bf16_t* out;
-  long ldc;
-  const float* bias;
-  __device__ void n4(int m, int n, f32x4 v) const {
-    float4 b = *reinterpret_cast<const float4*>(bias + n);
-    uint2 o;
-    o.x = pack_bf16x2(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y));
-    o.y = pack_bf16x2(gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
-    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
-  }
-};
-
-struct EpiBiasGeluF32 {
-  float* out;
-  long ldc;
-  const float* bias;
-  __device__ void n4(int m, int n, f32x4 v) const {
-    float4 b = *reinterpret_cast<const float4*>(bias + n);
-    float4 o = make_float4(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
-    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
-  }
-};
-
-// rotate the two (even, odd) pairs held in v for head-dim offsets d, d+2
-__device__ __forceinline__ void rope4(f32x4& v, int d, int pos, const RopeParams& rp) {
-  const int j0 = d >> 1;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int j = j0 + p;
-    if (j < rp.rot_pairs) {
-      const float c = rp.cos[(long)pos * rp.rot_pairs + j];
-      const float s = rp.sin[(long)pos * rp.rot_pairs + j];
-      const float x0 = v[2 * p], x1 = v[2 * p + 1];
-      v[2 * p] = x0 * c - x1 * s;
-      v[2 * p + 1] = x1 * c + x0 * s;
-    }
-  }
-}
-
-struct EpiQkvRopeBf16 {
-  bf16_t* out;
-  long ldc;
-  const int* row_pos;
-  RopeParams rp;
-  __device__ void n4(int m, int n, f32x4 v) const {
-    if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
-      int pos = row_pos[m];
-      pos = pos < 0 ? 0 : pos;
-      const int d = (n % rp.hidden) % rp.head_dim;
-      rope4(v, d, pos, rp);
-    }
-    uint2 o;
-    o.x = pack_bf16x2(v[0], v[1]);
-    o.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
-  }
-};
-
-struct EpiResidF32 {
-  float* H;
-  long ldc;
-  const float* bias;  // nullable
-  // decode path: the old residual value and the bias are fetched before the GEMM, not after it
-  struct Pre {
-    float4 h, b;
-  };
-  __device__ Pre pre(int m, int n) const {
-    Pre p;
-    p.h = *reinterpret_cast<const float4*>(H + (long)m * ldc + n);
-    p.b = bias != nullptr ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    return p;
-  }
-  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
-    *reinterpret_cast<float4*>(H + (long)m * ldc + n) =
-        make_float4(p.h.x + p.b.x + v[0], p.h.y + p.b.y + v[1], p.h.z + p.b.z + v[2], p.h.w + p.b.w + v[3]);
-  }
-  __device__ void n4(int m, int n, f32x4 v) const {
-    float4* p = reinterpret_cast<float4*>(H + (long)m * ldc + n);
-    float4 h = *p;
-    if (bias != nullptr) {
-      float4 b = *reinterpret_cast<const float4*>(bias + n);
-      h.x += b.x;
-      h.y += b.y;
-      h.z += b.z;
-      h.w += b.w;
-    }
-    h.x += v[0];
-    h.y += v[1];
-    h.z += v[2];
-    h.w += v[3];
-    *p = h;
-  }
-};
-
-// cross K/V, all decoder layers in one GEMM: n = layer*2D + which*D + c  ->  K^T/V^T[layer][clip][c][t]
-struct EpiCrossKV {
-  bf16_t* KT;
-  bf16_t* VT;
-  const int* row_clip;
-  const ClipMeta* clips;
-  int D;
-  long layer_stride;  // elements per layer = D * sum(Tk)
-  __device__ void m4(int m, int n, f32x4 v) const {
-    const int b = row_clip[m];
-    const ClipMeta cm = clips[b];
-    const int t = m - cm.row_start;
-    if (t >= cm.Tk) return;  // Tk is a multiple of 8 and t of 4: the group is all in or all out
-    const int layer = n / (2 * D);
-    const int r = n - layer * 2 * D;
-    const int which = r / D;
-    const int c = r - which * D;
-    bf16_t* base = (which ? VT : KT) + layer * layer_stride + (long)cm.kv_start * D + (long)c * cm.Tk + t;
-    float x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = (t + i < cm.T) ? v[i] : 0.0f;  // padding keys are exact zeros
-    uint2 o;
-    o.x = pack_bf16x2(x[0], x[1]);
-    o.y = pack_bf16x2(x[2], x[3]);
-    *reinterpret_cast<uint2*>(base) = o;
-  }
-};
-
-struct EpiDecQkv {
-  float* q;         // [M][D]
-  bf16_t* cacheK;   // [M][H][Smax][dh]
-  bf16_t* cacheV;
-  const int* pos_ptr;
-  RopeParams rp;
-  int Smax;
-  struct Pre {
-    int pos;
-    float c0, s0, c1, s1;
-  };
-  __device__ Pre pre(int /*m*/, int n) const {
-    Pre p;
-    p.pos = *pos_ptr;
-    const int d = (n % rp.hidden) % rp.head_dim, j0 = d >> 1;
-    p.c0 = p.c1 = 1.f;
-    p.s0 = p.s1 = 0.f;
-    if (n < 2 * rp.hidden) {  // q / k: rotation factors of the lane's two pairs (identity beyond rot_pairs)
-      if (j0 < rp.rot_pairs) {
-        p.c0 = rp.cos[(long)p.pos * rp.rot_pairs + j0];
-        p.s0 = rp.sin[(long)p.pos * rp.rot_pairs + j0];
-      }
-      if (j0 + 1 < rp.rot_pairs) {
-        p.c1 = rp.cos[(long)p.pos * rp.rot_pairs + j0 + 1];
-        p.s1 = rp.sin[(long)p.pos * rp.rot_pairs + j0 + 1];
-      }
-    }
-    return p;
-  }
-  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
-    const int D = rp.hidden, dh = rp.head_dim;
-    const int which = n / D;
-    const int c = n - which * D;
-    const int h = c / dh, d = c - h * dh;
-    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    v[0] = x0 * p.c0 - x1 * p.s0;
-    v[1] = x1 * p.c0 + x0 * p.s0;
-    v[2] = x2 * p.c1 - x3 * p.s1;
-    v[3] = x3 * p.c1 + x2 * p.s1;
-    if (which == 0) {
-      *reinterpret_cast<float4*>(q + (long)m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      bf16_t* dst = (which == 1 ? cacheK : cacheV) + (((long)m * (D / dh) + h) * Smax + p.pos) * dh + d;
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(dst) = o;
-    }
-  }
-  __device__ void n4(int m, int n, f32x4 v) const {
-    const int D = rp.hidden, dh = rp.head_dim;
-    const int pos = *pos_ptr;
-    const int which = n / D;
-    const int c = n - which * D;
-    const int h = c / dh, d = c - h * dh;
-    if (which < 2) rope4(v, d, pos, rp);
-    if (which == 0) {
-      *reinterpret_cast<float4*>(q + (long)m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      bf16_t* dst = (which == 1 ? cacheK : cacheV) + (((long)m * (D / dh) + h) * Smax + pos) * dh + d;
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(dst) = o;
-    }
-  }
-};
-
-struct EpiF32 {
-  float* out;
-  long ldc;
-  struct Pre {};
-  __device__ Pre pre(int, int) const { return Pre{}; }
-  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
-  __device__ void n4(int m, int n, f32x4 v) const {
-    *reinterpret_cast<float4*>(out + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-};
-
-// rows of W / bias interleaved as (value_j, gate_j): modeling_moonshine.py:92-96 chunk order
-struct EpiSwiGLU {
-  bf16_t* z;
-  long ldz;  // F
-  const float* bias;
-  struct Pre {
-    float4 b;
-  };
-  __device__ Pre pre(int, int n) const { return Pre{*reinterpret_cast<const float4*>(bias + n)}; }
-  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
-    const float val0 = v[0] + p.b.x, gate0 = v[1] + p.b.y, val1 = v[2] + p.b.z, gate1 = v[3] + p.b.w;
-    uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
-    *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
-  }
-  __device__ void n4(int m, int n, f32x4 v) const {
-    float4 b = *reinterpret_cast<const float4*>(bias + n);
-    const float val0 = v[0] + b.x, gate0 = v[1] + b.y, val1 = v[2] + b.z, gate1 = v[3] + b.w;
-    uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
-    *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // Tiled kernel
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
 
 template <int TM, int TN, bool SWAP, class Epi>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restrict__ A, long lda,
@@ -412,22 +156,9 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 // The DMA is issued from inline asm: hipcc otherwise treats it as an LDS store that may alias the
 // fragment reads and drains vmcnt(0) before every ds_read (cdna_hip_programming.md section 5).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) char lds_char_t;
-__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long)(lds_char_t*)(p); }
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_base)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi>
+// ABL (microbenchmark ablations, 0 in the product): bit 0 = no DMA after the prologue, bit 1 = no MFMA,
+// bit 2 = no fragment reads.
+template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ W, int M, int N, int K,
                                                              int ntn, int nblocks, Epi epi) {
@@ -502,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
     const int inflight = (kt + AHEAD - 1 < nk ? AHEAD - 1 : nk - 1 - kt);
     wait_stages(inflight);
     __builtin_amdgcn_s_barrier();              // every wave's pieces of slice kt have landed; slice kt-1 is consumed
-    if (kt + AHEAD < nk) issue(kt + AHEAD);
+    if (kt + AHEAD < nk && !(ABL & 1)) issue(kt + AHEAD);
     const uint4* st = lds + (kt % NSTAGE) * STAGE_SLOTS;
     // all fragment reads of the k-slice are issued before the first MFMA: one LDS latency per slice
     // instead of one per column tile (the two waves of a SIMD then cover each other's read phase)
@@ -510,14 +241,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wave * 16 * TM + i * 16 + li;
-      afr[i] = st[row * 4 + (kg ^ swz(row))];
+      afr[i] = (ABL & 4) ? make_uint4(kt, lane, 1, 2) : st[row * 4 + (kg ^ swz(row))];
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = j * 16 + li;
-      bfr[j] = st[BM * 4 + row * 4 + (kg ^ swz(row))];
+      bfr[j] = (ABL & 4) ? make_uint4(lane, kt, 3, 4) : st[BM * 4 + row * 4 + (kg ^ swz(row))];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((ABL & 2) != 0) {  // keep the fragments live without issuing MFMAs
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(afr[i].x), "v"(afr[i].y), "v"(afr[i].z), "v"(afr[i].w));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j].x), "v"(bfr[j].y), "v"(bfr[j].z), "v"(bfr[j].w));
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -606,188 +344,6 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Decode GEMM (M = batch rows): fragment-direct, split-K inside the workgroup.
-//
-// A workgroup owns one 16 x (16*TN) output tile; its 4 waves split the K loop (wave w takes the 32-wide
-// k-steps w, w+4, ...), each loading its MFMA fragments straight from global memory -- all loads of a
-// wave are independent and issued up front, so the kernel costs about one memory round trip instead of a
-// K/32-long dependent chain.  Partial tiles are summed through LDS in a fixed order (deterministic).
-// LN = true: A is the fp32 residual stream [M][K]; LayerNorm (no bias, eps 1e-5, exact two-pass) is
-// fused into the fragment build: row sums are combined across the 4 waves through LDS.
-// ------------------------------------------------------------------------------------------------
-template <int KS, int TN, bool LN, class Epi>
-__global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
-                                                       const float* __restrict__ gamma,
-                                                       const bf16_t* __restrict__ W, int M, int N, int n_tiles,
-                                                       Epi epi) {
-  constexpr int K = 32 * KS;
-  constexpr int KW = (KS + 3) / 4;  // k-steps per wave (upper bound)
-  __shared__ __attribute__((aligned(16))) float4 part[4][TN][64];
-  __shared__ float stat[2][4][16];
-  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = (blockIdx.x / n_tiles) * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
-  int gm = m0 + li;
-  gm = gm < M ? gm : M - 1;
-
-  // ---- issue every load of this wave first ----
-  uint4 wreg[KW][TN];
-#pragma unroll
-  for (int i = 0; i < KW; ++i) {
-    const int s = wave + 4 * i;
-    if (s < KS) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int gn = n0 + j * 16 + li;
-        gn = gn < N ? gn : N - 1;
-        wreg[i][j] = *reinterpret_cast<const uint4*>(W + (long)gn * K + s * 32 + kg * 8);
-      }
-    }
-  }
-  // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors): fetched now so
-  // that the kernel has ONE memory round trip on its critical path, not one per dependent stage
-  constexpr int NE = (TN + 3) / 4;
-  typename Epi::Pre epre[NE];
-  {
-    const int m = m0 + li;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int j = wave + 4 * e;
-      const int n = n0 + j * 16 + kg * 4;
-      if (j < TN && m < M && n < N) epre[e] = epi.pre(m, n);
-    }
-  }
-  bf16x8 afrag[KW];
-  if constexpr (LN) {
-    const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
-    float xv[KW][8];
-    float4 gam[KW][2];
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        gam[i][0] = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8);
-        gam[i][1] = *reinterpret_cast<const float4*>(gamma + s * 32 + kg * 8 + 4);
-      }
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
-        const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
-        xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
-        xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += xv[i][e];
-      }
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (kg == 0) stat[0][wave][li] = sum;
-    __syncthreads();
-    const float mean = ((stat[0][0][li] + stat[0][1][li]) + (stat[0][2][li] + stat[0][3][li])) * (1.0f / (float)K);
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      if (wave + 4 * i < KS) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = xv[i][e] - mean;
-          sq += d * d;
-        }
-      }
-    }
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    if (kg == 0) stat[1][wave][li] = sq;
-    __syncthreads();
-    const float var = ((stat[1][0][li] + stat[1][1][li]) + (stat[1][2][li] + stat[1][3][li])) * (1.0f / (float)K);
-    const float rstd = rsqrtf(var + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        const float4 g0 = gam[i][0], g1 = gam[i][1];
-        uint4 t;
-        t.x = pack_bf16x2((xv[i][0] - mean) * rstd * g0.x, (xv[i][1] - mean) * rstd * g0.y);
-        t.y = pack_bf16x2((xv[i][2] - mean) * rstd * g0.z, (xv[i][3] - mean) * rstd * g0.w);
-        t.z = pack_bf16x2((xv[i][4] - mean) * rstd * g1.x, (xv[i][5] - mean) * rstd * g1.y);
-        t.w = pack_bf16x2((xv[i][6] - mean) * rstd * g1.z, (xv[i][7] - mean) * rstd * g1.w);
-        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
-      }
-    }
-  } else {
-    const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        uint4 t = *reinterpret_cast<const uint4*>(a + s * 32);
-        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
-      }
-    }
-  }
-
-  f32x4 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < KW; ++i) {
-    if (wave + 4 * i < KS) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[i], acc[j], 0,
-                                                         0, 0);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) part[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-  __syncthreads();
-  // waves 0..TN-1 (round-robin when TN > 4) finish one column tile each: fixed summation order
-  const int m = m0 + li;
-#pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int j = wave + 4 * e;
-    if (j < TN) {
-      const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
-      f32x4 v;
-      v[0] = (p0.x + p1.x) + (p2.x + p3.x);
-      v[1] = (p0.y + p1.y) + (p2.y + p3.y);
-      v[2] = (p0.z + p1.z) + (p2.z + p3.z);
-      v[3] = (p0.w + p1.w) + (p2.w + p3.w);
-      const int n = n0 + j * 16 + kg * 4;
-      if (m < M && n < N) epi.n4p(m, n, v, epre[e]);
-    }
-  }
-}
-
-template <int KS, int TN, bool LN, class Epi>
-void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
-                    hipStream_t s) {
-  const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W, M,
-                     N, n_tiles, epi);
-}
-
-// K is a compile-time multiple of 32: D (LN-fused and attention-output GEMMs) or F (fc2)
-template <int TN, bool LN, class Epi>
-void launch_dec(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, int K, Epi epi,
-                hipStream_t s) {
-  if ((N & 3) != 0) throw std::runtime_error("gemm_dec: N must be a multiple of 4");
-  switch (K) {
-    case 416: return launch_dec_cfg<13, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    case 1664: return launch_dec_cfg<52, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    case 288: return launch_dec_cfg<9, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    case 1152: return launch_dec_cfg<36, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    case 64: return launch_dec_cfg<2, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    case 256: return launch_dec_cfg<8, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
-    default: throw std::runtime_error("gemm_dec: unsupported K " + std::to_string(K));
-  }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -815,28 +371,94 @@ void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int
   launch_tiled<false>(A, lda, W, M, N, K, EpiCrossKV{KT, VT, row_clip, clips, D, layer_stride}, s);
 }
 
-void dec_gemm_qkv(const float* H, const float* gamma, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp,
-                  float* q, bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
-  launch_dec<2, true>(H, D, gamma, W, M, 3 * D, D, EpiDecQkv{q, cacheK, cacheV, pos_ptr, rp, Smax}, s);
-}
-void dec_gemm_ln_f32(const float* H, const float* gamma, const bf16_t* W, int M, int N, int D, float* out,
-                     hipStream_t s) {
-  launch_dec<2, true>(H, D, gamma, W, M, N, D, EpiF32{out, N}, s);
-}
-void dec_gemm_ln_swiglu(const float* H, const float* gamma, const bf16_t* W, const float* bias, int M, int F, int D,
-                        bf16_t* z, hipStream_t s) {
-  launch_dec<2, true>(H, D, gamma, W, M, 2 * F, D, EpiSwiGLU{z, F, bias}, s);
-}
-void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
-                    hipStream_t s) {
-  launch_dec<2, false>(A, lda, nullptr, W, M, N, K, EpiResidF32{H, N, bias}, s);
-}
-void dec_gemm_logits(const float* H, const float* gamma, const bf16_t* E, int M, int V, int D, float* logits,
-                     hipStream_t s) {
-  launch_dec<4, true>(H, D, gamma, E, M, V, D, EpiF32{logits, V}, s);
-}
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiF32{out, N}, s);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Microbenchmark hook (tools/gemm_microbench.py): times one tiled-GEMM configuration on synthetic
+// operands with a plain bf16 store epilogue.  cfg: 0 = 4 waves 128x208 3 stages (product default),
+// 1 = 8 waves 256x208 4 stages, 2 = 4 waves 256x208 4 stages, 3 = 4 waves 128x208 2 stages,
+// 4 = 4 waves 128x208 4 stages.  abl: see gemm_tiled_dma_kernel.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct EpiBf16 {
+  bf16_t* out;
+  long ldc;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+  }
+};
+__global__ void fill_bf16_kernel(bf16_t* p, long n, unsigned seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    p[i] = f32_to_bf16(((float)(h & 0xffff) / 32768.0f - 1.0f));  // uniform [-1, 1)
+  }
+}
+template <int NW, int TM, int NSTAGE>
+void bench_launch(int abl, const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* C, hipStream_t s) {
+  constexpr int BM = 16 * NW * TM, BN = 208;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN, nb = ntm * ntn;
+  EpiBf16 epi{C, N};
+#define MSH_BL(X)                                                                                                     \
+  hipLaunchKernelGGL((gemm_tiled_dma_kernel<NW, TM, 13, NSTAGE, true, EpiBf16, X>), dim3(nb), dim3(64 * NW), 0, s, A, \
+                     lda, W, M, N, K, ntn, nb, epi)
+  switch (abl) {
+    case 0: MSH_BL(0); break;
+    case 1: MSH_BL(1); break;
+    case 2: MSH_BL(2); break;
+    case 3: MSH_BL(3); break;
+    case 5: MSH_BL(5); break;
+    case 6: MSH_BL(6); break;
+    default: throw std::runtime_error("bad ablation");
+  }
+#undef MSH_BL
+}
+}  // namespace
+
+float gemm_microbench(int M, int N, int K, long lda, int cfg, int abl, int iters) {
+  bf16_t *A = nullptr, *W = nullptr, *C = nullptr;
+  const long a_elems = (long)M * lda + K + 64;
+  MSH_HIP(hipMalloc(&A, a_elems * 2));
+  MSH_HIP(hipMalloc(&W, (long)N * K * 2));
+  MSH_HIP(hipMalloc(&C, (long)M * N * 2));
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+  MSH_HIP(hipDeviceSynchronize());
+  auto run = [&] {
+    switch (cfg) {
+      case 0: bench_launch<4, 2, 3>(abl, A, lda, W, M, N, K, C, 0); break;
+      case 1: bench_launch<8, 2, 4>(abl, A, lda, W, M, N, K, C, 0); break;
+      case 2: bench_launch<4, 4, 4>(abl, A, lda, W, M, N, K, C, 0); break;
+      case 3: bench_launch<4, 2, 2>(abl, A, lda, W, M, N, K, C, 0); break;
+      case 4: bench_launch<4, 2, 4>(abl, A, lda, W, M, N, K, C, 0); break;
+      default: throw std::runtime_error("bad config");
+    }
+  };
+  run();
+  MSH_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  MSH_HIP(hipEventCreate(&e0));
+  MSH_HIP(hipEventCreate(&e1));
+  MSH_HIP(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) run();
+  MSH_HIP(hipEventRecord(e1, 0));
+  MSH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MSH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A);
+  (void)hipFree(W);
+  (void)hipFree(C);
+  return ms / iters;
 }
 
 }  // namespace msh

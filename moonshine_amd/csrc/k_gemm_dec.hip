@@ -1,0 +1,392 @@
+// Decode-path GEMMs for gfx950 (M = batch rows, weights streamed): see the two kernels below.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace msh {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Decode GEMM (M = batch rows): fragment-direct, split-K inside the workgroup.
+//
+// A workgroup owns one 16 x (16*TN) output tile; its 4 waves split the K loop (wave w takes the 32-wide
+// k-steps w, w+4, ...), each loading its MFMA fragments straight from global memory -- all loads of a
+// wave are independent and issued up front, so the kernel costs about one memory round trip instead of a
+// K/32-long dependent chain.  Partial tiles are summed through LDS in a fixed order (deterministic).
+// LN = true: A is the fp32 residual stream [M][K]; LayerNorm (no bias, eps 1e-5, exact two-pass) is
+// fused into the fragment build: row sums are combined across the 4 waves through LDS.  The LayerNorm
+// scale gamma is folded into W at load time (W' = W * diag(gamma)), so the kernel only normalises.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int TN, bool LN, class Epi>
+__global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
+                                                       const float* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ W, int M, int N, int n_tiles,
+                                                       Epi epi) {
+  constexpr int K = 32 * KS;
+  constexpr int KW = (KS + 3) / 4;  // k-steps per wave (upper bound)
+  __shared__ __attribute__((aligned(16))) float4 part[4][TN][64];
+  __shared__ float stat[2][4][16];
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = (blockIdx.x / n_tiles) * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
+  int gm = m0 + li;
+  gm = gm < M ? gm : M - 1;
+
+  // ---- issue every load of this wave first ----
+  uint4 wreg[KW][TN];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int s = wave + 4 * i;
+    if (s < KS) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int gn = n0 + j * 16 + li;
+        gn = gn < N ? gn : N - 1;
+        wreg[i][j] = *reinterpret_cast<const uint4*>(W + (long)gn * K + s * 32 + kg * 8);
+      }
+    }
+  }
+  // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors): fetched now so
+  // that the kernel has ONE memory round trip on its critical path, not one per dependent stage
+  constexpr int NE = (TN + 3) / 4;
+  typename Epi::Pre epre[NE];
+  {
+    const int m = m0 + li;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int j = wave + 4 * e;
+      const int n = n0 + j * 16 + kg * 4;
+      if (j < TN && m < M && n < N) epre[e] = epi.pre(m, n);
+    }
+  }
+  bf16x8 afrag[KW];
+  if constexpr (LN) {
+    const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
+    float xv[KW][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
+        const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
+        xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+        xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[i][e];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (kg == 0) stat[0][wave][li] = sum;
+    __syncthreads();
+    const float mean = ((stat[0][0][li] + stat[0][1][li]) + (stat[0][2][li] + stat[0][3][li])) * (1.0f / (float)K);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      if (wave + 4 * i < KS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = xv[i][e] - mean;
+          sq += d * d;
+        }
+      }
+    }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    if (kg == 0) stat[1][wave][li] = sq;
+    __syncthreads();
+    const float var = ((stat[1][0][li] + stat[1][1][li]) + (stat[1][2][li] + stat[1][3][li])) * (1.0f / (float)K);
+    const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        uint4 t;
+        t.x = pack_bf16x2((xv[i][0] - mean) * rstd, (xv[i][1] - mean) * rstd);
+        t.y = pack_bf16x2((xv[i][2] - mean) * rstd, (xv[i][3] - mean) * rstd);
+        t.z = pack_bf16x2((xv[i][4] - mean) * rstd, (xv[i][5] - mean) * rstd);
+        t.w = pack_bf16x2((xv[i][6] - mean) * rstd, (xv[i][7] - mean) * rstd);
+        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
+      }
+    }
+  } else {
+    const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      const int s = wave + 4 * i;
+      if (s < KS) {
+        uint4 t = *reinterpret_cast<const uint4*>(a + s * 32);
+        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
+      }
+    }
+  }
+
+  f32x4 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    if (wave + 4 * i < KS) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[i], acc[j], 0,
+                                                         0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) part[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  __syncthreads();
+  // waves 0..TN-1 (round-robin when TN > 4) finish one column tile each: fixed summation order
+  const int m = m0 + li;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int j = wave + 4 * e;
+    if (j < TN) {
+      const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
+      f32x4 v;
+      v[0] = (p0.x + p1.x) + (p2.x + p3.x);
+      v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+      v[2] = (p0.z + p1.z) + (p2.z + p3.z);
+      v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+      const int n = n0 + j * 16 + kg * 4;
+      if (m < M && n < N) epi.n4p(m, n, v, epre[e]);
+    }
+  }
+}
+
+template <int KS, int TN, bool LN, class Epi>
+void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
+                    hipStream_t s) {
+  const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
+  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W, M,
+                     N, n_tiles, epi);
+}
+
+// K is a compile-time multiple of 32: D (LN-fused and attention-output GEMMs) or F (fc2)
+template <int TN, bool LN, class Epi>
+void launch_dec(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, int K, Epi epi,
+                hipStream_t s) {
+  if ((N & 3) != 0) throw std::runtime_error("gemm_dec: N must be a multiple of 4");
+  switch (K) {
+    case 416: return launch_dec_cfg<13, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 1664: return launch_dec_cfg<52, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 288: return launch_dec_cfg<9, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 1152: return launch_dec_cfg<36, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 64: return launch_dec_cfg<2, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    case 256: return launch_dec_cfg<8, TN, LN, Epi>(A, lda, gamma, W, M, N, epi, s);
+    default: throw std::runtime_error("gemm_dec: unsupported K " + std::to_string(K));
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Decode GEMM for larger batches (M >= 64): A fragments resident in registers, W streamed by LDS-DMA.
+//
+// A workgroup owns a 64 x (16*TN) tile: wave w holds the MFMA A fragments of its own 16 rows for the
+// whole K = 32*KS (LayerNorm fused: the row is normalised in registers, two-pass, gamma folded into W),
+// so the only operand that moves during the k-loop is the W slice -- TN KiB per 32-wide k-step, fetched
+// once per workgroup by `global_load_lds` into a 6-deep ring and shared by the 4 waves.  Compared with
+// gemm_dec_kernel (16-row tiles, W fragments loaded per wave) the weights are re-read M/64 instead of
+// M/16 times and the LayerNorm is recomputed N/(16*TN) / 4 times less often.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int TN, bool LN, class Epi>
+__global__ __launch_bounds__(256) void gemm_dec64_kernel(const void* __restrict__ Aptr, long lda,
+                                                         const bf16_t* __restrict__ W, int M, int N, int n_tiles,
+                                                         Epi epi) {
+  constexpr int K = 32 * KS;
+  constexpr int NST = 6;                      // ring depth (k-slices)
+  constexpr int AHEAD = NST - 1;
+  constexpr int PW = (TN + 3) / 4;            // 1-KiB pieces a wave issues per k-slice (upper bound)
+  __shared__ __attribute__((aligned(16))) uint4 lds[NST * TN * 64];
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = (blockIdx.x / n_tiles) * 64 + wave * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
+  const int m = m0 + li;
+  const int gm = m < M ? m : M - 1;
+  const int my_pieces = (TN - wave + 3) / 4;  // wave-uniform, 0 when TN < 4 and wave >= TN
+
+  // epilogue inputs first (oldest loads), then the A rows, then the DMA prologue
+  typename Epi::Pre epre[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + j * 16 + kg * 4;
+    if (m < M && n < N) epre[j] = epi.pre(m, n);
+  }
+  float xv[LN ? KS : 1][8];
+  uint4 araw[LN ? 1 : KS];
+  if constexpr (LN) {
+    const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
+      const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
+      xv[s][0] = a.x; xv[s][1] = a.y; xv[s][2] = a.z; xv[s][3] = a.w;
+      xv[s][4] = b.x; xv[s][5] = b.y; xv[s][6] = b.z; xv[s][7] = b.w;
+    }
+  } else {
+    const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) araw[s] = *reinterpret_cast<const uint4*>(a + s * 32);
+  }
+  const bf16_t* src[PW];
+  unsigned dst[PW];
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int p = wave + 4 * i;               // column tile this wave fetches
+    const int r = lane >> 2, pos = lane & 3, row = p * 16 + r;
+    int gn = n0 + row;
+    gn = gn < N ? gn : N - 1;
+    src[i] = W + (long)gn * K + ((pos ^ swz(row)) << 3);
+    dst[i] = lds_base + (unsigned)p * 1024u;
+  }
+  auto issue = [&](int kt) {
+    const unsigned sb = (unsigned)(kt % NST) * (TN * 1024u);
+#pragma unroll
+    for (int i = 0; i < PW; ++i)
+      if (i < my_pieces) dma16(src[i] + (kt << 5), dst[i] + sb);
+  };
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s)
+    if (s < KS) issue(s);
+
+  bf16x8 afr[KS];
+  if constexpr (LN) {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / (float)K);
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = xv[s][e] - mean;
+        sq += d * d;
+      }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / (float)K) + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4 t;
+      t.x = pack_bf16x2((xv[s][0] - mean) * rstd, (xv[s][1] - mean) * rstd);
+      t.y = pack_bf16x2((xv[s][2] - mean) * rstd, (xv[s][3] - mean) * rstd);
+      t.z = pack_bf16x2((xv[s][4] - mean) * rstd, (xv[s][5] - mean) * rstd);
+      t.w = pack_bf16x2((xv[s][6] - mean) * rstd, (xv[s][7] - mean) * rstd);
+      afr[s] = *reinterpret_cast<bf16x8*>(&t);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) afr[s] = *reinterpret_cast<bf16x8*>(&araw[s]);
+  }
+
+  f32x4 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // every compiler-issued load above is older than the DMAs, and vector-memory ops retire in order: a
+  // counted wait that leaves only this wave's newest DMA pieces outstanding therefore covers them too
+#pragma unroll
+  for (int kt = 0; kt < KS; ++kt) {
+    const int inflight = (kt + AHEAD - 1 < KS ? AHEAD - 1 : KS - 1 - kt);  // compile-time after unrolling
+    if (my_pieces == PW) {
+      switch (inflight) {
+        case 4: wait_vmcnt<4 * PW>(); break;
+        case 3: wait_vmcnt<3 * PW>(); break;
+        case 2: wait_vmcnt<2 * PW>(); break;
+        case 1: wait_vmcnt<PW>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+    } else {
+      switch (inflight) {
+        case 4: wait_vmcnt<4 * (PW - 1)>(); break;
+        case 3: wait_vmcnt<3 * (PW - 1)>(); break;
+        case 2: wait_vmcnt<2 * (PW - 1)>(); break;
+        case 1: wait_vmcnt<(PW - 1)>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + AHEAD < KS) issue(kt + AHEAD);
+    const uint4* st = lds + (kt % NST) * (TN * 64);
+    uint4 bfr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 16 + li;
+      bfr[j] = st[row * 4 + (kg ^ swz(row))];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&bfr[j]), afr[kt], acc[j], 0, 0, 0);
+  }
+  wait_vmcnt<0>();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + j * 16 + kg * 4;
+    if (m < M && n < N) epi.n4p(m, n, acc[j], epre[j]);
+  }
+}
+
+template <int KS, int TN, bool LN, class Epi>
+void launch_dec64_cfg(const void* A, long lda, const bf16_t* W, int M, int N, Epi epi, hipStream_t s) {
+  const int m_tiles = (M + 63) / 64, n_tiles = (N + 16 * TN - 1) / (16 * TN);
+  hipLaunchKernelGGL((gemm_dec64_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, W, M, N,
+                     n_tiles, epi);
+}
+
+// register-resident A needs K <= 416 (13 fragments): the hidden size of every supported model
+template <int TN, bool LN, class Epi>
+bool launch_dec64(const void* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  switch (K) {
+    case 416: launch_dec64_cfg<13, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
+    case 288: launch_dec64_cfg<9, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
+    case 64: launch_dec64_cfg<2, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// Batch threshold for the 64-row register-resident-A kernel.  Off by default (MSH_DEC64_M=0): on MI355X it
+// measured slower than the split-K kernel at M = 256 (qkv 23 vs 12 us) -- kept for further work.
+static bool use_dec64(int M) {
+  static int thr = [] {
+    const char* e = getenv("MSH_DEC64_M");
+    return e ? atoi(e) : 0;
+  }();
+  return thr > 0 && M >= thr;
+}
+
+void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
+                  bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
+  EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
+  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 3 * D, D, epi, s)) return;
+  launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+}
+void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
+  EpiF32 epi{out, N};
+  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, N, D, epi, s)) return;
+  launch_dec<2, true>(H, D, nullptr, W, M, N, D, epi, s);
+}
+void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int M, int F, int D, bf16_t* z,
+                        hipStream_t s) {
+  EpiSwiGLU epi{z, F, bias};
+  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
+  launch_dec<2, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+}
+void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                    hipStream_t s) {
+  EpiResidF32 epi{H, N, bias};
+  if (use_dec64(M) && launch_dec64<4, false>(A, lda, W, M, N, K, epi, s)) return;  // K = D only
+  launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
+}
+void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s) {
+  launch_dec<4, true>(H, D, nullptr, E, M, V, D, EpiF32{logits, V}, s);
+}
+
+}  // namespace msh

@@ -37,24 +37,23 @@ void gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bia
 void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
                    const ClipMeta* clips, int D, long layer_stride, bf16_t* KT, bf16_t* VT, hipStream_t s);
 
-// ---------------- fragment-direct MFMA GEMM (decode, M = batch) ----------------
-// q/k/v for one decoder layer from LN(H): q_f32[M,D] (rope), k (rope) / v appended to the
-// self cache [M][H][Smax][dh] at position *pos_ptr.
-void dec_gemm_qkv(const float* H, const float* gamma, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp,
-                  float* q, bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s);
+// ---------------- decode GEMMs (M = batch rows; k_gemm_dec.hip) ----------------
+// "LN" variants take the fp32 residual stream H and fuse LayerNorm (no bias, eps 1e-5) into the A-fragment
+// build; the LayerNorm scale gamma must already be folded into W (W' = W * diag(gamma), done at load).
+// q/k/v for one decoder layer: q_f32[M,D] (rope), k (rope) / v appended to the self cache
+// [M][H][Smax][dh] at position *pos_ptr.
+void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
+                  bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s);
 // out_f32[M,N] = LN(H) * W^T
-void dec_gemm_ln_f32(const float* H, const float* gamma, const bf16_t* W, int M, int N, int D, float* out,
-                     hipStream_t s);
+void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s);
 // z_bf16[M,F] = silu(gate) * value of (LN(H) * W^T + bias); W/bias rows interleaved (value_j, gate_j)
-void dec_gemm_ln_swiglu(const float* H, const float* gamma, const bf16_t* W, const float* bias, int M, int F, int D,
-                        bf16_t* z, hipStream_t s);
+void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int M, int F, int D, bf16_t* z,
+                        hipStream_t s);
 // H_f32[M,N] += A_bf16[M,K] * W^T (+ bias)
 void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                     hipStream_t s);
-// logits_f32[M,V] = LN(H) * E^T
-void dec_gemm_logits(const float* H, const float* gamma, const bf16_t* E, int M, int V, int D, float* logits,
-                     hipStream_t s);
-
+// logits_f32[M,V] = LN(H) * E'^T  (E' = tied embedding with the final LayerNorm scale folded in)
+void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s);
 // logits_f32[M,N] = A_bf16[M,K] * W^T with the tiled kernel (LM head at batch >= 128, after layernorm_bf16)
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
 
@@ -101,5 +100,8 @@ void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, De
                     int D, float* H, hipStream_t s);
 // H[b,:] = embed[BOS]; counters reset
 void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D, float* H, hipStream_t s);
+
+// tiled-GEMM microbenchmark (ms per launch); see k_gemm.hip
+float gemm_microbench(int M, int N, int K, long lda, int cfg, int abl, int iters);
 
 }  // namespace msh

@@ -3,6 +3,7 @@
 // reference applies at its own C boundary (reference core/moonshine-c-api.cpp:439-446).
 #include "../../include/moonshine_hip.h"
 
+#include <stdio.h>
 #include <string.h>
 
 #include <string>
@@ -189,6 +190,15 @@ int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_entry* out) {
   out->flops = p.flops;
   out->bytes = p.bytes;
   return MSH_OK;
+}
+
+float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl, int32_t iters) {
+  try {
+    return msh::gemm_microbench(M, N, K, lda, cfg, abl, iters);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "gemm_microbench: %s\n", ex.what());
+    return -1.0f;
+  }
 }
 
 int32_t msh_synchronize(msh_engine* e) {
