@@ -7,9 +7,10 @@
 //                       P fragment and the O accumulator all live in the same lane, no cross-lane moves
 //                       other than two xor-shuffles for the row max.
 //  dec_self_attention   one wave per (clip, head): <= Smax cached keys, latency-bound, plain VALU.
-//  dec_cross_attention  one wave per (clip, head) streaming K^T / V^T ([dh][Tk] bf16, keys contiguous)
-//                       with 16-byte loads: the HBM-bound kernel that dominates batched decode
-//                       (5.5 MB per clip per step at Moonshine-base).
+//  dec_cross_attention  one workgroup per (clip, head), 4 waves splitting the head dim, streaming K^T / V^T
+//                       ([dh][Tk] bf16, keys contiguous) with 16-byte non-temporal buffer loads: the
+//                       HBM-bound kernel that dominates batched decode (5.5 MB per clip per step at
+//                       Moonshine-base).
 #include "kernels.h"
 
 namespace msh {
@@ -240,10 +241,13 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
   float mloc = -INFINITY;
   for (int s = lane; s < S; s += 64) {
     const bf16_t* kr = kp + (long)s * DH;
+    uint2 kraw[DH / 4];  // the whole key row is requested before the first use: one round trip
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) kraw[d / 4] = *reinterpret_cast<const uint2*>(kr + d);
     float acc = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
-      uint2 u = *reinterpret_cast<const uint2*>(kr + d);
+      const uint2 u = kraw[d / 4];
       acc += qreg[d] * bf_lo(u.x) + qreg[d + 1] * bf_hi(u.x) + qreg[d + 2] * bf_lo(u.y) + qreg[d + 3] * bf_hi(u.y);
     }
     acc *= c;

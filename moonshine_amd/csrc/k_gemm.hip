@@ -295,6 +295,139 @@ void launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int
                      W, M, N, K, ntn, nblocks, epi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A-stationary tiled kernel for short K (K = 32*KS <= 416: qkv, o-proj, fc1, cross-KV).
+//
+// The microbenchmark ablations (profiles/r01g_gemm_microbench_ablations.txt) show the LDS-DMA kernel is
+// bound by per-CU ingest (its "DMA only" time equals its full time), and for K = 416 it also refills its
+// pipeline every 13 k-slices.  Here a workgroup keeps the MFMA A fragments of its 128 rows (4 waves x 32
+// rows x K) in registers for its whole life and walks over column tiles of 208: only W k-slices (13 KiB)
+// move through the LDS ring -- 128 flop per ingested byte instead of 79 -- and the ring keeps running
+// across column tiles, so the next tile's first slices are already in flight while a tile's epilogue
+// stores drain (one vmcnt(0) per tile, after the epilogue, covers both).
+// ------------------------------------------------------------------------------------------------
+template <int KS, int TN, int NST, bool SWAP, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __restrict__ A, long lda,
+                                                            const bf16_t* __restrict__ W, int M, int N, int ntn,
+                                                            int nsplit, Epi epi) {
+  constexpr int K = 32 * KS, BM = 128, BN = 16 * TN;
+  constexpr int PMAX = (TN + 3) / 4;          // 1-KiB W pieces per wave per k-slice
+  constexpr int AHEAD = NST - 1;
+  __shared__ __attribute__((aligned(16))) uint4 lds[NST * TN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = blockIdx.x / nsplit, part = blockIdx.x - mt * nsplit;
+  const int t0 = (int)((long)ntn * part / nsplit), t1 = (int)((long)ntn * (part + 1) / nsplit);
+  const int m0 = mt * BM + wave * 32;
+  const int my_pieces = (TN - wave + 3) / 4;
+
+  // A fragments: rows m0 + i*16 + li, k-chunk kg of every 32-wide slice
+  bf16x8 afr[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int gm = m0 + i * 16 + li;
+    gm = gm < M ? gm : M - 1;
+    const bf16_t* a = A + (long)gm * lda + kg * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 t = *reinterpret_cast<const uint4*>(a + s * 32);
+      afr[i][s] = *reinterpret_cast<const bf16x8*>(&t);
+    }
+  }
+  // W piece sources: row (within the column tile) and swizzled chunk are fixed per lane
+  // (N is a multiple of the 208-wide column tile here, so no row clamping is needed)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0])) + (unsigned)wave * 1024u;
+  const int wrow = wave * 16 + (lane >> 2);
+  const bf16_t* wsrc = W + (long)wrow * K + (((lane & 3) ^ swz(wrow)) << 3);  // swz(row + 64*i) == swz(row)
+  const int n_slices = (t1 - t0) * KS;
+  int it = t0, ik = 0, islice = 0;             // issue cursor (tile, k-slice, running index)
+  auto issue_next = [&]() {
+    if (islice < n_slices) {
+      const unsigned sb = (unsigned)(islice % NST) * (TN * 1024u);
+      const bf16_t* src = wsrc + (long)(it * BN) * K + (ik << 5);
+#pragma unroll
+      for (int i = 0; i < PMAX; ++i) {
+        if (i < my_pieces) dma16(src + (long)i * 64 * K, lds_base + sb + (unsigned)i * 4096u);
+      }
+      ++islice;
+      if (++ik == KS) {
+        ik = 0;
+        ++it;
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s) issue_next();
+
+  int cslice = 0;
+  for (int t = t0; t < t1; ++t) {
+    f32x4 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KS; ++kt) {
+      // slices cslice+1 .. cslice+AHEAD-1 may stay in flight (fewer at the very end)
+      const int left = n_slices - 1 - cslice;
+      const int inflight = left < AHEAD - 1 ? left : AHEAD - 1;
+      if (my_pieces == PMAX) {
+        if (inflight >= 2) wait_vmcnt<2 * PMAX>();
+        else if (inflight == 1) wait_vmcnt<PMAX>();
+        else wait_vmcnt<0>();
+      } else {
+        if (inflight >= 2) wait_vmcnt<2 * (PMAX - 1)>();
+        else if (inflight == 1) wait_vmcnt<PMAX - 1>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      issue_next();
+      const uint4* st = lds + (cslice % NST) * (TN * 64);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + li;
+        const uint4 b = st[row * 4 + (kg ^ swz(row))];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (SWAP)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&b), afr[i][kt],
+                                                                 acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i][kt], *reinterpret_cast<const bf16x8*>(&b),
+                                                                 acc[i][j], 0, 0, 0);
+        }
+      }
+      ++cslice;
+    }
+    const int n0 = t * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (SWAP) {
+          const int m = m0 + i * 16 + li, n = n0 + j * 16 + kg * 4;
+          if (m < M && n < N) epi.n4(m, n, acc[i][j]);
+        } else {
+          const int m = m0 + i * 16 + kg * 4, n = n0 + j * 16 + li;
+          if (m < M && n < N) epi.m4(m, n, acc[i][j]);
+        }
+      }
+    }
+    // the epilogue's loads / stores share the vmcnt counter with the DMAs: drain everything once per tile
+    // (the ring was refilled before the epilogue, so its latency overlaps the stores)
+    wait_vmcnt<0>();
+  }
+}
+
+template <int KS, int TN, int NST, bool SWAP, class Epi>
+void launch_astat_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, Epi epi, hipStream_t s) {
+  const int ntm = (M + 127) / 128, ntn = (N + 16 * TN - 1) / (16 * TN);
+  int nsplit = ntm >= 1024 ? 1 : (1024 + ntm - 1) / ntm;
+  if (nsplit > ntn) nsplit = ntn;
+  hipLaunchKernelGGL((gemm_astat_kernel<KS, TN, NST, SWAP, Epi>), dim3(ntm * nsplit), dim3(256), 0, s, A, lda, W, M, N,
+                     ntn, nsplit, epi);
+}
+
 // MSH_GEMM_MODE (debug / A-B switch): 0 = register-staged double buffer; 1 = LDS-DMA, 256x208 tile, 4 waves,
 // 4 stages (one workgroup per CU: measured ~2x slower than 2, nothing hides a wave's ds_read latency);
 // 2 = LDS-DMA, 128x208 tile, 4 waves, 3 stages, two workgroups per CU (default);
@@ -325,6 +458,7 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
   const bool big = (long)((M + 255) / 256) * ((N + 207) / 208) >= 512;
   if (N % 208 == 0 || (N % 144 != 0 && N >= 416)) {  // ragged last column tile (e.g. the 32768-wide LM head) is predicated
     const int mode = gemm_mode();
+    if (mode == 4 && K == 416 && M >= 2048 && N % 208 == 0) return launch_astat_cfg<13, 13, 3, SWAP, Epi>(A, lda, W, M, N, epi, s);
     if (mode == 0) {
       if (big)
         launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
@@ -380,7 +514,7 @@ void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, i
 // Microbenchmark hook (tools/gemm_microbench.py): times one tiled-GEMM configuration on synthetic
 // operands with a plain bf16 store epilogue.  cfg: 0 = 4 waves 128x208 3 stages (product default),
 // 1 = 8 waves 256x208 4 stages, 2 = 4 waves 256x208 4 stages, 3 = 4 waves 128x208 2 stages,
-// 4 = 4 waves 128x208 4 stages.  abl: see gemm_tiled_dma_kernel.
+// 4 = 4 waves 128x208 4 stages, 5 / 6 = A-stationary kernel with 3 / 4 stages (K = 416 only).  abl: see gemm_tiled_dma_kernel.
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct EpiBf16 {
@@ -439,6 +573,8 @@ float gemm_microbench(int M, int N, int K, long lda, int cfg, int abl, int iters
       case 2: bench_launch<4, 4, 4>(abl, A, lda, W, M, N, K, C, 0); break;
       case 3: bench_launch<4, 2, 2>(abl, A, lda, W, M, N, K, C, 0); break;
       case 4: bench_launch<4, 2, 4>(abl, A, lda, W, M, N, K, C, 0); break;
+      case 5: launch_astat_cfg<13, 13, 3, true>(A, lda, W, M, N, EpiBf16{C, N}, 0); break;  // K must be 416
+      case 6: launch_astat_cfg<13, 13, 4, true>(A, lda, W, M, N, EpiBf16{C, N}, 0); break;
       default: throw std::runtime_error("bad config");
     }
   };

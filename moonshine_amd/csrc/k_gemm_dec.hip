@@ -366,7 +366,10 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
   EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 3 * D, D, epi, s)) return;
-  launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+  if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
+    launch_dec<4, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+  else
+    launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
 }
 void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
   EpiF32 epi{out, N};
@@ -377,7 +380,10 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
                         hipStream_t s) {
   EpiSwiGLU epi{z, F, bias};
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
-  launch_dec<2, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+  if (M >= 96)
+    launch_dec<4, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+  else
+    launch_dec<2, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
 }
 void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                     hipStream_t s) {

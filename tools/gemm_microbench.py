@@ -20,3 +20,14 @@ for name, M, N, K, lda in shapes:
             ms = lib.msh_test_gemm_microbench(M, N, K, lda, cfg, abl, 5)
             row.append(f"{abls[abl]}={ms:.3f}ms({fl / ms / 1e9:.0f}TF)")
         print(f"{name:6s} cfg{cfg} [{cfgs[cfg]}]  " + "  ".join(row), flush=True)
+
+# A-stationary kernel (K = 416 shapes only)
+for name, M, N, K, lda in shapes + [("oproj", R, 416, 416, 416), ("crosskv", R, 6656, 416, 416)]:
+    if K != 416:
+        continue
+    fl = 2.0 * M * N * K
+    row = []
+    for cfg in (0, 5, 6):
+        ms = lib.msh_test_gemm_microbench(M, N, K, lda, cfg, 0, 5)
+        row.append(f"cfg{cfg}={ms:.3f}ms({fl / ms / 1e9:.0f}TF)")
+    print(f"{name:8s} astat  " + "  ".join(row), flush=True)
