@@ -458,7 +458,10 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
   const bool big = (long)((M + 255) / 256) * ((N + 207) / 208) >= 512;
   if (N % 208 == 0 || (N % 144 != 0 && N >= 416)) {  // ragged last column tile (e.g. the 32768-wide LM head) is predicated
     const int mode = gemm_mode();
-    if (mode == 4 && K == 416 && M >= 2048 && N % 208 == 0) return launch_astat_cfg<13, 13, 3, SWAP, Epi>(A, lda, W, M, N, epi, s);
+    // short K with many column tiles (fc1, cross-KV): the A-stationary kernel wins (r01k: fc1 386 -> 452,
+    // cross-KV 355 -> 389 TFLOP/s); with few column tiles (qkv, o-proj) its A preload is not amortised
+    if ((mode == 4 || (mode == 2 && N >= 1664)) && K == 416 && M >= 2048 && N % 208 == 0)
+      return launch_astat_cfg<13, 13, 3, SWAP, Epi>(A, lda, W, M, N, epi, s);
     if (mode == 0) {
       if (big)
         launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);

@@ -128,6 +128,170 @@ def make_weights(cfg: ArchConfig, seed: int = 0) -> dict[str, np.ndarray]:
     return out
 
 
+# ---------------------------------------------------------------------------
+# Streaming architectures (reference core/moonshine-streaming-model.{h,cpp}; float definition
+# transformers/models/moonshine_streaming/modeling_moonshine_streaming.py)
+# ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class StreamingArchConfig:
+    """Dimensions of a streaming Moonshine model (the keys of ``streaming_config.json``, reference
+    ``core/moonshine-streaming-model.cpp:97-113``, plus what the HF config adds).
+
+    ``tiny_streaming`` = HF defaults (``configuration_moonshine_streaming.py:51-69,106-137``).
+    The reference does not hold the medium model's dimensions (they come from its
+    ``streaming_config.json`` at load; the only hint is the 32768 x 640 head in
+    ``lora/export.py:199``): ``medium_streaming`` below is an ASSUMED medium-like shape used for
+    benchmarking only -- the engine reads every dimension from the config / tensor shapes.
+    """
+
+    name: str
+    enc_dim: int
+    enc_ffn: int
+    enc_layers: int
+    enc_heads: int
+    dec_dim: int
+    dec_ffn: int
+    depth: int               # decoder layers
+    heads: int               # decoder heads
+    windows: tuple           # per encoder layer (past, future), both inclusive (lora/export.py:119-122)
+    vocab: int = 32768
+    bos: int = 1
+    eos: int = 2
+    frame_len: int = 80      # 5 ms @ 16 kHz
+    max_pos: int = 4096      # pos_emb rows / max_position_embeddings
+    max_seq_len: int = 448   # streaming-model.cpp:111-113 default
+    rope_theta: float = 10000.0
+    partial_rotary: float = 0.8
+
+    @property
+    def head_dim(self) -> int:
+        return self.dec_dim // self.heads
+
+    @property
+    def enc_head_dim(self) -> int:
+        return self.enc_dim // self.enc_heads
+
+    @property
+    def total_lookahead(self) -> int:
+        return sum(int(w[1]) for w in self.windows)
+
+    def streaming_config_json(self) -> str:
+        """The ``streaming_config.json`` payload lora/export.py:455-463 writes."""
+        return json.dumps({
+            "encoder_dim": self.enc_dim, "decoder_dim": self.dec_dim, "depth": self.depth,
+            "nheads": self.heads, "head_dim": self.head_dim, "vocab_size": self.vocab,
+            "bos_id": self.bos, "eos_id": self.eos, "frame_len": self.frame_len,
+            "total_lookahead": self.total_lookahead, "d_model_frontend": self.enc_dim,
+            "c1": self.enc_dim * 2, "c2": self.enc_dim, "max_seq_len": self.max_seq_len,
+            # additive keys the MI355X engine needs and the ONNX graphs had baked in
+            "encoder_heads": self.enc_heads, "windows": [list(w) for w in self.windows],
+            "rope_theta": self.rope_theta, "partial_rotary_factor": self.partial_rotary,
+        }, indent=2)
+
+
+_W6 = ((16, 4), (16, 4), (16, 0), (16, 0), (16, 4), (16, 4))
+STREAMING_ARCHS = {
+    "tiny_streaming": StreamingArchConfig("tiny_streaming", 320, 1280, 6, 8, 320, 1280, 6, 8, _W6),
+    "medium_streaming": StreamingArchConfig(
+        "medium_streaming", 768, 3072, 12, 12, 640, 2560, 12, 8,
+        ((16, 4), (16, 4)) + ((16, 0),) * 8 + ((16, 4), (16, 4))),
+    # test-only: encoder_dim != decoder_dim (exercises decoder.proj) and an odd rotary dim
+    "micro_streaming": StreamingArchConfig(
+        "micro_streaming", 64, 128, 2, 4, 96, 192, 2, 4, ((16, 4), (16, 0)), vocab=512, max_pos=512),
+}
+
+
+def streaming_tensor_specs(cfg: StreamingArchConfig):
+    """(name, shape, kind, fan_in) in HF state_dict order (modeling_moonshine_streaming.py:283-296,
+    185-207, 133-139, 595-604, 455-456, 782-794, 1005-1010)."""
+    De, Fe, Dd, Fd, V = cfg.enc_dim, cfg.enc_ffn, cfg.dec_dim, cfg.dec_ffn, cfg.vocab
+    specs = [
+        ("model.encoder.embedder.comp.log_k", (), "log_k", 0),
+        ("model.encoder.embedder.conv1.weight", (2 * De, De, 5), "matrix", 5 * De),
+        ("model.encoder.embedder.conv1.bias", (2 * De,), "bias", 0),
+        ("model.encoder.embedder.conv2.weight", (De, 2 * De, 5), "matrix", 10 * De),
+        ("model.encoder.embedder.conv2.bias", (De,), "bias", 0),
+        ("model.encoder.embedder.linear.weight", (De, cfg.frame_len), "matrix", cfg.frame_len),
+    ]
+    for l in range(cfg.enc_layers):
+        p = f"model.encoder.layers.{l}."
+        for n in ("q", "k", "v", "o"):
+            specs.append((p + f"self_attn.{n}_proj.weight", (De, De), "matrix", De))
+        specs += [
+            (p + "mlp.fc1.weight", (Fe, De), "matrix", De),
+            (p + "mlp.fc1.bias", (Fe,), "bias", 0),
+            (p + "mlp.fc2.weight", (De, Fe), "matrix", Fe),
+            (p + "mlp.fc2.bias", (De,), "bias", 0),
+            (p + "input_layernorm.gamma", (De,), "gamma0", 0),
+            (p + "post_attention_layernorm.gamma", (De,), "gamma0", 0),
+        ]
+    specs.append(("model.encoder.final_norm.gamma", (De,), "gamma0", 0))
+    specs.append(("model.decoder.embed_tokens.weight", (V, Dd), "matrix", Dd))
+    for l in range(cfg.depth):
+        p = f"model.decoder.layers.{l}."
+        for a in ("self_attn", "encoder_attn"):
+            for n in ("q", "k", "v", "o"):
+                specs.append((p + f"{a}.{n}_proj.weight", (Dd, Dd), "matrix", Dd))
+        specs += [
+            (p + "mlp.fc1.weight", (2 * Fd, Dd), "matrix", Dd),
+            (p + "mlp.fc1.bias", (2 * Fd,), "bias", 0),
+            (p + "mlp.fc2.weight", (Dd, Fd), "matrix", Fd),
+            (p + "mlp.fc2.bias", (Dd,), "bias", 0),
+            (p + "input_layernorm.weight", (Dd,), "scale", 0),
+            (p + "post_attention_layernorm.weight", (Dd,), "scale", 0),
+            (p + "final_layernorm.weight", (Dd,), "scale", 0),
+        ]
+    specs.append(("model.decoder.norm.weight", (Dd,), "scale", 0))
+    specs.append(("model.decoder.pos_emb.weight", (cfg.max_pos, De), "posemb", 0))
+    if De != Dd:
+        specs.append(("model.decoder.proj.weight", (Dd, De), "matrix", De))
+    specs.append(("proj_out.weight", (V, Dd), "matrix", Dd))
+    return specs
+
+
+def make_streaming_weights(cfg: StreamingArchConfig, seed: int = 0) -> dict[str, np.ndarray]:
+    """Deterministic synthetic fp32 weights ("fanin-v1" as above).  Extra kinds: ``gamma0`` = the
+    unit-offset LayerNorm scale, stored as gamma - 1 (modeling_moonshine_streaming.py:120-130) ~ 0.1 N;
+    ``posemb`` ~ 0.5 N; ``log_k`` = log 0.75 (the module's init).  ``proj_out`` is a separate
+    (untied) matrix: tie_word_embeddings defaults to False for this family."""
+    out: dict[str, np.ndarray] = {}
+    for idx, (name, shape, kind, fan_in) in enumerate(streaming_tensor_specs(cfg)):
+        rng = np.random.Generator(np.random.PCG64([seed, 7000 + idx]))
+        if kind == "log_k":
+            out[name] = np.asarray(np.log(0.75), dtype=np.float32)
+            continue
+        x = rng.standard_normal(shape, dtype=np.float32)
+        if kind == "matrix":
+            x *= np.float32(1.0 / np.sqrt(fan_in))
+        elif kind == "bias":
+            x *= np.float32(0.1)
+        elif kind == "scale":
+            x = np.float32(1.0) + np.float32(0.1) * x
+        elif kind == "gamma0":
+            x *= np.float32(0.1)
+        elif kind == "posemb":
+            x *= np.float32(0.5)
+        out[name] = np.ascontiguousarray(x, dtype=np.float32)
+    return out
+
+
+def write_streaming_model_dir(path: str, cfg: StreamingArchConfig, seed: int = 0,
+                              weights: dict[str, np.ndarray] | None = None) -> dict[str, np.ndarray]:
+    """``model.safetensors`` + ``streaming_config.json`` + ``tokenizer.bin``: the streaming model
+    directory of the MI355X engine (the reference's holds five ``.ort`` graphs instead of the
+    safetensors file, core/moonshine-streaming-model.cpp:233-300)."""
+    import os
+
+    os.makedirs(path, exist_ok=True)
+    w = weights if weights is not None else make_streaming_weights(cfg, seed)
+    save_safetensors(os.path.join(path, "model.safetensors"), w,
+                     {"arch": cfg.name, "format": "moonshine-streaming-hf-f32", "seed": str(seed)})
+    with open(os.path.join(path, "streaming_config.json"), "w") as f:
+        f.write(cfg.streaming_config_json())
+    write_synthetic_tokenizer(os.path.join(path, "tokenizer.bin"), cfg.vocab)
+    return w
+
+
 def make_audio(index: int, n_samples: int = 160000) -> np.ndarray:
     """Synthetic clip ``index``: white noise sigma 0.1 clipped to [-1, 1]
     (BASELINE.md section 3 / SURVEY.md section 8d)."""
