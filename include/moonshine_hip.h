@@ -128,6 +128,65 @@ MSH_EXPORT int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* ou
 MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out,
                                      uint64_t out_cap);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Streaming models (reference core/moonshine-streaming-model.h:73-201).  One msh_stream_engine replaces the
+ * five ORT sessions of MoonshineStreamingModel (frontend / encoder / adapter / cross_kv / decoder_kv) and
+ * holds the per-stream state the reference keeps in MoonshineStreamingState (:36-71) on the device, one
+ * "slot" per stream.  Every call takes a list of slots and processes them as one batch.
+ *
+ *   msh_stream_create         MoonshineStreamingModel ctor + load (:112-119); weights = safetensors with the
+ *                             HuggingFace MoonshineStreamingForConditionalGeneration names, config = the
+ *                             streaming_config.json text (lora/export.py:455-463; additive keys
+ *                             "encoder_heads", "windows", "rope_theta", "partial_rotary_factor").
+ *   msh_stream_open / _close / _reset     create_state (:181) / delete / MoonshineStreamingState::reset (:70)
+ *   msh_stream_process_audio  process_audio_chunk (:145) for n streams; whole 320-sample periods are consumed,
+ *                             the rest waits for the next call
+ *   msh_stream_encode         encode (:149) for n streams (+ the cross K/V the reference computes lazily, :200)
+ *   msh_stream_decoder_reset  decoder_reset (:178)
+ *   msh_stream_decode_tokens  decode_tokens (:159) / decode_step (:153): logits rows of all streams concatenated
+ *   msh_stream_decode_full    decode_full (:174) for n streams: drafts[i] (nullable) is stream i's speculative
+ *                             draft; tokens_out[i * stride ...] / counts_out[i] get the content tokens (no BOS /
+ *                             EOS), accepted_out[i] (nullable) the number of draft tokens kept;
+ *                             max_tokens[i] < 0 (or a null array) = the reference's rule from the memory length
+ *                             (:1217-1219), otherwise an explicit budget.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct msh_stream_engine msh_stream_engine;
+
+typedef struct msh_stream_info {
+  int32_t encoder_dim, decoder_dim, depth, nheads, head_dim, vocab_size, bos_id, eos_id;
+  int32_t frame_len, total_lookahead, max_seq_len, enc_layers, encoder_heads;
+  int32_t max_slots, memory_capacity; /* engine limits: concurrent streams, memory frames (20 ms) per stream */
+} msh_stream_info;
+
+MSH_EXPORT int32_t msh_stream_create(int32_t device, const char* safetensors_path, const char* config_json,
+                                     int32_t max_slots, int32_t max_memory_frames, msh_stream_engine** out);
+MSH_EXPORT int32_t msh_stream_create_from_memory(int32_t device, const void* safetensors, uint64_t size,
+                                                 const char* config_json, int32_t max_slots,
+                                                 int32_t max_memory_frames, msh_stream_engine** out);
+MSH_EXPORT void msh_stream_destroy(msh_stream_engine* e);
+MSH_EXPORT const char* msh_stream_last_error(const msh_stream_engine* e);
+MSH_EXPORT int32_t msh_stream_info_get(const msh_stream_engine* e, msh_stream_info* out);
+MSH_EXPORT int32_t msh_stream_open(msh_stream_engine* e);                 /* slot id >= 0, or a negative status */
+MSH_EXPORT int32_t msh_stream_close(msh_stream_engine* e, int32_t slot);
+MSH_EXPORT int32_t msh_stream_reset(msh_stream_engine* e, int32_t slot);
+MSH_EXPORT int32_t msh_stream_process_audio(msh_stream_engine* e, int32_t n, const int32_t* slots,
+                                            const float* const* pcm, const uint64_t* n_samples,
+                                            int32_t* features_out);
+MSH_EXPORT int32_t msh_stream_encode(msh_stream_engine* e, int32_t n, const int32_t* slots, const uint8_t* is_final,
+                                     int32_t* new_frames_out);
+MSH_EXPORT int32_t msh_stream_decoder_reset(msh_stream_engine* e, int32_t n, const int32_t* slots);
+MSH_EXPORT int32_t msh_stream_decode_tokens(msh_stream_engine* e, int32_t n, const int32_t* slots,
+                                            const int32_t* const* tokens, const int32_t* n_tokens,
+                                            float* logits_out);
+MSH_EXPORT int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const int32_t* slots,
+                                          const int32_t* const* drafts, const int32_t* draft_lens,
+                                          const int32_t* max_tokens, int32_t* tokens_out, int32_t* counts_out,
+                                          int32_t tokens_stride, int32_t* accepted_out);
+/* state queries: 0 memory_len, 1 feature_count, 2 cache_len, 3 frames_emitted, 4 max_tokens for the memory */
+MSH_EXPORT int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what);
+MSH_EXPORT int32_t msh_stream_get_memory(msh_stream_engine* e, int32_t slot, float* out);   /* [memory_len][Dd] */
+MSH_EXPORT int32_t msh_stream_get_features(msh_stream_engine* e, int32_t slot, float* out); /* [features][De] */
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,6 +263,39 @@ struct EpiSwiGLU {
   }
 };
 
+// Generic epilogue of the streaming path (frontend linear / causal convs, projections without a fused
+// consumer): out = act(acc + bias) written as bf16 and / or fp32.  act: 0 none, 1 SiLU, 2 GELU(erf).
+struct EpiAct {
+  bf16_t* out16;     // nullable
+  float* out32;      // nullable
+  long ldc;
+  const float* bias;  // nullable
+  int act;
+  __device__ void n4(int m, int n, f32x4 v) const {
+    if (bias != nullptr) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      v[0] += b.x;
+      v[1] += b.y;
+      v[2] += b.z;
+      v[3] += b.w;
+    }
+    if (act == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+    } else if (act == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    }
+    if (out16 != nullptr) {
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(out16 + (long)m * ldc + n) = o;
+    }
+    if (out32 != nullptr) *reinterpret_cast<float4*>(out32 + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
 // XOR swizzle of the 16-B k-chunk position inside a 64-B row of an LDS k-slice (conflict-free
 // ds_read_b128 fragment reads for the lane groups of gfx950; verified: SQ_LDS_BANK_CONFLICT = 0)
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }

@@ -508,6 +508,14 @@ void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int
   launch_tiled<false>(A, lda, W, M, N, K, EpiCrossKV{KT, VT, row_clip, clips, D, layer_stride}, s);
 }
 
+void gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,
+              bf16_t* out_bf16, float* out_f32, hipStream_t s) {
+  launch_tiled<true>(A, lda, W, M, N, K, EpiAct{out_bf16, out_f32, N, bias, act}, s);
+}
+void gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, bf16_t* z,
+                      hipStream_t s) {
+  launch_tiled<true>(A, lda, W, M, N, K, EpiSwiGLU{z, N / 2, bias}, s);
+}
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiF32{out, N}, s);
 }

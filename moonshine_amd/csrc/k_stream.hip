@@ -1,0 +1,461 @@
+// Streaming-path kernels for gfx950 (everything that is not a GEMM): frame normalisation, the sliding-window
+// encoder attention, row-based decoder attention over per-stream caches, and the device-side bookkeeping
+// of the speculative decode.  Rows of a decoder pass are (stream, position) pairs, so one launch serves
+// the wide verify pass (many rows per stream) and the auto-regressive steps (one row per stream) alike.
+//
+// These kernels are small HBM/latency-bound pieces: one 64-lane wave per (row, head) for the short
+// attentions, one workgroup per (row, head) for cross-attention, wave-level shuffles for every reduction.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "stream_kernels.h"
+
+namespace msh {
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float bf(bf16_t h) { return bf16_to_f32(h); }
+
+// dot of an fp32 vector in LDS with a bf16 row in global memory, n % 4 == 0
+__device__ __forceinline__ float dot_row(const float* __restrict__ q, const bf16_t* __restrict__ k, int n) {
+  float acc = 0.f;
+  for (int d = 0; d < n; d += 4) {
+    const uint2 r = *reinterpret_cast<const uint2*>(k + d);
+    acc += q[d] * __uint_as_float(r.x << 16) + q[d + 1] * __uint_as_float(r.x & 0xffff0000u) +
+           q[d + 2] * __uint_as_float(r.y << 16) + q[d + 3] * __uint_as_float(r.y & 0xffff0000u);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one wave per 80-sample frame: mean / rms over the frame, asinh compression, bf16 row of 96
+__global__ __launch_bounds__(256) void frames_kernel(const float* __restrict__ audio, const FrameJob* __restrict__ jobs,
+                                                     float k, bf16_t* __restrict__ frames) {
+  const FrameJob job = jobs[blockIdx.y];
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (f >= job.n_frames) return;
+  const float* a = audio + job.audio_off + (long)f * 80;
+  const float x0 = a[lane];
+  const float x1 = lane < 16 ? a[64 + lane] : 0.f;
+  const float mean = wsum(x0 + x1) * (1.0f / 80.0f);
+  const float c0 = x0 - mean, c1 = lane < 16 ? x1 - mean : 0.f;
+  const float rms = sqrtf(wsum(c0 * c0 + c1 * c1) * (1.0f / 80.0f) + 1e-6f);
+  bf16_t* o = frames + (long)(job.row0 + f) * 96;
+  o[lane] = f32_to_bf16(asinhf(k * (c0 / rms)));
+  if (lane < 32) o[64 + lane] = lane < 16 ? f32_to_bf16(asinhf(k * (c1 / rms))) : (bf16_t)0;
+}
+
+__global__ __launch_bounds__(256) void copy_segments_kernel(const StreamSeg* __restrict__ segs) {
+  const StreamSeg sg = segs[blockIdx.x];
+  const uint4* s = reinterpret_cast<const uint4*>(sg.src);
+  uint4* d = reinterpret_cast<uint4*>(sg.dst);
+  const long n = sg.bytes >> 4;
+  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.y * blockDim.x) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// sliding-window encoder attention: one wave per (row, head), at most 64 keys in the window
+__global__ __launch_bounds__(256) void enc_window_attention_kernel(const bf16_t* __restrict__ qkv,
+                                                                   const int* __restrict__ row_lo,
+                                                                   const int* __restrict__ row_hi, int R, int D,
+                                                                   int heads, int past, int future,
+                                                                   bf16_t* __restrict__ out) {
+  __shared__ float sq[4][128];
+  __shared__ float sp[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= R * heads) return;
+  const int row = item / heads, head = item - row * heads, dh = D / heads;
+  const float scale = rsqrtf((float)dh);
+  const bf16_t* q = qkv + (long)row * 3 * D + head * dh;
+  for (int d = lane; d < dh; d += 64) sq[w][d] = bf(q[d]) * scale;
+  int jlo = row - past, jhi = row + future;
+  jlo = jlo < row_lo[row] ? row_lo[row] : jlo;
+  jhi = jhi > row_hi[row] - 1 ? row_hi[row] - 1 : jhi;
+  const int nk = jhi - jlo + 1;
+  __builtin_amdgcn_wave_barrier();
+  float sc = -INFINITY;
+  if (lane < nk) sc = dot_row(sq[w], qkv + (long)(jlo + lane) * 3 * D + D + head * dh, dh);
+  const float mx = wmax(sc);
+  const float e = lane < nk ? __expf(sc - mx) : 0.f;
+  const float inv = 1.0f / wsum(e);
+  sp[w][lane] = e * inv;
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float acc = 0.f;
+    const bf16_t* v = qkv + (long)jlo * 3 * D + 2 * D + head * dh + d;
+    for (int j = 0; j < nk; ++j) acc += sp[w][j] * bf(v[(long)j * 3 * D]);
+    out[(long)row * D + head * dh + d] = f32_to_bf16(acc);
+  }
+}
+
+__global__ void adapter_in_kernel(const float* __restrict__ y32, const int* __restrict__ rows,
+                                  const int* __restrict__ pos, int D, const float* __restrict__ pos_emb,
+                                  bf16_t* __restrict__ out16, float* __restrict__ out32) {
+  const int i = blockIdx.x;
+  const float* y = y32 + (long)rows[i] * D;
+  const float* p = pos_emb + (long)pos[i] * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float v = y[d] + p[d];
+    out16[(long)i * D + d] = f32_to_bf16(v);
+    out32[(long)i * D + d] = v;
+  }
+}
+
+__global__ void scatter_cross_kernel(const bf16_t* __restrict__ tmp, const int* __restrict__ slot,
+                                     const int* __restrict__ idx, int L, int D, int Mcap, bf16_t* __restrict__ crossK,
+                                     bf16_t* __restrict__ crossV) {
+  const int i = blockIdx.x, l = blockIdx.y;
+  const bf16_t* src = tmp + ((long)i * L + l) * 2 * D;
+  const long dst = (((long)slot[i] * L + l) * Mcap + idx[i]) * D;
+  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8) {
+    *reinterpret_cast<uint4*>(crossK + dst + d) = *reinterpret_cast<const uint4*>(src + d);
+    *reinterpret_cast<uint4*>(crossV + dst + d) = *reinterpret_cast<const uint4*>(src + D + d);
+  }
+}
+
+__global__ void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ embed, int D,
+                             float* __restrict__ H) {
+  const int r = blockIdx.x;
+  const float4* e = reinterpret_cast<const float4*>(embed + (long)tokens[r] * D);
+  float4* h = reinterpret_cast<float4*>(H + (long)r * D);
+  for (int d = threadIdx.x; d < D / 4; d += blockDim.x) h[d] = e[d];
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void self_append_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_slot,
+                                   const int* __restrict__ row_pos, int D, int layer, int L, int Scap,
+                                   bf16_t* __restrict__ cacheK, bf16_t* __restrict__ cacheV) {
+  const int r = blockIdx.x;
+  const long dst = (((long)row_slot[r] * L + layer) * Scap + row_pos[r]) * D;
+  const bf16_t* src = qkv + (long)r * 3 * D;
+  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8) {
+    *reinterpret_cast<uint4*>(cacheK + dst + d) = *reinterpret_cast<const uint4*>(src + D + d);
+    *reinterpret_cast<uint4*>(cacheV + dst + d) = *reinterpret_cast<const uint4*>(src + 2 * D + d);
+  }
+}
+
+// one wave per (row, head): keys [0, pos], scores through LDS (at most SMAX keys)
+constexpr int SELF_SMAX = 512;
+__global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __restrict__ qkv,
+                                                             const int* __restrict__ row_slot,
+                                                             const int* __restrict__ row_pos, int M, int D, int heads,
+                                                             int layer, int L, int Scap,
+                                                             const bf16_t* __restrict__ cacheK,
+                                                             const bf16_t* __restrict__ cacheV,
+                                                             bf16_t* __restrict__ out) {
+  __shared__ float sq[4][128];
+  __shared__ float sp[4][SELF_SMAX];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= M * heads) return;
+  const int row = item / heads, head = item - row * heads, dh = D / heads;
+  const float scale = rsqrtf((float)dh);
+  const bf16_t* q = qkv + (long)row * 3 * D + head * dh;
+  for (int d = lane; d < dh; d += 64) sq[w][d] = bf(q[d]) * scale;
+  const int nk = row_pos[row] + 1;
+  const long base = (((long)row_slot[row] * L + layer) * Scap) * D + head * dh;
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    const float sc = dot_row(sq[w], cacheK + base + (long)j * D, dh);
+    sp[w][j] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wmax(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float e = __expf(sp[w][j] - mx);
+    sp[w][j] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / wsum(sum);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float acc = 0.f;
+    const bf16_t* v = cacheV + base + d;
+    for (int j = 0; j < nk; ++j) acc += sp[w][j] * bf(v[(long)j * D]);
+    out[(long)row * D + head * dh + d] = f32_to_bf16(acc * inv);
+  }
+}
+
+// one workgroup per (row, head): all memory keys of the row's stream
+constexpr int CROSS_MMAX = 4096;
+__global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __restrict__ q,
+                                                              const int* __restrict__ row_slot,
+                                                              const SlotDev* __restrict__ slots, int D, int heads,
+                                                              int layer, int L, int Mcap,
+                                                              const bf16_t* __restrict__ crossK,
+                                                              const bf16_t* __restrict__ crossV,
+                                                              bf16_t* __restrict__ out) {
+  __shared__ float sq[128];
+  __shared__ float sp[CROSS_MMAX];
+  __shared__ float red[8];
+  __shared__ float part[4][128];
+  const int row = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int dh = D / heads;
+  const float scale = rsqrtf((float)dh);
+  const int slot = row_slot[row];
+  const int nk = slots[slot].mem_len;
+  for (int d = tid; d < dh; d += 256) sq[d] = bf(q[(long)row * D + head * dh + d]) * scale;
+  __syncthreads();
+  const long base = (((long)slot * L + layer) * Mcap) * D + head * dh;
+  float mx = -INFINITY;
+  for (int j = tid; j < nk; j += 256) {
+    const float sc = dot_row(sq, crossK + base + (long)j * D, dh);
+    sp[j] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wmax(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int j = tid; j < nk; j += 256) {
+    const float e = __expf(sp[j] - mx);
+    sp[j] = e;
+    sum += e;
+  }
+  sum = wsum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  // wave w takes keys j = w (mod 4); lanes take head dims lane and lane + 64
+  float a0 = 0.f, a1 = 0.f;
+  const bool has0 = lane < dh, has1 = lane + 64 < dh;
+  const bf16_t* v = crossV + base;
+  for (int j = w; j < nk; j += 4) {
+    const float p = sp[j];
+    if (has0) a0 += p * bf(v[(long)j * D + lane]);
+    if (has1) a1 += p * bf(v[(long)j * D + lane + 64]);
+  }
+  part[w][lane] = a0;
+  part[w][lane + 64] = a1;
+  __syncthreads();
+  for (int d = tid; d < dh; d += 256)
+    out[(long)row * D + head * dh + d] = f32_to_bf16((part[0][d] + part[1][d] + part[2][d] + part[3][d]) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ pred) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float4* x = reinterpret_cast<const float4*>(logits + (long)r * V);
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int c = tid; c < V / 4; c += 256) {
+    const float4 v = x[c];
+    const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (vals[k] > best) {  // strictly greater: within a thread indices only grow, so the first max wins
+        best = vals[k];
+        idx = c * 4 + k;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) {
+      best = ov;
+      idx = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    bv[tid >> 6] = best;
+    bi[tid >> 6] = idx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (bv[k] > best || (bv[k] == best && bi[k] < idx)) {
+        best = bv[k];
+        idx = bi[k];
+      }
+    pred[r] = idx == 0x7fffffff ? 0 : idx;  // all-NaN / -inf row: the reference's scan stays at index 0
+  }
+}
+
+__global__ void verify_kernel(const DecJob* __restrict__ jobs, const int* __restrict__ pred,
+                              const int* __restrict__ draft, SlotDev* __restrict__ slots, int* __restrict__ result,
+                              int result_stride, int eos, const float* __restrict__ embed, int D, float* __restrict__ H,
+                              int* __restrict__ step_pos, int* __restrict__ n_active) {
+  __shared__ int s_cur, s_fin;
+  const DecJob job = jobs[blockIdx.x];
+  if (threadIdx.x == 0) {
+    SlotDev sd = slots[job.slot];
+    int* res = result + (long)job.slot * result_stride;
+    int d = 0;
+    for (int i = 0; i < job.draft_len; ++i) {
+      if (pred[job.row0 + i] == draft[job.draft_off + i])
+        d = i + 1;
+      else
+        break;
+    }
+    for (int i = 0; i < d; ++i) res[i] = draft[job.draft_off + i];
+    sd.accepted = d;
+    sd.count = d;
+    sd.cache_len = d + 1;  // BOS + the accepted prefix; later cache rows are stale and get overwritten
+    sd.max_tokens = job.max_tokens;
+    sd.current = pred[job.row0 + d];
+    sd.finished = (sd.current == eos || sd.count >= sd.max_tokens) ? 1 : 0;
+    if (!sd.finished) {
+      res[sd.count++] = sd.current;
+      atomicAdd(n_active, 1);
+    }
+    step_pos[blockIdx.x] = sd.cache_len;
+    slots[job.slot] = sd;
+    s_cur = sd.current;
+    s_fin = sd.finished;
+  }
+  __syncthreads();
+  if (!s_fin) {
+    const float* e = embed + (long)s_cur * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+  }
+}
+
+__global__ void advance_kernel(const DecJob* __restrict__ jobs, const int* __restrict__ pred,
+                               SlotDev* __restrict__ slots, int* __restrict__ result, int result_stride, int eos,
+                               const float* __restrict__ embed, int D, float* __restrict__ H,
+                               int* __restrict__ step_pos, int* __restrict__ n_active) {
+  __shared__ int s_cur, s_fin;
+  const DecJob job = jobs[blockIdx.x];
+  if (threadIdx.x == 0) {
+    SlotDev sd = slots[job.slot];
+    s_fin = 1;
+    if (!sd.finished) {
+      sd.cache_len += 1;  // the token just fed is now cached
+      sd.current = pred[blockIdx.x];
+      if (sd.current == eos || sd.count >= sd.max_tokens) {
+        sd.finished = 1;
+        atomicSub(n_active, 1);
+      } else {
+        result[(long)job.slot * result_stride + sd.count++] = sd.current;
+        step_pos[blockIdx.x] = sd.cache_len;
+        s_fin = 0;
+      }
+      slots[job.slot] = sd;
+      s_cur = sd.current;
+    }
+  }
+  __syncthreads();
+  if (!s_fin) {
+    const float* e = embed + (long)s_cur * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+  }
+}
+
+__global__ void slot_update_kernel(const int4* __restrict__ upd, int n, SlotDev* __restrict__ slots) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int4 u = upd[j];  // (slot, mem_len or -1, cache_len or -1, zero-the-decode-fields flag)
+  SlotDev sd = slots[u.x];
+  if (u.y >= 0) sd.mem_len = u.y;
+  if (u.z >= 0) sd.cache_len = u.z;
+  if (u.w) sd.count = sd.finished = sd.current = sd.accepted = sd.max_tokens = 0;
+  slots[u.x] = sd;
+}
+
+__global__ void bump_cache_kernel(const DecJob* __restrict__ jobs, int n, SlotDev* __restrict__ slots) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) slots[jobs[j].slot].cache_len += jobs[j].n_rows;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+void stream_frames(const float* audio, const FrameJob* jobs, int n_jobs, int max_frames, float k, bf16_t* frames,
+                   hipStream_t s) {
+  if (n_jobs <= 0 || max_frames <= 0) return;
+  hipLaunchKernelGGL(frames_kernel, dim3((max_frames + 3) / 4, n_jobs), dim3(256), 0, s, audio, jobs, k, frames);
+}
+void copy_segments(const StreamSeg* segs, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(n, 4), dim3(256), 0, s, segs);
+}
+void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_hi, int R, int D, int heads, int past,
+                          int future, bf16_t* out, hipStream_t s) {
+  const int dh = D / heads;
+  if (past + future + 1 > 64 || dh > 128 || (dh & 3) != 0)
+    throw std::runtime_error("stream_enc_attention: window wider than 64 keys or unsupported head_dim");
+  if (R <= 0) return;
+  hipLaunchKernelGGL(enc_window_attention_kernel, dim3((R * heads + 3) / 4), dim3(256), 0, s, qkv, row_lo, row_hi, R,
+                     D, heads, past, future, out);
+}
+void stream_adapter_in(const float* y32, const int* rows, const int* pos, int n, int D, const float* pos_emb,
+                       bf16_t* out16, float* out32, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(adapter_in_kernel, dim3(n), dim3(256), 0, s, y32, rows, pos, D, pos_emb, out16, out32);
+}
+void stream_scatter_cross(const bf16_t* tmp, const int* slot, const int* idx, int n, int L, int D, int Mcap,
+                          bf16_t* crossK, bf16_t* crossV, hipStream_t s) {
+  if (n <= 0) return;
+  if ((D & 7) != 0) throw std::runtime_error("stream_scatter_cross: width must be a multiple of 8");
+  hipLaunchKernelGGL(scatter_cross_kernel, dim3(n, L), dim3(128), 0, s, tmp, slot, idx, L, D, Mcap, crossK, crossV);
+}
+void stream_embed(const int* tokens, int M, const float* embed, int D, float* H, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(128), 0, s, tokens, embed, D, H);
+}
+void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* row_pos, int M, int D, int heads, int layer,
+                           int L, int Scap, bf16_t* cacheK, bf16_t* cacheV, bf16_t* out, hipStream_t s) {
+  const int dh = D / heads;
+  if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
+    throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
+  if (M <= 0) return;
+  hipLaunchKernelGGL(self_append_kernel, dim3(M), dim3(128), 0, s, qkv, row_slot, row_pos, D, layer, L, Scap, cacheK,
+                     cacheV);
+  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, row_slot, row_pos, M, D,
+                     heads, layer, L, Scap, cacheK, cacheV, out);
+}
+void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
+                            int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
+                            hipStream_t s) {
+  const int dh = D / heads;
+  if (Mcap > CROSS_MMAX || dh > 128 || (dh & 3) != 0)
+    throw std::runtime_error("stream_cross_attention: unsupported memory length or head_dim");
+  if (M <= 0) return;
+  hipLaunchKernelGGL(cross_attention_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L,
+                     Mcap, crossK, crossV, out);
+}
+void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s) {
+  if ((V & 3) != 0) throw std::runtime_error("stream_argmax: vocabulary must be a multiple of 4");
+  if (M <= 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, pred);
+}
+void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* draft, SlotDev* slots, int* result,
+                   int result_stride, int eos, const float* embed, int D, float* H, int* step_pos, int* n_active,
+                   hipStream_t s) {
+  if (n_jobs <= 0) return;
+  hipLaunchKernelGGL(verify_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, draft, slots, result, result_stride, eos,
+                     embed, D, H, step_pos, n_active);
+}
+void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
+                    int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s) {
+  if (n_jobs <= 0) return;
+  hipLaunchKernelGGL(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
+                     D, H, step_pos, n_active);
+}
+void stream_slot_update(const int4* upd, int n, SlotDev* slots, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(slot_update_kernel, dim3((n + 63) / 64), dim3(64), 0, s, upd, n, slots);
+}
+void stream_bump_cache(const DecJob* jobs, int n_jobs, SlotDev* slots, hipStream_t s) {
+  if (n_jobs <= 0) return;
+  hipLaunchKernelGGL(bump_cache_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs, n_jobs, slots);
+}
+
+}  // namespace msh

@@ -57,6 +57,13 @@ void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float
 // logits_f32[M,N] = A_bf16[M,K] * W^T with the tiled kernel (LM head at batch >= 128, after layernorm_bf16)
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
 
+// out = act(acc + bias) as bf16 and / or fp32 (either pointer may be null); act 0 none, 1 SiLU, 2 GELU(erf)
+void gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,
+              bf16_t* out_bf16, float* out_f32, hipStream_t s);
+// z_bf16[M,N/2] = silu(gate) * value of (acc + bias); W / bias rows interleaved (value_j, gate_j)
+void gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, bf16_t* z,
+                      hipStream_t s);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "engine.h"
+#include "stream_engine.h"
 
 struct msh_engine {
   msh::Engine* eng = nullptr;
@@ -16,11 +17,16 @@ struct msh_engine {
   std::vector<msh::ProfEntry> prof_cache;
 };
 
+struct msh_stream_engine {
+  msh::StreamingEngine* eng = nullptr;
+  std::string last_error;
+};
+
 namespace {
 thread_local std::string g_create_error;
 
-template <class F>
-int32_t guarded(msh_engine* e, F&& f) {
+template <class E, class F>
+int32_t guarded(E* e, F&& f) {
   if (e == nullptr) return MSH_ERR_INVALID_ARGUMENT;
   try {
     f();
@@ -199,6 +205,168 @@ float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int
     fprintf(stderr, "gemm_microbench: %s\n", ex.what());
     return -1.0f;
   }
+}
+
+// ---- streaming ----
+static int32_t stream_create_impl(int32_t device, msh::SafeTensors& st, const char* config_json, int32_t max_slots,
+                                  int32_t max_memory_frames, msh_stream_engine** out) {
+  try {
+    if (config_json == nullptr) throw std::invalid_argument("null config json");
+    msh_stream_engine* e = new msh_stream_engine();
+    try {
+      e->eng = new msh::StreamingEngine(device, max_slots > 0 ? max_slots : 64,
+                                        max_memory_frames > 0 ? max_memory_frames : 2048);
+      e->eng->load(st, config_json);
+    } catch (...) {
+      delete e->eng;
+      delete e;
+      throw;
+    }
+    *out = e;
+    return MSH_OK;
+  } catch (const std::invalid_argument& ex) {
+    g_create_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  } catch (const msh::HipError& ex) {
+    g_create_error = ex.what();
+    return msh_device_count() == 0 ? MSH_ERR_NO_DEVICE : MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    g_create_error = ex.what();
+    return MSH_ERR_UNKNOWN;
+  }
+}
+
+int32_t msh_stream_create(int32_t device, const char* path, const char* config_json, int32_t max_slots,
+                          int32_t max_memory_frames, msh_stream_engine** out) {
+  if (out == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  msh::SafeTensors st;
+  try {
+    if (path == nullptr) throw std::invalid_argument("null path");
+    st.load_file(path);
+  } catch (const std::exception& ex) {
+    g_create_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+  return stream_create_impl(device, st, config_json, max_slots, max_memory_frames, out);
+}
+
+int32_t msh_stream_create_from_memory(int32_t device, const void* data, uint64_t size, const char* config_json,
+                                      int32_t max_slots, int32_t max_memory_frames, msh_stream_engine** out) {
+  if (out == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  msh::SafeTensors st;
+  try {
+    if (data == nullptr) throw std::invalid_argument("null data");
+    st.parse(reinterpret_cast<const uint8_t*>(data), (size_t)size);
+  } catch (const std::exception& ex) {
+    g_create_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+  return stream_create_impl(device, st, config_json, max_slots, max_memory_frames, out);
+}
+
+void msh_stream_destroy(msh_stream_engine* e) {
+  if (e == nullptr) return;
+  try {
+    delete e->eng;
+  } catch (...) {
+  }
+  delete e;
+}
+
+const char* msh_stream_last_error(const msh_stream_engine* e) {
+  if (e == nullptr) return g_create_error.c_str();
+  return e->last_error.c_str();
+}
+
+int32_t msh_stream_info_get(const msh_stream_engine* e, msh_stream_info* out) {
+  if (e == nullptr || out == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  const msh::StreamingConfig& c = e->eng->config();
+  memset(out, 0, sizeof(*out));
+  out->encoder_dim = c.encoder_dim;
+  out->decoder_dim = c.decoder_dim;
+  out->depth = c.depth;
+  out->nheads = c.nheads;
+  out->head_dim = c.head_dim;
+  out->vocab_size = c.vocab_size;
+  out->bos_id = c.bos_id;
+  out->eos_id = c.eos_id;
+  out->frame_len = c.frame_len;
+  out->total_lookahead = c.total_lookahead;
+  out->max_seq_len = c.max_seq_len;
+  out->enc_layers = c.enc_layers;
+  out->encoder_heads = c.encoder_heads;
+  out->max_slots = e->eng->max_slots();
+  out->memory_capacity = e->eng->memory_capacity();
+  return MSH_OK;
+}
+
+int32_t msh_stream_open(msh_stream_engine* e) {
+  int32_t slot = -1;
+  int32_t rc = guarded(e, [&] { slot = e->eng->create_stream(); });
+  return rc == MSH_OK ? slot : rc;
+}
+int32_t msh_stream_close(msh_stream_engine* e, int32_t slot) {
+  return guarded(e, [&] { e->eng->free_stream(slot); });
+}
+int32_t msh_stream_reset(msh_stream_engine* e, int32_t slot) {
+  return guarded(e, [&] { e->eng->reset_stream(slot); });
+}
+int32_t msh_stream_process_audio(msh_stream_engine* e, int32_t n, const int32_t* slots, const float* const* pcm,
+                                 const uint64_t* n_samples, int32_t* features_out) {
+  return guarded(e, [&] {
+    if (n > 0 && (pcm == nullptr || n_samples == nullptr)) throw std::invalid_argument("null input");
+    e->eng->process_audio(n, slots, pcm, n_samples, features_out);
+  });
+}
+int32_t msh_stream_encode(msh_stream_engine* e, int32_t n, const int32_t* slots, const uint8_t* is_final,
+                          int32_t* new_frames_out) {
+  return guarded(e, [&] { e->eng->encode(n, slots, is_final, new_frames_out); });
+}
+int32_t msh_stream_decoder_reset(msh_stream_engine* e, int32_t n, const int32_t* slots) {
+  return guarded(e, [&] { e->eng->decoder_reset(n, slots); });
+}
+int32_t msh_stream_decode_tokens(msh_stream_engine* e, int32_t n, const int32_t* slots, const int32_t* const* tokens,
+                                 const int32_t* n_tokens, float* logits_out) {
+  return guarded(e, [&] {
+    if (n > 0 && (tokens == nullptr || n_tokens == nullptr)) throw std::invalid_argument("null input");
+    e->eng->decode_tokens(n, slots, tokens, n_tokens, logits_out);
+  });
+}
+int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const int32_t* slots, const int32_t* const* drafts,
+                               const int32_t* draft_lens, const int32_t* max_tokens, int32_t* tokens_out,
+                               int32_t* counts_out, int32_t tokens_stride, int32_t* accepted_out) {
+  return guarded(e, [&] {
+    e->eng->decode_full(n, slots, drafts, draft_lens, max_tokens, tokens_out, counts_out, tokens_stride, accepted_out);
+  });
+}
+int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what) {
+  if (e == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  try {
+    switch (what) {
+      case 0: return e->eng->memory_len(slot);
+      case 1: return e->eng->feature_count(slot);
+      case 2: return e->eng->cache_len(slot);
+      case 3: return e->eng->frames_emitted(slot);
+      case 4: return e->eng->max_tokens_for(slot);
+      default: return MSH_ERR_INVALID_ARGUMENT;
+    }
+  } catch (const std::exception&) {
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+int32_t msh_stream_get_memory(msh_stream_engine* e, int32_t slot, float* out) {
+  return guarded(e, [&] {
+    if (out == nullptr) throw std::invalid_argument("null output");
+    e->eng->get_memory(slot, out);
+  });
+}
+int32_t msh_stream_get_features(msh_stream_engine* e, int32_t slot, float* out) {
+  return guarded(e, [&] {
+    if (out == nullptr) throw std::invalid_argument("null output");
+    e->eng->get_features(slot, out);
+  });
 }
 
 int32_t msh_synchronize(msh_engine* e) {

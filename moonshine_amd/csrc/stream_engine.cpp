@@ -1,0 +1,758 @@
+#include "stream_engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace msh {
+
+namespace {
+
+// Minimal reader for the flat streaming_config.json (the reference parses it the same way:
+// first "key": then an integer, core/moonshine-streaming-model.cpp:75-117).
+bool json_number(const std::string& j, const char* key, double* out) {
+  const std::string k = std::string("\"") + key + "\"";
+  size_t p = j.find(k);
+  if (p == std::string::npos) return false;
+  p = j.find(':', p + k.size());
+  if (p == std::string::npos) return false;
+  ++p;
+  while (p < j.size() && (j[p] == ' ' || j[p] == '\t' || j[p] == '\n' || j[p] == '\r')) ++p;
+  char* end = nullptr;
+  const double v = strtod(j.c_str() + p, &end);
+  if (end == j.c_str() + p) return false;
+  *out = v;
+  return true;
+}
+int json_int(const std::string& j, const char* key, int dflt) {
+  double v;
+  return json_number(j, key, &v) ? (int)v : dflt;
+}
+// "windows": [[16, 4], [16, 0], ...]
+std::vector<std::pair<int, int>> json_windows(const std::string& j) {
+  std::vector<std::pair<int, int>> out;
+  size_t p = j.find("\"windows\"");
+  if (p == std::string::npos) return out;
+  p = j.find('[', p);
+  if (p == std::string::npos) return out;
+  int depth = 0;
+  std::vector<int> nums;
+  for (size_t i = p; i < j.size(); ++i) {
+    const char c = j[i];
+    if (c == '[') {
+      ++depth;
+    } else if (c == ']') {
+      if (--depth == 0) break;
+    } else if ((c >= '0' && c <= '9') || c == '-') {
+      char* end = nullptr;
+      nums.push_back((int)strtol(j.c_str() + i, &end, 10));
+      i = (size_t)(end - j.c_str()) - 1;
+    }
+  }
+  for (size_t i = 0; i + 1 < nums.size(); i += 2) out.emplace_back(nums[i], nums[i + 1]);
+  return out;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+StreamingEngine::StreamingEngine(int device, int max_slots, int max_memory_frames)
+    : device_(device), max_slots_(max_slots), Mcap_(round_up(std::max(max_memory_frames, 64), 8)) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    throw HipError("no HIP device available: the MI355X engine has no CPU fallback (" +
+                   std::string(hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= n) throw HipError("invalid device index " + std::to_string(device));
+  if (max_slots_ <= 0 || max_slots_ > 4096) throw std::invalid_argument("max_slots out of range");
+  if (Mcap_ > 4096) throw std::invalid_argument("memory capacity above 4096 frames (81 s) is not supported");
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  slots_.resize(max_slots_);
+}
+
+StreamingEngine::~StreamingEngine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (void* p : allocs_) (void)hipFree(p);
+  DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
+                    &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
+                    &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
+                    &steppos_};
+  for (DevBuf* b : bufs) b->release();
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void StreamingEngine::synchronize() {
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+void StreamingEngine::upload(const std::vector<float>& src, float** dst) {
+  void* p = nullptr;
+  MSH_HIP(hipMalloc(&p, std::max<size_t>(src.size(), 4) * sizeof(float)));
+  allocs_.push_back(p);
+  MSH_HIP(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<float*>(p);
+}
+void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
+  std::vector<bf16_t> tmp(src.size());
+  for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
+  void* p = nullptr;
+  MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  allocs_.push_back(p);
+  MSH_HIP(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<bf16_t*>(p);
+}
+
+// Small descriptor arrays go host -> device on the engine stream.  The copy is issued from pageable memory
+// and the stream is drained before the host vector dies: these arrays are a few KiB and every public call
+// ends with a host-visible result anyway.
+template <class T>
+T* StreamingEngine::stage(DevBuf& buf, const std::vector<T>& host) {
+  buf.reserve(std::max<size_t>(host.size(), 1) * sizeof(T));
+  if (!host.empty()) {
+    MSH_HIP(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
+    MSH_HIP(hipStreamSynchronize(stream_));
+  }
+  return buf.as<T>();
+}
+
+const StreamingEngine::SlotHost& StreamingEngine::st(int slot) const {
+  if (slot < 0 || slot >= max_slots_ || !slots_[slot].used) throw std::invalid_argument("invalid stream slot");
+  return slots_[slot];
+}
+StreamingEngine::SlotHost& StreamingEngine::st(int slot) {
+  if (slot < 0 || slot >= max_slots_ || !slots_[slot].used) throw std::invalid_argument("invalid stream slot");
+  return slots_[slot];
+}
+void StreamingEngine::check_slots(int n, const int* slots) const {
+  if (n < 0 || (n > 0 && slots == nullptr)) throw std::invalid_argument("null slot list");
+  std::vector<char> seen(max_slots_, 0);
+  for (int i = 0; i < n; ++i) {
+    (void)st(slots[i]);
+    if (seen[slots[i]]) throw std::invalid_argument("a stream appears twice in one call");
+    seen[slots[i]] = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weights: HuggingFace MoonshineStreamingForConditionalGeneration state_dict
+// (modeling_moonshine_streaming.py:283-296 embedder, :185-207 / :133-139 encoder layer, :595-604 / :455-456
+// decoder layer, :782-794 decoder, :1005-1010 head).  Layout changes made once, here:
+//   embedder.linear [De,80]      -> [De][96] (zero-padded K)
+//   conv1 [2De,De,5] / conv2 [De,2De,5] -> tap-major [Cout][5][Cin]: a window of 5 channels-last rows is one
+//                                   contiguous K = 5*Cin vector, so the causal convs are strided GEMMs
+//   LayerNorm gamma (unit offset) -> gamma + 1
+//   q,k,v -> fused [3D][D]; decoder fc1 rows interleaved (value_j, gate_j); cross k,v of all layers -> [L*2Dd][Dd]
+// ------------------------------------------------------------------------------------------------
+void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
+  MSH_HIP(hipSetDevice(device_));
+  if (loaded_) throw std::runtime_error("weights already loaded");
+  StreamingConfig c;
+  c.encoder_dim = json_int(json, "encoder_dim", 0);
+  c.decoder_dim = json_int(json, "decoder_dim", 0);
+  c.depth = json_int(json, "depth", 0);
+  c.nheads = json_int(json, "nheads", 0);
+  c.head_dim = json_int(json, "head_dim", 0);
+  c.vocab_size = json_int(json, "vocab_size", 0);
+  c.bos_id = json_int(json, "bos_id", 1);
+  c.eos_id = json_int(json, "eos_id", 2);
+  c.frame_len = json_int(json, "frame_len", 80);
+  c.total_lookahead = json_int(json, "total_lookahead", -1);
+  const int msl = json_int(json, "max_seq_len", 0);
+  c.max_seq_len = msl > 0 ? msl : 448;  // streaming-model.cpp:111-113
+  c.encoder_heads = json_int(json, "encoder_heads", c.nheads);
+  double v;
+  if (json_number(json, "rope_theta", &v)) c.rope_theta = (float)v;
+  if (json_number(json, "partial_rotary_factor", &v)) c.partial_rotary = (float)v;
+  c.windows = json_windows(json);
+  if (c.depth <= 0 || c.decoder_dim <= 0 || c.vocab_size <= 0 || c.encoder_dim <= 0 || c.nheads <= 0)
+    throw std::runtime_error("streaming_config.json: missing depth / dims / vocab_size");
+
+  const int De = c.encoder_dim, Dd = c.decoder_dim, V = c.vocab_size, L = c.depth;
+  auto shape_is = [&](const std::string& name, std::vector<int64_t> shape) {
+    if (st.get(name).shape != shape) throw std::runtime_error("unexpected shape for " + name);
+  };
+  while (st.has("model.encoder.layers." + std::to_string(c.enc_layers) + ".mlp.fc1.weight")) ++c.enc_layers;
+  int dec_layers = 0;
+  while (st.has("model.decoder.layers." + std::to_string(dec_layers) + ".mlp.fc1.weight")) ++dec_layers;
+  if (dec_layers != L) throw std::runtime_error("decoder layer count differs from streaming_config depth");
+  if (c.enc_layers == 0) throw std::runtime_error("no encoder layers in the checkpoint");
+  c.enc_ffn = (int)st.get("model.encoder.layers.0.mlp.fc1.weight").shape[0];
+  c.dec_ffn = (int)st.get("model.decoder.layers.0.mlp.fc2.weight").shape[1];
+  c.max_pos = (int)st.get("model.decoder.pos_emb.weight").shape[0];
+  if (c.windows.empty()) {
+    // the reference's json does not carry the windows (they are baked into encoder.onnx); HF default pattern
+    if (c.enc_layers != 6) throw std::runtime_error("streaming_config.json needs a \"windows\" array for this encoder depth");
+    c.windows = {{16, 4}, {16, 4}, {16, 0}, {16, 0}, {16, 4}, {16, 4}};
+  }
+  if ((int)c.windows.size() != c.enc_layers) throw std::runtime_error("windows array does not match the encoder depth");
+  int look = 0;
+  for (auto& w : c.windows) look += w.second;
+  if (c.total_lookahead < 0) c.total_lookahead = look;
+  if (c.total_lookahead != look) throw std::runtime_error("total_lookahead disagrees with the windows array");
+  if (c.head_dim * c.nheads != Dd) throw std::runtime_error("nheads * head_dim != decoder_dim");
+  if (c.frame_len != 80) throw std::runtime_error("frame_len other than 80 is not supported");
+  if (De % 32 || Dd % 32 || c.enc_ffn % 32 || c.dec_ffn % 32 || V % 4 || De % c.encoder_heads || (c.head_dim & 3) ||
+      ((De / c.encoder_heads) & 3) || c.head_dim > 128 || De / c.encoder_heads > 128 || De > 1024 || Dd > 1024)
+    throw std::runtime_error("unsupported streaming model dimensions");
+  Scap_ = round_up(c.max_seq_len + 8, 8);
+  if (Scap_ > 512) throw std::runtime_error("max_seq_len above 504 is not supported");
+  cfg_ = c;
+  const int Fe = c.enc_ffn, Fd = c.dec_ffn;
+
+  {  // frontend
+    k_scale_ = expf(st.to_f32("model.encoder.embedder.comp.log_k").at(0));
+    shape_is("model.encoder.embedder.linear.weight", {De, 80});
+    std::vector<float> w = st.to_f32("model.encoder.embedder.linear.weight"), r((size_t)De * 96, 0.f);
+    for (int n = 0; n < De; ++n)
+      for (int k = 0; k < 80; ++k) r[(size_t)n * 96 + k] = w[(size_t)n * 80 + k];
+    upload_bf16(r, &lin_w_);
+    shape_is("model.encoder.embedder.conv1.weight", {2 * De, De, 5});
+    w = st.to_f32("model.encoder.embedder.conv1.weight");
+    r.assign((size_t)2 * De * 5 * De, 0.f);
+    for (int n = 0; n < 2 * De; ++n)
+      for (int ch = 0; ch < De; ++ch)
+        for (int k = 0; k < 5; ++k) r[((size_t)n * 5 + k) * De + ch] = w[((size_t)n * De + ch) * 5 + k];
+    upload_bf16(r, &conv1_w_);
+    shape_is("model.encoder.embedder.conv2.weight", {De, 2 * De, 5});
+    w = st.to_f32("model.encoder.embedder.conv2.weight");
+    r.assign((size_t)De * 5 * 2 * De, 0.f);
+    for (int n = 0; n < De; ++n)
+      for (int ch = 0; ch < 2 * De; ++ch)
+        for (int k = 0; k < 5; ++k) r[((size_t)n * 5 + k) * 2 * De + ch] = w[((size_t)n * 2 * De + ch) * 5 + k];
+    upload_bf16(r, &conv2_w_);
+    upload(st.to_f32("model.encoder.embedder.conv1.bias"), &conv1_b_);
+    upload(st.to_f32("model.encoder.embedder.conv2.bias"), &conv2_b_);
+  }
+  auto cat = [&](std::initializer_list<std::string> names, int rows, int cols) {
+    std::vector<float> out;
+    for (const std::string& n : names) {
+      shape_is(n, {rows, cols});
+      std::vector<float> w = st.to_f32(n);
+      out.insert(out.end(), w.begin(), w.end());
+    }
+    return out;
+  };
+  auto gamma1 = [&](const std::string& name) {
+    std::vector<float> g = st.to_f32(name);
+    for (float& x : g) x += 1.0f;  // unit_offset LayerNorm, modeling_moonshine_streaming.py:127-130
+    return g;
+  };
+  enc_.resize(c.enc_layers);
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
+    EncW& E = enc_[l];
+    upload_bf16(cat({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, De, De),
+                &E.wqkv);
+    upload_bf16(cat({p + "self_attn.o_proj.weight"}, De, De), &E.wo);
+    upload_bf16(cat({p + "mlp.fc1.weight"}, Fe, De), &E.fc1);
+    upload_bf16(cat({p + "mlp.fc2.weight"}, De, Fe), &E.fc2);
+    upload(st.to_f32(p + "mlp.fc1.bias"), &E.b1);
+    upload(st.to_f32(p + "mlp.fc2.bias"), &E.b2);
+    upload(gamma1(p + "input_layernorm.gamma"), &E.ln1);
+    upload(gamma1(p + "post_attention_layernorm.gamma"), &E.ln2);
+  }
+  upload(gamma1("model.encoder.final_norm.gamma"), &enc_ln_);
+  shape_is("model.decoder.pos_emb.weight", {c.max_pos, De});
+  upload(st.to_f32("model.decoder.pos_emb.weight"), &pos_emb_);
+  if (st.has("model.decoder.proj.weight")) {
+    upload_bf16(cat({"model.decoder.proj.weight"}, Dd, De), &proj_w_);
+  } else if (De != Dd) {
+    throw std::runtime_error("encoder_dim != decoder_dim but model.decoder.proj.weight is missing");
+  }
+  {
+    shape_is("model.decoder.embed_tokens.weight", {V, Dd});
+    std::vector<float> e = st.to_f32("model.decoder.embed_tokens.weight");
+    upload(e, &embed_f32_);
+    // untied head when the checkpoint has one (lora/export.py:198-203), else the embedding
+    if (st.has("proj_out.weight")) {
+      upload_bf16(cat({"proj_out.weight"}, V, Dd), &head_w_);
+    } else {
+      upload_bf16(e, &head_w_);
+    }
+    upload(st.to_f32("model.decoder.norm.weight"), &dec_ln_);
+  }
+  dec_.resize(L);
+  std::vector<float> cross;
+  for (int l = 0; l < L; ++l) {
+    const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
+    DecW& W = dec_[l];
+    upload_bf16(cat({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, Dd, Dd),
+                &W.wqkv);
+    upload_bf16(cat({p + "self_attn.o_proj.weight"}, Dd, Dd), &W.wo);
+    upload_bf16(cat({p + "encoder_attn.q_proj.weight"}, Dd, Dd), &W.wq_c);
+    upload_bf16(cat({p + "encoder_attn.o_proj.weight"}, Dd, Dd), &W.wo_c);
+    std::vector<float> kv = cat({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"}, Dd, Dd);
+    cross.insert(cross.end(), kv.begin(), kv.end());
+    shape_is(p + "mlp.fc1.weight", {2 * Fd, Dd});
+    std::vector<float> f1 = st.to_f32(p + "mlp.fc1.weight"), b1 = st.to_f32(p + "mlp.fc1.bias");
+    std::vector<float> f1i((size_t)2 * Fd * Dd), b1i((size_t)2 * Fd);
+    for (int j = 0; j < Fd; ++j) {  // chunk(2): first half value, second half gate (modeling_moonshine_streaming.py:459-461)
+      memcpy(&f1i[(size_t)(2 * j) * Dd], &f1[(size_t)j * Dd], Dd * sizeof(float));
+      memcpy(&f1i[(size_t)(2 * j + 1) * Dd], &f1[(size_t)(Fd + j) * Dd], Dd * sizeof(float));
+      b1i[2 * j] = b1[j];
+      b1i[2 * j + 1] = b1[Fd + j];
+    }
+    upload_bf16(f1i, &W.fc1);
+    upload(b1i, &W.b1);
+    upload_bf16(cat({p + "mlp.fc2.weight"}, Dd, Fd), &W.fc2);
+    upload(st.to_f32(p + "mlp.fc2.bias"), &W.b2);
+    upload(st.to_f32(p + "input_layernorm.weight"), &W.ln1);
+    upload(st.to_f32(p + "post_attention_layernorm.weight"), &W.ln2);
+    upload(st.to_f32(p + "final_layernorm.weight"), &W.ln3);
+  }
+  upload_bf16(cross, &cross_w_);
+  {  // RoPE tables: inv_freq over dim = int(head_dim * factor); ceil(dim / 2) rotated pairs
+     // (modeling_moonshine_streaming.py:498-506, 552-557)
+    const int dim = (int)(c.head_dim * c.partial_rotary);
+    rot_pairs_ = (dim + 1) / 2;
+    std::vector<float> cs((size_t)Scap_ * rot_pairs_), sn((size_t)Scap_ * rot_pairs_);
+    for (int j = 0; j < rot_pairs_; ++j) {
+      const float inv = 1.0f / powf(c.rope_theta, (float)(2 * j) / (float)dim);
+      for (int pos = 0; pos < Scap_; ++pos) {
+        const float a = (float)pos * inv;
+        cs[(size_t)pos * rot_pairs_ + j] = cosf(a);
+        sn[(size_t)pos * rot_pairs_ + j] = sinf(a);
+      }
+    }
+    upload(cs, &rope_cos_);
+    upload(sn, &rope_sin_);
+  }
+  // per-slot state slabs
+  auto slab = [&](size_t bytes) {
+    void* p = nullptr;
+    MSH_HIP(hipMalloc(&p, bytes));
+    MSH_HIP(hipMemset(p, 0, bytes));
+    allocs_.push_back(p);
+    return p;
+  };
+  const size_t S = (size_t)max_slots_;
+  conv1_buf_ = (bf16_t*)slab(S * 4 * De * 2);
+  conv2_buf_ = (bf16_t*)slab(S * 4 * 2 * De * 2);
+  features_ = (float*)slab(S * Mcap_ * De * 4);
+  memory_ = (float*)slab(S * Mcap_ * Dd * 4);
+  crossK_ = (bf16_t*)slab(S * L * Mcap_ * Dd * 2);
+  crossV_ = (bf16_t*)slab(S * L * Mcap_ * Dd * 2);
+  selfK_ = (bf16_t*)slab(S * L * Scap_ * Dd * 2);
+  selfV_ = (bf16_t*)slab(S * L * Scap_ * Dd * 2);
+  result_ = (int32_t*)slab(S * Scap_ * 4);
+  slots_d_ = (SlotDev*)slab(S * sizeof(SlotDev));
+  n_active_d_ = (int32_t*)slab(64);
+  loaded_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+int StreamingEngine::create_stream() {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  for (int s = 0; s < max_slots_; ++s)
+    if (!slots_[s].used) {
+      slots_[s].used = true;
+      reset_stream(s);
+      return s;
+    }
+  throw std::runtime_error("all " + std::to_string(max_slots_) + " stream slots are in use");
+}
+void StreamingEngine::free_stream(int slot) { st(slot).used = false; }
+
+void StreamingEngine::reset_stream(int slot) {
+  SlotHost& h = st(slot);
+  h.pending.clear();
+  h.feat_count = h.emitted = h.pos_offset = h.mem_len = h.cache_len = 0;
+  MSH_HIP(hipSetDevice(device_));
+  const int De = cfg_.encoder_dim;
+  MSH_HIP(hipMemsetAsync(conv1_buf_ + (size_t)slot * 4 * De, 0, (size_t)4 * De * 2, stream_));
+  MSH_HIP(hipMemsetAsync(conv2_buf_ + (size_t)slot * 8 * De, 0, (size_t)8 * De * 2, stream_));
+  MSH_HIP(hipMemsetAsync(slots_d_ + slot, 0, sizeof(SlotDev), stream_));
+}
+
+int StreamingEngine::max_tokens_for(int slot) const {
+  // streaming-model.cpp:1217-1219: float duration, double product, ceil, capped by max_seq_len
+  const float duration = (float)st(slot).mem_len * 0.020f;
+  return std::min((int)ceil((double)duration * 6.5), cfg_.max_seq_len);
+}
+
+void StreamingEngine::get_memory(int slot, float* out) {
+  const SlotHost& h = st(slot);
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  MSH_HIP(hipMemcpy(out, memory_ + (size_t)slot * Mcap_ * cfg_.decoder_dim,
+                    (size_t)h.mem_len * cfg_.decoder_dim * sizeof(float), hipMemcpyDeviceToHost));
+}
+void StreamingEngine::get_features(int slot, float* out) {
+  const SlotHost& h = st(slot);
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  MSH_HIP(hipMemcpy(out, features_ + (size_t)slot * Mcap_ * cfg_.encoder_dim,
+                    (size_t)h.feat_count * cfg_.encoder_dim * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frontend (lora/export.py:67-97, driver streaming-model.cpp:441-602).  A "period" is 320 samples = 4 frames
+// = 2 conv1 rows = 1 feature row.  Stream i gets periods [b_i, b_i + n_i + 2) of one packed row stream whose
+// first two periods hold the carried context, so that every stage is a uniform-stride GEMM over all streams:
+//   hidden  row 4b+8+f   = frame f          rows 4b+4..4b+7 = conv1_buf (previous 4 frames)
+//   conv1   row 2b+4+c   = conv1 output c   rows 2b..2b+3   = conv2_buf (previous 4 outputs)
+//   feature row  b+2+m   = new feature m
+// conv1 row R reads hidden rows [2R-4, 2R], conv2 row R reads conv1 rows [2R-4, 2R]  (kernel 5, stride 2,
+// left pad 4).  Samples that do not fill a period wait in `pending` (the reference keeps < 80 of them in
+// sample_buffer and is only ever fed 1280-sample chunks, transcriber.cpp:1341-1357).
+// ------------------------------------------------------------------------------------------------
+void StreamingEngine::process_audio(int n, const int* slots, const float* const* pcm, const uint64_t* lens,
+                                    int* features_out) {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  check_slots(n, slots);
+  MSH_HIP(hipSetDevice(device_));
+  const int De = cfg_.encoder_dim;
+  struct Job {
+    int slot, n_per, base;
+    long audio_off;
+  };
+  std::vector<Job> jobs;
+  std::vector<float> audio;
+  int P = 0, max_frames = 0;
+  for (int i = 0; i < n; ++i) {
+    SlotHost& h = st(slots[i]);
+    if (lens[i] > 0 && pcm[i] == nullptr) throw std::invalid_argument("null audio pointer");
+    h.pending.insert(h.pending.end(), pcm[i], pcm[i] + lens[i]);
+    const int n_per = (int)(h.pending.size() / 320);
+    if (features_out) features_out[i] = n_per;
+    if (n_per == 0) continue;
+    if (h.feat_count + n_per > Mcap_)
+      throw std::runtime_error("stream exceeds the engine's memory capacity of " + std::to_string(Mcap_) + " frames");
+    jobs.push_back({slots[i], n_per, P, (long)audio.size()});
+    audio.insert(audio.end(), h.pending.begin(), h.pending.begin() + (size_t)n_per * 320);
+    h.pending.erase(h.pending.begin(), h.pending.begin() + (size_t)n_per * 320);
+    P += n_per + 2;
+    max_frames = std::max(max_frames, 4 * n_per);
+  }
+  if (jobs.empty()) return;
+  frames_.reserve((size_t)4 * P * 96 * 2);
+  hidden_.reserve((size_t)4 * P * De * 2);
+  c1out_.reserve((size_t)2 * P * 2 * De * 2);
+  feat_pk_.reserve((size_t)P * De * 4);
+  const float* audio_d = stage(audio_, audio);
+  std::vector<FrameJob> fj;
+  std::vector<StreamSeg> segA, segB, segC;
+  bf16_t* hid = hidden_.as<bf16_t>();
+  bf16_t* c1o = c1out_.as<bf16_t>();
+  float* fpk = feat_pk_.as<float>();
+  for (const Job& j : jobs) {
+    const long b = j.base;
+    const int nf = 4 * j.n_per, nc = 2 * j.n_per;
+    fj.push_back({j.audio_off, nf, (int)(4 * b + 8)});
+    bf16_t* c1b = conv1_buf_ + (size_t)j.slot * 4 * De;
+    bf16_t* c2b = conv2_buf_ + (size_t)j.slot * 8 * De;
+    segA.push_back({c1b, hid + (4 * b + 4) * De, (long)4 * De * 2});
+    segB.push_back({hid + (4 * b + 8 + nf - 4) * De, c1b, (long)4 * De * 2});
+    segB.push_back({c2b, c1o + (2 * b) * 2 * De, (long)8 * De * 2});
+    segC.push_back({c1o + (2 * b + 4 + nc - 4) * 2 * De, c2b, (long)8 * De * 2});
+    SlotHost& h = st(j.slot);
+    segC.push_back({fpk + (b + 2) * De, features_ + ((size_t)j.slot * Mcap_ + h.feat_count) * De,
+                    (long)j.n_per * De * 4});
+    h.feat_count += j.n_per;
+  }
+  const FrameJob* fj_d = stage(jobs_, fj);
+  std::vector<StreamSeg> all(segA);
+  all.insert(all.end(), segB.begin(), segB.end());
+  all.insert(all.end(), segC.begin(), segC.end());
+  const StreamSeg* segs_d = stage(segs_, all);
+  stream_frames(audio_d, fj_d, (int)fj.size(), max_frames, k_scale_, frames_.as<bf16_t>(), stream_);
+  gemm_act(frames_.as<bf16_t>(), 96, lin_w_, nullptr, 1, 4 * P, De, 96, hid, nullptr, stream_);
+  copy_segments(segs_d, (int)segA.size(), stream_);
+  gemm_act(hid, 2 * De, conv1_w_, conv1_b_, 1, 2 * P - 2, 2 * De, 5 * De, c1o + (size_t)2 * 2 * De, nullptr, stream_);
+  copy_segments(segs_d + segA.size(), (int)segB.size(), stream_);
+  gemm_act(c1o, 4 * De, conv2_w_, conv2_b_, 0, P - 2, De, 10 * De, nullptr, fpk + (size_t)2 * De, stream_);
+  copy_segments(segs_d + segA.size() + segB.size(), (int)segC.size(), stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder window + adapter + cross K/V (streaming-model.cpp:604-772 and :779-860).
+// ------------------------------------------------------------------------------------------------
+void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, int* new_frames_out) {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  check_slots(n, slots);
+  MSH_HIP(hipSetDevice(device_));
+  const int De = cfg_.encoder_dim, Dd = cfg_.decoder_dim, L = cfg_.depth, Fe = cfg_.enc_ffn;
+  struct Job {
+    int slot, start, total, stable, fresh, r0;
+  };
+  std::vector<Job> jobs;
+  int R = 0, Nn = 0;
+  for (int i = 0; i < n; ++i) {
+    SlotHost& h = st(slots[i]);
+    if (new_frames_out) new_frames_out[i] = 0;
+    const int total = h.feat_count;
+    if (total == 0) continue;
+    const int stable = (is_final && is_final[i]) ? total : std::max(0, total - cfg_.total_lookahead);
+    const int fresh = stable - h.emitted;
+    if (fresh <= 0) continue;
+    const int start = std::max(0, h.emitted - 16 * L);  // streaming-model.cpp:638-642 (16 * depth)
+    if (h.pos_offset + fresh > cfg_.max_pos) throw std::runtime_error("stream exceeds max_position_embeddings");
+    jobs.push_back({slots[i], start, total, stable, fresh, R});
+    R += total - start;
+    Nn += fresh;
+    if (new_frames_out) new_frames_out[i] = fresh;
+  }
+  if (jobs.empty()) return;
+  H_.reserve((size_t)R * De * 4);
+  Y_.reserve((size_t)R * std::max(De, Dd) * 2);
+  Y32_.reserve((size_t)R * De * 4);
+  QKV_.reserve((size_t)R * 3 * std::max(De, Dd) * 2);
+  AO_.reserve((size_t)R * std::max(De, Dd) * 2);
+  Z_.reserve((size_t)R * std::max(Fe, cfg_.dec_ffn) * 2);
+  adp16_.reserve((size_t)Nn * De * 2);
+  adp32_.reserve((size_t)Nn * De * 4);
+  mem16_.reserve((size_t)Nn * Dd * 2);
+  mem32_.reserve((size_t)Nn * Dd * 4);
+  crosstmp_.reserve((size_t)Nn * L * 2 * Dd * 2);
+  std::vector<StreamSeg> gather, memseg;
+  std::vector<int> lo(R), hi(R), nrow(Nn), npos(Nn), nslot(Nn), nidx(Nn);
+  std::vector<int4> upd;
+  float* H = H_.as<float>();
+  int k = 0;
+  for (const Job& j : jobs) {
+    SlotHost& h = st(j.slot);
+    const int W = j.total - j.start;
+    gather.push_back({features_ + ((size_t)j.slot * Mcap_ + j.start) * De, H + (size_t)j.r0 * De, (long)W * De * 4});
+    for (int r = 0; r < W; ++r) {
+      lo[j.r0 + r] = j.r0;
+      hi[j.r0 + r] = j.r0 + W;
+    }
+    memseg.push_back({mem32_.as<float>() + (size_t)k * Dd, memory_ + ((size_t)j.slot * Mcap_ + h.mem_len) * Dd,
+                      (long)j.fresh * Dd * 4});
+    for (int i = 0; i < j.fresh; ++i, ++k) {
+      nrow[k] = j.r0 + (h.emitted - j.start) + i;
+      npos[k] = h.pos_offset + i;
+      nslot[k] = j.slot;
+      nidx[k] = h.mem_len + i;
+    }
+    h.mem_len += j.fresh;
+    h.emitted = j.stable;
+    h.pos_offset += j.fresh;
+    upd.push_back(make_int4(j.slot, h.mem_len, -1, 0));
+  }
+  std::vector<StreamSeg> all(gather);
+  all.insert(all.end(), memseg.begin(), memseg.end());
+  const StreamSeg* segs_d = stage(segs_, all);
+  const int* lo_d = stage(rowlo_, lo);
+  const int* hi_d = stage(rowhi_, hi);
+  const int* nrow_d = stage(newrows_, nrow);
+  const int* npos_d = stage(newpos_, npos);
+  const int* nslot_d = stage(newslot_, nslot);
+  const int* nidx_d = stage(newidx_, nidx);
+  const int4* upd_d = stage(jobs_, upd);
+
+  copy_segments(segs_d, (int)gather.size(), stream_);
+  bf16_t* Y = Y_.as<bf16_t>();
+  bf16_t* QKV = QKV_.as<bf16_t>();
+  bf16_t* AO = AO_.as<bf16_t>();
+  bf16_t* Z = Z_.as<bf16_t>();
+  for (int l = 0; l < cfg_.enc_layers; ++l) {
+    const EncW& E = enc_[l];
+    layernorm_bf16(H, E.ln1, R, De, Y, nullptr, stream_);
+    gemm_act(Y, De, E.wqkv, nullptr, 0, R, 3 * De, De, QKV, nullptr, stream_);
+    stream_enc_attention(QKV, lo_d, hi_d, R, De, cfg_.encoder_heads, cfg_.windows[l].first, cfg_.windows[l].second, AO,
+                         stream_);
+    gemm_resid_f32(AO, De, E.wo, nullptr, R, De, De, H, stream_);
+    layernorm_bf16(H, E.ln2, R, De, Y, nullptr, stream_);
+    gemm_bias_gelu_bf16(Y, De, E.fc1, E.b1, R, Fe, De, Z, stream_);
+    gemm_resid_f32(Z, Fe, E.fc2, E.b2, R, De, Fe, H, stream_);
+  }
+  layernorm_bf16(H, enc_ln_, R, De, Y, Y32_.as<float>(), stream_);
+  stream_adapter_in(Y32_.as<float>(), nrow_d, npos_d, Nn, De, pos_emb_, adp16_.as<bf16_t>(), adp32_.as<float>(),
+                    stream_);
+  const bf16_t* mem16 = adp16_.as<bf16_t>();
+  if (proj_w_ != nullptr) {
+    gemm_act(adp16_.as<bf16_t>(), De, proj_w_, nullptr, 0, Nn, Dd, De, mem16_.as<bf16_t>(), mem32_.as<float>(), stream_);
+    mem16 = mem16_.as<bf16_t>();
+  } else {
+    MSH_HIP(hipMemcpyAsync(mem32_.p, adp32_.p, (size_t)Nn * Dd * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  copy_segments(segs_d + gather.size(), (int)memseg.size(), stream_);
+  gemm_act(mem16, Dd, cross_w_, nullptr, 0, Nn, L * 2 * Dd, Dd, crosstmp_.as<bf16_t>(), nullptr, stream_);
+  stream_scatter_cross(crosstmp_.as<bf16_t>(), nslot_d, nidx_d, Nn, L, Dd, Mcap_, crossK_, crossV_, stream_);
+  stream_slot_update(upd_d, (int)upd.size(), slots_d_, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
+void StreamingEngine::decoder_reset(int n, const int* slots) {
+  check_slots(n, slots);
+  if (n == 0) return;
+  MSH_HIP(hipSetDevice(device_));
+  std::vector<int4> upd;
+  for (int i = 0; i < n; ++i) {
+    st(slots[i]).cache_len = 0;
+    upd.push_back(make_int4(slots[i], -1, 0, 1));
+  }
+  stream_slot_update(stage(jobs_, upd), n, slots_d_, stream_);
+}
+
+// One pass of the decoder (lora/export.py:207-256) over M rows whose embeddings sit in H; row r belongs to
+// stream row_slot[r] at position row_pos[r].
+void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_pos, float* logits) {
+  const int Dd = cfg_.decoder_dim, L = cfg_.depth, Fd = cfg_.dec_ffn, V = cfg_.vocab_size;
+  Y_.reserve((size_t)M * Dd * 2);
+  QKV_.reserve((size_t)M * 3 * Dd * 2);
+  AO_.reserve((size_t)M * Dd * 2);
+  Q_.reserve((size_t)M * Dd * 2);
+  Z_.reserve((size_t)M * Fd * 2);
+  float* H = stepH_.as<float>();
+  bf16_t* Y = Y_.as<bf16_t>();
+  bf16_t* QKV = QKV_.as<bf16_t>();
+  bf16_t* AO = AO_.as<bf16_t>();
+  bf16_t* Q = Q_.as<bf16_t>();
+  bf16_t* Z = Z_.as<bf16_t>();
+  const RopeParams rp{rope_cos_, rope_sin_, rot_pairs_, cfg_.head_dim, Dd};
+  for (int l = 0; l < L; ++l) {
+    const DecW& W = dec_[l];
+    layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
+    gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
+    stream_self_attention(QKV, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
+    gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
+    layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
+    gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+    stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+    gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
+    layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
+    gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+    gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
+  }
+  layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
+  gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_);
+}
+
+void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* const* tokens, const int* lens,
+                                    float* logits_out) {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  check_slots(n, slots);
+  MSH_HIP(hipSetDevice(device_));
+  const int Dd = cfg_.decoder_dim, V = cfg_.vocab_size;
+  std::vector<int> rs, rpos, tok;
+  std::vector<DecJob> jobs;
+  for (int i = 0; i < n; ++i) {
+    SlotHost& h = st(slots[i]);
+    if (lens[i] <= 0 || tokens[i] == nullptr) throw std::invalid_argument("empty token list");
+    if (h.mem_len == 0) throw std::invalid_argument("memory is empty");  // streaming-model.cpp:1151-1154
+    if (h.cache_len + lens[i] > Scap_) throw std::invalid_argument("self-attention cache capacity exceeded");
+    jobs.push_back({slots[i], (int)rs.size(), lens[i], 0, 0, 0, h.cache_len, 0});
+    for (int t = 0; t < lens[i]; ++t) {
+      if (tokens[i][t] < 0 || tokens[i][t] >= V) throw std::invalid_argument("token id out of range");
+      rs.push_back(slots[i]);
+      rpos.push_back(h.cache_len + t);
+      tok.push_back(tokens[i][t]);
+    }
+    h.cache_len += lens[i];
+  }
+  const int M = (int)rs.size();
+  if (M == 0) return;
+  stepH_.reserve((size_t)M * Dd * 4);
+  logits_.reserve((size_t)M * V * 4);
+  const int* rs_d = stage(rowslot_, rs);
+  const int* rp_d = stage(rowpos_, rpos);
+  const int* tok_d = stage(tokens_, tok);
+  const DecJob* jobs_d = stage(decjobs_, jobs);
+  stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
+  decoder_pass(M, rs_d, rp_d, logits_.as<float>());
+  stream_bump_cache(jobs_d, (int)jobs.size(), slots_d_, stream_);
+  if (logits_out != nullptr)
+    MSH_HIP(hipMemcpyAsync(logits_out, logits_.p, (size_t)M * V * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode_full (streaming-model.cpp:1192-1397) for n streams: one wide pass over [BOS, draft...] of every
+// stream, device-side verify, then lock-step auto-regressive steps (one row per stream) until every stream
+// hit EOS or its budget.  Token choice, EOS / budget tests and the rollback all run on the device; the host
+// only polls a counter of active streams.
+// ------------------------------------------------------------------------------------------------
+void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const* drafts, const int* draft_lens,
+                                  const int* max_tokens, int32_t* tokens_out, int32_t* counts_out, int tokens_stride,
+                                  int32_t* accepted_out) {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  check_slots(n, slots);
+  if (n > 0 && (tokens_out == nullptr || counts_out == nullptr)) throw std::invalid_argument("null output");
+  MSH_HIP(hipSetDevice(device_));
+  const int Dd = cfg_.decoder_dim, V = cfg_.vocab_size;
+  std::vector<int> rs, rpos, tok, draft_flat, job_slot, job_index;
+  std::vector<DecJob> jobs;
+  int max_budget = 0;
+  for (int i = 0; i < n; ++i) {
+    SlotHost& h = st(slots[i]);
+    counts_out[i] = 0;
+    if (accepted_out) accepted_out[i] = 0;
+    if (h.mem_len == 0) continue;  // streaming-model.cpp:1205-1210: empty result, success
+    if (h.cache_len != 0)
+      throw std::invalid_argument("decode_full needs an empty self-attention cache: call decoder_reset first "
+                                  "(reference transcriber.cpp:1385)");
+    const int dl = (drafts != nullptr && draft_lens != nullptr && drafts[i] != nullptr) ? draft_lens[i] : 0;
+    const int budget = (max_tokens != nullptr && max_tokens[i] >= 0) ? max_tokens[i] : max_tokens_for(slots[i]);
+    if (1 + std::max(dl, budget) + 1 > Scap_) throw std::invalid_argument("draft or budget exceeds the cache capacity");
+    if (std::max(dl, budget) > tokens_stride) throw std::invalid_argument("tokens_stride too small");
+    jobs.push_back({slots[i], (int)rs.size(), 1 + dl, (int)draft_flat.size(), dl, budget, 0, 0});
+    job_slot.push_back(slots[i]);
+    job_index.push_back(i);
+    rs.push_back(slots[i]);
+    rpos.push_back(0);
+    tok.push_back(cfg_.bos_id);
+    for (int t = 0; t < dl; ++t) {
+      if (drafts[i][t] < 0 || drafts[i][t] >= V) throw std::invalid_argument("draft token out of range");
+      rs.push_back(slots[i]);
+      rpos.push_back(1 + t);
+      tok.push_back(drafts[i][t]);
+      draft_flat.push_back(drafts[i][t]);
+    }
+    max_budget = std::max(max_budget, budget);
+  }
+  const int J = (int)jobs.size(), M = (int)rs.size();
+  if (J == 0) return;
+  stepH_.reserve((size_t)M * Dd * 4);
+  logits_.reserve((size_t)M * V * 4);
+  pred_.reserve((size_t)M * 4);
+  steppos_.reserve((size_t)J * 4);
+  const int* rs_d = stage(rowslot_, rs);
+  const int* rp_d = stage(rowpos_, rpos);
+  const int* tok_d = stage(tokens_, tok);
+  const int* draft_d = stage(draft_, draft_flat);
+  const DecJob* jobs_d = stage(decjobs_, jobs);
+  const int* jslot_d = stage(newslot_, job_slot);
+  MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
+  stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
+  decoder_pass(M, rs_d, rp_d, logits_.as<float>());
+  stream_argmax(logits_.as<float>(), M, V, pred_.as<int>(), stream_);
+  stream_verify(jobs_d, J, pred_.as<int>(), draft_d, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd,
+                stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
+  int32_t active = 1;
+  for (int step = 0; step < max_budget; ++step) {
+    if (step % 8 == 0) {
+      MSH_HIP(hipMemcpyAsync(&active, n_active_d_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+      MSH_HIP(hipStreamSynchronize(stream_));
+      if (active <= 0) break;
+    }
+    decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
+    stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
+    stream_advance(jobs_d, J, pred_.as<int>(), slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd, stepH_.as<float>(),
+                   steppos_.as<int>(), n_active_d_, stream_);
+  }
+  std::vector<SlotDev> sd(J);
+  for (int j = 0; j < J; ++j)
+    MSH_HIP(hipMemcpyAsync(&sd[j], slots_d_ + jobs[j].slot, sizeof(SlotDev), hipMemcpyDeviceToHost, stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  for (int j = 0; j < J; ++j) {
+    const int i = job_index[j];
+    counts_out[i] = sd[j].count;
+    if (accepted_out) accepted_out[i] = sd[j].accepted;
+    st(jobs[j].slot).cache_len = sd[j].cache_len;
+    if (sd[j].count > 0)
+      MSH_HIP(hipMemcpyAsync(tokens_out + (size_t)i * tokens_stride, result_ + (size_t)jobs[j].slot * Scap_,
+                             (size_t)sd[j].count * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+  }
+  MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace msh

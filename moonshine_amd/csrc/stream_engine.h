@@ -1,0 +1,134 @@
+// MI355X streaming Moonshine engine: the device-side replacement of the five ORT sessions behind
+// reference core/moonshine-streaming-model.{h,cpp} (frontend, encoder, adapter, cross_kv, decoder_kv),
+// batched over streams.
+//
+// Every stream owns a slot of fixed-capacity device state (what MoonshineStreamingState keeps in host
+// vectors, streaming-model.h:36-71):
+//   conv1_buf [4][De] / conv2_buf [4][2De] bf16    the frontend's carried frames
+//   features  [Mcap][De] fp32                       accumulated_features
+//   memory    [Mcap][Dd] fp32                       adapter output (kept for inspection)
+//   crossK/V  [L][Mcap][Dd] bf16                    cross-attention keys / values, appended per update
+//   selfK/V   [L][Scap][Dd] bf16                    decoder self-attention cache
+//   result    [Scap] int32 + SlotDev                decode_full bookkeeping
+// Calls take a list of slots and work on all of them at once: rows of every GEMM are the concatenation of
+// the streams' rows, attention kernels look the owning stream up per row.
+//
+// Differences from the reference driver that do not change results:
+//   * cross K/V are appended for the new memory frames only (the reference re-projects the whole memory on
+//     every update, streaming-model.cpp:779-860; a key's projection does not depend on later frames);
+//   * a rejected draft suffix is rolled back by truncating the self cache instead of re-running the accepted
+//     prefix (streaming-model.cpp:1337-1365): causal attention makes the two identical.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "stream_kernels.h"
+
+namespace msh {
+
+struct StreamingConfig {  // streaming_config.json (streaming-model.cpp:97-113) + additive keys
+  int encoder_dim = 0, decoder_dim = 0, depth = 0, nheads = 0, head_dim = 0, vocab_size = 0;
+  int bos_id = 1, eos_id = 2, frame_len = 80, total_lookahead = 0, max_seq_len = 448;
+  int encoder_heads = 8, enc_layers = 0, enc_ffn = 0, dec_ffn = 0, max_pos = 0;
+  float rope_theta = 10000.f, partial_rotary = 0.8f;
+  std::vector<std::pair<int, int>> windows;
+};
+
+class StreamingEngine {
+ public:
+  StreamingEngine(int device, int max_slots, int max_memory_frames);
+  ~StreamingEngine();
+
+  void load(const SafeTensors& st, const std::string& config_json);
+  const StreamingConfig& config() const { return cfg_; }
+  bool loaded() const { return loaded_; }
+  int max_slots() const { return max_slots_; }
+  int memory_capacity() const { return Mcap_; }
+
+  int create_stream();        // returns a slot id
+  void free_stream(int slot);
+  void reset_stream(int slot);  // MoonshineStreamingState::reset
+
+  // frontend over the new audio of n streams (host pointers); features_out[i] = new feature frames
+  void process_audio(int n, const int* slots, const float* const* pcm, const uint64_t* lens, int* features_out);
+  // window encoder + adapter + cross-K/V append (MoonshineStreamingModel::encode)
+  void encode(int n, const int* slots, const uint8_t* is_final, int* new_frames_out);
+  void decoder_reset(int n, const int* slots);
+  // wide decoder pass: tokens of stream i appended to its cache; logits_out (nullable) gets the rows of all
+  // streams concatenated, [sum(lens)][V]
+  void decode_tokens(int n, const int* slots, const int32_t* const* tokens, const int* lens, float* logits_out);
+  // decode_full for n streams at once.  max_tokens[i] < 0 = the reference rule from the memory length.
+  void decode_full(int n, const int* slots, const int32_t* const* drafts, const int* draft_lens, const int* max_tokens,
+                   int32_t* tokens_out, int32_t* counts_out, int tokens_stride, int32_t* accepted_out);
+
+  int memory_len(int slot) const { return st(slot).mem_len; }
+  int feature_count(int slot) const { return st(slot).feat_count; }
+  int cache_len(int slot) const { return st(slot).cache_len; }
+  int frames_emitted(int slot) const { return st(slot).emitted; }
+  void get_memory(int slot, float* out);    // [memory_len][Dd]
+  void get_features(int slot, float* out);  // [feature_count][De]
+  int max_tokens_for(int slot) const;       // streaming-model.cpp:1217-1219
+  void synchronize();
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  struct SlotHost {
+    bool used = false;
+    std::vector<float> pending;  // samples that do not fill a 320-sample period yet
+    int feat_count = 0, emitted = 0, pos_offset = 0, mem_len = 0, cache_len = 0;
+  };
+  const SlotHost& st(int slot) const;
+  SlotHost& st(int slot);
+  void check_slots(int n, const int* slots) const;
+  void upload(const std::vector<float>& src, float** dst);
+  void upload_bf16(const std::vector<float>& src, bf16_t** dst);
+  template <class T>
+  T* stage(DevBuf& buf, const std::vector<T>& host);  // async H2D of a small descriptor array
+  void decoder_pass(int M, const int* row_slot_d, const int* row_pos_d, float* logits);
+  void push_slot_state(int slot);
+
+  struct EncW {
+    float *ln1, *ln2, *b1, *b2;
+    bf16_t *wqkv, *wo, *fc1, *fc2;
+  };
+  struct DecW {
+    float *ln1, *ln2, *ln3, *b1, *b2;
+    bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;
+  };
+
+  int device_;
+  hipStream_t stream_ = nullptr;
+  bool loaded_ = false;
+  StreamingConfig cfg_;
+  int max_slots_, Mcap_, Scap_ = 0;
+  std::vector<void*> allocs_;
+
+  // weights
+  float k_scale_ = 0.75f;
+  bf16_t *lin_w_ = nullptr, *conv1_w_ = nullptr, *conv2_w_ = nullptr, *proj_w_ = nullptr, *cross_w_ = nullptr,
+         *head_w_ = nullptr;
+  float *conv1_b_ = nullptr, *conv2_b_ = nullptr, *enc_ln_ = nullptr, *pos_emb_ = nullptr, *embed_f32_ = nullptr,
+        *dec_ln_ = nullptr, *rope_cos_ = nullptr, *rope_sin_ = nullptr;
+  int rot_pairs_ = 0;
+  std::vector<EncW> enc_;
+  std::vector<DecW> dec_;
+
+  // per-slot device state (slabs over max_slots)
+  bf16_t *conv1_buf_ = nullptr, *conv2_buf_ = nullptr, *crossK_ = nullptr, *crossV_ = nullptr, *selfK_ = nullptr,
+         *selfV_ = nullptr;
+  float *features_ = nullptr, *memory_ = nullptr;
+  int32_t* result_ = nullptr;
+  SlotDev* slots_d_ = nullptr;
+  int32_t* n_active_d_ = nullptr;
+  std::vector<SlotHost> slots_;
+
+  // workspace (grow-only)
+  DevBuf audio_, frames_, hidden_, c1out_, feat_pk_, segs_, jobs_, H_, Y_, Y32_, QKV_, AO_, Z_, Q_, rowlo_, rowhi_,
+      newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_,
+      logits_, pred_, draft_, decjobs_, stepH_, steppos_;
+  std::vector<char> pinned_;  // unused placeholder for future pinned staging
+};
+
+}  // namespace msh

@@ -30,6 +30,12 @@ class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint64), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+class StreamInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "encoder_dim", "decoder_dim", "depth", "nheads", "head_dim", "vocab_size", "bos_id", "eos_id", "frame_len",
+        "total_lookahead", "max_seq_len", "enc_layers", "encoder_heads", "max_slots", "memory_capacity")]
+
+
 _lib = None
 
 
@@ -65,6 +71,22 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_profile_count": (i32, [vp]),
         "msh_profile_get": (i32, [vp, i32, P(ProfileEntry)]),
         "msh_synchronize": (i32, [vp]),
+        "msh_stream_create": (i32, [i32, C.c_char_p, C.c_char_p, i32, i32, P(vp)]),
+        "msh_stream_create_from_memory": (i32, [i32, vp, u64, C.c_char_p, i32, i32, P(vp)]),
+        "msh_stream_destroy": (None, [vp]),
+        "msh_stream_last_error": (C.c_char_p, [vp]),
+        "msh_stream_info_get": (i32, [vp, P(StreamInfo)]),
+        "msh_stream_open": (i32, [vp]),
+        "msh_stream_close": (i32, [vp, i32]),
+        "msh_stream_reset": (i32, [vp, i32]),
+        "msh_stream_process_audio": (i32, [vp, i32, vp, P(vp), P(u64), vp]),
+        "msh_stream_encode": (i32, [vp, i32, vp, vp, vp]),
+        "msh_stream_decoder_reset": (i32, [vp, i32, vp]),
+        "msh_stream_decode_tokens": (i32, [vp, i32, vp, P(vp), vp, vp]),
+        "msh_stream_decode_full": (i32, [vp, i32, vp, P(vp), vp, vp, vp, vp, i32, vp]),
+        "msh_stream_query": (i32, [vp, i32, i32]),
+        "msh_stream_get_memory": (i32, [vp, i32, vp]),
+        "msh_stream_get_features": (i32, [vp, i32, vp]),
         "msh_host_tokens_to_text": (C.c_int64, [vp, u64, vp, u64, vp, u64]),
         "msh_host_sanitize_utf8": (C.c_int64, [vp, u64, vp, u64]),
         "msh_host_resample": (C.c_int64, [vp, u64, f32, f32, vp, u64]),
@@ -206,3 +228,138 @@ class Engine:
 
     def synchronize(self):
         self._check(self.lib.msh_synchronize(self.h))
+
+
+class StreamEngine:
+    """msh_stream_engine: the batched streaming model (reference core/moonshine-streaming-model.h:73-201)."""
+
+    def __init__(self, safetensors_path: str, config_json: str, device: int = 0, max_slots: int = 64,
+                 max_memory_frames: int = 2048):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.msh_stream_create(device, safetensors_path.encode(), config_json.encode(), max_slots,
+                                        max_memory_frames, C.byref(h))
+        if rc != 0:
+            raise MshError(rc, (self.lib.msh_stream_last_error(None) or b"").decode())
+        self.h = h
+        self._info = StreamInfo()
+        self._check(self.lib.msh_stream_info_get(self.h, C.byref(self._info)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.msh_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise MshError(rc, (self.lib.msh_stream_last_error(self.h) or b"").decode())
+        return rc
+
+    @property
+    def info(self) -> StreamInfo:
+        return self._info
+
+    def open(self) -> int:
+        return self._check(self.lib.msh_stream_open(self.h))
+
+    def close_stream(self, slot: int):
+        self._check(self.lib.msh_stream_close(self.h, slot))
+
+    def reset(self, slot: int):
+        self._check(self.lib.msh_stream_reset(self.h, slot))
+
+    @staticmethod
+    def _slots(slots):
+        return np.ascontiguousarray(slots, dtype=np.int32)
+
+    def process_audio(self, slots, chunks) -> np.ndarray:
+        s = self._slots(slots)
+        keep = [np.ascontiguousarray(c, dtype=np.float32) for c in chunks]
+        ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+        lens = (C.c_uint64 * len(keep))(*[c.shape[0] for c in keep])
+        out = np.zeros(len(keep), np.int32)
+        self._check(self.lib.msh_stream_process_audio(self.h, len(keep), s.ctypes.data, ptrs, lens, out.ctypes.data))
+        return out
+
+    def encode(self, slots, is_final) -> np.ndarray:
+        s = self._slots(slots)
+        fin = np.ascontiguousarray(np.broadcast_to(np.asarray(is_final, dtype=np.uint8), s.shape))
+        out = np.zeros(s.shape[0], np.int32)
+        self._check(self.lib.msh_stream_encode(self.h, s.shape[0], s.ctypes.data, fin.ctypes.data, out.ctypes.data))
+        return out
+
+    def decoder_reset(self, slots):
+        s = self._slots(slots)
+        self._check(self.lib.msh_stream_decoder_reset(self.h, s.shape[0], s.ctypes.data))
+
+    def decode_tokens(self, slots, tokens, want_logits: bool = True):
+        """tokens: one int sequence per stream.  Returns a list of [n_i, V] logits arrays."""
+        s = self._slots(slots)
+        keep = [np.ascontiguousarray(t, dtype=np.int32) for t in tokens]
+        ptrs = (C.c_void_p * len(keep))(*[t.ctypes.data for t in keep])
+        lens = np.asarray([t.shape[0] for t in keep], np.int32)
+        total = int(lens.sum())
+        logits = np.empty((total, self._info.vocab_size), np.float32) if want_logits else None
+        self._check(self.lib.msh_stream_decode_tokens(self.h, s.shape[0], s.ctypes.data, ptrs, lens.ctypes.data,
+                                                      logits.ctypes.data if want_logits else None))
+        if not want_logits:
+            return None
+        out, o = [], 0
+        for n in lens:
+            out.append(logits[o:o + n])
+            o += n
+        return out
+
+    def decode_full(self, slots, drafts=None, max_tokens=None):
+        """Returns (list of token lists, accepted counts)."""
+        s = self._slots(slots)
+        n = s.shape[0]
+        stride = self._info.max_seq_len + 8
+        toks = np.zeros((n, stride), np.int32)
+        counts = np.zeros(n, np.int32)
+        acc = np.zeros(n, np.int32)
+        if drafts is not None:
+            keep = [np.ascontiguousarray(d if d is not None else [], dtype=np.int32) for d in drafts]
+            ptrs = (C.c_void_p * n)(*[(d.ctypes.data if d.shape[0] else None) for d in keep])
+            dl = np.asarray([d.shape[0] for d in keep], np.int32)
+            pa, la = ptrs, dl.ctypes.data
+        else:
+            pa, la = None, None
+        mt = np.ascontiguousarray(max_tokens, dtype=np.int32) if max_tokens is not None else None
+        self._check(self.lib.msh_stream_decode_full(self.h, n, s.ctypes.data, pa, la,
+                                                    mt.ctypes.data if mt is not None else None, toks.ctypes.data,
+                                                    counts.ctypes.data, stride, acc.ctypes.data))
+        return [toks[i, :counts[i]].tolist() for i in range(n)], acc
+
+    def query(self, slot: int, what: int) -> int:
+        return self._check(self.lib.msh_stream_query(self.h, slot, what))
+
+    def memory_len(self, slot: int) -> int:
+        return self.query(slot, 0)
+
+    def feature_count(self, slot: int) -> int:
+        return self.query(slot, 1)
+
+    def cache_len(self, slot: int) -> int:
+        return self.query(slot, 2)
+
+    def max_tokens_for(self, slot: int) -> int:
+        return self.query(slot, 4)
+
+    def memory(self, slot: int) -> np.ndarray:
+        out = np.empty((self.memory_len(slot), self._info.decoder_dim), np.float32)
+        if out.size:
+            self._check(self.lib.msh_stream_get_memory(self.h, slot, out.ctypes.data))
+        return out
+
+    def features(self, slot: int) -> np.ndarray:
+        out = np.empty((self.feature_count(slot), self._info.encoder_dim), np.float32)
+        if out.size:
+            self._check(self.lib.msh_stream_get_features(self.h, slot, out.ctypes.data))
+        return out

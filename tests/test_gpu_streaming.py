@@ -1,0 +1,296 @@
+"""GPU parity tests of the streaming path through the C ABI
+(msh_stream_*): engine vs the numpy oracle (oracle/streaming_ref.py) and vs the golden vectors made
+from the reference's own graph modules (tests/golden/make_golden_streaming.py).
+
+Tolerances (bf16 operands, fp32 accumulation, fp32 residual stream / softmax / LayerNorm):
+  features / memory : rel-RMS <= 1e-2 and max-abs <= 8e-2 against fp32
+  logits            : max-abs <= 6e-2 on O(1) logits; token ids must match wherever the oracle's
+                      top-2 margin exceeds 0.12
+Integer outputs (frame / memory counts, accepted-draft counts, budgets) are exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import streaming_ref as sr
+from oracle.weights import STREAMING_ARCHS, make_audio, make_streaming_weights, write_streaming_model_dir
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RELRMS = 1e-2
+MAXABS = 8e-2
+LOGIT_MAXABS = 6e-2
+MARGIN = 0.12
+
+
+def relrms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-12))
+
+
+def make_engine(tmp_path, arch, seed, weights=None, max_slots=8, max_frames=512):
+    from moonshine_amd.hip_api import StreamEngine
+
+    cfg = STREAMING_ARCHS[arch]
+    d = str(tmp_path / f"{arch}_{seed}")
+    w = write_streaming_model_dir(d, cfg, seed, weights)
+    eng = StreamEngine(os.path.join(d, "model.safetensors"), cfg.streaming_config_json(), max_slots=max_slots,
+                       max_memory_frames=max_frames)
+    return eng, cfg, w
+
+
+def feed(eng, slot, audio, chunks_per_update, finals=True):
+    """The golden schedule: `chunks_per_update` 1280-sample chunks, then encode; final on the last update."""
+    n_chunks = audio.shape[0] // 1280
+    c = 0
+    mem_lens = []
+    while c < n_chunks:
+        k = min(chunks_per_update, n_chunks - c)
+        for i in range(k):
+            assert eng.process_audio([slot], [audio[(c + i) * 1280:(c + i + 1) * 1280]])[0] == 4
+        c += k
+        eng.encode([slot], [finals and c >= n_chunks])
+        mem_lens.append(eng.memory_len(slot))
+    return mem_lens
+
+
+def oracle_state(w, cfg, audio, chunks_per_update):
+    st = sr.StreamState(cfg)
+    n_chunks = audio.shape[0] // 1280
+    c = 0
+    while c < n_chunks:
+        k = min(chunks_per_update, n_chunks - c)
+        for i in range(k):
+            sr.process_audio_chunk(w, cfg, st, audio[(c + i) * 1280:(c + i + 1) * 1280])
+        c += k
+        sr.encode(w, cfg, st, c >= n_chunks)
+    return st
+
+
+@pytest.mark.parametrize("name", ["micro_2s", "tiny_3s"])
+def test_stream_matches_reference_graphs(tmp_path, name):
+    g = np.load(os.path.join(GOLD, f"golden_stream_{name}.npz"))
+    eng, cfg, w = make_engine(tmp_path, str(g["arch"]), int(g["seed"]))
+    info = eng.info
+    assert (info.encoder_dim, info.decoder_dim, info.depth, info.total_lookahead) == (
+        cfg.enc_dim, cfg.dec_dim, cfg.depth, cfg.total_lookahead)
+    audio = make_audio(int(g["audio_index"]), int(g["n_samples"]))
+    s = eng.open()
+    mem_lens = feed(eng, s, audio, int(g["update_chunks"]))
+    assert mem_lens == g["mem_lens"].tolist()
+    feats, mem = eng.features(s), eng.memory(s)
+    assert feats.shape == g["features"].shape and mem.shape == g["memory"].shape
+    assert relrms(feats, g["features"]) < RELRMS and np.abs(feats - g["features"]).max() < MAXABS
+    assert relrms(mem, g["memory"]) < 2 * RELRMS and np.abs(mem - g["memory"]).max() < 2 * MAXABS
+    # wide (teacher-forced) pass over the golden tokens
+    toks = g["greedy_tokens"].tolist()
+    eng.decoder_reset([s])
+    logits = eng.decode_tokens([s], [toks[:-1]])[0]
+    assert eng.cache_len(s) == len(toks) - 1
+    ti = g["wide_top8_idx"].astype(np.int64)
+    got = np.take_along_axis(logits, ti, axis=-1)
+    assert np.abs(got - g["wide_top8_val"]).max() < LOGIT_MAXABS
+    assert np.abs(logits[:, :64] - g["wide_logits_sel"]).max() < LOGIT_MAXABS
+    margin = g["wide_top8_val"][:, 0] - g["wide_top8_val"][:, 1]
+    for t in range(len(toks) - 1):
+        if margin[t] > MARGIN:
+            assert int(np.argmax(logits[t])) == toks[t + 1]
+    # one token per call reproduces the wide pass (cache growth path)
+    eng.decoder_reset([s])
+    step = np.stack([eng.decode_tokens([s], [[t]])[0][0] for t in toks[:-1]])
+    assert np.abs(step - logits).max() < 2e-2
+    eng.close()
+
+
+def test_stream_oracle_parity_and_batch_independence(tmp_path):
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21)
+    audios = [make_audio(30 + i, 1280 * n) for i, n in enumerate((30, 17, 45))]
+    upd = (4, 3, 7)
+    # alone
+    alone = []
+    for a, u in zip(audios, upd):
+        s = eng.open()
+        feed(eng, s, a, u)
+        alone.append((eng.features(s), eng.memory(s)))
+        eng.close_stream(s)
+    # together: different lengths and update rhythms in the same batched calls
+    slots = [eng.open() for _ in audios]
+    pos = [0] * 3
+    while any(p < a.shape[0] // 1280 for p, a in zip(pos, audios)):
+        act, chunks = [], []
+        for i, a in enumerate(audios):
+            nc = a.shape[0] // 1280
+            if pos[i] < nc:
+                k = min(upd[i], nc - pos[i])
+                act.append(i)
+                chunks.append(a[pos[i] * 1280:(pos[i] + k) * 1280])
+                pos[i] += k
+        got = eng.process_audio([slots[i] for i in act], chunks)
+        assert got.tolist() == [c.shape[0] // 320 for c in chunks]
+        eng.encode([slots[i] for i in act], [pos[i] >= audios[i].shape[0] // 1280 for i in act])
+    for i, s in enumerate(slots):
+        f, m = eng.features(s), eng.memory(s)
+        st = oracle_state(w, cfg, audios[i], upd[i])
+        assert m.shape == st.memory.shape
+        assert relrms(f, st.features) < RELRMS and relrms(m, st.memory) < 2 * RELRMS
+        # a stream's result does not depend on what else is in the batch, nor on how its audio was cut
+        np.testing.assert_array_equal(f, alone[i][0])
+        np.testing.assert_array_equal(m, alone[i][1])
+    eng.close()
+
+
+def test_stream_period_buffering(tmp_path):
+    """Samples that do not fill a 320-sample period wait; the result equals feeding whole chunks."""
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21)
+    audio = make_audio(40, 1280 * 6)
+    a, b = eng.open(), eng.open()
+    for c in range(6):
+        eng.process_audio([a], [audio[c * 1280:(c + 1) * 1280]])
+    cuts = [0, 100, 1317, 1317 + 1243, 5000, 5001, 1280 * 6]
+    got = [int(eng.process_audio([b], [audio[x:y]])[0]) for x, y in zip(cuts[:-1], cuts[1:])]
+    assert got == [0, 4, 4, 7, 0, 9] and eng.feature_count(b) == 24
+    np.testing.assert_array_equal(eng.features(a), eng.features(b))
+    assert eng.encode([a, b], [False, False]).tolist() == [24 - cfg.total_lookahead] * 2
+    assert eng.encode([a, b], [True, True]).tolist() == [cfg.total_lookahead] * 2
+    assert eng.encode([a, b], [True, True]).tolist() == [0, 0]
+    np.testing.assert_array_equal(eng.memory(a), eng.memory(b))
+    eng.close()
+
+
+def oracle_greedy_with_margin(w, cfg, st, max_tokens):
+    """Oracle decode_full token list plus, per position, the top-2 margin of the logits that chose it."""
+    st.decoder_reset()
+    toks, margins = [], []
+    cur = cfg.bos
+    while True:
+        lg = sr.decode_tokens(w, cfg, st, [cur])[0]
+        top = np.sort(lg)[-2:]
+        nxt = int(np.argmax(lg))
+        margins.append(float(top[1] - top[0]))
+        if nxt == cfg.eos or len(toks) >= max_tokens:
+            break
+        toks.append(nxt)
+        cur = nxt
+    return toks, margins
+
+
+def agree_until_close_call(got, want, margins):
+    for i, (a, b) in enumerate(zip(got, want)):
+        if margins[i] < MARGIN:
+            return
+        assert a == b, (i, got, want)
+    if all(m >= MARGIN for m in margins[:len(want) + 1]):
+        assert len(got) == len(want)
+
+
+def test_decode_full_speculative(tmp_path):
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21)
+    audio = make_audio(5, 1280 * 30)
+    s = eng.open()
+    feed(eng, s, audio, 30)
+    assert eng.memory_len(s) == 120 and eng.max_tokens_for(s) == 16
+    st = oracle_state(w, cfg, audio, 30)
+    want, margins = oracle_greedy_with_margin(w, cfg, st, sr.max_tokens_for_memory(cfg, 120))
+    eng.decoder_reset([s])
+    (plain,), acc = eng.decode_full([s])
+    assert acc[0] == 0 and 0 < len(plain) <= 16
+    agree_until_close_call(plain, want, margins)
+    assert eng.cache_len(s) == len(plain) + 1 or len(plain) == 16
+    # a correct draft is accepted whole, a corrupted one is cut at the corruption; same final tokens
+    eng.decoder_reset([s])
+    (t1,), acc = eng.decode_full([s], drafts=[plain[:7]])
+    assert t1 == plain and acc[0] == 7
+    bad = list(plain[:9])
+    bad[4] = 7 if bad[4] != 7 else 8
+    eng.decoder_reset([s])
+    (t2,), acc = eng.decode_full([s], drafts=[bad])
+    assert t2 == plain and acc[0] == 4
+    # explicit budgets
+    eng.decoder_reset([s])
+    (t3,), _ = eng.decode_full([s], max_tokens=[5])
+    assert t3 == plain[:5]
+    eng.decoder_reset([s])
+    (t4,), acc = eng.decode_full([s], drafts=[plain[:9]], max_tokens=[5])   # accepted prefix is kept beyond the budget
+    assert t4 == plain[:9] and acc[0] == 9
+    # decode_full refuses a non-empty cache (the reference's caller always resets first)
+    from moonshine_amd.hip_api import MshError
+    with pytest.raises(MshError):
+        eng.decode_full([s])
+    eng.close()
+
+
+def test_decode_full_batch_of_streams(tmp_path):
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 23)
+    lens = (20, 33, 12, 27)
+    audios = [make_audio(50 + i, 1280 * n) for i, n in enumerate(lens)]
+    slots = [eng.open() for _ in lens]
+    for s, a in zip(slots, audios):
+        feed(eng, s, a, 10)
+    single = []
+    for s in slots:
+        eng.decoder_reset([s])
+        (t,), _ = eng.decode_full([s])
+        single.append(t)
+    assert len({len(t) for t in single}) > 1          # different budgets in one batch
+    eng.decoder_reset(slots)
+    toks, acc = eng.decode_full(slots)
+    assert toks == single and acc.tolist() == [0] * 4
+    # mixed drafts: none / full / corrupted / longer than what will be accepted
+    drafts = [None, single[1], [single[2][0], 9, 9], single[3][:5] + [11, 12, 13]]
+    if drafts[3][5] == single[3][5]:
+        drafts[3][5] += 1
+    eng.decoder_reset(slots)
+    toks, acc = eng.decode_full(slots, drafts=drafts)
+    assert toks == single
+    assert acc.tolist() == [0, len(single[1]), 1 if single[2][1] != 9 else acc[2], 5]
+    for s, t in zip(slots, single):
+        assert eng.cache_len(s) in (len(t), len(t) + 1)
+    eng.close()
+
+
+def test_decode_full_stops_on_eos(tmp_path):
+    """Swap two rows of the output head so that a token the model likes becomes EOS."""
+    cfg = STREAMING_ARCHS["micro_streaming"]
+    w = make_streaming_weights(cfg, 29)
+    audio = make_audio(7, 1280 * 40)
+    st = oracle_state(w, cfg, audio, 40)
+    want, _ = oracle_greedy_with_margin(w, cfg, st, 64)
+    assert len(want) >= 6
+    x = want[3]
+    first = want.index(x)
+    w2 = dict(w)
+    head = w["proj_out.weight"].copy()
+    head[[x, cfg.eos]] = head[[cfg.eos, x]]
+    w2["proj_out.weight"] = head
+    st2 = oracle_state(w2, cfg, audio, 40)
+    st2.decoder_reset()
+    want2 = sr.decode_full(w2, cfg, st2)
+    assert want2 == want[:first]
+    eng, _, _ = make_engine(tmp_path, "micro_streaming", 29, weights=w2)
+    s = eng.open()
+    feed(eng, s, audio, 40)
+    eng.decoder_reset([s])
+    (got,), _ = eng.decode_full([s])
+    assert got == want2 and eng.cache_len(s) == len(got) + 1
+    eng.close()
+
+
+def test_stream_errors(tmp_path):
+    from moonshine_amd.hip_api import MshError
+
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21, max_slots=2, max_frames=64)
+    a, b = eng.open(), eng.open()
+    with pytest.raises(MshError):
+        eng.open()                                   # out of slots
+    with pytest.raises(MshError):
+        eng.process_audio([a, a], [np.zeros(1280, np.float32)] * 2)   # a stream twice in one call
+    with pytest.raises(MshError):
+        eng.decode_tokens([a], [[1]])                # memory is empty (streaming-model.cpp:1151)
+    toks, _ = eng.decode_full([a])                   # empty memory: empty result, no error (:1205-1210)
+    assert toks == [[]]
+    with pytest.raises(MshError):
+        eng.process_audio([b], [np.zeros(320 * 65, np.float32)])       # beyond the memory capacity
+    eng.close_stream(a)
+    assert eng.open() == a
+    eng.close()
