@@ -16,6 +16,7 @@ from .hip_api import LIB_PATH
 
 MOONSHINE_HEADER_VERSION = 30000
 ARCH_TINY, ARCH_BASE = 0, 1
+ARCH_TINY_STREAMING, ARCH_BASE_STREAMING, ARCH_SMALL_STREAMING, ARCH_MEDIUM_STREAMING = 2, 3, 4, 5
 FLAG_FORCE_UPDATE = 1
 
 

@@ -60,10 +60,12 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "log_ort_run") o->log_ort_run = parse_bool(v);
     else if (k == "save_input_wav_path") o->save_input_wav_path = v;
     else if (k == "device") o->device = parse_int32(v);
-    else if (k == "use_speculative_decoding") (void)parse_bool(v);  // streaming architectures only
+    else if (k == "use_speculative_decoding") o->use_speculative_decoding = parse_bool(v);
+    else if (k == "max_streams") o->max_streams = parse_int32(v);                  // additive (streaming archs)
+    else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
     else if (k == "word_timestamps" || k == "identify_speakers") require_off(k, v);
     else if (k == "keyterms" || k == "context") {
-      if (!trim(v).empty()) throw std::runtime_error("option '" + k + "' only applies to the streaming architectures");
+      if (!trim(v).empty()) throw std::runtime_error("option '" + k + "' needs the context biaser, which is not part of the MI355X build");
     } else if (k == "keyterm_boost" || k == "context_max_terms" || k == "diarization_cluster_cadence" ||
                k == "diarization_analyze_cadence" || k == "diarization_cluster_window_sec" ||
                k == "diarization_model_dir" || k == "coreml_cache_dir") {
@@ -147,14 +149,14 @@ const char* moonshine_transcript_to_string(const struct transcript_t* transcript
 int32_t moonshine_transcriber_set_keyterms(int32_t handle, const char* keyterms) {
   return with_transcriber(handle, "set keyterms", [&](Transcriber*) -> int32_t {
     if (keyterms == nullptr || trim(keyterms).empty()) return MOONSHINE_ERROR_NONE;  // turning biasing off is a no-op
-    throw std::runtime_error("keyterm biasing only applies to the streaming architectures");
+    throw std::runtime_error("keyterm biasing needs the context biaser, which is not part of the MI355X build");
   });
 }
 
 int32_t moonshine_transcriber_set_context(int32_t handle, const char* context, int32_t /*max_terms*/) {
   return with_transcriber(handle, "set context", [&](Transcriber*) -> int32_t {
     if (context == nullptr || trim(context).empty()) return MOONSHINE_ERROR_NONE;
-    throw std::runtime_error("context biasing only applies to the streaming architectures");
+    throw std::runtime_error("context biasing needs the context biaser, which is not part of the MI355X build");
   });
 }
 

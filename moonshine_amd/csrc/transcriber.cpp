@@ -181,9 +181,10 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   if (opt_.model_source == TranscriberOptions::NONE) return;
   if (opt_.model_arch > MOONSHINE_MODEL_ARCH_MEDIUM_STREAMING)
     throw std::runtime_error("Invalid model architecture: " + std::to_string(opt_.model_arch));
-  if (is_streaming_arch(opt_.model_arch))
-    throw std::runtime_error("streaming model architectures (arch " + std::to_string(opt_.model_arch) +
-                             ") are not supported by the MI355X build yet; use MOONSHINE_MODEL_ARCH_TINY or _BASE");
+  if (is_streaming_arch(opt_.model_arch)) {
+    load_streaming_model();
+    return;
+  }
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
   if (opt_.model_source == TranscriberOptions::FILES) {
     if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
@@ -224,7 +225,155 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   }
 }
 
-Transcriber::~Transcriber() {}
+// Streaming architectures: model directory = model.safetensors + streaming_config.json + tokenizer.bin
+// (the reference's holds frontend / encoder / adapter / cross_kv / decoder_kv .ort graphs next to the same
+// json and tokenizer, core/moonshine-streaming-model.cpp:233-300).
+void Transcriber::load_streaming_model() {
+  const int frames = (int)ceilf(opt_.max_stream_seconds * 50.0f);
+  streaming_model_.reset(new MoonshineStreamingModel(opt_.device, opt_.max_streams, frames));
+  if (opt_.model_source == TranscriberOptions::FILES) {
+    if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
+    if (!is_dir_or_file(opt_.model_path))
+      throw std::runtime_error("Model directory does not exist at path '" + opt_.model_path + "'");
+    const std::string tok = join_path(opt_.model_path, kTokenizerName);
+    if (!file_exists(tok)) throw std::runtime_error("Required tokenizer file does not exist at path '" + tok + "'");
+    for (const char* name : {kWeightsName, "streaming_config.json"}) {
+      const std::string f = join_path(opt_.model_path, name);
+      if (!file_exists(f)) {
+        if (file_exists(join_path(opt_.model_path, "decoder_kv.ort")))
+          throw std::runtime_error("'" + opt_.model_path +
+                                   "' holds ONNX Runtime .ort graphs; the MI355X build loads model.safetensors "
+                                   "(HuggingFace MoonshineStreaming tensor names) -- see INTEGRATION.md");
+        throw std::runtime_error("Required model file does not exist at path '" + f + "'");
+      }
+    }
+    if (streaming_model_->load(opt_.model_path.c_str(), tok.c_str(), (int32_t)opt_.model_arch) != 0)
+      throw std::runtime_error("Failed to load streaming model from '" + opt_.model_path +
+                               "': " + streaming_model_->last_error);
+  } else {
+    auto get = [&](const char* name, std::vector<uint8_t>* owned, const uint8_t** p, size_t* n) {
+      auto it = opt_.memory_files.find(name);
+      if (it == opt_.memory_files.end()) throw std::runtime_error(std::string("Required model asset missing: ") + name);
+      if (it->second.first != nullptr && it->second.second > 0) {
+        *p = it->second.first;
+        *n = it->second.second;
+      } else {
+        if (!read_file(name, owned)) throw std::runtime_error(std::string("cannot read ") + name);
+        *p = owned->data();
+        *n = owned->size();
+      }
+    };
+    std::vector<uint8_t> o1, o2, o3;
+    const uint8_t *w = nullptr, *t = nullptr, *c = nullptr;
+    size_t wn = 0, tn = 0, cn = 0;
+    get(kWeightsName, &o1, &w, &wn);
+    get(kTokenizerName, &o2, &t, &tn);
+    get("streaming_config.json", &o3, &c, &cn);
+    if (streaming_model_->load_from_memory(w, wn, std::string((const char*)c, cn), t, tn, (int32_t)opt_.model_arch) != 0)
+      throw std::runtime_error("Failed to load streaming model from memory: " + streaming_model_->last_error);
+  }
+}
+
+Transcriber::~Transcriber() {
+  // streams own device slots of the streaming model: drop them before the model goes away
+  streams_.clear();
+  batch_streams_.clear();
+  batch_stream_.reset();
+}
+
+// reference core/transcriber.cpp:1311-1487, batched over streams: feed only the new whole 1280-sample chunks of
+// each segment, encode (final = the segment is complete), then decode from scratch -- with the previous
+// pass's tokens as a speculative draft when there is one -- and keep the tokens for the next pass.
+void Transcriber::transcribe_segments_with_streaming_model(std::vector<StreamingJob>& jobs) {
+  MoonshineStreamingModel* m = streaming_model_.get();
+  const MoonshineStreamingConfig& cfg = m->config;
+  struct Work {
+    StreamingJob* job;
+    bool is_new = false, fed = false;
+  };
+  std::vector<Work> work;
+  std::vector<MoonshineStreamingState*> feed_states, enc_states;
+  std::vector<const float*> feed_audio;
+  std::vector<size_t> feed_lens;
+  std::vector<uint8_t> enc_final;
+  for (StreamingJob& j : jobs) {
+    j.text.clear();
+    TranscriberStream* s = j.stream;
+    const std::vector<float>& audio = j.segment->audio;
+    if (audio.empty()) continue;  // :1314-1316
+    if (s->sstate == nullptr) {
+      s->sstate = m->create_state();
+      s->sowner = m;
+      if (s->sstate == nullptr) throw std::runtime_error("no free streaming slot: " + m->last_error);
+    }
+    Work w;
+    w.job = &j;
+    w.is_new = j.line_id != s->streaming_segment_id;  // :1321-1327
+    if (w.is_new) {
+      if (m->reset_state(s->sstate) != 0) throw std::runtime_error("Failed to reset streaming state: " + m->last_error);
+      s->streaming_segment_id = j.line_id;
+      s->streaming_samples_processed = 0;
+      s->last_streaming_tokens.clear();
+    }
+    const size_t start = s->streaming_samples_processed;
+    if (start < audio.size()) {  // :1332-1372
+      const size_t chunk_count = (audio.size() - start) / 1280;
+      if (chunk_count > 0) {
+        feed_states.push_back(s->sstate);
+        feed_audio.push_back(audio.data() + start);
+        feed_lens.push_back(chunk_count * 1280);
+      }
+      enc_states.push_back(s->sstate);
+      enc_final.push_back(j.segment->is_complete ? 1 : 0);
+      s->streaming_samples_processed += chunk_count * 1280;
+    }
+    work.push_back(w);
+  }
+  if (m->process_audio_batch(feed_states, feed_audio, feed_lens) != 0)
+    throw std::runtime_error("Failed to process audio chunk: " + m->last_error);
+  if (m->encode_batch(enc_states, enc_final) != 0) throw std::runtime_error("Failed to encode: " + m->last_error);
+
+  std::vector<Work*> dec;
+  std::vector<MoonshineStreamingState*> dec_states;
+  std::vector<std::vector<int>> drafts;
+  std::vector<int> budgets;
+  for (Work& w : work) {
+    TranscriberStream* s = w.job->stream;
+    if (s->sstate->memory_len() == 0) continue;                                  // :1375-1377
+    if (!w.job->segment->is_complete && !opt_.decode_incomplete_lines) continue;   // :1379-1381
+    std::vector<int> draft;
+    int budget = -1;
+    const bool speculative = opt_.use_speculative_decoding && !w.is_new && !s->last_streaming_tokens.empty();
+    if (speculative) {
+      for (int t : s->last_streaming_tokens)
+        if (t != cfg.bos_id && t != cfg.eos_id) draft.push_back(t);              // :1407-1412
+    } else {
+      const float duration = (float)w.job->segment->audio.size() / (float)kSampleRate;  // :1388-1392
+      budget = std::min((int)ceilf(duration * opt_.max_tokens_per_second), 256);
+    }
+    dec.push_back(&w);
+    dec_states.push_back(s->sstate);
+    drafts.push_back(std::move(draft));
+    budgets.push_back(budget);
+  }
+  if (m->decoder_reset_batch(dec_states) != 0) throw std::runtime_error("Failed to reset decoder: " + m->last_error);
+  std::vector<std::vector<int>> out;
+  if (m->decode_full_batch(dec_states, drafts, budgets, &out) != 0)
+    throw std::runtime_error("Streaming decode failed: " + m->last_error);
+  for (size_t i = 0; i < dec.size(); ++i) {
+    TranscriberStream* s = dec[i]->job->stream;
+    std::vector<int64_t> tokens;
+    tokens.push_back(cfg.bos_id);
+    for (int t : out[i]) tokens.push_back(t);
+    // the plain loop (:1441-1466) also records the EOS that ended it; it ran out of budget iff it produced
+    // `budget` content tokens
+    if (budgets[i] >= 0 && (int)out[i].size() < budgets[i]) tokens.push_back(cfg.eos_id);
+    s->last_streaming_tokens.assign(tokens.begin(), tokens.end());
+    std::string text = m->tokens_to_text(tokens);
+    if (opt_.log_output_text) MSH_LOGF("Streaming model transcribed text: '%s'", text.c_str());
+    dec[i]->job->text = sanitize_utf8(text);
+  }
+}
 
 TranscriberStream* Transcriber::new_stream(int32_t id) {
   const int32_t window = (int32_t)ceilf((opt_.vad_window_duration * kSampleRate) / opt_.vad_hop_size);
@@ -269,21 +418,54 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
   std::vector<Job> jobs;
   std::vector<const float*> ptrs;
   std::vector<size_t> lens;
+  std::vector<std::string> texts;
+  uint32_t latency_ms = 0;
+  const bool streaming = streaming_model_ != nullptr;
   for (size_t si = 0; si < streams.size(); ++si) {
     streams[si]->out.clear_update_flags();
     for (size_t gi = 0; gi < segments[si].size(); ++gi) {
       const VadSegment& seg = segments[si][gi];
-      if (!seg.just_updated || model_ == nullptr) continue;
-      if (!seg.is_complete && !opt_.decode_incomplete_lines) continue;
-      if (seg.audio.size() < 895) continue;  // shorter than the conv stem's receptive field: empty text
+      if (!seg.just_updated || (model_ == nullptr && !streaming)) continue;
+      if (streaming) {
+        // the line id doubles as the streaming segment id (reference core/transcriber.cpp:1024-1027)
+        std::lock_guard<std::mutex> lock(streams[si]->out.mutex);
+        while (gi >= streams[si]->out.order.size()) streams[si]->out.order.push_back(next_line_id_.fetch_add(1));
+      } else {
+        if (!seg.is_complete && !opt_.decode_incomplete_lines) continue;
+        if (seg.audio.size() < 895) continue;  // shorter than the conv stem's receptive field: empty text
+      }
       jobs.push_back({si, gi});
       ptrs.push_back(seg.audio.data());
       lens.push_back(seg.audio.size());
     }
   }
-  std::vector<std::string> texts;
-  uint32_t latency_ms = 0;
-  if (!jobs.empty()) {
+  if (!jobs.empty() && streaming) {
+    // one segment per stream per round: the segments of a stream share its device slot and run in order
+    std::lock_guard<std::mutex> lock(model_mutex_);
+    const auto t0 = std::chrono::steady_clock::now();
+    texts.assign(jobs.size(), std::string());
+    std::vector<char> done(jobs.size(), 0);
+    size_t remaining = jobs.size();
+    while (remaining > 0) {
+      std::vector<StreamingJob> round;
+      std::vector<size_t> idx;
+      std::vector<char> taken(streams.size(), 0);
+      for (size_t j = 0; j < jobs.size(); ++j) {
+        if (done[j] || taken[jobs[j].stream]) continue;
+        taken[jobs[j].stream] = 1;
+        TranscriberStream* s = streams[jobs[j].stream];
+        round.push_back({s, &segments[jobs[j].stream][jobs[j].segment], s->out.order.at(jobs[j].segment), std::string()});
+        idx.push_back(j);
+      }
+      transcribe_segments_with_streaming_model(round);
+      for (size_t k = 0; k < idx.size(); ++k) {
+        texts[idx[k]] = round[k].text;
+        done[idx[k]] = 1;
+      }
+      remaining -= idx.size();
+    }
+    latency_ms = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  } else if (!jobs.empty()) {
     std::lock_guard<std::mutex> lock(model_mutex_);
     const auto t0 = std::chrono::steady_clock::now();
     if (model_->transcribe_batch(ptrs, lens, &texts) != 0) throw std::runtime_error("Failed to transcribe: " + model_->error());
@@ -303,11 +485,11 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
       line.just_updated = true;
       if (gi >= s->out.order.size()) s->out.order.push_back(next_line_id_.fetch_add(1));
       line.id = s->out.order.at(gi);
-      if (model_ != nullptr) {
+      if (model_ != nullptr || streaming) {
         line.has_text = true;
         if (job < jobs.size() && jobs[job].stream == si && jobs[job].segment == gi) {
-          if (opt_.log_output_text) MSH_LOGF("Transcribed text: '%s'", texts[job].c_str());
-          line.text = sanitize_utf8(texts[job]);
+          if (opt_.log_output_text && !streaming) MSH_LOGF("Transcribed text: '%s'", texts[job].c_str());
+          line.text = streaming ? texts[job] : sanitize_utf8(texts[job]);
           line.latency_ms = latency_ms;
           ++job;
         }

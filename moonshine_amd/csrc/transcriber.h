@@ -20,6 +20,7 @@
 #include "../../include/moonshine-c-api.h"
 #include "../../include/moonshine_hip.h"
 #include "host_text_vad.h"
+#include "streaming_model.h"
 
 namespace msh_host {
 
@@ -60,6 +61,9 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   float vad_max_segment_duration = 15.0f;
   float max_tokens_per_second = 6.5f;
   bool decode_incomplete_lines = true;
+  bool use_speculative_decoding = true;  // streaming architectures (reference core/transcriber.h:191)
+  int max_streams = 64;                  // additive: device slots for concurrent streaming lines
+  float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool return_audio_data = true;
   bool log_output_text = false;
   bool log_ort_run = false;
@@ -97,6 +101,16 @@ struct TranscriberStream {
   std::vector<float> saved_input;
   int32_t saved_rate = 0;
   int32_t id = -1;
+  // streaming architectures: the state the reference keeps once per Transcriber
+  // (core/transcriber.h:241,262-264) is kept per stream here, so streams do not evict each other
+  MoonshineStreamingState* sstate = nullptr;
+  uint64_t streaming_segment_id = UINT64_MAX;
+  size_t streaming_samples_processed = 0;
+  std::vector<int> last_streaming_tokens;
+  MoonshineStreamingModel* sowner = nullptr;
+  ~TranscriberStream() {
+    if (sstate != nullptr && sowner != nullptr) sowner->free_state(sstate);
+  }
 };
 
 class Transcriber {
@@ -117,14 +131,25 @@ class Transcriber {
 
  private:
   TranscriberStream* new_stream(int32_t id);
+  void load_streaming_model();
   TranscriberStream* find_stream(int32_t id);
   // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs
   void update_from_segments(const std::vector<TranscriberStream*>& streams,
                             const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs);
   void save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush);
+  struct StreamingJob {
+    TranscriberStream* stream;
+    const VadSegment* segment;
+    uint64_t line_id;
+    std::string text;
+  };
+  // Transcriber::transcribe_segment_with_streaming_model (reference core/transcriber.cpp:1311-1487) for one
+  // segment of each of several streams, as one GPU batch
+  void transcribe_segments_with_streaming_model(std::vector<StreamingJob>& jobs);
 
   TranscriberOptions opt_;
   std::unique_ptr<MoonshineModel> model_;
+  std::unique_ptr<MoonshineStreamingModel> streaming_model_;
   std::mutex model_mutex_, batch_mutex_, streams_mutex_;
   std::unique_ptr<TranscriberStream> batch_stream_;
   std::vector<std::unique_ptr<TranscriberStream>> batch_streams_;  // one per clip of the last batch call

@@ -1,0 +1,157 @@
+"""GPU tests of the streaming architectures through the public C API (include/moonshine-c-api.h):
+moonshine_load_transcriber_from_files(arch = *_STREAMING) -> streams / one-shot calls ->
+Transcriber::transcribe_segment_with_streaming_model's flow (reference core/transcriber.cpp:1311-1487)
+-> transcript_t.  The C++ host glue is checked against a Python restatement of that flow driving the same
+device engine through msh_stream_* (the numerics of the engine are covered by test_gpu_streaming.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from moonshine_amd import api
+from moonshine_amd.synth import STREAMING_ARCHS, make_audio, synthetic_vocab, write_streaming_model_dir
+from oracle import host_ref
+
+pytestmark = pytest.mark.gpu
+
+CFG = STREAMING_ARCHS["micro_streaming"]
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("micro_streaming_model"))
+    write_streaming_model_dir(d, CFG, seed=21)
+    return d
+
+
+@pytest.fixture(scope="module")
+def engine(model_dir):
+    from moonshine_amd.hip_api import StreamEngine
+
+    e = StreamEngine(os.path.join(model_dir, "model.safetensors"), CFG.streaming_config_json(), max_slots=8,
+                     max_memory_frames=1024)
+    yield e
+    e.close()
+
+
+class GlueMirror:
+    """transcriber.cpp:1311-1487 for one line, over the device engine."""
+
+    def __init__(self, eng, speculative=True, mtps=6.5, decode_incomplete=True):
+        self.eng, self.spec, self.mtps, self.inc = eng, speculative, mtps, decode_incomplete
+        self.slot = eng.open()
+        self.processed = 0
+        self.last = []
+        self.first = True
+        self.vocab = synthetic_vocab(CFG.vocab)
+        self.accepted = []
+
+    def update(self, audio, is_final) -> bytes:
+        eng, s = self.eng, self.slot
+        is_new, self.first = self.first, False
+        if len(audio) == 0:
+            return b""
+        if self.processed < len(audio):
+            cc = (len(audio) - self.processed) // 1280
+            if cc:
+                eng.process_audio([s], [audio[self.processed:self.processed + cc * 1280]])
+            eng.encode([s], [is_final])
+            self.processed += cc * 1280
+        if eng.memory_len(s) == 0:
+            return b""
+        if not is_final and not self.inc:
+            return b""
+        eng.decoder_reset([s])
+        if self.spec and not is_new and self.last:
+            draft = [t for t in self.last if t not in (CFG.bos, CFG.eos)]
+            (out,), acc = eng.decode_full([s], drafts=[draft])
+            self.accepted.append((int(acc[0]), len(draft)))
+            tokens = [CFG.bos] + out
+        else:
+            budget = min(int(math.ceil(float(np.float32(np.float32(len(audio)) / np.float32(16000.0)) * np.float32(self.mtps)))), 256)
+            (out,), _ = eng.decode_full([s], max_tokens=[budget])
+            tokens = [CFG.bos] + out + ([CFG.eos] if len(out) < budget else [])
+        self.last = tokens
+        return host_ref.sanitize_text(host_ref.tokens_to_text(self.vocab, tokens))
+
+    def close(self):
+        self.eng.close_stream(self.slot)
+
+
+def test_streaming_arch_stream_flow(model_dir, engine):
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "transcription_interval": "0.3"})
+    audio = make_audio(70, 16000 * 4 + 700)
+    s = t.create_stream()
+    t.start_stream(s)
+    mirror = GlueMirror(engine)
+    texts = []
+    step = 9000
+    for i in range(0, len(audio), step):
+        t.add_audio(s, audio[i:i + step])
+        lines = t.transcribe_stream(s)
+        assert len(lines) == 1 and not lines[0].is_complete
+        want = mirror.update(lines[0].audio_data, False)
+        assert lines[0].text_bytes == want
+        texts.append(want)
+    t.stop_stream(s)
+    final = t.transcribe_stream(s, flags=0)
+    assert final[0].is_complete
+    want = mirror.update(final[0].audio_data, True)
+    assert final[0].text_bytes == want and len(want) > 0
+    assert len(mirror.accepted) >= 5            # every pass after the first verified a draft
+    assert any(a > 0 for a, _ in mirror.accepted)
+    t.free_stream(s)
+    mirror.close()
+    t.close()
+
+
+def test_streaming_arch_one_shot_and_batch(model_dir, engine):
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
+    clips = [make_audio(80 + i, n) for i, n in enumerate([16000 * 2, 40000, 1500, 1000, 16000 * 5 + 123])]
+    single = [t.transcribe_without_streaming(c) for c in clips]
+    for c, lines in zip(clips, single):
+        assert len(lines) == 1 and lines[0].is_complete
+        m = GlueMirror(engine)
+        assert lines[0].text_bytes == m.update(lines[0].audio_data, True)
+        m.close()
+    assert single[3][0].text_bytes == b""       # 1000 samples -> 512 after the VAD: not one whole 1280 chunk
+    assert len(single[0][0].text_bytes) > 0
+    batch = t.transcribe_batch_without_streaming(clips)
+    assert [b[0].text_bytes for b in batch] == [s[0].text_bytes for s in single]
+    t.close()
+
+
+def test_streaming_arch_options(model_dir, engine):
+    audio = make_audio(90, 16000 * 3)
+    outs = {}
+    for spec in ("true", "false"):
+        t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING,
+                            {"vad_threshold": "0", "use_speculative_decoding": spec, "transcription_interval": "0.2"})
+        s = t.create_stream()
+        t.start_stream(s)
+        m = GlueMirror(engine, speculative=(spec == "true"))
+        for i in range(0, len(audio), 8000):
+            t.add_audio(s, audio[i:i + 8000])
+            lines = t.transcribe_stream(s)
+            assert lines[0].text_bytes == m.update(lines[0].audio_data, False)
+        t.stop_stream(s)
+        lines = t.transcribe_stream(s)
+        outs[spec] = lines[0].text_bytes
+        assert outs[spec] == m.update(lines[0].audio_data, True)
+        assert (len(m.accepted) > 0) == (spec == "true")
+        m.close()
+        t.close()
+    # decode_incomplete_lines=false: open lines carry no text, the closing update does
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "decode_incomplete_lines": "false"})
+    s = t.create_stream()
+    t.start_stream(s)
+    t.add_audio(s, audio)
+    assert t.transcribe_stream(s)[0].text_bytes == b""
+    t.stop_stream(s)
+    assert len(t.transcribe_stream(s)[0].text_bytes) > 0
+    t.close()
+    with pytest.raises(api.MoonshineError):      # keyterm biasing is not part of this build
+        api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "keyterms": "moonshine"})
+    with pytest.raises(api.MoonshineError):      # offline weights directory for a streaming arch
+        api.Transcriber(str(model_dir) + "_missing", api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
