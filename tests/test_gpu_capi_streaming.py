@@ -116,7 +116,8 @@ def test_streaming_arch_one_shot_and_batch(model_dir, engine):
         assert lines[0].text_bytes == m.update(lines[0].audio_data, True)
         m.close()
     assert single[3][0].text_bytes == b""       # 1000 samples -> 512 after the VAD: not one whole 1280 chunk
-    assert len(single[0][0].text_bytes) > 0
+    # (texts can be empty even for long clips: half of the 512-entry synthetic vocabulary is <0xNN> byte tokens,
+    #  which tokens_to_text skips)
     batch = t.transcribe_batch_without_streaming(clips)
     assert [b[0].text_bytes for b in batch] == [s[0].text_bytes for s in single]
     t.close()
@@ -146,10 +147,15 @@ def test_streaming_arch_options(model_dir, engine):
     t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "decode_incomplete_lines": "false"})
     s = t.create_stream()
     t.start_stream(s)
+    m = GlueMirror(engine, decode_incomplete=False)
     t.add_audio(s, audio)
-    assert t.transcribe_stream(s)[0].text_bytes == b""
+    lines = t.transcribe_stream(s)
+    assert lines[0].text_bytes == b"" == m.update(lines[0].audio_data, False)
     t.stop_stream(s)
-    assert len(t.transcribe_stream(s)[0].text_bytes) > 0
+    lines = t.transcribe_stream(s)
+    assert lines[0].is_complete and lines[0].text_bytes == m.update(lines[0].audio_data, True)
+    assert m.last[0] == CFG.bos and len(m.last) > 1      # the closing update did decode
+    m.close()
     t.close()
     with pytest.raises(api.MoonshineError):      # keyterm biasing is not part of this build
         api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "keyterms": "moonshine"})
