@@ -84,6 +84,9 @@ struct EpiQkvRopeBf16 {
   long ldc;
   const int* row_pos;
   RopeParams rp;
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
   __device__ void n4(int m, int n, f32x4 v) const {
     if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
       int pos = row_pos[m];
@@ -271,6 +274,9 @@ struct EpiAct {
   long ldc;
   const float* bias;  // nullable
   int act;
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
   __device__ void n4(int m, int n, f32x4 v) const {
     if (bias != nullptr) {
       const float4 b = *reinterpret_cast<const float4*>(bias + n);

@@ -391,6 +391,46 @@ void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bia
   if (use_dec64(M) && launch_dec64<4, false>(A, lda, W, M, N, K, epi, s)) return;  // K = D only
   launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
 }
+// ---- bf16-input small-batch GEMMs of the streaming decoder (row-based passes with M <= 256) ----
+// Same split-K kernel, LayerNorm done by the caller; K covers the streaming widths (320 / 640 tiny / assumed-medium,
+// 1280 / 2560 their ffn, 96 / 192 the test model) next to the offline ones.
+template <int TN, class Epi>
+bool launch_dec_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  if ((N & 3) != 0) return false;
+  switch (K) {
+    case 96: launch_dec_cfg<3, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 192: launch_dec_cfg<6, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 288: launch_dec_cfg<9, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 320: launch_dec_cfg<10, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 416: launch_dec_cfg<13, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 640: launch_dec_cfg<20, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 1152: launch_dec_cfg<36, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 1280: launch_dec_cfg<40, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 1664: launch_dec_cfg<52, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 2560: launch_dec_cfg<80, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    default: return false;
+  }
+}
+bool small_gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,
+                    bf16_t* out_bf16, float* out_f32, hipStream_t s) {
+  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiAct{out_bf16, out_f32, N, bias, act}, s);
+}
+bool small_gemm_qkv_rope_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_pos,
+                              RopeParams rp, bf16_t* out, hipStream_t s) {
+  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiQkvRopeBf16{out, N, row_pos, rp}, s);
+}
+bool small_gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
+                            bf16_t* z, hipStream_t s) {
+  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiSwiGLU{z, N / 2, bias}, s);
+}
+bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                          hipStream_t s) {
+  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiResidF32{H, N, bias}, s);
+}
+bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
+  return launch_dec_bf16<4>(A, lda, W, M, N, K, EpiF32{out, N}, s);
+}
+
 void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s) {
   launch_dec<4, true>(H, D, nullptr, E, M, V, D, EpiF32{logits, V}, s);
 }

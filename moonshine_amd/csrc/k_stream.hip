@@ -112,16 +112,18 @@ __global__ void adapter_in_kernel(const float* __restrict__ y32, const int* __re
   }
 }
 
+// K goes in transposed ([slot][L][D][Mcap], keys contiguous: the score pass of cross-attention reads one head
+// dimension of many keys per load), V row-major ([slot][L][Mcap][D]: the value pass reads whole rows).
 __global__ void scatter_cross_kernel(const bf16_t* __restrict__ tmp, const int* __restrict__ slot,
                                      const int* __restrict__ idx, int L, int D, int Mcap, bf16_t* __restrict__ crossK,
                                      bf16_t* __restrict__ crossV) {
   const int i = blockIdx.x, l = blockIdx.y;
   const bf16_t* src = tmp + ((long)i * L + l) * 2 * D;
-  const long dst = (((long)slot[i] * L + l) * Mcap + idx[i]) * D;
-  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8) {
-    *reinterpret_cast<uint4*>(crossK + dst + d) = *reinterpret_cast<const uint4*>(src + d);
-    *reinterpret_cast<uint4*>(crossV + dst + d) = *reinterpret_cast<const uint4*>(src + D + d);
-  }
+  const long base = ((long)slot[i] * L + l) * Mcap * D;
+  const int key = idx[i];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) crossK[base + (long)d * Mcap + key] = src[d];
+  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8)
+    *reinterpret_cast<uint4*>(crossV + base + (long)key * D + d) = *reinterpret_cast<const uint4*>(src + D + d);
 }
 
 __global__ void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ embed, int D,
@@ -189,19 +191,24 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
   }
 }
 
-// one workgroup per (row, head): all memory keys of the row's stream
+// one workgroup per (row, head): all memory keys of the row's stream.
+//   scores : a thread takes 4 consecutive keys and walks the head dims of K^T -- every load instruction of a wave
+//            covers 512 contiguous bytes;
+//   values : dh/4 threads share one key row of V (8-byte loads), 256 / (dh/4) keys in flight per pass, partial
+//            sums of the key groups combined through LDS.
 constexpr int CROSS_MMAX = 4096;
+constexpr int CROSS_GMAX = 16;
 __global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __restrict__ q,
                                                               const int* __restrict__ row_slot,
                                                               const SlotDev* __restrict__ slots, int D, int heads,
                                                               int layer, int L, int Mcap,
-                                                              const bf16_t* __restrict__ crossK,
+                                                              const bf16_t* __restrict__ crossKT,
                                                               const bf16_t* __restrict__ crossV,
                                                               bf16_t* __restrict__ out) {
   __shared__ float sq[128];
   __shared__ float sp[CROSS_MMAX];
   __shared__ float red[8];
-  __shared__ float part[4][128];
+  __shared__ float part[CROSS_GMAX][128];
   const int row = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int dh = D / heads;
   const float scale = rsqrtf((float)dh);
@@ -209,20 +216,36 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __re
   const int nk = slots[slot].mem_len;
   for (int d = tid; d < dh; d += 256) sq[d] = bf(q[(long)row * D + head * dh + d]) * scale;
   __syncthreads();
-  const long base = (((long)slot * L + layer) * Mcap) * D + head * dh;
+  const long base = ((long)slot * L + layer) * Mcap * D;
+  const bf16_t* kt = crossKT + base + (long)head * dh * Mcap;
   float mx = -INFINITY;
-  for (int j = tid; j < nk; j += 256) {
-    const float sc = dot_row(sq, crossK + base + (long)j * D, dh);
-    sp[j] = sc;
-    mx = fmaxf(mx, sc);
+  for (int j = tid * 4; j < nk; j += 1024) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < dh; ++d) {
+      const uint2 r = *reinterpret_cast<const uint2*>(kt + (long)d * Mcap + j);
+      const float qd = sq[d];
+      a0 += qd * __uint_as_float(r.x << 16);
+      a1 += qd * __uint_as_float(r.x & 0xffff0000u);
+      a2 += qd * __uint_as_float(r.y << 16);
+      a3 += qd * __uint_as_float(r.y & 0xffff0000u);
+    }
+    const float sc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = j + i < nk ? sc[i] : -INFINITY;
+      sp[j + i] = v;
+      mx = fmaxf(mx, v);
+    }
   }
   mx = wmax(mx);
   if (lane == 0) red[w] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
-  for (int j = tid; j < nk; j += 256) {
-    const float e = __expf(sp[j] - mx);
+  const int nk4 = (nk + 3) & ~3;
+  for (int j = tid; j < nk4; j += 256) {
+    const float e = j < nk ? __expf(sp[j] - mx) : 0.f;
     sp[j] = e;
     sum += e;
   }
@@ -230,20 +253,30 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __re
   if (lane == 0) red[4 + w] = sum;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  // wave w takes keys j = w (mod 4); lanes take head dims lane and lane + 64
-  float a0 = 0.f, a1 = 0.f;
-  const bool has0 = lane < dh, has1 = lane + 64 < dh;
-  const bf16_t* v = crossV + base;
-  for (int j = w; j < nk; j += 4) {
-    const float p = sp[j];
-    if (has0) a0 += p * bf(v[(long)j * D + lane]);
-    if (has1) a1 += p * bf(v[(long)j * D + lane + 64]);
+  const int tpk = dh >> 2;                       // threads per key row
+  int G = 256 / tpk;
+  G = G > CROSS_GMAX ? CROSS_GMAX : G;
+  const int g = tid / tpk, c = tid - g * tpk;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+    const bf16_t* v = crossV + base + head * dh + c * 4;
+#pragma unroll 4
+    for (int j = g; j < nk; j += G) {
+      const uint2 r = *reinterpret_cast<const uint2*>(v + (long)j * D);
+      const float p = sp[j];
+      acc.x += p * __uint_as_float(r.x << 16);
+      acc.y += p * __uint_as_float(r.x & 0xffff0000u);
+      acc.z += p * __uint_as_float(r.y << 16);
+      acc.w += p * __uint_as_float(r.y & 0xffff0000u);
+    }
+    *reinterpret_cast<float4*>(&part[g][c * 4]) = acc;
   }
-  part[w][lane] = a0;
-  part[w][lane + 64] = a1;
   __syncthreads();
-  for (int d = tid; d < dh; d += 256)
-    out[(long)row * D + head * dh + d] = f32_to_bf16((part[0][d] + part[1][d] + part[2][d] + part[3][d]) * inv);
+  for (int d = tid; d < dh; d += 256) {
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += part[k][d];
+    out[(long)row * D + head * dh + d] = f32_to_bf16(t * inv);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

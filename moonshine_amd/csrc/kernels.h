@@ -64,6 +64,18 @@ void gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int
 void gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, bf16_t* z,
                       hipStream_t s);
 
+// Small-batch (M <= 256) forms of the five GEMMs above on the split-K decode kernel, bf16 input.  Return false
+// (nothing launched) when K is not one of the compiled widths; the caller then uses the tiled kernel.
+bool small_gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,
+                    bf16_t* out_bf16, float* out_f32, hipStream_t s);
+bool small_gemm_qkv_rope_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_pos,
+                              RopeParams rp, bf16_t* out, hipStream_t s);
+bool small_gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
+                            bf16_t* z, hipStream_t s);
+bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                          hipStream_t s);
+bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,

@@ -609,22 +609,30 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
   bf16_t* Q = Q_.as<bf16_t>();
   bf16_t* Z = Z_.as<bf16_t>();
   const RopeParams rp{rope_cos_, rope_sin_, rot_pairs_, cfg_.head_dim, Dd};
+  const bool small = M <= 256;  // split-K decode kernel (16-row tiles) instead of 128-row MFMA tiles
   for (int l = 0; l < L; ++l) {
     const DecW& W = dec_[l];
     layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
-    gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
+    if (!(small && small_gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_)))
+      gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
     stream_self_attention(QKV, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
-    gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
+    if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
+      gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
     layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
-    gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+    if (!(small && small_gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_)))
+      gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
     stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
-    gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
+    if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
+      gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
     layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
-    gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
-    gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
+    if (!(small && small_gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_)))
+      gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+    if (!(small && small_gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_)))
+      gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
   }
   layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
-  gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_);
+  if (!(small && small_gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_)))
+    gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_);
 }
 
 void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* const* tokens, const int* lens,

@@ -7,7 +7,8 @@
 //   conv1_buf [4][De] / conv2_buf [4][2De] bf16    the frontend's carried frames
 //   features  [Mcap][De] fp32                       accumulated_features
 //   memory    [Mcap][Dd] fp32                       adapter output (kept for inspection)
-//   crossK/V  [L][Mcap][Dd] bf16                    cross-attention keys / values, appended per update
+//   crossK    [L][Dd][Mcap] bf16 (keys contiguous)    cross-attention keys, transposed; appended per update
+//   crossV    [L][Mcap][Dd] bf16                      cross-attention values
 //   selfK/V   [L][Scap][Dd] bf16                    decoder self-attention cache
 //   result    [Scap] int32 + SlotDev                decode_full bookkeeping
 // Calls take a list of slots and work on all of them at once: rows of every GEMM are the concatenation of

@@ -57,7 +57,8 @@ void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_h
 // adapter input: out[i] = y32[rows[i]] + pos_emb[pos[i]]  (lora/export.py:141-144), as bf16 and fp32
 void stream_adapter_in(const float* y32, const int* rows, const int* pos, int n, int D, const float* pos_emb,
                        bf16_t* out16, float* out32, hipStream_t s);
-// tmp [n][L*2*D] (per layer: k row, v row) -> crossK / crossV [slot][L][Mcap][D] at memory index idx[i]
+// tmp [n][L*2*D] (per layer: k row, v row) -> crossK [slot][L][D][Mcap] (transposed) / crossV [slot][L][Mcap][D]
+// at memory index idx[i]
 void stream_scatter_cross(const bf16_t* tmp, const int* slot, const int* idx, int n, int L, int D, int Mcap,
                           bf16_t* crossK, bf16_t* crossV, hipStream_t s);
 void stream_embed(const int* tokens, int M, const float* embed, int D, float* H, hipStream_t s);
