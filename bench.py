@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--arch", default="base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=3)
+    ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--workload", default="offline", choices=["offline", "streaming"],
                     help="offline = BASELINE.json configs[2] (default); streaming = configs[4] (speculative streaming decode)")
     ap.add_argument("--streams", type=int, default=64, help="streaming workload: concurrent streams per GPU")
@@ -251,6 +251,14 @@ def main():
     eng.profile_enable(False)
     prof = [p for p in prof if p["launches"] > 0]
     kernels = sorted((roofline_entry(p) | {"total_ms": round(p["ms"], 3)} for p in prof), key=lambda r: -r["total_ms"])
+    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (tools/gpu_final.sh), so
+    # the figure is read from the committed summary of the last such run on this workload, not measured live.
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and B == 256 and args.arch == "base":
+        pmc = json.load(open(pmc_path)).get("groups", {})
+        for kr in kernels:
+            if kr["kernel"] in pmc:
+                kr["traffic"] = round(pmc[kr["kernel"]]["traffic_bytes_per_launch"], 1)
     dominant = dict(kernels[0])
     prof_total = sum(p["ms"] for p in prof)
 
@@ -286,7 +294,14 @@ def main():
             enc = ref.encoder_forward(w, cfg, host[i])
             ref.greedy_decode(w, cfg, enc, args.decode_steps, ignore_eos=True)
         dt = time.perf_counter() - t0
-        cpu = {"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": os.cpu_count(),
+        try:  # threads the BLAS behind numpy actually runs (the oracle's matmuls are the only parallel part)
+            from threadpoolctl import threadpool_info
+
+            blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+        except Exception:
+            blas_threads = os.cpu_count()
+        cpu = {"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": blas_threads,
+               "host_cores_visible": os.cpu_count(),
                "kind": "port", "sample": f"{n_clips} clips x 10 s, {args.decode_steps} forced decode steps, batch 1, "
                f"numpy fp32 oracle (multi-threaded BLAS), {dt:.1f} s of CPU time"}
 

@@ -127,6 +127,17 @@ MSH_EXPORT int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_
 MSH_EXPORT int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap);
 MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out,
                                      uint64_t out_cap);
+/* msh_host_text_to_tokens : BinTokenizer::text_to_tokens (reference core/bin-tokenizer/bin-tokenizer.cpp:277-402);
+ *                           bpe != 0 = byte-pair encoding (falls back to longest match without a byte block).
+ *                           Returns the id count (ids beyond out_cap are dropped) or a negative status.
+ * msh_host_biaser_bonuses : builds a ContextBiaser (reference core/context-biaser.cpp) from n_seqs token sequences
+ *                           (flat ids + lengths), advances it over `prefix`, and adds its bonuses to out[0..vocab). */
+MSH_EXPORT int64_t msh_host_text_to_tokens(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* text,
+                                           uint64_t text_len, const char* space_marker, int32_t bpe, int32_t* out,
+                                           uint64_t out_cap);
+MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
+                                           float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
+                                           uint64_t vocab);
 
 /* ---------------------------------------------------------------------------------------------------
  * Streaming models (reference core/moonshine-streaming-model.h:73-201).  One msh_stream_engine replaces the
@@ -182,6 +193,13 @@ MSH_EXPORT int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const
                                           const int32_t* const* drafts, const int32_t* draft_lens,
                                           const int32_t* max_tokens, int32_t* tokens_out, int32_t* counts_out,
                                           int32_t tokens_stride, int32_t* accepted_out);
+/* Contextual biasing (reference core/context-biaser.cpp:88-149, applied inside decode_full,
+ * core/moonshine-streaming-model.cpp:1234-1246): a flat trie over token ids -- children of node n are entries
+ * [child_off[n], child_off[n+1]) of child_tok / child_node, sorted by token; node 0 is the root; depth[n] its depth;
+ * depth_bonus[d] the logit bonus of a depth-d token.  n_nodes == 0 switches biasing off.  The trie is copied. */
+MSH_EXPORT int32_t msh_stream_set_bias(msh_stream_engine* e, int32_t n_nodes, const int32_t* child_off,
+                                       const int32_t* child_tok, const int32_t* child_node, const int32_t* depth,
+                                       const float* depth_bonus, int32_t n_depth_bonus);
 /* state queries: 0 memory_len, 1 feature_count, 2 cache_len, 3 frames_emitted, 4 max_tokens for the memory */
 MSH_EXPORT int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what);
 MSH_EXPORT int32_t msh_stream_get_memory(msh_stream_engine* e, int32_t slot, float* out);   /* [memory_len][Dd] */

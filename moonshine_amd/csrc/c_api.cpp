@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "host_utils.h"
+#include "context_biaser.h"
 #include "transcriber.h"
 
 using namespace msh_host;
@@ -41,6 +42,20 @@ void require_off(const std::string& name, const std::string& value) {
     throw std::runtime_error("option '" + name + "' needs a component that is not part of the MI355X build");
 }
 
+// comma-separated list, each term trimmed, empties dropped (reference core/moonshine-c-api.cpp:114-127)
+std::vector<std::string> parse_keyterms(const std::string& v) {
+  std::vector<std::string> out;
+  size_t pos = 0;
+  while (pos <= v.size()) {
+    const size_t c = v.find(',', pos);
+    const std::string term = trim(v.substr(pos, c == std::string::npos ? std::string::npos : c - pos));
+    if (!term.empty()) out.push_back(term);
+    if (c == std::string::npos) break;
+    pos = c + 1;
+  }
+  return out;
+}
+
 void apply_options(const OptionList& options, TranscriberOptions* o) {
   for (const auto& kv : options) {
     const std::string& k = kv.first;
@@ -64,9 +79,15 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "max_streams") o->max_streams = parse_int32(v);                  // additive (streaming archs)
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
     else if (k == "word_timestamps" || k == "identify_speakers") require_off(k, v);
-    else if (k == "keyterms" || k == "context") {
-      if (!trim(v).empty()) throw std::runtime_error("option '" + k + "' needs the context biaser, which is not part of the MI355X build");
-    } else if (k == "keyterm_boost" || k == "context_max_terms" || k == "diarization_cluster_cadence" ||
+    else if (k == "keyterms") {
+      o->keyterms = parse_keyterms(v);
+    } else if (k == "keyterm_boost") {
+      o->keyterm_boost = parse_float(v);
+    } else if (k == "context") {
+      if (!trim(v).empty())
+        throw std::runtime_error("option 'context' needs the context extractor, which is not part of the MI355X build; "
+                                 "pass the terms through 'keyterms'");
+    } else if (k == "context_max_terms" || k == "diarization_cluster_cadence" ||
                k == "diarization_analyze_cadence" || k == "diarization_cluster_window_sec" ||
                k == "diarization_model_dir" || k == "coreml_cache_dir") {
       // tuning knobs of features that are off: nothing to do
@@ -147,9 +168,9 @@ const char* moonshine_transcript_to_string(const struct transcript_t* transcript
 }
 
 int32_t moonshine_transcriber_set_keyterms(int32_t handle, const char* keyterms) {
-  return with_transcriber(handle, "set keyterms", [&](Transcriber*) -> int32_t {
-    if (keyterms == nullptr || trim(keyterms).empty()) return MOONSHINE_ERROR_NONE;  // turning biasing off is a no-op
-    throw std::runtime_error("keyterm biasing needs the context biaser, which is not part of the MI355X build");
+  return with_transcriber(handle, "set keyterms", [&](Transcriber* t) -> int32_t {
+    t->set_keyterms(keyterms == nullptr ? std::vector<std::string>() : parse_keyterms(keyterms));
+    return MOONSHINE_ERROR_NONE;
   });
 }
 
@@ -301,6 +322,36 @@ int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_t tokenizer
     return copy_out(tok.tokens_to_text(ids, (size_t)n_ids), out, out_cap);
   } catch (const std::exception& e) {
     MSH_LOGF("tokens_to_text failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_text_to_tokens(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* text, uint64_t text_len,
+                                const char* space_marker, int32_t bpe, int32_t* out, uint64_t out_cap) {
+  try {
+    BinTokenizer tok(tokenizer_bin, (size_t)tokenizer_size, space_marker ? space_marker : "\xE2\x96\x81");
+    const std::vector<int32_t> ids = tok.text_to_tokens(std::string(text ? text : "", (size_t)text_len), bpe != 0);
+    for (size_t i = 0; i < ids.size() && i < out_cap; ++i) out[i] = ids[i];
+    return (int64_t)ids.size();
+  } catch (const std::exception& e) {
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs, float boost,
+                                const int32_t* prefix, uint64_t n_prefix, float* out, uint64_t vocab) {
+  try {
+    ContextBiaser b;
+    b.set_boost(boost);
+    size_t off = 0;
+    for (uint64_t i = 0; i < n_seqs; ++i) {
+      b.add_token_sequence(std::vector<int32_t>(flat_tokens + off, flat_tokens + off + seq_lens[i]));
+      off += seq_lens[i];
+    }
+    for (uint64_t i = 0; i < n_prefix; ++i) b.advance(prefix[i]);
+    b.apply(out, (int)vocab);
+    return (int64_t)b.sequence_count();
+  } catch (const std::exception& e) {
     return MSH_ERR_INVALID_ARGUMENT;
   }
 }

@@ -26,6 +26,95 @@ BinTokenizer::BinTokenizer(const uint8_t* data, size_t size, const std::string& 
     i += n;
   }
   if (tokens_.empty()) throw std::runtime_error("tokenizer.bin: no tokens found");
+  build_indexes();
+}
+
+void BinTokenizer::build_indexes() {
+  by_first_byte_.assign(256, {});
+  for (size_t i = 0; i < tokens_.size(); ++i)
+    if (!tokens_[i].empty()) by_first_byte_[(uint8_t)tokens_[i][0]].push_back((int32_t)i);
+  // byte fallback block: 256 consecutive single-byte entries 0x00..0xFF (searched, not assumed at a fixed id)
+  byte_base_ = -1;
+  for (size_t start = 0; start + 256 <= tokens_.size() && byte_base_ < 0; ++start) {
+    bool complete = true;
+    for (size_t o = 0; o < 256 && complete; ++o)
+      complete = tokens_[start + o].size() == 1 && (uint8_t)tokens_[start + o][0] == o;
+    if (complete) byte_base_ = (int32_t)start;
+  }
+  if (byte_base_ < 0) return;
+  // only entries after the byte block can be produced by a merge; the first spelling wins
+  for (size_t i = (size_t)byte_base_ + 256; i < tokens_.size(); ++i)
+    if (!tokens_[i].empty()) merge_ids_.emplace(tokens_[i], (int32_t)i);
+}
+
+std::vector<int32_t> BinTokenizer::text_to_tokens(const std::string& text, bool bpe) const {
+  return (bpe && byte_base_ >= 0) ? encode_bpe(text) : encode_longest_match(text);
+}
+
+std::vector<int32_t> BinTokenizer::encode_longest_match(const std::string& text) const {
+  std::vector<int32_t> out;
+  const std::string s = replace_all(text, " ", space_);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t best_len = 0;
+    int32_t best = -1;
+    for (const int32_t i : by_first_byte_[(uint8_t)s[pos]]) {
+      const std::string& t = tokens_[i];
+      if (s.size() - pos < t.size()) continue;
+      if (t.size() > best_len && s.compare(pos, t.size(), t) == 0) {  // strictly longer: the lowest id keeps a tie
+        best_len = t.size();
+        best = i;
+      }
+    }
+    if (best < 0) throw std::runtime_error("No match found for remaining bytes " + s.substr(pos));
+    out.push_back(best);
+    pos += best_len;
+  }
+  return out;
+}
+
+std::vector<int32_t> BinTokenizer::encode_bpe(const std::string& text) const {
+  const std::string s = replace_all(text, " ", space_);
+  auto seq_len = [](uint8_t lead) -> size_t {
+    if ((lead & 0x80) == 0x00) return 1;
+    if ((lead & 0xE0) == 0xC0) return 2;
+    if ((lead & 0xF0) == 0xE0) return 3;
+    if ((lead & 0xF8) == 0xF0) return 4;
+    return 1;
+  };
+  std::vector<std::string> pieces;
+  for (size_t off = 0; off < s.size();) {
+    const size_t n = std::min(seq_len((uint8_t)s[off]), s.size() - off);
+    pieces.push_back(s.substr(off, n));
+    off += n;
+  }
+  std::string cand;
+  while (pieces.size() > 1) {
+    int32_t best_id = -1;
+    size_t best_pos = 0;
+    for (size_t p = 0; p + 1 < pieces.size(); ++p) {
+      cand.assign(pieces[p]);
+      cand.append(pieces[p + 1]);
+      const auto f = merge_ids_.find(cand);
+      if (f != merge_ids_.end() && (best_id < 0 || f->second < best_id)) {
+        best_id = f->second;
+        best_pos = p;
+      }
+    }
+    if (best_id < 0) break;
+    pieces[best_pos].append(pieces[best_pos + 1]);
+    pieces.erase(pieces.begin() + best_pos + 1);
+  }
+  std::vector<int32_t> out;
+  for (const std::string& piece : pieces) {
+    const auto f = merge_ids_.find(piece);
+    if (f != merge_ids_.end()) {
+      out.push_back(f->second);
+      continue;
+    }
+    for (const char b : piece) out.push_back(byte_base_ + (int32_t)(uint8_t)b);
+  }
+  return out;
 }
 
 BinTokenizer* BinTokenizer::from_file(const std::string& path) {

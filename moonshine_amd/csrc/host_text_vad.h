@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace msh_host {
@@ -20,9 +21,21 @@ class BinTokenizer {
   // (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).  Throws on an id with no bytes.
   std::string tokens_to_text(const int32_t* ids, size_t count, bool skip_specials = true) const;
 
+  // text -> ids (reference core/bin-tokenizer/bin-tokenizer.cpp:277-402).  bpe = true replays the merges with a
+  // piece's id as its rank and falls back to raw bytes for what no merge spells; it needs the vocabulary's block of
+  // 256 single-byte entries and degrades to longest-match (which throws on an unspellable byte) without one.
+  std::vector<int32_t> text_to_tokens(const std::string& text, bool bpe) const;
+  bool has_byte_fallback() const { return byte_base_ >= 0; }
+
  private:
+  std::vector<int32_t> encode_longest_match(const std::string& text) const;
+  std::vector<int32_t> encode_bpe(const std::string& text) const;
+  void build_indexes();
   std::vector<std::string> tokens_;
   std::string space_;
+  std::vector<std::vector<int32_t>> by_first_byte_;
+  std::unordered_map<std::string, int32_t> merge_ids_;
+  int32_t byte_base_ = -1;
 };
 
 // Replace every byte that does not start a structurally valid UTF-8 sequence by '?'

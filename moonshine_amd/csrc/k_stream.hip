@@ -391,6 +391,85 @@ __global__ void advance_kernel(const DecJob* __restrict__ jobs, const int* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Contextual biasing: one 64-lane wave per logits row.
+constexpr int BIAS_MAX_ACTIVE = 64;
+__device__ __forceinline__ int trie_child(const BiasTrie& T, int node, int token) {
+  int lo = T.child_off[node], hi = T.child_off[node + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int t = T.child_tok[mid];
+    if (t == token) return T.child_node[mid];
+    if (t < token)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return -1;
+}
+__global__ __launch_bounds__(64) void bias_rows_kernel(BiasTrie T, const int2* __restrict__ prefix,
+                                                       const int* __restrict__ tokens, const DecJob* __restrict__ jobs,
+                                                       const SlotDev* __restrict__ slots, const int* __restrict__ result,
+                                                       int result_stride, float* __restrict__ logits, int V) {
+  __shared__ int active[2][BIAS_MAX_ACTIVE];
+  __shared__ int n_active_s;
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int* pre;
+  int n_pre;
+  if (jobs != nullptr) {
+    const int slot = jobs[row].slot;
+    const SlotDev sd = slots[slot];
+    if (sd.finished) return;
+    pre = result + (long)slot * result_stride;
+    n_pre = sd.count;
+  } else {
+    pre = tokens + prefix[row].x;
+    n_pre = prefix[row].y;
+  }
+  if (lane == 0) {  // the walk of ContextBiaser::advance: root always active, plus every continued path
+    int cur = 0, n = 1;
+    active[0][0] = 0;
+    for (int i = 0; i < n_pre; ++i) {
+      const int tok = pre[i];
+      int m = 1;
+      active[cur ^ 1][0] = 0;
+      for (int a = 0; a < n; ++a) {
+        const int c = trie_child(T, active[cur][a], tok);
+        if (c >= 0 && m < BIAS_MAX_ACTIVE) active[cur ^ 1][m++] = c;
+      }
+      cur ^= 1;
+      n = m;
+    }
+    if (cur == 1)
+      for (int a = 0; a < n; ++a) active[0][a] = active[1][a];
+    n_active_s = n;
+  }
+  __syncthreads();
+  const int n = n_active_s;
+  float* lg = logits + (long)row * V;
+  // every (active node, child) pair proposes a token; the largest bonus among the active nodes that propose it is
+  // added once -- by the first such node in the active list
+  for (int a = 0; a < n; ++a) {
+    const int node = active[0][a];
+    const int beg = T.child_off[node], end = T.child_off[node + 1];
+    const float mine = T.depth_bonus[T.depth[node] + 1];
+    for (int c = beg + lane; c < end; c += 64) {
+      const int tok = T.child_tok[c];
+      if (tok < 0 || tok >= V) continue;
+      float best = mine;
+      bool owner = true;
+      for (int b = 0; b < n; ++b) {
+        if (b == a) continue;
+        if (trie_child(T, active[0][b], tok) >= 0) {
+          if (b < a) owner = false;
+          best = fmaxf(best, T.depth_bonus[T.depth[active[0][b]] + 1]);
+        }
+      }
+      if (owner) lg[tok] += best;
+    }
+  }
+}
+
 __global__ void slot_update_kernel(const int4* __restrict__ upd, int n, SlotDev* __restrict__ slots) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -481,6 +560,12 @@ void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* sl
   if (n_jobs <= 0) return;
   hipLaunchKernelGGL(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
                      D, H, step_pos, n_active);
+}
+void stream_bias_rows(BiasTrie trie, const int2* prefix, const int* tokens, const DecJob* jobs, const SlotDev* slots,
+                      const int* result, int result_stride, int rows, float* logits, int V, hipStream_t s) {
+  if (rows <= 0 || trie.n_nodes <= 0) return;
+  hipLaunchKernelGGL(bias_rows_kernel, dim3(rows), dim3(64), 0, s, trie, prefix, tokens, jobs, slots, result,
+                     result_stride, logits, V);
 }
 void stream_slot_update(const int4* upd, int n, SlotDev* slots, hipStream_t s) {
   if (n <= 0) return;

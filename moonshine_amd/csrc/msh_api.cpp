@@ -341,6 +341,11 @@ int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const int32_t* s
     e->eng->decode_full(n, slots, drafts, draft_lens, max_tokens, tokens_out, counts_out, tokens_stride, accepted_out);
   });
 }
+int32_t msh_stream_set_bias(msh_stream_engine* e, int32_t n_nodes, const int32_t* child_off, const int32_t* child_tok,
+                            const int32_t* child_node, const int32_t* depth, const float* depth_bonus,
+                            int32_t n_depth_bonus) {
+  return guarded(e, [&] { e->eng->set_bias(n_nodes, child_off, child_tok, child_node, depth, depth_bonus, n_depth_bonus); });
+}
 int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what) {
   if (e == nullptr) return MSH_ERR_INVALID_ARGUMENT;
   try {

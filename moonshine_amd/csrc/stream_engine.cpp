@@ -82,7 +82,7 @@ StreamingEngine::~StreamingEngine() {
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
-                    &steppos_};
+                    &steppos_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -673,6 +673,35 @@ void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* cons
   MSH_HIP(hipStreamSynchronize(stream_));
 }
 
+void StreamingEngine::set_bias(int n_nodes, const int32_t* child_off, const int32_t* child_tok, const int32_t* child_node,
+                               const int32_t* depth, const float* depth_bonus, int n_depth_bonus) {
+  MSH_HIP(hipSetDevice(device_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  bias_ = BiasTrie{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (n_nodes <= 0) return;
+  if (child_off == nullptr || depth == nullptr || depth_bonus == nullptr) throw std::invalid_argument("null trie array");
+  const int n_children = child_off[n_nodes];
+  if (n_children > 0 && (child_tok == nullptr || child_node == nullptr)) throw std::invalid_argument("null trie array");
+  int max_depth = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    if (child_off[i] > child_off[i + 1]) throw std::invalid_argument("trie offsets must be non-decreasing");
+    for (int c = child_off[i]; c < child_off[i + 1]; ++c) {
+      if (c > child_off[i] && child_tok[c] <= child_tok[c - 1]) throw std::invalid_argument("trie children must be sorted by token");
+      if (child_node[c] <= 0 || child_node[c] >= n_nodes) throw std::invalid_argument("trie child index out of range");
+    }
+    max_depth = std::max(max_depth, depth[i]);
+  }
+  if (max_depth + 2 > n_depth_bonus) throw std::invalid_argument("depth_bonus table too short");
+  if (max_depth + 1 > 64) throw std::invalid_argument("key terms longer than 63 tokens are not supported");
+  stage(bias_off_, std::vector<int32_t>(child_off, child_off + n_nodes + 1));
+  stage(bias_tok_, std::vector<int32_t>(child_tok, child_tok + n_children));
+  stage(bias_node_, std::vector<int32_t>(child_node, child_node + n_children));
+  stage(bias_depth_, std::vector<int32_t>(depth, depth + n_nodes));
+  stage(bias_bonus_, std::vector<float>(depth_bonus, depth_bonus + n_depth_bonus));
+  bias_ = BiasTrie{bias_off_.as<int>(), bias_tok_.as<int>(), bias_node_.as<int>(), bias_depth_.as<int>(),
+                   bias_bonus_.as<float>(), n_nodes};
+}
+
 // ------------------------------------------------------------------------------------------------
 // decode_full (streaming-model.cpp:1192-1397) for n streams: one wide pass over [BOS, draft...] of every
 // stream, device-side verify, then lock-step auto-regressive steps (one row per stream) until every stream
@@ -688,6 +717,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   MSH_HIP(hipSetDevice(device_));
   const int Dd = cfg_.decoder_dim, V = cfg_.vocab_size;
   std::vector<int> rs, rpos, tok, draft_flat, job_slot, job_index;
+  std::vector<int2> prefix;  // per wide-pass row: (offset into draft_flat, tokens before the row) for the biaser walk
   std::vector<DecJob> jobs;
   int max_budget = 0;
   for (int i = 0; i < n; ++i) {
@@ -708,12 +738,15 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     rs.push_back(slots[i]);
     rpos.push_back(0);
     tok.push_back(cfg_.bos_id);
+    const int doff = (int)draft_flat.size();
+    prefix.push_back(make_int2(doff, 0));
     for (int t = 0; t < dl; ++t) {
       if (drafts[i][t] < 0 || drafts[i][t] >= V) throw std::invalid_argument("draft token out of range");
       rs.push_back(slots[i]);
       rpos.push_back(1 + t);
       tok.push_back(drafts[i][t]);
       draft_flat.push_back(drafts[i][t]);
+      prefix.push_back(make_int2(doff, t + 1));
     }
     max_budget = std::max(max_budget, budget);
   }
@@ -731,7 +764,11 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   const int* jslot_d = stage(newslot_, job_slot);
   MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
+  const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
   decoder_pass(M, rs_d, rp_d, logits_.as<float>());
+  // the biaser's bonuses go in before every token choice, the verify pass included (streaming-model.cpp:1241-1246,
+  // 1304-1315); row t of a stream is conditioned on draft[0..t)
+  stream_bias_rows(bias_, prefix_d, draft_d, nullptr, nullptr, nullptr, 0, M, logits_.as<float>(), V, stream_);
   stream_argmax(logits_.as<float>(), M, V, pred_.as<int>(), stream_);
   stream_verify(jobs_d, J, pred_.as<int>(), draft_d, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd,
                 stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
@@ -743,6 +780,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       if (active <= 0) break;
     }
     decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
+    stream_bias_rows(bias_, nullptr, nullptr, jobs_d, slots_d_, result_, Scap_, J, logits_.as<float>(), V, stream_);
     stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
     stream_advance(jobs_d, J, pred_.as<int>(), slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd, stepH_.as<float>(),
                    steppos_.as<int>(), n_active_d_, stream_);

@@ -64,6 +64,10 @@ class StreamingEngine {
   void decode_full(int n, const int* slots, const int32_t* const* drafts, const int* draft_lens, const int* max_tokens,
                    int32_t* tokens_out, int32_t* counts_out, int tokens_stride, int32_t* accepted_out);
 
+  // contextual biasing trie (copied to the device); n_nodes == 0 switches it off
+  void set_bias(int n_nodes, const int32_t* child_off, const int32_t* child_tok, const int32_t* child_node,
+                const int32_t* depth, const float* depth_bonus, int n_depth_bonus);
+
   int memory_len(int slot) const { return st(slot).mem_len; }
   int feature_count(int slot) const { return st(slot).feat_count; }
   int cache_len(int slot) const { return st(slot).cache_len; }
@@ -129,7 +133,8 @@ class StreamingEngine {
   DevBuf audio_, frames_, hidden_, c1out_, feat_pk_, segs_, jobs_, H_, Y_, Y32_, QKV_, AO_, Z_, Q_, rowlo_, rowhi_,
       newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_,
       logits_, pred_, draft_, decjobs_, stepH_, steppos_;
-  std::vector<char> pinned_;  // unused placeholder for future pinned staging
+  DevBuf bias_off_, bias_tok_, bias_node_, bias_depth_, bias_bonus_, bias_prefix_;
+  BiasTrie bias_{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 };
 
 }  // namespace msh

@@ -79,6 +79,22 @@ void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* d
 // one auto-regressive step of decode_full's loop (moonshine-streaming-model.cpp:1271-1288)
 void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
                     int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s);
+// Contextual biasing (reference core/context-biaser.cpp:88-149): flat trie over token ids, children sorted by token.
+struct BiasTrie {
+  const int* child_off;    // [n_nodes + 1]
+  const int* child_tok;
+  const int* child_node;
+  const int* depth;        // [n_nodes]
+  const float* depth_bonus;  // [max_depth + 2]
+  int n_nodes;
+};
+// Adds the bonuses to logits rows before the argmax.  The active trie nodes of a row are recomputed from the tokens
+// that precede it (the walk of ContextBiaser::advance from the root over that prefix):
+//   wide pass (jobs == nullptr): row r has prefix tokens[prefix[r].x .. prefix[r].x + prefix[r].y)
+//   AR step   (jobs != nullptr): row j belongs to jobs[j].slot, prefix = result[slot][0 .. slots[slot].count);
+//                                 finished streams are skipped
+void stream_bias_rows(BiasTrie trie, const int2* prefix, const int* tokens, const DecJob* jobs, const SlotDev* slots,
+                      const int* result, int result_stride, int rows, float* logits, int V, hipStream_t s);
 // per entry (slot, mem_len or -1 = keep, cache_len or -1 = keep, nonzero = clear the decode_full fields)
 void stream_slot_update(const int4* upd, int n, SlotDev* slots, hipStream_t s);
 // slots[slot].cache_len += n for the rows of a plain wide pass (decode_tokens)

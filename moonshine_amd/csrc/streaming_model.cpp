@@ -208,6 +208,24 @@ std::string MoonshineStreamingModel::tokens_to_text(const std::vector<int64_t>& 
   return tokenizer->tokens_to_text(ids.data(), ids.size());
 }
 
+std::vector<int32_t> MoonshineStreamingModel::text_to_tokens(const std::string& text) {
+  if (tokenizer == nullptr) return {};
+  return tokenizer->text_to_tokens(text, /*bpe=*/true);
+}
+
+int MoonshineStreamingModel::set_biaser(const ContextBiaser& biaser) {
+  std::lock_guard<std::mutex> lock(processing_mutex);
+  int32_t rc;
+  if (biaser.empty()) {
+    rc = msh_stream_set_bias(engine, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  } else {
+    const ContextBiaser::Flat f = biaser.flatten();
+    rc = msh_stream_set_bias(engine, (int32_t)f.depth.size(), f.child_off.data(), f.child_tok.data(), f.child_node.data(),
+                             f.depth.data(), f.depth_bonus.data(), (int32_t)f.depth_bonus.size());
+  }
+  return rc == MSH_OK ? 0 : fail(rc);
+}
+
 // ---- batched forms ----
 int MoonshineStreamingModel::process_audio_batch(const std::vector<MoonshineStreamingState*>& states,
                                                  const std::vector<const float*>& audio,

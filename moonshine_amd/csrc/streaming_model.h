@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/moonshine_hip.h"
+#include "context_biaser.h"
 #include "host_text_vad.h"
 
 namespace msh_host {
@@ -65,6 +66,11 @@ struct MoonshineStreamingModel {
                   int** tokens_out, int* tokens_len_out);                               // :174
   void decoder_reset(MoonshineStreamingState* state);                                   // :178
   std::string tokens_to_text(const std::vector<int64_t>& tokens);                       // :184
+  // :189 -- byte-pair encoding (kTokenizerEncoding = kBpe, streaming-model.cpp:57); empty without a tokenizer
+  std::vector<int32_t> text_to_tokens(const std::string& text);
+  // Hands the compiled key terms to the device (the reference passes a ContextBiaser* into decode_full, :174-176;
+  // here token choice runs on the GPU, so the trie lives there).  An empty biaser switches biasing off.
+  int set_biaser(const ContextBiaser& biaser);
 
   // batched forms (no reference counterpart)
   int process_audio_batch(const std::vector<MoonshineStreamingState*>& states, const std::vector<const float*>& audio,

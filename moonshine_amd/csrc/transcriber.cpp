@@ -183,8 +183,12 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
     throw std::runtime_error("Invalid model architecture: " + std::to_string(opt_.model_arch));
   if (is_streaming_arch(opt_.model_arch)) {
     load_streaming_model();
+    if (!opt_.keyterms.empty()) set_keyterms(opt_.keyterms);  // needs the tokenizer the load just brought up
     return;
   }
+  if (!opt_.keyterms.empty())
+    throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
+                             "does not decode through a path that can apply it.");
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
   if (opt_.model_source == TranscriberOptions::FILES) {
     if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
@@ -272,6 +276,34 @@ void Transcriber::load_streaming_model() {
     if (streaming_model_->load_from_memory(w, wn, std::string((const char*)c, cn), t, tn, (int32_t)opt_.model_arch) != 0)
       throw std::runtime_error("Failed to load streaming model from memory: " + streaming_model_->last_error);
   }
+}
+
+void Transcriber::set_keyterms(const std::vector<std::string>& keyterms) {
+  std::lock_guard<std::mutex> lock(context_biaser_mutex_);
+  opt_.keyterms = keyterms;
+  context_biaser_.clear();
+  context_biaser_.set_boost(opt_.keyterm_boost);
+  {  // the drafts were decoded under the previous key terms: drop them (costs one re-decode from BOS)
+    std::lock_guard<std::mutex> sl(streams_mutex_);
+    for (auto& kv : streams_) kv.second->last_streaming_tokens.clear();
+    if (batch_stream_) batch_stream_->last_streaming_tokens.clear();
+  }
+  if (streaming_model_ == nullptr) {
+    if (!keyterms.empty() && model_ != nullptr)
+      throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
+                               "does not decode through a path that can apply it.");
+    return;  // no model at all (skip_transcription): nothing to tokenize against
+  }
+  for (const std::string& term : keyterms)
+    for (const std::string& variant : ContextBiaser::variants_for_term(term)) {
+      const std::vector<int32_t> tokens = streaming_model_->text_to_tokens(variant);
+      if (!tokens.empty()) context_biaser_.add_token_sequence(tokens);
+    }
+  std::lock_guard<std::mutex> ml(model_mutex_);
+  if (streaming_model_->set_biaser(context_biaser_) != 0)
+    throw std::runtime_error("Failed to install the key terms: " + streaming_model_->last_error);
+  if (opt_.log_output_text)
+    MSH_LOGF("Compiled %zu key terms for contextual biasing (boost %.2f)", keyterms.size(), context_biaser_.boost());
 }
 
 Transcriber::~Transcriber() {
@@ -440,7 +472,9 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
     }
   }
   if (!jobs.empty() && streaming) {
-    // one segment per stream per round: the segments of a stream share its device slot and run in order
+    // one segment per stream per round: the segments of a stream share its device slot and run in order.
+    // The biaser lock is held across the decode so a concurrent set_keyterms cannot swap the trie under it.
+    std::lock_guard<std::mutex> biaser_lock(context_biaser_mutex_);
     std::lock_guard<std::mutex> lock(model_mutex_);
     const auto t0 = std::chrono::steady_clock::now();
     texts.assign(jobs.size(), std::string());

@@ -62,6 +62,8 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   float max_tokens_per_second = 6.5f;
   bool decode_incomplete_lines = true;
   bool use_speculative_decoding = true;  // streaming architectures (reference core/transcriber.h:191)
+  std::vector<std::string> keyterms;     // contextual biasing (streaming architectures only)
+  float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool return_audio_data = true;
@@ -128,6 +130,9 @@ class Transcriber {
   void add_audio_to_stream(int32_t id, const float* audio, uint64_t n, int32_t sample_rate);
   void transcribe_stream(int32_t id, uint32_t flags, transcript_t** out);
   static std::string transcript_to_string(const transcript_t* t);
+  // reference core/transcriber.cpp:250-288: compile the key terms (each in its mid-sentence and utterance-initial
+  // spelling) into the biasing trie; drops every stream's speculative draft
+  void set_keyterms(const std::vector<std::string>& keyterms);
 
  private:
   TranscriberStream* new_stream(int32_t id);
@@ -150,6 +155,8 @@ class Transcriber {
   TranscriberOptions opt_;
   std::unique_ptr<MoonshineModel> model_;
   std::unique_ptr<MoonshineStreamingModel> streaming_model_;
+  ContextBiaser context_biaser_;
+  std::mutex context_biaser_mutex_;  // taken before model_mutex_ (reference core/transcriber.cpp:1394-1396)
   std::mutex model_mutex_, batch_mutex_, streams_mutex_;
   std::unique_ptr<TranscriberStream> batch_stream_;
   std::vector<std::unique_ptr<TranscriberStream>> batch_streams_;  // one per clip of the last batch call

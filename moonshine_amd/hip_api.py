@@ -84,6 +84,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_stream_decoder_reset": (i32, [vp, i32, vp]),
         "msh_stream_decode_tokens": (i32, [vp, i32, vp, P(vp), vp, vp]),
         "msh_stream_decode_full": (i32, [vp, i32, vp, P(vp), vp, vp, vp, vp, i32, vp]),
+        "msh_stream_set_bias": (i32, [vp, i32, vp, vp, vp, vp, vp, i32]),
         "msh_stream_query": (i32, [vp, i32, i32]),
         "msh_stream_get_memory": (i32, [vp, i32, vp]),
         "msh_stream_get_features": (i32, [vp, i32, vp]),
@@ -336,6 +337,23 @@ class StreamEngine:
                                                     mt.ctypes.data if mt is not None else None, toks.ctypes.data,
                                                     counts.ctypes.data, stride, acc.ctypes.data))
         return [toks[i, :counts[i]].tolist() for i in range(n)], acc
+
+    def set_bias(self, children: list[dict] | None, depth: list[int] | None = None, depth_bonus=None):
+        """Install (or, with None / an empty trie, remove) the contextual-biasing trie.  children[n] = {token: child
+        node} of node n (node 0 = root), depth[n] its depth, depth_bonus[d] the bonus of a depth-d token."""
+        if not children or len(children) <= 1:
+            self._check(self.lib.msh_stream_set_bias(self.h, 0, None, None, None, None, None, 0))
+            return
+        off, tok, node = [0], [], []
+        for ch in children:
+            for t in sorted(ch):
+                tok.append(t)
+                node.append(ch[t])
+            off.append(len(tok))
+        a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+        off, tok, node, dep, bon = a(off, np.int32), a(tok, np.int32), a(node, np.int32), a(depth, np.int32), a(depth_bonus, np.float32)
+        self._check(self.lib.msh_stream_set_bias(self.h, len(children), off.ctypes.data, tok.ctypes.data, node.ctypes.data,
+                                                 dep.ctypes.data, bon.ctypes.data, bon.shape[0]))
 
     def query(self, slot: int, what: int) -> int:
         return self._check(self.lib.msh_stream_query(self.h, slot, what))

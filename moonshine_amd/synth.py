@@ -392,6 +392,8 @@ def synthetic_vocab(vocab: int) -> list[bytes]:
         body = bytes(letters[(k * 31 + j * 17) % 26] for j in range(n))
         if k % 3 == 0:
             body = SPACE + body
+        if k == 259:
+            body = SPACE                          # the bare word-start marker, so " word" is always spellable
         if k % 997 == 0:
             body = body * 40                      # > 127 bytes: 2-byte length prefix
         elif k % 1013 == 0:

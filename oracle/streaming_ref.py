@@ -287,26 +287,42 @@ def max_tokens_for_memory(cfg, memory_len: int) -> int:
     return min(int(math.ceil(float(duration) * 6.5)), cfg.max_seq_len)
 
 
-def decode_full(w, cfg, st: StreamState, draft=None, stats: dict | None = None):
+def decode_full(w, cfg, st: StreamState, draft=None, stats: dict | None = None, biaser=None):
     """ref:1192-1397: greedy decode from BOS; with a draft, one wide verify call, keep the agreeing
     prefix, and on divergence reset the self cache and re-run the accepted prefix before continuing.
-    Returns the content tokens (no BOS / EOS).  The caller resets the decoder first (tr:1385)."""
+    ``biaser`` (oracle.biaser_ref.ContextBiaser, optional) adds its bonuses before every token choice,
+    the verify pass included; its walk follows the teacher-forced prefix (ref:1234-1246, 1304-1315,
+    1354-1361).  Returns the content tokens (no BOS / EOS).  The caller resets the decoder first (tr:1385)."""
     if st.memory_len == 0:
         return []
     out: list[int] = []
     max_tokens = max_tokens_for_memory(cfg, st.memory_len)
+    if biaser is not None:
+        biaser.reset()
+
+    def biased_argmax(row: np.ndarray) -> int:
+        if biaser is not None:
+            row = row.copy()
+            biaser.apply(row)
+        return argmax_first(row)
 
     def continue_ar(tok: int):
         cur = tok
         while cur != cfg.eos and len(out) < max_tokens:                      # ref:1275-1276
             out.append(cur)
-            cur = argmax_first(_run_decoder(w, cfg, st, [cur])[0])
+            if biaser is not None:
+                biaser.advance(cur)
+            cur = biased_argmax(_run_decoder(w, cfg, st, [cur])[0])
 
     draft = list(draft) if draft is not None else []
     if draft:
         toks = [cfg.bos] + draft
         logits = _run_decoder(w, cfg, st, toks)
-        pred = [argmax_first(logits[t]) for t in range(len(toks))]
+        pred = []
+        for t in range(len(toks)):                                           # ref:1307-1315
+            pred.append(biased_argmax(logits[t]))
+            if biaser is not None and t + 1 < len(toks):
+                biaser.advance(toks[t + 1])
         d = 0
         for i in range(len(draft)):                                          # ref:1318-1325
             if pred[i] == draft[i]:
@@ -322,10 +338,14 @@ def decode_full(w, cfg, st: StreamState, draft=None, stats: dict | None = None):
         else:
             st.decoder_reset()                                               # ref:1338-1340
             logits2 = _run_decoder(w, cfg, st, [cfg.bos] + draft[:d])
-            continue_ar(argmax_first(logits2[d]))
+            if biaser is not None:                                           # ref:1354-1361
+                biaser.reset()
+                for i in range(d):
+                    biaser.advance(draft[i])
+            continue_ar(biased_argmax(logits2[d]))
     else:
         logits = _run_decoder(w, cfg, st, [cfg.bos])
-        continue_ar(argmax_first(logits[0]))
+        continue_ar(biased_argmax(logits[0]))
     return out
 
 

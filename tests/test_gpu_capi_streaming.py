@@ -157,7 +157,49 @@ def test_streaming_arch_options(model_dir, engine):
     assert m.last[0] == CFG.bos and len(m.last) > 1      # the closing update did decode
     m.close()
     t.close()
-    with pytest.raises(api.MoonshineError):      # keyterm biasing is not part of this build
-        api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "keyterms": "moonshine"})
+    with pytest.raises(api.MoonshineError):      # the context extractor is not part of this build
+        api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "context": "some passage of text"})
     with pytest.raises(api.MoonshineError):      # offline weights directory for a streaming arch
         api.Transcriber(str(model_dir) + "_missing", api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
+
+
+def compile_terms(terms, boost):
+    """Transcriber::set_keyterms (transcriber.cpp:250-288) restated: both spellings of every term, encoded with the
+    tokenizer's text -> ids direction (longest match here: the synthetic vocabulary has no raw-byte block)."""
+    from oracle.biaser_ref import ContextBiaser, text_to_tokens_bpe
+
+    vocab = synthetic_vocab(CFG.vocab)
+    b = ContextBiaser(boost)
+    for term in terms:
+        for variant in ContextBiaser.variants_for_term(term):
+            b.add_token_sequence(text_to_tokens_bpe(vocab, variant.encode()))
+    return b
+
+
+def test_streaming_arch_keyterms(model_dir, engine):
+    audio = make_audio(95, 16000 * 3)
+    terms = ["qjx", " wvut ", "abcab"]
+    plain_t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
+    plain = plain_t.transcribe_without_streaming(audio)[0].text_bytes
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING,
+                        {"vad_threshold": "0", "keyterms": ",".join(terms), "keyterm_boost": "5.0"})
+    b = compile_terms(terms, 5.0)
+    assert b.sequence_count == 6
+    md = max(b.depth)
+    engine.set_bias(b.children, b.depth, [float(b.bonus_for_depth(d)) for d in range(md + 2)])
+    try:
+        lines = t.transcribe_without_streaming(audio)
+        m = GlueMirror(engine)
+        assert lines[0].text_bytes == m.update(lines[0].audio_data, True)
+        m.close()
+        # runtime call: clearing the terms restores the unbiased transcript, setting them again the biased one
+        biased = lines[0].text_bytes
+        lib = api.lib()
+        assert lib.moonshine_transcriber_set_keyterms(t.handle, b"") == 0
+        assert t.transcribe_without_streaming(audio)[0].text_bytes == plain
+        assert lib.moonshine_transcriber_set_keyterms(t.handle, ",".join(terms).encode()) == 0
+        assert t.transcribe_without_streaming(audio)[0].text_bytes == biased
+    finally:
+        engine.set_bias(None)
+    t.close()
+    plain_t.close()

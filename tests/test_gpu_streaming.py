@@ -294,3 +294,79 @@ def test_stream_errors(tmp_path):
     eng.close_stream(a)
     assert eng.open() == a
     eng.close()
+
+
+# ---- contextual biasing (row A16) ----
+def install(eng, biaser):
+    md = max(biaser.depth)
+    eng.set_bias(biaser.children, biaser.depth, [float(biaser.bonus_for_depth(d)) for d in range(md + 2)])
+
+
+def oracle_biased_greedy(w, cfg, st, biaser, max_tokens):
+    """decode_full(no draft) on the oracle with per-step margins of the biased logits."""
+    st.decoder_reset()
+    biaser.reset()
+    toks, margins, cur = [], [], cfg.bos
+    while True:
+        lg = sr.decode_tokens(w, cfg, st, [cur])[0].copy()
+        biaser.apply(lg)
+        top = np.sort(lg)[-2:]
+        nxt = int(np.argmax(lg))
+        margins.append(float(top[1] - top[0]))
+        if nxt == cfg.eos or len(toks) >= max_tokens:
+            break
+        toks.append(nxt)
+        biaser.advance(nxt)
+        cur = nxt
+    return toks, margins
+
+
+def test_decode_full_with_context_biaser(tmp_path):
+    from oracle.biaser_ref import ContextBiaser
+
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21)
+    audio = make_audio(5, 1280 * 40)
+    s = eng.open()
+    feed(eng, s, audio, 40)
+    st = oracle_state(w, cfg, audio, 40)
+    cap = sr.max_tokens_for_memory(cfg, st.memory_len)
+    eng.decoder_reset([s])
+    (plain,), _ = eng.decode_full([s])
+    # key terms built from the runner-up tokens of the unbiased pass, so the bonuses flip real decisions; one term
+    # shares its first token with another, one starts inside another (the two dedup cases of context-biaser.cpp)
+    st.decoder_reset()
+    lg = sr.decode_tokens(w, cfg, st, [cfg.bos] + plain[:-1])
+    runner = [int(np.argsort(r)[-2]) for r in lg]
+    b = ContextBiaser(4.0)
+    for seq in ([runner[1], runner[2], runner[3]], [runner[1], plain[2]], [plain[0], runner[1]], [runner[5]], [900, 3]):
+        b.add_token_sequence(seq)
+    want, margins = oracle_biased_greedy(w, cfg, st, b, cap)
+    assert want != plain[:len(want)] or len(want) != len(plain)          # the biasing changed the transcript
+    install(eng, b)
+    eng.decoder_reset([s])
+    (got,), _ = eng.decode_full([s])
+    agree_until_close_call(got, want, margins)
+    # the verify pass is biased too: the unbiased tokens as a draft are cut where the key terms take over ...
+    eng.decoder_reset([s])
+    (got2,), acc = eng.decode_full([s], drafts=[plain])
+    assert got2 == got
+    first_diff = next((i for i, (a, c) in enumerate(zip(plain, got)) if a != c), min(len(plain), len(got)))
+    assert acc[0] == first_diff
+    # ... and the biased tokens as a draft are accepted whole
+    eng.decoder_reset([s])
+    (got3,), acc = eng.decode_full([s], drafts=[got])
+    assert got3 == got and acc[0] == len(got)
+    # several streams, one trie
+    s2 = eng.open()
+    feed(eng, s2, make_audio(6, 1280 * 25), 25)
+    eng.decoder_reset([s2])
+    (alone2,), _ = eng.decode_full([s2])
+    eng.decoder_reset([s, s2])
+    both, _ = eng.decode_full([s, s2])
+    assert both == [got, alone2]
+    # removing the trie restores the unbiased result
+    eng.set_bias(None)
+    eng.decoder_reset([s])
+    (back,), _ = eng.decode_full([s])
+    assert back == plain
+    eng.close()

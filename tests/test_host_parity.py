@@ -159,7 +159,9 @@ def test_option_parsing_and_error_rules():
     assert lib.moonshine_transcribe_without_streaming(-1, None, 0, 16000, 0, C.byref(out)) == -2
     assert lib.moonshine_create_stream(9999, 0) == -2
     assert lib.moonshine_transcriber_set_keyterms(t.handle, b"") == 0
-    assert lib.moonshine_transcriber_set_keyterms(t.handle, b"Kubernetes") == -1
+    # no model at all (skip_transcription): nothing to tokenize against, accepted (reference transcriber.cpp:266-277)
+    assert lib.moonshine_transcriber_set_keyterms(t.handle, b"Kubernetes, etcd") == 0
+    assert lib.moonshine_transcriber_set_keyterms(4242, b"x") == -2
     assert lib.moonshine_load_transcriber_from_memory(None, 0, None, 0, None, 0, None, 0, 1, None, 0, 30000) == -3
     t.close()
     t.close()  # double free is harmless

@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round-end evidence run: GPU tests, smoke, default bench, rocprofv3 kernel stats of the same command, and HBM-byte
+# counters (separate --pmc passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) for the decode kernels.
+set -u
+TAG=${1:-final}
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -2 gpurun_out/${TAG}_pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- $CMD > /tmp/prof_${TAG}.log 2>&1)
+f=$(find /tmp/prof_${TAG} -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256.csv && head -8 "$f" | cut -c1-160
+pass() { # name counters...
+  local name=$1; shift
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /tmp/pmc_${TAG}_$name.log 2>&1)
+  tail -1 /tmp/pmc_${TAG}_$name.log | cut -c1-160
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+python - <<PY
+import csv, glob, collections, json, re
+GROUPS = {  # bench.py kernel group -> kernel-name pattern
+    "dec_cross_attention": r"dec_cross_attention_kernel", "dec_self_attention": r"dec_self_attention_kernel",
+    "enc_attention": r"enc_attention_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
+    "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiBiasGeluBf16",
+}
+out = {}
+for name in ("fetch", "write"):
+    files = glob.glob(f"/tmp/pmc_${TAG}_{name}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        print("no counter file for", name); continue
+    agg = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"]
+        agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"])); cnt[k] += 1
+    for (k, c), v in agg.items():
+        out.setdefault(k, {"dispatches": cnt[k]})[c] = v
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, B=256; "
+                 "units KiB summed over dispatches; FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md) "
+                 "in traffic_bytes_per_launch; WRITE_SIZE uncalibrated", "groups": {}}
+for g, pat in GROUPS.items():
+    ks = [k for k in out if re.search(pat, k)]
+    if not ks: continue
+    n = sum(out[k]["dispatches"] for k in ks)
+    fetch = sum(out[k].get("FETCH_SIZE", 0.0) for k in ks); write = sum(out[k].get("WRITE_SIZE", 0.0) for k in ks)
+    res["groups"][g] = {"dispatches": n, "fetch_kib_per_launch": fetch / n, "write_kib_per_launch": write / n,
+                        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n}
+    print(g, res["groups"][g])
+json.dump(res, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
+PY
