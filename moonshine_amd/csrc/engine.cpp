@@ -522,14 +522,16 @@ struct Engine::DecodeGroup {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int first = 0, M = 0;
-  DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher;
+  DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher, pval, pidx;
+  bool fused_argmax = false;  // LM head writes per-tile (max, index) pairs instead of logits
   hipGraphExec_t graph = nullptr;
   std::string key;
   uint64_t gen = 0;
   int32_t n_active_h = 0;
   ~DecodeGroup() {
     if (graph) (void)hipGraphExecDestroy(graph);
-    DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher};
+    DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher,
+                      &pval, &pidx};
     for (DevBuf* b : bufs) b->release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -595,8 +597,14 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       ProfScope p(this, "dec_final_layernorm", 0, M * D * 6.0);
       layernorm_bf16(dH, dec_ln_, M, D, g.dy.as<bf16_t>(), nullptr, s);
     }
-    ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
-    gemm_logits_f32(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.logits.as<float>(), s);
+    if (g.fused_argmax) {
+      // nobody reads the logits: reduce every 128 x 208 tile to (max, first index) per row in the GEMM epilogue
+      ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)gemm_argmax_tiles(V) * 8);
+      gemm_argmax_partials(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.pval.as<float>(), g.pidx.as<int>(), s);
+    } else {
+      ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
+      gemm_logits_f32(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.logits.as<float>(), s);
+    }
   } else {
     ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
     dec_gemm_logits(dH, embed_head_folded_, M, V, D, g.logits.as<float>(), s);
@@ -660,6 +668,15 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     moved |= g.dz.reserve((size_t)M * F * sizeof(bf16_t));
     moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
     moved |= g.logits.reserve((size_t)M * V * sizeof(float));
+    moved |= g.pval.reserve((size_t)M * gemm_argmax_tiles(V) * sizeof(float));
+    moved |= g.pidx.reserve((size_t)M * gemm_argmax_tiles(V) * sizeof(int));
+    {
+      static const bool off = [] {
+        const char* e = getenv("MSH_NO_FUSED_ARGMAX");
+        return e != nullptr && e[0] == '1';
+      }();
+      g.fused_argmax = !off && logits_out == nullptr && M >= 128;
+    }
     moved |= g.cacheK.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
     moved |= g.cacheV.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
     moved |= g.tokens.reserve((size_t)M * stride * sizeof(int32_t));
@@ -694,7 +711,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(ws_gen_) + ":" +
                               std::to_string(g.gen) + ":" + std::to_string(Smax_) + ":" + std::to_string(stride) + ":" +
                               std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
-                              std::to_string(kv_keys_);
+                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax);
       if (g.graph == nullptr || g.key != key) {
         if (g.graph) {
           MSH_HIP(hipGraphExecDestroy(g.graph));
@@ -703,7 +720,11 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
         hipGraph_t gr = nullptr;
         MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
         decode_step_enqueue(g);
-        decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+        if (g.fused_argmax)
+          decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
+                                  g.dH.as<float>(), g.stream);
+        else
+          decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
         MSH_HIP(hipStreamEndCapture(g.stream, &gr));
         MSH_HIP(hipGraphInstantiate(&g.graph, gr, nullptr, nullptr, 0));
         MSH_HIP(hipGraphDestroy(gr));
@@ -725,9 +746,15 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
         if (logits_out != nullptr && i < max_logit_steps)
           MSH_HIP(hipMemcpyAsync(logits_out + (size_t)i * Mtot * V, g.logits.p, (size_t)Mtot * V * sizeof(float),
                                  hipMemcpyDeviceToHost, g.stream));
-        ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * V * 4);
-        decode_advance(g.logits.as<float>(), g.M, V, clips_d_.as<ClipMeta>() + g.first, states[gi], embed_f32_, D,
-                       g.dH.as<float>(), g.stream);
+        if (g.fused_argmax) {
+          ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * gemm_argmax_tiles(V) * 8);
+          decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), g.M,
+                                  clips_d_.as<ClipMeta>() + g.first, states[gi], embed_f32_, D, g.dH.as<float>(), g.stream);
+        } else {
+          ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * V * 4);
+          decode_advance(g.logits.as<float>(), g.M, V, clips_d_.as<ClipMeta>() + g.first, states[gi], embed_f32_, D,
+                         g.dH.as<float>(), g.stream);
+        }
       }
     }
     ++steps_run;

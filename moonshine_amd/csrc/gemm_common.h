@@ -3,6 +3,8 @@
 // internal-linkage (anonymous namespace) device code.
 #pragma once
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace msh {
@@ -301,6 +303,21 @@ struct EpiAct {
     if (out32 != nullptr) *reinterpret_cast<float4*>(out32 + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
+
+// LM head without the logits round trip: every workgroup reduces its 128 x 208 tile to one (max, first index)
+// pair per row; the decode bookkeeping kernel then reduces N/208 pairs per row instead of scanning V logits.
+// Handled inside gemm_tiled_dma_kernel (kRowArgmax), not through n4.
+struct EpiArgmaxPartial {
+  static constexpr bool kRowArgmax = true;
+  float* pval;  // [M][ntn]
+  int* pidx;
+  int ntn;
+  __device__ void n4(int, int, f32x4) const {}
+};
+template <class E, class = void>
+struct is_row_argmax : std::false_type {};
+template <class E>
+struct is_row_argmax<E, std::void_t<decltype(E::kRowArgmax)>> : std::true_type {};
 
 // XOR swizzle of the 16-B k-chunk position inside a 64-B row of an LDS k-slice (conflict-free
 // ds_read_b128 fragment reads for the lane groups of gfx950; verified: SQ_LDS_BANK_CONFLICT = 0)

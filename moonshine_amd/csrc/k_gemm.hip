@@ -271,6 +271,44 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
   }
   wait_vmcnt<0>();
 
+  if constexpr (is_row_argmax<Epi>::value) {
+    // row m = li of this wave's row tile; its columns of the tile sit in j (TN), kg (4 lane groups) and the 4
+    // accumulator registers: reduce locally, then across the 4 lane groups.  Ties keep the lowest column.
+    static_assert(SWAP, "row argmax needs the n4 orientation");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float best = -INFINITY;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + kg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r];
+          if (n + r < N && v > best) {  // columns are visited in ascending order: '>' keeps the first maximum
+            best = v;
+            bidx = n + r;
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) {
+          best = ov;
+          bidx = oi;
+        }
+      }
+      const int m = m0 + wave * 16 * TM + i * 16 + li;
+      if (kg == 0 && m < M) {
+        const int tile_n = n0 / (16 * TN);
+        epi.pval[(long)m * epi.ntn + tile_n] = best;
+        epi.pidx[(long)m * epi.ntn + tile_n] = bidx;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -515,6 +553,13 @@ void gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int
 void gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, bf16_t* z,
                       hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiSwiGLU{z, N / 2, bias}, s);
+}
+int gemm_argmax_tiles(int N) { return (N + 207) / 208; }
+void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* pval, int* pidx,
+                          hipStream_t s) {
+  if ((K & 31) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_argmax_partials: unsupported shape");
+  launch_tiled_dma_cfg<4, 2, 13, 3, true, EpiArgmaxPartial>(A, lda, W, M, N, K,
+                                                            EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
 }
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiF32{out, N}, s);

@@ -168,6 +168,23 @@ __global__ void decode_begin_kernel(int M, DecodeState st, int bos, const float*
   for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)b * D + d] = embed[(long)bos * D + d];
 }
 
+// Loop bookkeeping of reference core/moonshine-model.cpp:511-516 for clip b once its token is chosen: append, stop
+// on EOS / step budget; returns the id the next step feeds.
+__device__ __forceinline__ int advance_bookkeeping(int besti, int b, const ClipMeta* __restrict__ clips, DecodeState st) {
+  if (besti == 0x7fffffff) besti = 0;  // all-NaN row: behave like the linear scan (index 0)
+  const int cnt = st.counts[b];
+  st.tokens[(long)b * st.stride + cnt] = besti;
+  st.counts[b] = cnt + 1;
+  int nxt = besti;
+  if (st.forced != nullptr && cnt < st.stride) nxt = st.forced[(long)b * st.stride + cnt];
+  // cnt generated tokens so far (BOS excluded): stop on EOS or when the step budget is used up
+  if ((besti == st.eos && !st.ignore_eos) || cnt >= clips[b].max_len) {
+    st.finished[b] = 1;
+    atomicSub(st.n_active, 1);
+  }
+  return nxt;
+}
+
 // One block per clip: first-max argmax (strict '>' scan order, ties -> lowest index, the rule of
 // reference core/ort-utils/moonshine-tensor-view.cpp:222-236), then the loop bookkeeping of
 // reference core/moonshine-model.cpp:511-516 (append, stop on EOS / step budget, next input id).
@@ -216,22 +233,62 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const float* __res
           best = bv[w];
           besti = bi[w];
         }
-      if (besti == 0x7fffffff) besti = 0;  // all-NaN row: behave like the linear scan (index 0)
-      const int cnt = st.counts[b];
-      st.tokens[(long)b * st.stride + cnt] = besti;
-      st.counts[b] = cnt + 1;
-      int nxt = besti;
-      if (st.forced != nullptr && cnt < st.stride) nxt = st.forced[(long)b * st.stride + cnt];
-      next_tok = nxt;
-      // cnt generated tokens so far (BOS excluded): stop on EOS or when the step budget is used up
-      if ((besti == st.eos && !st.ignore_eos) || cnt >= clips[b].max_len) {
-        st.finished[b] = 1;
-        atomicSub(st.n_active, 1);
-      }
+      next_tok = advance_bookkeeping(besti, b, clips, st);
     }
     __syncthreads();
     const int nt = next_tok;
     for (int d = tid; d < D; d += 1024) H[(long)b * D + d] = embed[(long)nt * D + d];
+  }
+  if (b == 0 && tid == 0) *st.pos += 1;
+}
+
+// The same step from per-tile (max, first index) pairs: tiles are in ascending column order, so among equal maxima
+// the lowest index is the first maximum of the whole row.
+__global__ __launch_bounds__(256) void decode_advance_partials_kernel(const float* __restrict__ pval,
+                                                                      const int* __restrict__ pidx, int ntn,
+                                                                      const ClipMeta* __restrict__ clips,
+                                                                      DecodeState st, const float* __restrict__ embed,
+                                                                      int D, float* __restrict__ H) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ int next_tok;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (st.finished[b] == 0) {
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = tid; i < ntn; i += 256) {
+      const float v = pval[(long)b * ntn + i];
+      const int ix = pidx[(long)b * ntn + i];
+      if (v > best || (v == best && ix < besti)) {
+        best = v;
+        besti = ix;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(besti, o);
+      if (ov > best || (ov == best && oi < besti)) {
+        best = ov;
+        besti = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      bv[tid >> 6] = best;
+      bi[tid >> 6] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
+          best = bv[w];
+          besti = bi[w];
+        }
+      next_tok = advance_bookkeeping(besti, b, clips, st);
+    }
+    __syncthreads();
+    const int nt = next_tok;
+    for (int d = tid; d < D; d += 256) H[(long)b * D + d] = embed[(long)nt * D + d];
   }
   if (b == 0 && tid == 0) *st.pos += 1;
 }
@@ -282,6 +339,12 @@ void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D,
 void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, DecodeState st, const float* embed_f32,
                     int D, float* H, hipStream_t s) {
   hipLaunchKernelGGL(decode_advance_kernel, dim3(M), dim3(1024), 0, s, logits, V, clips, st, embed_f32, D, H);
+}
+
+void decode_advance_partials(const float* pval, const int* pidx, int ntn, int M, const ClipMeta* clips, DecodeState st,
+                             const float* embed_f32, int D, float* H, hipStream_t s) {
+  hipLaunchKernelGGL(decode_advance_partials_kernel, dim3(M), dim3(256), 0, s, pval, pidx, ntn, clips, st, embed_f32, D,
+                     H);
 }
 
 }  // namespace msh

@@ -76,6 +76,12 @@ bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const floa
                           hipStream_t s);
 bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
 
+// LM head fused with the first stage of the argmax: per row and per 208-column tile the maximum logit and its
+// (lowest) column -> pval / pidx [M][gemm_argmax_tiles(N)]; the logits themselves are never written.
+int gemm_argmax_tiles(int N);
+void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* pval, int* pidx,
+                          hipStream_t s);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,
@@ -117,6 +123,9 @@ struct DecodeState {
 };
 void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, DecodeState st, const float* embed_f32,
                     int D, float* H, hipStream_t s);
+// same, from the per-tile (max, index) pairs of gemm_argmax_partials
+void decode_advance_partials(const float* pval, const int* pidx, int ntn, int M, const ClipMeta* clips, DecodeState st,
+                             const float* embed_f32, int D, float* H, hipStream_t s);
 // H[b,:] = embed[BOS]; counters reset
 void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D, float* H, hipStream_t s);
 

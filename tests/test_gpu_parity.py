@@ -264,3 +264,27 @@ def test_decode_groups_match_single_stream(tmp_path_factory, monkeypatch, micro)
     forced = e3.transcribe_tokens(clips, forced_steps=9)
     monkeypatch.delenv("MSH_DEC_GROUPS")
     assert forced == e1.transcribe_tokens(clips, forced_steps=9)
+
+
+def test_fused_argmax_lm_head_matches_logits_path(tmp_path_factory):
+    """At batch >= 128 the LM head reduces each 128 x 208 tile to (max, first index) in its epilogue and the
+    logits are never written.  Tokens must equal the path that materialises the logits (requested here through
+    want_logits) exactly -- reference EOS / budget semantics and forced steps, ragged batch of 150 clips."""
+    cfg, w, lens, clips = eos_test_weights()
+    e, w, cfg = _engine(tmp_path_factory, "micro", 39, w)
+    many = [clips[i % len(clips)][: len(clips[i % len(clips)]) - 64 * (i // len(clips))] for i in range(150)]
+    e.encode(many)
+    fused, _ = e.decode()
+    e.encode(many)
+    plain, lg = e.decode(want_logits=3)
+    assert fused == plain
+    assert lg is not None and len({len(t) for t in fused}) > 2
+    # the tokens are the first-max argmax of those logits
+    for b in range(0, 150, 7):
+        for step in range(min(3, len(plain[b]) - 1)):
+            assert plain[b][step + 1] == int(np.argmax(lg[step, b]))
+    e.encode(many)
+    f9, _ = e.decode(forced_steps=9)
+    e.encode(many)
+    p9, _ = e.decode(forced_steps=9, want_logits=1)
+    assert f9 == p9
