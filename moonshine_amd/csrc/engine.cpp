@@ -570,11 +570,20 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
       dec_gemm_resid(dao, D, W.wo, nullptr, M, D, D, dH, s);
     }
-    {
-      ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
-      dec_gemm_ln_f32(dH, W.wq_c, M, D, D, dq, s);
-    }
-    {
+    static const bool fuse_q = [] {
+      const char* e = getenv("MSH_NO_FUSED_CROSSQ");
+      return !(e != nullptr && e[0] == '1');
+    }();
+    if (fuse_q && D <= 512 && M < 64) {  // latency-bound regime only (see k_attn.hip)
+      // LayerNorm + query projection of the clip's row run inside the attention kernel
+      ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * 2 + w_dd + M * D * 4.0);
+      dec_cross_attention_fused_q(dH, W.wq_c, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
+                                  VT_.as<bf16_t>() + (size_t)l * D * kv_keys_, clips, M, D, Hh, dao, s);
+    } else {
+      {
+        ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
+        dec_gemm_ln_f32(dH, W.wq_c, M, D, D, dq, s);
+      }
       ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
       dec_cross_attention(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
                           clips, M, D, Hh, dao, s);

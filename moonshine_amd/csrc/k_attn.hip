@@ -316,8 +316,15 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
 // chunk -- short enough to be latency-friendly at batch 1 and, with 4x more waves in flight than a
 // one-wave-per-head layout, enough bytes in flight to stream at HBM rate at batch 256.
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+// FUSEQ: the query projection runs here too.  `q` is then the fp32 residual stream H [M][D] and Wq the cross-q
+// weight [D][D] with the LayerNorm scale folded in (the layout of dec_gemm_ln_f32); each wave normalises the clip's
+// row (lane l owns k = 8l..8l+7) and reduces its own dh/4 query dims across lanes -- 13 extra 16-byte loads and a
+// few dozen shuffles that sit under the latency of the first K loads, instead of a separate 7 us GEMM launch.
+// Only for small batches: every (clip, head) workgroup re-reads its 43 KB slice of Wq, which at batch 256 adds
+// 88 MB of L2 traffic per layer next to the 177 MB K/V stream and costs more (31 -> 48 us) than the GEMM saved.
+template <int DH, bool FUSEQ>
 __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float* __restrict__ q,
+                                                                  const bf16_t* __restrict__ Wq,
                                                                   const bf16_t* __restrict__ KT,
                                                                   const bf16_t* __restrict__ VT,
                                                                   const ClipMeta* __restrict__ clips, int D,
@@ -338,8 +345,55 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
   const float c = rsqrtf((float)DH) * kLog2e;
 
   float qd[DQ];
+  if constexpr (FUSEQ) {
+    const int k0q = lane * 8;
+    const bool act = k0q < D;  // D / 8 lanes hold the row
+    const float* x = q + (long)b * D + k0q;
+    float xv[8];
+    if (act) {
+      const float4 a = *reinterpret_cast<const float4*>(x), c4 = *reinterpret_cast<const float4*>(x + 4);
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = c4.x; xv[5] = c4.y; xv[6] = c4.z; xv[7] = c4.w;
+    } else {
 #pragma unroll
-  for (int d = 0; d < DQ; ++d) qd[d] = qp[d];
+      for (int e = 0; e < 8; ++e) xv[e] = 0.f;
+    }
+    u32x4 wr[DQ];
+    const bf16_t* wrow = Wq + (long)(h * DH + wave * DQ) * D + k0q;
+#pragma unroll
+    for (int d = 0; d < DQ; ++d)
+      wr[d] = act ? *reinterpret_cast<const u32x4*>(wrow + (long)d * D) : u32x4{0u, 0u, 0u, 0u};
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += xv[e];
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xv[e] -= mean;
+        sq += xv[e] * xv[e];
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-5f);
+    // the decode GEMM this replaces rounds the normalised row to bf16 before the MFMA: do the same, so the two
+    // paths differ only in summation order
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const uint32_t pk = pack_bf16x2(xv[e] * rstd, xv[e + 1] * rstd);
+      xv[e] = bf_lo(pk);
+      xv[e + 1] = bf_hi(pk);
+    }
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) {
+      const u32x4 u = wr[d];
+      const float part = xv[0] * bf_lo(u.x) + xv[1] * bf_hi(u.x) + xv[2] * bf_lo(u.y) + xv[3] * bf_hi(u.y) +
+                         xv[4] * bf_lo(u.z) + xv[5] * bf_hi(u.z) + xv[6] * bf_lo(u.w) + xv[7] * bf_hi(u.w);
+      qd[d] = wave_sum(part);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) qd[d] = qp[d];
+  }
   float opart[DQ];
 #pragma unroll
   for (int d = 0; d < DQ; ++d) opart[d] = 0.f;
@@ -446,10 +500,23 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
   const int dh = D / heads;
   dim3 grid(M * heads);
   switch (dh) {
-    case 52: hipLaunchKernelGGL(dec_cross_attention_kernel<52>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
-    case 36: hipLaunchKernelGGL(dec_cross_attention_kernel<36>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
-    case 16: hipLaunchKernelGGL(dec_cross_attention_kernel<16>, grid, dim3(256), 0, s, q, KT, VT, clips, D, heads, out); break;
-    default: throw std::runtime_error("dec_cross_attention: unsupported head_dim " + std::to_string(dh));
+    case 52: hipLaunchKernelGGL((dec_cross_attention_kernel<52, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    case 36: hipLaunchKernelGGL((dec_cross_attention_kernel<36, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    case 16: hipLaunchKernelGGL((dec_cross_attention_kernel<16, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
+  }
+}
+
+void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t* KT, const bf16_t* VT,
+                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s) {
+  const int dh = D / heads;
+  if (D > 512 || (D & 7) != 0) throw std::runtime_error("dec_cross_attention_fused_q: unsupported width");
+  dim3 grid(M * heads);
+  switch (dh) {
+    case 52: hipLaunchKernelGGL((dec_cross_attention_kernel<52, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    case 36: hipLaunchKernelGGL((dec_cross_attention_kernel<36, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    case 16: hipLaunchKernelGGL((dec_cross_attention_kernel<16, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
   }
 }
 

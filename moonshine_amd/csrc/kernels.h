@@ -93,6 +93,11 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                          int heads, bf16_t* out, hipStream_t s);
 
+// same with the query projection fused in: H = fp32 residual stream [M,D], Wq = cross-q weight [D,D] with the
+// LayerNorm scale folded in (replaces dec_gemm_ln_f32 + dec_cross_attention)
+void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t* KT, const bf16_t* VT,
+                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s);
+
 // ---------------- elementwise / reductions ----------------
 // pack fp32 clips into the bf16 conv1 input stream (clip b at 384*row_start samples)
 void pack_audio(const float* const* clip_ptrs, const ClipMeta* clips, int n_clips, bf16_t* out, long out_elems,
