@@ -17,20 +17,27 @@ namespace {
 // fused into the fragment build: row sums are combined across the 4 waves through LDS.  The LayerNorm
 // scale gamma is folded into W at load time (W' = W * diag(gamma)), so the kernel only normalises.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int TN, bool LN, class Epi>
+template <int KS, int TN, bool LN, class Epi, int TM = 1>
 __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
                                                        const float* __restrict__ gamma,
                                                        const bf16_t* __restrict__ W, int M, int N, int n_tiles,
                                                        Epi epi) {
+  // TM = 2: the workgroup owns 32 rows (two MFMA row tiles) and every W fragment it loads feeds two MFMAs -- the
+  // weights are re-read M/32 instead of M/16 times.  At M = 256 these GEMMs are bound by exactly that L2 -> CU
+  // re-read traffic (fc1: 832 workgroups x 66 KB = 55 MB per launch at ~4 TB/s), not by HBM or latency.
   constexpr int K = 32 * KS;
   constexpr int KW = (KS + 3) / 4;  // k-steps per wave (upper bound)
-  __shared__ __attribute__((aligned(16))) float4 part[4][TN][64];
-  __shared__ float stat[2][4][16];
+  __shared__ __attribute__((aligned(16))) float4 part[4][TM * TN][64];
+  __shared__ float stat[2][4][16 * TM];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = (blockIdx.x / n_tiles) * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
-  int gm = m0 + li;
-  gm = gm < M ? gm : M - 1;
+  const int m0 = (blockIdx.x / n_tiles) * (16 * TM), n0 = (blockIdx.x % n_tiles) * (16 * TN);
+  int gm[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    gm[t] = m0 + t * 16 + li;
+    gm[t] = gm[t] < M ? gm[t] : M - 1;
+  }
 
   // ---- issue every load of this wave first ----
   uint4 wreg[KW][TN];
@@ -48,119 +55,156 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
   }
   // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors): fetched now so
   // that the kernel has ONE memory round trip on its critical path, not one per dependent stage
-  constexpr int NE = (TN + 3) / 4;
+  constexpr int NT = TM * TN;            // output tiles of the workgroup
+  constexpr int NE = (NT + 3) / 4;
   typename Epi::Pre epre[NE];
-  {
-    const int m = m0 + li;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int j = wave + 4 * e;
-      const int n = n0 + j * 16 + kg * 4;
-      if (j < TN && m < M && n < N) epre[e] = epi.pre(m, n);
-    }
+  for (int e = 0; e < NE; ++e) {
+    const int o = wave + 4 * e, t = o / TN, j = o - t * TN;
+    const int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
+    if (o < NT && m < M && n < N) epre[e] = epi.pre(m, n);
   }
-  bf16x8 afrag[KW];
+  bf16x8 afrag[TM][KW];
   if constexpr (LN) {
-    const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
-    float xv[KW][8];
-    float sum = 0.f;
+    float xv[TM][KW][8];
 #pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
-        const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
-        xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
-        xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+    for (int t = 0; t < TM; ++t) {
+      const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm[t] * lda + kg * 8;
+      float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum += xv[i][e];
+      for (int i = 0; i < KW; ++i) {
+        const int s = wave + 4 * i;
+        if (s < KS) {
+          const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
+          const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
+          xv[t][i][0] = a.x; xv[t][i][1] = a.y; xv[t][i][2] = a.z; xv[t][i][3] = a.w;
+          xv[t][i][4] = b.x; xv[t][i][5] = b.y; xv[t][i][6] = b.z; xv[t][i][7] = b.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += xv[t][i][e];
+        }
       }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (kg == 0) stat[0][wave][t * 16 + li] = sum;
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (kg == 0) stat[0][wave][li] = sum;
     __syncthreads();
-    const float mean = ((stat[0][0][li] + stat[0][1][li]) + (stat[0][2][li] + stat[0][3][li])) * (1.0f / (float)K);
-    float sq = 0.f;
+    float mean[TM];
 #pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      if (wave + 4 * i < KS) {
+    for (int t = 0; t < TM; ++t) {
+      const int r = t * 16 + li;
+      mean[t] = ((stat[0][0][r] + stat[0][1][r]) + (stat[0][2][r] + stat[0][3][r])) * (1.0f / (float)K);
+      float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = xv[i][e] - mean;
-          sq += d * d;
+      for (int i = 0; i < KW; ++i) {
+        if (wave + 4 * i < KS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = xv[t][i][e] - mean[t];
+            sq += d * d;
+          }
+        }
+      }
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      if (kg == 0) stat[1][wave][r] = sq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int r = t * 16 + li;
+      const float var = ((stat[1][0][r] + stat[1][1][r]) + (stat[1][2][r] + stat[1][3][r])) * (1.0f / (float)K);
+      const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        const int s = wave + 4 * i;
+        if (s < KS) {
+          uint4 q;
+          q.x = pack_bf16x2((xv[t][i][0] - mean[t]) * rstd, (xv[t][i][1] - mean[t]) * rstd);
+          q.y = pack_bf16x2((xv[t][i][2] - mean[t]) * rstd, (xv[t][i][3] - mean[t]) * rstd);
+          q.z = pack_bf16x2((xv[t][i][4] - mean[t]) * rstd, (xv[t][i][5] - mean[t]) * rstd);
+          q.w = pack_bf16x2((xv[t][i][6] - mean[t]) * rstd, (xv[t][i][7] - mean[t]) * rstd);
+          afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
         }
       }
     }
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    if (kg == 0) stat[1][wave][li] = sq;
-    __syncthreads();
-    const float var = ((stat[1][0][li] + stat[1][1][li]) + (stat[1][2][li] + stat[1][3][li])) * (1.0f / (float)K);
-    const float rstd = rsqrtf(var + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        uint4 t;
-        t.x = pack_bf16x2((xv[i][0] - mean) * rstd, (xv[i][1] - mean) * rstd);
-        t.y = pack_bf16x2((xv[i][2] - mean) * rstd, (xv[i][3] - mean) * rstd);
-        t.z = pack_bf16x2((xv[i][4] - mean) * rstd, (xv[i][5] - mean) * rstd);
-        t.w = pack_bf16x2((xv[i][6] - mean) * rstd, (xv[i][7] - mean) * rstd);
-        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
-      }
-    }
   } else {
-    const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
 #pragma unroll
-    for (int i = 0; i < KW; ++i) {
-      const int s = wave + 4 * i;
-      if (s < KS) {
-        uint4 t = *reinterpret_cast<const uint4*>(a + s * 32);
-        afrag[i] = *reinterpret_cast<bf16x8*>(&t);
+    for (int t = 0; t < TM; ++t) {
+      const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm[t] * lda + kg * 8;
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        const int s = wave + 4 * i;
+        if (s < KS) {
+          uint4 q = *reinterpret_cast<const uint4*>(a + s * 32);
+          afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
+        }
       }
     }
   }
 
-  f32x4 acc[TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
     if (wave + 4 * i < KS) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[i], acc[j], 0,
-                                                         0, 0);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[t][i],
+                                                               acc[t][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int j = 0; j < TN; ++j) part[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      part[wave][t * TN + j][lane] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
   __syncthreads();
-  // waves 0..TN-1 (round-robin when TN > 4) finish one column tile each: fixed summation order
-  const int m = m0 + li;
+  // the waves finish the output tiles round-robin: fixed summation order
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
-    const int j = wave + 4 * e;
-    if (j < TN) {
-      const float4 p0 = part[0][j][lane], p1 = part[1][j][lane], p2 = part[2][j][lane], p3 = part[3][j][lane];
+    const int o = wave + 4 * e;
+    if (o < NT) {
+      const int t = o / TN, j = o - t * TN;
+      const float4 p0 = part[0][o][lane], p1 = part[1][o][lane], p2 = part[2][o][lane], p3 = part[3][o][lane];
       f32x4 v;
       v[0] = (p0.x + p1.x) + (p2.x + p3.x);
       v[1] = (p0.y + p1.y) + (p2.y + p3.y);
       v[2] = (p0.z + p1.z) + (p2.z + p3.z);
       v[3] = (p0.w + p1.w) + (p2.w + p3.w);
-      const int n = n0 + j * 16 + kg * 4;
+      const int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
       if (m < M && n < N) epi.n4p(m, n, v, epre[e]);
     }
   }
 }
 
-template <int KS, int TN, bool LN, class Epi>
+template <int KS, int TN, bool LN, class Epi, int TM = 1>
 void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
                     hipStream_t s) {
-  const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W, M,
-                     N, n_tiles, epi);
+  const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
+  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W,
+                     M, N, n_tiles, epi);
+}
+// 32-row workgroups for the K = D GEMMs of large batches (see gemm_dec_kernel); false if K has no such instance
+template <int TN, bool LN, class Epi>
+bool launch_dec_tm2(const void* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  switch (K) {
+    case 416: launch_dec_cfg<13, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 288: launch_dec_cfg<9, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 64: launch_dec_cfg<2, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
+    default: return false;
+  }
+}
+static int dec_tm2_threshold() {
+  static int thr = [] {
+    const char* e = getenv("MSH_DEC_TM2_M");
+    return e ? atoi(e) : 128;
+  }();
+  return thr;
 }
 
 // K is a compile-time multiple of 32: D (LN-fused and attention-output GEMMs) or F (fc2)
@@ -380,6 +424,9 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
                         hipStream_t s) {
   EpiSwiGLU epi{z, F, bias};
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
+  // 32-row workgroups pay off only where there are many column tiles (r01t, M = 256: fc1 14.1 -> 12.4 us, but
+  // qkv 9.8 -> 11.1 and cross-q 7.9 -> 11.1 us with half as many workgroups in flight)
+  if (M >= dec_tm2_threshold() && launch_dec_tm2<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
   if (M >= 96)
     launch_dec<4, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
   else
