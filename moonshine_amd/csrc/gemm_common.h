@@ -268,6 +268,38 @@ struct EpiSwiGLU {
   }
 };
 
+// Streaming decoder QKV: row m belongs to stream row_slot[m] at position row_pos[m].  q (RoPE applied) goes to
+// q_out [M][D]; k (RoPE) and v go straight into the stream's self-attention cache [slot][L][Scap][D] at that
+// position -- no [M][3D] round trip and no separate append kernel.
+struct EpiStreamQkv {
+  bf16_t* q_out;
+  bf16_t* cacheK;
+  bf16_t* cacheV;
+  const int* row_slot;
+  const int* row_pos;
+  RopeParams rp;
+  int layer, L, Scap;
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    const int D = rp.hidden;
+    const int which = n / D, c = n - which * D;
+    int pos = row_pos[m];
+    pos = pos < 0 ? 0 : pos;
+    if (which < 2) rope4(v, c % rp.head_dim, pos, rp);
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    bf16_t* dst;
+    if (which == 0)
+      dst = q_out + (long)m * D + c;
+    else
+      dst = (which == 1 ? cacheK : cacheV) + (((long)row_slot[m] * L + layer) * Scap + pos) * D + c;
+    *reinterpret_cast<uint2*>(dst) = o;
+  }
+};
+
 // Generic epilogue of the streaming path (frontend linear / causal convs, projections without a fused
 // consumer): out = act(acc + bias) written as bf16 and / or fp32.  act: 0 none, 1 SiLU, 2 GELU(erf).
 struct EpiAct {

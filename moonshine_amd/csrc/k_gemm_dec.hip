@@ -458,6 +458,34 @@ bool launch_dec_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, i
     default: return false;
   }
 }
+// LayerNorm-fused forms (A = fp32 residual stream, LayerNorm scale folded into W): K = decoder width only
+template <int TN, class Epi>
+bool launch_dec_ln(const float* H, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  if ((N & 3) != 0) return false;
+  switch (K) {
+    case 96: launch_dec_cfg<3, TN, true, Epi>(H, K, nullptr, W, M, N, epi, s); return true;
+    case 288: launch_dec_cfg<9, TN, true, Epi>(H, K, nullptr, W, M, N, epi, s); return true;
+    case 320: launch_dec_cfg<10, TN, true, Epi>(H, K, nullptr, W, M, N, epi, s); return true;
+    case 416: launch_dec_cfg<13, TN, true, Epi>(H, K, nullptr, W, M, N, epi, s); return true;
+    case 640: launch_dec_cfg<20, TN, true, Epi>(H, K, nullptr, W, M, N, epi, s); return true;
+    default: return false;
+  }
+}
+bool small_ln_gemm_stream_qkv(const float* H, const bf16_t* Wf, int M, int D, bf16_t* q_out, bf16_t* cacheK,
+                              bf16_t* cacheV, const int* row_slot, const int* row_pos, RopeParams rp, int layer, int L,
+                              int Scap, hipStream_t s) {
+  return launch_dec_ln<2>(H, Wf, M, 3 * D, D, EpiStreamQkv{q_out, cacheK, cacheV, row_slot, row_pos, rp, layer, L, Scap}, s);
+}
+bool small_ln_gemm_bf16(const float* H, const bf16_t* Wf, int M, int N, int D, bf16_t* out, hipStream_t s) {
+  return launch_dec_ln<2>(H, Wf, M, N, D, EpiAct{out, nullptr, N, nullptr, 0}, s);
+}
+bool small_ln_gemm_swiglu(const float* H, const bf16_t* Wf, const float* bias, int M, int N, int D, bf16_t* z,
+                          hipStream_t s) {
+  return launch_dec_ln<2>(H, Wf, M, N, D, EpiSwiGLU{z, N / 2, bias}, s);
+}
+bool small_ln_gemm_logits(const float* H, const bf16_t* Wf, int M, int N, int D, float* out, hipStream_t s) {
+  return launch_dec_ln<4>(H, Wf, M, N, D, EpiF32{out, N}, s);
+}
 bool small_gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,
                     bf16_t* out_bf16, float* out_f32, hipStream_t s) {
   return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiAct{out_bf16, out_f32, N, bias, act}, s);

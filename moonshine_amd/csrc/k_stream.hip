@@ -112,8 +112,8 @@ __global__ void adapter_in_kernel(const float* __restrict__ y32, const int* __re
   }
 }
 
-// K goes in transposed ([slot][L][D][Mcap], keys contiguous: the score pass of cross-attention reads one head
-// dimension of many keys per load), V row-major ([slot][L][Mcap][D]: the value pass reads whole rows).
+// K and V go in transposed ([slot][L][D][Mcap], keys contiguous): the cross-attention kernel streams 16 bytes
+// (8 keys) per lane per head-dim row, for the scores and for the values alike.
 __global__ void scatter_cross_kernel(const bf16_t* __restrict__ tmp, const int* __restrict__ slot,
                                      const int* __restrict__ idx, int L, int D, int Mcap, bf16_t* __restrict__ crossK,
                                      bf16_t* __restrict__ crossV) {
@@ -121,9 +121,10 @@ __global__ void scatter_cross_kernel(const bf16_t* __restrict__ tmp, const int* 
   const bf16_t* src = tmp + ((long)i * L + l) * 2 * D;
   const long base = ((long)slot[i] * L + l) * Mcap * D;
   const int key = idx[i];
-  for (int d = threadIdx.x; d < D; d += blockDim.x) crossK[base + (long)d * Mcap + key] = src[d];
-  for (int d = threadIdx.x * 8; d < D; d += blockDim.x * 8)
-    *reinterpret_cast<uint4*>(crossV + base + (long)key * D + d) = *reinterpret_cast<const uint4*>(src + D + d);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    crossK[base + (long)d * Mcap + key] = src[d];
+    crossV[base + (long)d * Mcap + key] = src[D + d];
+  }
 }
 
 __global__ void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ embed, int D,
@@ -147,9 +148,10 @@ __global__ void self_append_kernel(const bf16_t* __restrict__ qkv, const int* __
   }
 }
 
-// one wave per (row, head): keys [0, pos], scores through LDS (at most SMAX keys)
+// one wave per (row, head): keys [0, pos], scores through LDS (at most SMAX keys).  Value pass: dh/4 lanes share one
+// cached row (8-byte loads), 64 / (dh/4) keys in flight per step, the key groups' partial sums meet in LDS.
 constexpr int SELF_SMAX = 512;
-__global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __restrict__ q, int q_stride,
                                                              const int* __restrict__ row_slot,
                                                              const int* __restrict__ row_pos, int M, int D, int heads,
                                                              int layer, int L, int Scap,
@@ -158,13 +160,14 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ out) {
   __shared__ float sq[4][128];
   __shared__ float sp[4][SELF_SMAX];
+  __shared__ float part[4][16][128];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + w;
   if (item >= M * heads) return;
   const int row = item / heads, head = item - row * heads, dh = D / heads;
   const float scale = rsqrtf((float)dh);
-  const bf16_t* q = qkv + (long)row * 3 * D + head * dh;
-  for (int d = lane; d < dh; d += 64) sq[w][d] = bf(q[d]) * scale;
+  const bf16_t* qr = q + (long)row * q_stride + head * dh;
+  for (int d = lane; d < dh; d += 64) sq[w][d] = bf(qr[d]) * scale;
   const int nk = row_pos[row] + 1;
   const long base = (((long)row_slot[row] * L + layer) * Scap) * D + head * dh;
   __builtin_amdgcn_wave_barrier();
@@ -183,32 +186,145 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
   }
   const float inv = 1.0f / wsum(sum);
   __builtin_amdgcn_wave_barrier();
+  const int tpk = dh >> 2;
+  int G = 64 / tpk;
+  G = G > 16 ? 16 : G;
+  const int g = lane / tpk, c = lane - g * tpk;
+  if (g < G) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bf16_t* v = cacheV + base + c * 4;
+#pragma unroll 4
+    for (int j = g; j < nk; j += G) {
+      const uint2 r = *reinterpret_cast<const uint2*>(v + (long)j * D);
+      const float p = sp[w][j];
+      acc.x += p * __uint_as_float(r.x << 16);
+      acc.y += p * __uint_as_float(r.x & 0xffff0000u);
+      acc.z += p * __uint_as_float(r.y << 16);
+      acc.w += p * __uint_as_float(r.y & 0xffff0000u);
+    }
+    *reinterpret_cast<float4*>(&part[w][g][c * 4]) = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
   for (int d = lane; d < dh; d += 64) {
-    float acc = 0.f;
-    const bf16_t* v = cacheV + base + d;
-    for (int j = 0; j < nk; ++j) acc += sp[w][j] * bf(v[(long)j * D]);
-    out[(long)row * D + head * dh + d] = f32_to_bf16(acc * inv);
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += part[w][k][d];
+    out[(long)row * D + head * dh + d] = f32_to_bf16(t * inv);
   }
 }
 
-// one workgroup per (row, head): all memory keys of the row's stream.
-//   scores : a thread takes 4 consecutive keys and walks the head dims of K^T -- every load instruction of a wave
-//            covers 512 contiguous bytes;
-//   values : dh/4 threads share one key row of V (8-byte loads), 256 / (dh/4) keys in flight per pass, partial
-//            sums of the key groups combined through LDS.
+// Cross-attention: one workgroup per (row, head), its 4 waves split the head dim (the layout of the offline
+// dec_cross_attention_kernel).  K^T / V^T rows are keys-contiguous: lane l owns keys 8l..8l+7 of a 512-key chunk
+// and loads 16 bytes per head-dim row; wave w covers rows d in [w*dh/4, (w+1)*dh/4).  All 2*dh/4 loads of a chunk
+// are independent and issued back to back -- one memory round trip per chunk instead of one per head dim --
+// partial q.k sums meet in LDS, every wave runs the same fp32 online softmax (exp2 domain) and accumulates its
+// own output dims, reduced across lanes at the end.
 constexpr int CROSS_MMAX = 4096;
-constexpr int CROSS_GMAX = 16;
-__global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __restrict__ q,
-                                                              const int* __restrict__ row_slot,
-                                                              const SlotDev* __restrict__ slots, int D, int heads,
-                                                              int layer, int L, int Mcap,
-                                                              const bf16_t* __restrict__ crossKT,
-                                                              const bf16_t* __restrict__ crossV,
-                                                              bf16_t* __restrict__ out) {
+typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float s_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float s_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+template <int DH>
+__global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* __restrict__ q,
+                                                                 const int* __restrict__ row_slot,
+                                                                 const SlotDev* __restrict__ slots, int D, int heads,
+                                                                 int layer, int L, int Mcap,
+                                                                 const bf16_t* __restrict__ crossKT,
+                                                                 const bf16_t* __restrict__ crossVT,
+                                                                 bf16_t* __restrict__ out) {
+  constexpr int DQ = DH / 4;
+  __shared__ float sp[4][512];
+  __shared__ float red[4][DQ][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = blockIdx.x, h = blockIdx.y;
+  const int slot = row_slot[row];
+  const int nk = slots[slot].mem_len;
+  const long base = (((long)slot * L + layer) * D + h * DH + wave * DQ) * Mcap;
+  const bf16_t* kt = crossKT + base;
+  const bf16_t* vt = crossVT + base;
+  const float c = rsqrtf((float)DH) * 1.4426950408889634f;
+  float qd[DQ];
+#pragma unroll
+  for (int d = 0; d < DQ; ++d) qd[d] = bf(q[(long)row * D + h * DH + wave * DQ + d]);
+  float opart[DQ];
+#pragma unroll
+  for (int d = 0; d < DQ; ++d) opart[d] = 0.f;
+  float m_run = -INFINITY, l_part = 0.f;
+#pragma unroll 1
+  for (int k0 = 0; k0 < nk; k0 += 512) {
+    const int key = k0 + lane * 8;
+    const bool in = key < nk;  // nk <= Mcap and Mcap % 8 == 0: an "in" lane's 8 keys are inside the row
+    su32x4 kr[DQ], vr[DQ];
+#pragma unroll
+    for (int d = 0; d < DQ; ++d)
+      kr[d] = in ? *reinterpret_cast<const su32x4*>(kt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+    float sc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sc[e] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) {
+      const su32x4 u = kr[d];
+      sc[0] += qd[d] * s_lo(u.x); sc[1] += qd[d] * s_hi(u.x);
+      sc[2] += qd[d] * s_lo(u.y); sc[3] += qd[d] * s_hi(u.y);
+      sc[4] += qd[d] * s_lo(u.z); sc[5] += qd[d] * s_hi(u.z);
+      sc[6] += qd[d] * s_lo(u.w); sc[7] += qd[d] * s_hi(u.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the V rows are requested only now (K registers are dead)
+#pragma unroll
+    for (int d = 0; d < DQ; ++d)
+      vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+    if (k0 > 0) __syncthreads();
+    *reinterpret_cast<float4*>(&sp[wave][lane * 8]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+    *reinterpret_cast<float4*>(&sp[wave][lane * 8 + 4]) = make_float4(sc[4], sc[5], sc[6], sc[7]);
+    __syncthreads();
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = lane * 8 + e;
+      const float t = (sp[0][i] + sp[1][i]) + (sp[2][i] + sp[3][i]);
+      sc[e] = (key + e < nk) ? t * c : -INFINITY;
+      mloc = fmaxf(mloc, sc[e]);
+    }
+    mloc = wmax(mloc);
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = exp2f(sc[e] - m_new);
+      psum += sc[e];
+    }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) {
+      const su32x4 u = vr[d];
+      const float part = sc[0] * s_lo(u.x) + sc[1] * s_hi(u.x) + sc[2] * s_lo(u.y) + sc[3] * s_hi(u.y) +
+                         sc[4] * s_lo(u.z) + sc[5] * s_hi(u.z) + sc[6] * s_lo(u.w) + sc[7] * s_hi(u.w);
+      opart[d] = opart[d] * alpha + part;
+    }
+  }
+  const float l = wsum(l_part);
+#pragma unroll
+  for (int d = 0; d < DQ; ++d) red[wave][d][lane] = opart[d];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DQ) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
+    out[(long)row * D + h * DH + wave * DQ + lane] = f32_to_bf16(acc / l);
+  }
+}
+
+// Any other head_dim (multiple of 4, <= 128): plain two-pass kernel over the same transposed layouts.
+__global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16_t* __restrict__ q,
+                                                                      const int* __restrict__ row_slot,
+                                                                      const SlotDev* __restrict__ slots, int D,
+                                                                      int heads, int layer, int L, int Mcap,
+                                                                      const bf16_t* __restrict__ crossKT,
+                                                                      const bf16_t* __restrict__ crossVT,
+                                                                      bf16_t* __restrict__ out) {
   __shared__ float sq[128];
   __shared__ float sp[CROSS_MMAX];
   __shared__ float red[8];
-  __shared__ float part[CROSS_GMAX][128];
   const int row = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int dh = D / heads;
   const float scale = rsqrtf((float)dh);
@@ -216,36 +332,21 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __re
   const int nk = slots[slot].mem_len;
   for (int d = tid; d < dh; d += 256) sq[d] = bf(q[(long)row * D + head * dh + d]) * scale;
   __syncthreads();
-  const long base = ((long)slot * L + layer) * Mcap * D;
-  const bf16_t* kt = crossKT + base + (long)head * dh * Mcap;
+  const long base = (((long)slot * L + layer) * D + head * dh) * Mcap;
   float mx = -INFINITY;
-  for (int j = tid * 4; j < nk; j += 1024) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < dh; ++d) {
-      const uint2 r = *reinterpret_cast<const uint2*>(kt + (long)d * Mcap + j);
-      const float qd = sq[d];
-      a0 += qd * __uint_as_float(r.x << 16);
-      a1 += qd * __uint_as_float(r.x & 0xffff0000u);
-      a2 += qd * __uint_as_float(r.y << 16);
-      a3 += qd * __uint_as_float(r.y & 0xffff0000u);
-    }
-    const float sc[4] = {a0, a1, a2, a3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = j + i < nk ? sc[i] : -INFINITY;
-      sp[j + i] = v;
-      mx = fmaxf(mx, v);
-    }
+  for (int j = tid; j < nk; j += 256) {
+    float a = 0.f;
+    for (int d = 0; d < dh; ++d) a += sq[d] * bf(crossKT[base + (long)d * Mcap + j]);
+    sp[j] = a;
+    mx = fmaxf(mx, a);
   }
   mx = wmax(mx);
   if (lane == 0) red[w] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
-  const int nk4 = (nk + 3) & ~3;
-  for (int j = tid; j < nk4; j += 256) {
-    const float e = j < nk ? __expf(sp[j] - mx) : 0.f;
+  for (int j = tid; j < nk; j += 256) {
+    const float e = __expf(sp[j] - mx);
     sp[j] = e;
     sum += e;
   }
@@ -253,29 +354,12 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const bf16_t* __re
   if (lane == 0) red[4 + w] = sum;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  const int tpk = dh >> 2;                       // threads per key row
-  int G = 256 / tpk;
-  G = G > CROSS_GMAX ? CROSS_GMAX : G;
-  const int g = tid / tpk, c = tid - g * tpk;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g < G) {
-    const bf16_t* v = crossV + base + head * dh + c * 4;
-#pragma unroll 4
-    for (int j = g; j < nk; j += G) {
-      const uint2 r = *reinterpret_cast<const uint2*>(v + (long)j * D);
-      const float p = sp[j];
-      acc.x += p * __uint_as_float(r.x << 16);
-      acc.y += p * __uint_as_float(r.x & 0xffff0000u);
-      acc.z += p * __uint_as_float(r.y << 16);
-      acc.w += p * __uint_as_float(r.y & 0xffff0000u);
-    }
-    *reinterpret_cast<float4*>(&part[g][c * 4]) = acc;
-  }
-  __syncthreads();
-  for (int d = tid; d < dh; d += 256) {
-    float t = 0.f;
-    for (int k = 0; k < G; ++k) t += part[k][d];
-    out[(long)row * D + head * dh + d] = f32_to_bf16(t * inv);
+  // one wave per head dim (round-robin), lanes over keys
+  for (int d = w; d < dh; d += 4) {
+    float a = 0.f;
+    for (int j = lane; j < nk; j += 64) a += sp[j] * bf(crossVT[base + (long)d * Mcap + j]);
+    a = wsum(a);
+    if (lane == 0) out[(long)row * D + head * dh + d] = f32_to_bf16(a * inv);
   }
 }
 
@@ -530,18 +614,44 @@ void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* ro
   if (M <= 0) return;
   hipLaunchKernelGGL(self_append_kernel, dim3(M), dim3(128), 0, s, qkv, row_slot, row_pos, D, layer, L, Scap, cacheK,
                      cacheV);
-  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, row_slot, row_pos, M, D,
+  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, 3 * D, row_slot, row_pos, M,
+                     D, heads, layer, L, Scap, cacheK, cacheV, out);
+}
+void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
+                                  int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
+                                  hipStream_t s) {
+  const int dh = D / heads;
+  if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
+    throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
+  if (M <= 0) return;
+  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, q, D, row_slot, row_pos, M, D,
                      heads, layer, L, Scap, cacheK, cacheV, out);
 }
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
                             hipStream_t s) {
   const int dh = D / heads;
-  if (Mcap > CROSS_MMAX || dh > 128 || (dh & 3) != 0)
+  if (Mcap > CROSS_MMAX || dh > 128 || (dh & 3) != 0 || (Mcap & 7) != 0)
     throw std::runtime_error("stream_cross_attention: unsupported memory length or head_dim");
   if (M <= 0) return;
-  hipLaunchKernelGGL(cross_attention_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L,
-                     Mcap, crossK, crossV, out);
+#define MSH_XATT(DHV)                                                                                                  \
+  case DHV:                                                                                                            \
+    hipLaunchKernelGGL(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
+                       layer, L, Mcap, crossK, crossV, out);                                                          \
+    break
+  switch (dh) {
+    MSH_XATT(16);
+    MSH_XATT(24);
+    MSH_XATT(36);
+    MSH_XATT(40);
+    MSH_XATT(52);
+    MSH_XATT(64);
+    MSH_XATT(80);
+    default:
+      hipLaunchKernelGGL(cross_attention_generic_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,
+                         layer, L, Mcap, crossK, crossV, out);
+  }
+#undef MSH_XATT
 }
 void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s) {
   if ((V & 3) != 0) throw std::runtime_error("stream_argmax: vocabulary must be a multiple of 4");

@@ -76,6 +76,17 @@ bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const floa
                           hipStream_t s);
 bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
 
+// LayerNorm-fused small-batch forms for the streaming decoder's AR steps: H = fp32 residual stream [M][D], Wf = the
+// weight with the LayerNorm scale folded in.  small_ln_gemm_stream_qkv writes q to q_out and k / v straight into
+// the per-stream self-attention cache (see EpiStreamQkv).  False when D is not a compiled width.
+bool small_ln_gemm_stream_qkv(const float* H, const bf16_t* Wf, int M, int D, bf16_t* q_out, bf16_t* cacheK,
+                              bf16_t* cacheV, const int* row_slot, const int* row_pos, RopeParams rp, int layer, int L,
+                              int Scap, hipStream_t s);
+bool small_ln_gemm_bf16(const float* H, const bf16_t* Wf, int M, int N, int D, bf16_t* out, hipStream_t s);
+bool small_ln_gemm_swiglu(const float* H, const bf16_t* Wf, const float* bias, int M, int N, int D, bf16_t* z,
+                          hipStream_t s);
+bool small_ln_gemm_logits(const float* H, const bf16_t* Wf, int M, int N, int D, float* out, hipStream_t s);
+
 // LM head fused with the first stage of the argmax: per row and per 208-column tile the maximum logit and its
 // (lowest) column -> pval / pidx [M][gemm_argmax_tiles(N)]; the logits themselves are never written.
 int gemm_argmax_tiles(int N);

@@ -7,8 +7,7 @@
 //   conv1_buf [4][De] / conv2_buf [4][2De] bf16    the frontend's carried frames
 //   features  [Mcap][De] fp32                       accumulated_features
 //   memory    [Mcap][Dd] fp32                       adapter output (kept for inspection)
-//   crossK    [L][Dd][Mcap] bf16 (keys contiguous)    cross-attention keys, transposed; appended per update
-//   crossV    [L][Mcap][Dd] bf16                      cross-attention values
+//   crossK/V  [L][Dd][Mcap] bf16 (keys contiguous)   cross-attention keys / values, transposed; appended per update
 //   selfK/V   [L][Scap][Dd] bf16                    decoder self-attention cache
 //   result    [Scap] int32 + SlotDev                decode_full bookkeeping
 // Calls take a list of slots and work on all of them at once: rows of every GEMM are the concatenation of
@@ -101,6 +100,7 @@ class StreamingEngine {
   struct DecW {
     float *ln1, *ln2, *ln3, *b1, *b2;
     bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;
+    bf16_t *wqkv_f, *wq_c_f, *fc1_f;  // LayerNorm scale folded in (LN-fused small-batch GEMMs of the AR steps)
   };
 
   int device_;
@@ -113,7 +113,7 @@ class StreamingEngine {
   // weights
   float k_scale_ = 0.75f;
   bf16_t *lin_w_ = nullptr, *conv1_w_ = nullptr, *conv2_w_ = nullptr, *proj_w_ = nullptr, *cross_w_ = nullptr,
-         *head_w_ = nullptr;
+         *head_w_ = nullptr, *head_wf_ = nullptr;
   float *conv1_b_ = nullptr, *conv2_b_ = nullptr, *enc_ln_ = nullptr, *pos_emb_ = nullptr, *embed_f32_ = nullptr,
         *dec_ln_ = nullptr, *rope_cos_ = nullptr, *rope_sin_ = nullptr;
   int rot_pairs_ = 0;

@@ -57,7 +57,7 @@ void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_h
 // adapter input: out[i] = y32[rows[i]] + pos_emb[pos[i]]  (lora/export.py:141-144), as bf16 and fp32
 void stream_adapter_in(const float* y32, const int* rows, const int* pos, int n, int D, const float* pos_emb,
                        bf16_t* out16, float* out32, hipStream_t s);
-// tmp [n][L*2*D] (per layer: k row, v row) -> crossK [slot][L][D][Mcap] (transposed) / crossV [slot][L][Mcap][D]
+// tmp [n][L*2*D] (per layer: k row, v row) -> crossK / crossV [slot][L][D][Mcap] (transposed, keys contiguous)
 // at memory index idx[i]
 void stream_scatter_cross(const bf16_t* tmp, const int* slot, const int* idx, int n, int L, int D, int Mcap,
                           bf16_t* crossK, bf16_t* crossV, hipStream_t s);
@@ -65,6 +65,10 @@ void stream_embed(const int* tokens, int M, const float* embed, int D, float* H,
 // append k / v of every row to the self cache [slot][L][Scap][D] at row_pos, then causal attention over [0, row_pos]
 void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* row_pos, int M, int D, int heads, int layer,
                            int L, int Scap, bf16_t* cacheK, bf16_t* cacheV, bf16_t* out, hipStream_t s);
+// same attention when k / v of the rows are already in the cache (written by the QKV GEMM epilogue): q [M,D] bf16
+void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
+                                  int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
+                                  hipStream_t s);
 // cross-attention of every row over its stream's memory (keys [0, slots[slot].mem_len))
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
