@@ -83,11 +83,12 @@ def gather_tokens(local: list[list[int]], n_total: int, world: int, rank: int, d
     width = torch.tensor([max((len(t) for t in local), default=0)], dtype=torch.int64, device=device)
     dist.all_reduce(width, op=dist.ReduceOp.MAX)
     w = int(width.item())
-    mine = torch.full((per, w + 1), -1, dtype=torch.int32, device=device)  # column 0 = length
+    host = np.full((per, w + 1), -1, dtype=np.int32)  # column 0 = length; packed on the host, ONE copy to the device
     for i, t in enumerate(local):
-        mine[i, 0] = len(t)
+        host[i, 0] = len(t)
         if t:
-            mine[i, 1 : 1 + len(t)] = torch.tensor(t, dtype=torch.int32, device=device)
+            host[i, 1 : 1 + len(t)] = t
+    mine = torch.from_numpy(host).to(device)
     out = torch.empty((world * per, w + 1), dtype=torch.int32, device=device)  # concatenated along dim 0
     dist.all_gather_into_tensor(out, mine)
     out = out.view(world, per, w + 1).cpu().numpy()
