@@ -11,6 +11,8 @@
 //                       ([dh][Tk] bf16, keys contiguous) with 16-byte non-temporal buffer loads: the
 //                       HBM-bound kernel that dominates batched decode (5.5 MB per clip per step at
 //                       Moonshine-base).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace msh {
@@ -45,7 +47,10 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 constexpr int KB = 64;        // keys per LDS block
 constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: conflict-free ds_read_b64)
 
-template <int DH>
+// QT query tiles of 16 per wave: a workgroup covers 64 * QT queries of one (clip, head).  With QT = 2 every staged
+// K / V^T block and every LDS fragment read serves two MFMAs, and a 415-frame clip needs 4 passes over its keys
+// instead of 7.
+template <int DH, int QT>
 __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __restrict__ qkv,
                                                             bf16_t* __restrict__ out,
                                                             const ClipMeta* __restrict__ clips, int D) {
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
   __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VT_LD];    // [d][key]
 
   const ClipMeta cm = clips[blockIdx.z];
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * 64 * QT;
   if (q0 >= cm.rows) return;
   const int h = blockIdx.y;
   const int T = cm.T;
@@ -71,24 +76,33 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
   for (int p = tid; p < (64 - DH) * VT_LD; p += 256) Vt[DH * VT_LD + p] = 0;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds q row (li), d = s*32 + kg*8 .. +8
-  int qrow = q0 + wave * 16 + li;
-  const int qrow_ld = qrow < cm.rows ? qrow : cm.rows - 1;
-  bf16x8 qf[2];
+  int qrow[QT];
+  bf16x8 qf[QT][2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int d = s * 32 + kg * 8;
-    uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-    if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
-    if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
-    uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    qf[s] = *reinterpret_cast<bf16x8*>(&t);
+  for (int qi = 0; qi < QT; ++qi) {
+    qrow[qi] = q0 + (wave * QT + qi) * 16 + li;
+    const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int d = s * 32 + kg * 8;
+      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+      if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
+      if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
+      uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
+    }
   }
 
   const float c = rsqrtf((float)DH) * kLog2e;  // scores are compared / exponentiated in the exp2 domain
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4 o[4];
+  float m_run[QT], l_run[QT];
+  f32x4 o[QT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qi = 0; qi < QT; ++qi) {
+    m_run[qi] = -INFINITY;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nkb = (T + KB - 1) / KB;
   for (int kb = 0; kb < nkb; ++kb) {
@@ -115,54 +129,72 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     }
     __syncthreads();
 
-    // S^T tiles: rows = keys, cols = queries.  st[kt][r] = score(q = li, key = kb*64 + kt*16 + kg*4 + r)
-    f32x4 st[4];
+    // S^T tiles: rows = keys, cols = queries.  st[qi][kt][r] = score(q = li of tile qi, key = kb*64 + kt*16 + kg*4 + r)
+    f32x4 st[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
       const int key = kt * 16 + li;
+      uint4 kf[2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint4 t = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&t), qf[s], a, 0, 0, 0);
+      for (int s = 0; s < 2; ++s) kf[s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
+#pragma unroll
+      for (int qi = 0; qi < QT; ++qi) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[s]), qf[qi][s], a, 0, 0, 0);
+        st[qi][kt] = a;
       }
-      st[kt] = a;
     }
-    float mloc = -INFINITY;
+    bf16x8 pf[QT][2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int qi = 0; qi < QT; ++qi) {
+      // the softmax is VALU-bound (16 exp2 per lane per tile): keep the per-score work to max, one fma and the
+      // exp2 -- the scale is folded into the fma (c > 0, so the max of the raw scores is the max), and keys past
+      // the clip's length are masked only in the block that contains them
+      if (kb * KB + KB > T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = kb * KB + kt * 16 + kg * 4 + r;
-        st[kt][r] = t < T ? st[kt][r] * c : -INFINITY;
-        mloc = fmaxf(mloc, st[kt][r]);
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kb * KB + kt * 16 + kg * 4 + r >= T) st[qi][kt][r] = -INFINITY;
       }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+      float mloc = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
-        psum += st[kt][r];
+        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[qi][kt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float m_new = fmaxf(m_run[qi], mloc * c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+      m_run[qi] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[qi][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][kt][r], c, -m_new));
+          psum += st[qi][kt][r];
+        }
+      l_run[qi] = l_run[qi] * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+      // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 pt;
+        pt.x = pack_bf16x2(st[qi][2 * ks][0], st[qi][2 * ks][1]);
+        pt.y = pack_bf16x2(st[qi][2 * ks][2], st[qi][2 * ks][3]);
+        pt.z = pack_bf16x2(st[qi][2 * ks + 1][0], st[qi][2 * ks + 1][1]);
+        pt.w = pack_bf16x2(st[qi][2 * ks + 1][2], st[qi][2 * ks + 1][3]);
+        pf[qi][ks] = *reinterpret_cast<bf16x8*>(&pt);
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    }
 
-    // O^T += V^T P^T.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
+    // O^T += V^T P^T: every V^T fragment read from LDS feeds the QT query tiles
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 pt;
-      pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
-      pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
-      pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-      pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-      const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pt);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         if (dt * 16 >= DH) continue;
@@ -170,27 +202,33 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
         const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
         const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
         uint4 vt = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vt), pf, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi)
+          o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vt), pf[qi][ks], o[qi][dt], 0, 0, 0);
       }
     }
   }
 
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_run;
-  if (qrow < cm.rows) {
-    const bool valid = qrow < T;
-    bf16_t* orow = out + (long)(cm.row_start + qrow) * D + h * DH;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int d = dt * 16 + kg * 4;
-      if (d < DH) {
-        uint2 w = make_uint2(0u, 0u);
-        if (valid) {
-          w.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-          w.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+  for (int qi = 0; qi < QT; ++qi) {
+    float l = l_run[qi];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (qrow[qi] < cm.rows) {
+      const bool valid = qrow[qi] < T;
+      bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + kg * 4;
+        if (d < DH) {
+          uint2 w = make_uint2(0u, 0u);
+          if (valid) {
+            w.x = pack_bf16x2(o[qi][dt][0] * inv, o[qi][dt][1] * inv);
+            w.y = pack_bf16x2(o[qi][dt][2] * inv, o[qi][dt][3] * inv);
+          }
+          *reinterpret_cast<uint2*>(orow + d) = w;
         }
-        *reinterpret_cast<uint2*>(orow + d) = w;
       }
     }
   }
@@ -473,13 +511,27 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows, int D, int heads,
                    hipStream_t s) {
   const int dh = D / heads;
-  dim3 grid((max_rows + 63) / 64, heads, n_clips);
+  static const int qt_env = [] {
+    const char* e = getenv("MSH_ENC_ATTN_QT");
+    return e ? atoi(e) : 2;
+  }();
+  // two query tiles per wave once a clip has more than one 64-query block (see enc_attention_kernel)
+  const int qt = (qt_env == 2 && max_rows > 64) ? 2 : 1;
+  dim3 grid((max_rows + 64 * qt - 1) / (64 * qt), heads, n_clips);
+#define MSH_EATT(DHV)                                                                                          \
+  case DHV:                                                                                                    \
+    if (qt == 2)                                                                                               \
+      hipLaunchKernelGGL((enc_attention_kernel<DHV, 2>), grid, dim3(256), 0, s, qkv, out, clips, D);           \
+    else                                                                                                       \
+      hipLaunchKernelGGL((enc_attention_kernel<DHV, 1>), grid, dim3(256), 0, s, qkv, out, clips, D);           \
+    break
   switch (dh) {
-    case 52: hipLaunchKernelGGL(enc_attention_kernel<52>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
-    case 36: hipLaunchKernelGGL(enc_attention_kernel<36>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
-    case 16: hipLaunchKernelGGL(enc_attention_kernel<16>, grid, dim3(256), 0, s, qkv, out, clips, D); break;
+    MSH_EATT(52);
+    MSH_EATT(36);
+    MSH_EATT(16);
     default: throw std::runtime_error("enc_attention: unsupported head_dim " + std::to_string(dh));
   }
+#undef MSH_EATT
 }
 
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
