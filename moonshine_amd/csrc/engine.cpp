@@ -15,7 +15,11 @@ bool DevBuf::reserve(size_t bytes) {
   size_t want = bytes + bytes / 8 + 256;  // a little slack so ragged batches do not thrash
   void* np = nullptr;
   MSH_HIP(hipMalloc(&np, want));
+  // hipMemset on device memory is asynchronous to the host and runs on the null stream, which the engines'
+  // non-blocking streams do not wait for: without the sync the zero-fill can land AFTER the first kernel or copy
+  // that writes the new buffer (seen as a rare garbage-logits failure of the streaming tests).
   MSH_HIP(hipMemset(np, 0, want));
+  MSH_HIP(hipDeviceSynchronize());
   if (p) MSH_HIP(hipFree(p));
   p = np;
   cap = want;

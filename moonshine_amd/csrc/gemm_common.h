@@ -42,16 +42,18 @@ struct EpiTanhF32 {
 };
 
 struct EpiBiasGeluBf16 {
+  static constexpr bool kStagedBf16 = true;
   bf16_t* out;
   long ldc;
   const float* bias;
-  __device__ void n4(int m, int n, f32x4 v) const {
+  __device__ uint2 pack4(int /*m*/, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     uint2 o;
     o.x = pack_bf16x2(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y));
     o.y = pack_bf16x2(gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
-    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+    return o;
   }
+  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
 };
 
 struct EpiBiasGeluF32 {
@@ -89,9 +91,10 @@ struct EpiQkvRopeBf16 {
   struct Pre {};
   __device__ Pre pre(int, int) const { return Pre{}; }
   __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
-  __device__ void n4(int m, int n, f32x4 v) const {
+  static constexpr bool kStagedBf16 = true;
+  __device__ uint2 pack4(int m, int n, f32x4 v) const {
     if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
-      int pos = row_pos[m];
+      int pos = row_pos[m];   // (rows past M are clamped by the caller's guard before the store, not here)
       pos = pos < 0 ? 0 : pos;
       const int d = (n % rp.hidden) % rp.head_dim;
       rope4(v, d, pos, rp);
@@ -99,8 +102,9 @@ struct EpiQkvRopeBf16 {
     uint2 o;
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+    return o;
   }
+  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
 };
 
 struct EpiResidF32 {
@@ -350,6 +354,48 @@ template <class E, class = void>
 struct is_row_argmax : std::false_type {};
 template <class E>
 struct is_row_argmax<E, std::void_t<decltype(E::kRowArgmax)>> : std::true_type {};
+
+// Row-major bf16 outputs: the accumulator layout gives every store instruction sixteen 32-byte row segments, and the
+// microbenchmark shows those stores, not the MFMA loop, holding the wide-N GEMMs back (fc1: 0.166 ms without the
+// epilogue, 0.295 ms with it -- profiles/r01z_gemm_epilogue_probe.txt).  Epilogues that declare kStagedBf16 hand back
+// packed values (pack4) and the kernel transposes a 16-row slab through LDS so that each lane stores 16 contiguous
+// bytes and a wave covers whole rows of the tile.
+template <class E, class = void>
+struct is_staged_bf16 : std::false_type {};
+template <class E>
+struct is_staged_bf16<E, std::void_t<decltype(E::kStagedBf16)>> : std::true_type {};
+
+template <int TN>
+struct StagedRow {
+  static constexpr int ROWP = TN * 4 + 2;  // uint2 per staged row: 16 * TN columns + 16 bytes of padding
+};
+// acc = the TN accumulators of one 16-row tile of this wave; stg = this wave's [16][ROWP] uint2 staging slab
+template <int TN, class Epi>
+__device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restrict__ stg, const f32x4 (&acc)[TN],
+                                                  int mbase, int n0, int M, int N, int lane) {
+  constexpr int ROWP = StagedRow<TN>::ROWP;
+  const int li = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) stg[li * ROWP + j * 4 + kg] = epi.pack4(mbase + li, n0 + j * 16 + kg * 4, acc[j]);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q0 = 0; q0 < 16 * TN * 2; q0 += 64) {
+    const int q = q0 + lane;
+    if (q < 16 * TN * 2) {
+      const int r = q / (TN * 2), c = q - r * (TN * 2);
+      const uint4 v = *reinterpret_cast<const uint4*>(stg + r * ROWP + c * 2);
+      const int m = mbase + r, n = n0 + c * 8;
+      if (m < M) {
+        bf16_t* dst = epi.out + (long)m * epi.ldc + n;
+        if (n + 8 <= N)
+          *reinterpret_cast<uint4*>(dst) = v;
+        else if (n + 4 <= N)
+          *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
 // XOR swizzle of the 16-B k-chunk position inside a 64-B row of an LDS k-slice (conflict-free
 // ds_read_b128 fragment reads for the lane groups of gfx950; verified: SQ_LDS_BANK_CONFLICT = 0)

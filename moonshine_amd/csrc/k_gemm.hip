@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 // fragment reads and drains vmcnt(0) before every ds_read (cdna_hip_programming.md section 5).
 // ------------------------------------------------------------------------------------------------
 // ABL (microbenchmark ablations, 0 in the product): bit 0 = no DMA after the prologue, bit 1 = no MFMA,
-// bit 2 = no fragment reads.
+// bit 2 = no fragment reads, bit 3 = no epilogue stores, bit 4 = direct (unstaged) stores; ABL >> 8 = b + 1: workgroups whose id has bit b set start
+// ~10 us late (probe for co-resident workgroups running their main loops and epilogues in lockstep).
 template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ W, int M, int N, int K,
@@ -172,6 +173,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
   const int q8 = nblocks >> 3, r8 = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
   const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
+  if constexpr ((ABL >> 8) != 0) {
+    if ((bid >> ((ABL >> 8) - 1)) & 1) {
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,6 +278,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
   }
   wait_vmcnt<0>();
 
+  if constexpr ((ABL & 8) != 0) {  // keep the accumulators live, store nothing
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) epi.n4(m0, n0, acc[0][0]);
+    return;
+  }
   if constexpr (is_row_argmax<Epi>::value) {
     // row m = li of this wave's row tile; its columns of the tile sit in j (TN), kg (4 lane groups) and the 4
     // accumulator registers: reduce locally, then across the 4 lane groups.  Ties keep the lowest column.
@@ -307,6 +323,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
         epi.pidx[(long)m * epi.ntn + tile_n] = bidx;
       }
     }
+    return;
+  }
+  if constexpr (is_staged_bf16<Epi>::value && SWAP && (ABL & 16) == 0) {
+    // the pipeline ring is dead once every wave has read the last k-slice: reuse it as the store staging area
+    static_assert(NW * 16 * StagedRow<TN>::ROWP * 8 <= NSTAGE * STAGE_SLOTS * 16, "staging does not fit the ring");
+    __builtin_amdgcn_s_barrier();
+    uint2* stg = reinterpret_cast<uint2*>(lds) + wave * (16 * StagedRow<TN>::ROWP);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      staged_store_tile<TN>(epi, stg, acc[i], m0 + wave * 16 * TM + i * 16, n0, M, N, lane);
     return;
   }
 #pragma unroll
@@ -352,6 +378,10 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
   constexpr int PMAX = (TN + 3) / 4;          // 1-KiB W pieces per wave per k-slice
   constexpr int AHEAD = NST - 1;
   __shared__ __attribute__((aligned(16))) uint4 lds[NST * TN * 64];
+  // Staged (LDS-transposed) stores are off here: the ring keeps running across column tiles, so they would need
+  // their own slab, and the extra live state spilled 46 VGPRs -- fc1 went from 339 to 460 us (r02b).
+  constexpr bool STAGED = false;
+  __shared__ __attribute__((aligned(16))) uint2 stage_lds[STAGED ? 4 * 16 * StagedRow<TN>::ROWP : 1];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mt = blockIdx.x / nsplit, part = blockIdx.x - mt * nsplit;
@@ -438,6 +468,11 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
       ++cslice;
     }
     const int n0 = t * BN;
+    if constexpr (STAGED) {
+      uint2* stg = stage_lds + wave * (16 * StagedRow<TN>::ROWP);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) staged_store_tile<TN>(epi, stg, acc[i], m0 + i * 16, n0, M, N, lane);
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -450,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
           if (m < M && n < N) epi.m4(m, n, acc[i][j]);
         }
       }
+    }
     }
     // the epilogue's loads / stores share the vmcnt counter with the DMAs: drain everything once per tile
     // (the ring was refilled before the epilogue, so its latency overlaps the stores)
@@ -574,14 +610,16 @@ void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, i
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct EpiBf16 {
+  static constexpr bool kStagedBf16 = true;
   bf16_t* out;
   long ldc;
-  __device__ void n4(int m, int n, f32x4 v) const {
+  __device__ uint2 pack4(int, int, f32x4 v) const {
     uint2 o;
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+    return o;
   }
+  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
 };
 __global__ void fill_bf16_kernel(bf16_t* p, long n, unsigned seed) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -607,6 +645,14 @@ void bench_launch(int abl, const bf16_t* A, long lda, const bf16_t* W, int M, in
     case 3: MSH_BL(3); break;
     case 5: MSH_BL(5); break;
     case 6: MSH_BL(6); break;
+    case 8: MSH_BL(8); break;
+    case 16: MSH_BL(16); break;
+    case 0x400: MSH_BL(0x400); break;
+    case 0x900: MSH_BL(0x900); break;
+    case 0xA00: MSH_BL(0xA00); break;
+    case 0xB00: MSH_BL(0xB00); break;
+    case 0xC00: MSH_BL(0xC00); break;
+    case 0xD00: MSH_BL(0xD00); break;
     default: throw std::runtime_error("bad ablation");
   }
 #undef MSH_BL

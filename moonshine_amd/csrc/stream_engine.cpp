@@ -346,6 +346,9 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     allocs_.push_back(p);
     return p;
   };
+  struct SyncAtExit {  // the zero-fills above are asynchronous null-stream work (see DevBuf::reserve)
+    ~SyncAtExit() { (void)hipDeviceSynchronize(); }
+  } sync_at_exit;
   const size_t S = (size_t)max_slots_;
   conv1_buf_ = (bf16_t*)slab(S * 4 * De * 2);
   conv2_buf_ = (bf16_t*)slab(S * 4 * 2 * De * 2);
