@@ -280,7 +280,9 @@ def main():
             enc_t.append((b - a) * 1e3)
             dec_t.append((c - b) * 1e3)
         latency = {"batch": 1, "p50_total": round(statistics.median(tot), 3), "p50_encode": round(statistics.median(enc_t), 3),
-                   "p50_decode": round(statistics.median(dec_t), 3), "decode_steps": args.decode_steps, "runs": 20}
+                   "p50_decode": round(statistics.median(dec_t), 3), "decode_steps": args.decode_steps, "runs": 20,
+                   # BASELINE.json configs[1] (batch = 1, one 10 s clip) as a rate
+                   "audio_seconds_per_sec": round(CLIP_SECONDS / (statistics.median(tot) * 1e-3), 1)}
 
     # ---- CPU baseline: the numpy oracle on this box's host cores (rank 0, N = 1 only) ----
     cpu = None
