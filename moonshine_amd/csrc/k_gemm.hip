@@ -173,10 +173,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
   const int q8 = nblocks >> 3, r8 = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
   const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
-  if constexpr ((ABL >> 8) != 0) {
-    if ((bid >> ((ABL >> 8) - 1)) & 1) {
+  if constexpr (((ABL >> 8) & 0xff) != 0) {
+    if ((bid >> (((ABL >> 8) & 0xff) - 1)) & 1) {
 #pragma unroll 1
-      for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_sleep(127);
+      for (int i = 0; i < ((ABL >> 16) ? (ABL >> 16) : 3); ++i) __builtin_amdgcn_s_sleep(127);
     }
   }
 
@@ -647,12 +647,14 @@ void bench_launch(int abl, const bf16_t* A, long lda, const bf16_t* W, int M, in
     case 6: MSH_BL(6); break;
     case 8: MSH_BL(8); break;
     case 16: MSH_BL(16); break;
-    case 0x400: MSH_BL(0x400); break;
-    case 0x900: MSH_BL(0x900); break;
-    case 0xA00: MSH_BL(0xA00); break;
-    case 0xB00: MSH_BL(0xB00); break;
-    case 0xC00: MSH_BL(0xC00); break;
-    case 0xD00: MSH_BL(0xD00); break;
+    case 0x10400: MSH_BL(0x10400); break;
+    case 0x20400: MSH_BL(0x20400); break;
+    case 0x40400: MSH_BL(0x40400); break;
+    case 0x10C00: MSH_BL(0x10C00); break;
+    case 0x20C00: MSH_BL(0x20C00); break;
+    case 0x40C00: MSH_BL(0x40C00); break;
+    case 0x10100: MSH_BL(0x10100); break;
+    case 0x20100: MSH_BL(0x20100); break;
     default: throw std::runtime_error("bad ablation");
   }
 #undef MSH_BL
