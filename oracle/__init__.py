@@ -15,4 +15,15 @@ oracle is HuggingFace ``transformers`` ``modeling_moonshine.py`` (reference
 This restatement is pinned against outputs of that implementation generated in
 the build container by ``tests/golden/make_golden.py`` and committed under
 ``tests/golden/`` (see ``tests/test_oracle_golden.py``).
+
+Modules and what pins them:
+  moonshine_ref.py   offline encoder / decoder / greedy loop     <- HF MoonshineForConditionalGeneration vectors
+  streaming_ref.py   the five streaming graphs + their C++ driver <- outputs of the reference's own graph wrapper
+                     (frontend, window encoder, adapter, cross-KV,   modules (lora/export.py) over HF
+                     multi-token decoder, speculative decode_full)   MoonshineStreaming, tests/golden/make_golden_streaming.py
+  biaser_ref.py      ContextBiaser + tokenizer text -> ids        <- the known-answer cases of the reference's
+                                                                     context-biaser-test.cpp / bin-tokenizer-test.cpp
+  host_ref.py        tokenizer.bin, tokens_to_text, sanitize_text, VAD (threshold 0), resampler, step budgets
+                     (byte / integer rules restated from the cited C++; the reference holds no fixtures for them)
+Unpinned everywhere: agreement with the shipped int8 ``.ort`` graphs themselves (absent from the checkout).
 """
