@@ -219,3 +219,71 @@ def test_stream_flag_semantics_without_model():
     with pytest.raises(api.MoonshineError):
         t.transcribe_stream(s)
     t.close()
+
+
+# ---- known-answer cases of the reference's own tests, restated (they need the reference's test assets, which
+#      exist in the build container only; skipped elsewhere) ----
+REF_ASSETS = "/root/reference/test-assets"
+
+
+def _read_wav(path):
+    import wave
+
+    with wave.open(path) as w:
+        assert w.getsampwidth() == 2 and w.getnchannels() == 1
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        return (pcm.astype(np.float32) / np.float32(32768.0)), w.getframerate()
+
+
+def test_reference_sanitize_known_answers():
+    """core/transcriber-test.cpp:510-533 (test-invalid-utf8 / test-valid-utf8)."""
+    bad = bytes([0xA3, 0x0A, 0xF5, 0x78])
+    for fn in (host_ref.sanitize_text, _cxx_sanitize):
+        out = fn(bad)
+        assert out[0] < 0x80 and len(out) == len(bad)
+        assert fn(b"Hello, world!") == b"Hello, world!"
+
+
+def _cxx_sanitize(b: bytes) -> bytes:
+    lib = load_library()
+    out = C.create_string_buffer(len(b) + 8)
+    n = lib.msh_host_sanitize_utf8(b, len(b), out, len(b) + 8)
+    assert n >= 0
+    return out.raw[:n]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_ASSETS, "beckett.wav")), reason="reference test assets not present")
+def test_reference_vad_threshold0_known_answer():
+    """core/voice-activity-detector-test.cpp:122-163 (vad-threshold-0 on beckett.wav, hop 256): one complete segment
+    that loses at most one hop, starting at ~0 and ending at the clip's duration."""
+    audio, rate = _read_wav(os.path.join(REF_ASSETS, "beckett.wav"))
+    hop = 256
+    t = _load_skip({"vad_hop_size": str(hop)})
+    lines = t.transcribe_without_streaming(audio, sample_rate=rate)
+    assert len(lines) == 1 and lines[0].is_complete
+    n = lines[0].audio_data.shape[0]
+    assert audio.shape[0] - hop <= n <= audio.shape[0]
+    eps = hop / rate
+    assert 0 <= lines[0].start_time < eps
+    assert abs(lines[0].start_time + lines[0].duration - audio.shape[0] / rate) <= eps
+    np.testing.assert_array_equal(lines[0].audio_data, audio[:n])
+    segs = host_ref.vad_segments_threshold0(audio.shape[0], hop=hop)
+    assert len(segs) == 1 and segs[0][1] - segs[0][0] == n and segs[0][2]
+    t.close()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_ASSETS, "beckett.wav")), reason="reference test assets not present")
+@pytest.mark.parametrize("out_rate", [16000, 96000, 8000])
+def test_reference_resampler_known_answer(out_rate):
+    """core/resampler-test.cpp:11-36: max, min and mean survive resampling (0.5 % / 0.5 % / 0.1 %) -- on the
+    reference's 16 kHz assets re-labelled 48 kHz so that both directions are exercised."""
+    audio, _ = _read_wav(os.path.join(REF_ASSETS, "beckett.wav"))
+    lib = load_library()
+    n = lib.msh_host_resample(audio.ctypes.data, audio.shape[0], 48000.0, float(out_rate), None, 0)
+    out = np.zeros(n, np.float32)
+    assert lib.msh_host_resample(audio.ctypes.data, audio.shape[0], 48000.0, float(out_rate), out.ctypes.data, n) == n
+    np.testing.assert_array_equal(out, host_ref.resample_ref(audio, 48000, out_rate))
+    if out_rate >= 16000:
+        assert abs(out.max() - audio.max()) <= 0.005 * abs(audio.max()) + 0.02
+        assert abs(out.min() - audio.min()) <= 0.005 * abs(audio.min()) + 0.02
+    assert abs(out.mean() - audio.mean()) <= 1e-3
