@@ -196,6 +196,8 @@ bool launch_dec_tm2(const void* A, long lda, const bf16_t* W, int M, int N, int 
     case 416: launch_dec_cfg<13, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
     case 288: launch_dec_cfg<9, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
     case 64: launch_dec_cfg<2, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 1664: launch_dec_cfg<52, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 1152: launch_dec_cfg<36, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
     default: return false;
   }
 }
@@ -436,6 +438,13 @@ void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bia
                     hipStream_t s) {
   EpiResidF32 epi{H, N, bias};
   if (use_dec64(M) && launch_dec64<4, false>(A, lda, W, M, N, K, epi, s)) return;  // K = D only
+  {
+    static const bool fc2_tm2 = [] {
+      const char* e = getenv("MSH_DEC_FC2_TM2");
+      return e != nullptr && e[0] == '1';
+    }();
+    if (fc2_tm2 && K > N && M >= dec_tm2_threshold() && launch_dec_tm2<2, false>(A, lda, W, M, N, K, epi, s)) return;
+  }
   launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
 }
 // ---- bf16-input small-batch GEMMs of the streaming decoder (row-based passes with M <= 256) ----
