@@ -135,6 +135,10 @@ MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate,
 MSH_EXPORT int64_t msh_host_text_to_tokens(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* text,
                                            uint64_t text_len, const char* space_marker, int32_t bpe, int32_t* out,
                                            uint64_t out_cap);
+/* msh_host_context_terms   : ContextExtractor::extract (reference core/context-extractor.cpp:152-226) with the subword count
+ *                           of the given tokenizer; the chosen terms come back joined by '\n'. */
+MSH_EXPORT int64_t msh_host_context_terms(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* context,
+                                          uint64_t context_len, int32_t max_terms, char* out, uint64_t out_cap);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

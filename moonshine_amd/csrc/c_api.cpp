@@ -17,6 +17,7 @@
 
 #include "host_utils.h"
 #include "context_biaser.h"
+#include "context_extractor.h"
 #include "transcriber.h"
 
 using namespace msh_host;
@@ -84,10 +85,10 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     } else if (k == "keyterm_boost") {
       o->keyterm_boost = parse_float(v);
     } else if (k == "context") {
-      if (!trim(v).empty())
-        throw std::runtime_error("option 'context' needs the context extractor, which is not part of the MI355X build; "
-                                 "pass the terms through 'keyterms'");
-    } else if (k == "context_max_terms" || k == "diarization_cluster_cadence" ||
+      o->context = v;
+    } else if (k == "context_max_terms") {
+      o->context_max_terms = parse_int32(v);
+    } else if ( k == "diarization_cluster_cadence" ||
                k == "diarization_analyze_cadence" || k == "diarization_cluster_window_sec" ||
                k == "diarization_model_dir" || k == "coreml_cache_dir") {
       // tuning knobs of features that are off: nothing to do
@@ -174,10 +175,10 @@ int32_t moonshine_transcriber_set_keyterms(int32_t handle, const char* keyterms)
   });
 }
 
-int32_t moonshine_transcriber_set_context(int32_t handle, const char* context, int32_t /*max_terms*/) {
-  return with_transcriber(handle, "set context", [&](Transcriber*) -> int32_t {
-    if (context == nullptr || trim(context).empty()) return MOONSHINE_ERROR_NONE;
-    throw std::runtime_error("context biasing needs the context biaser, which is not part of the MI355X build");
+int32_t moonshine_transcriber_set_context(int32_t handle, const char* context, int32_t max_terms) {
+  return with_transcriber(handle, "set context", [&](Transcriber* t) -> int32_t {
+    t->set_context(context == nullptr ? std::string() : std::string(context), max_terms);
+    return MOONSHINE_ERROR_NONE;
   });
 }
 
@@ -351,6 +352,26 @@ int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_l
     for (uint64_t i = 0; i < n_prefix; ++i) b.advance(prefix[i]);
     b.apply(out, (int)vocab);
     return (int64_t)b.sequence_count();
+  } catch (const std::exception& e) {
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_context_terms(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* context,
+                               uint64_t context_len, int32_t max_terms, char* out, uint64_t out_cap) {
+  try {
+    BinTokenizer tok(tokenizer_bin, (size_t)tokenizer_size);
+    const std::vector<std::string> terms = ContextExtractor::extract(
+        std::string(context ? context : "", (size_t)context_len), max_terms, [&](const std::string& w) -> size_t {
+          try {
+            return tok.text_to_tokens(w, true).size();
+          } catch (const std::exception&) {
+            return 0;
+          }
+        });
+    std::string joined;
+    for (size_t i = 0; i < terms.size(); ++i) joined += (i ? "\n" : "") + terms[i];
+    return copy_out(joined, out, out_cap);
   } catch (const std::exception& e) {
     return MSH_ERR_INVALID_ARGUMENT;
   }

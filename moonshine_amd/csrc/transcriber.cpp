@@ -183,10 +183,17 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
     throw std::runtime_error("Invalid model architecture: " + std::to_string(opt_.model_arch));
   if (is_streaming_arch(opt_.model_arch)) {
     load_streaming_model();
-    if (!opt_.keyterms.empty()) set_keyterms(opt_.keyterms);  // needs the tokenizer the load just brought up
+    // compiled last: this needs the tokenizer the load just brought up (reference core/transcriber.cpp:201-213)
+    if (!opt_.context.empty()) {
+      std::vector<std::string> terms = opt_.keyterms;  // terms named outright are kept next to the passage's
+      for (const std::string& t : keyterms_from_context(opt_.context, opt_.context_max_terms)) terms.push_back(t);
+      set_keyterms(terms);
+    } else if (!opt_.keyterms.empty()) {
+      set_keyterms(opt_.keyterms);
+    }
     return;
   }
-  if (!opt_.keyterms.empty())
+  if (!opt_.keyterms.empty() || !opt_.context.empty())
     throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
                              "does not decode through a path that can apply it.");
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
@@ -276,6 +283,26 @@ void Transcriber::load_streaming_model() {
     if (streaming_model_->load_from_memory(w, wn, std::string((const char*)c, cn), t, tn, (int32_t)opt_.model_arch) != 0)
       throw std::runtime_error("Failed to load streaming model from memory: " + streaming_model_->last_error);
   }
+}
+
+std::vector<std::string> Transcriber::keyterms_from_context(const std::string& context, int32_t max_terms) {
+  if (streaming_model_ == nullptr) {
+    if (model_ != nullptr)
+      throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
+                               "does not decode through a path that can apply it.");
+    return {};  // no model at all (skip_transcription)
+  }
+  return ContextExtractor::extract(context, max_terms, [this](const std::string& word) -> size_t {
+    try {
+      return streaming_model_->text_to_tokens(word).size();
+    } catch (const std::exception&) {
+      return 0;  // a word the tokenizer cannot spell costs that word and nothing else
+    }
+  });
+}
+
+void Transcriber::set_context(const std::string& context, int32_t max_terms) {
+  set_keyterms(keyterms_from_context(context, max_terms));
 }
 
 void Transcriber::set_keyterms(const std::vector<std::string>& keyterms) {

@@ -19,6 +19,7 @@
 
 #include "../../include/moonshine-c-api.h"
 #include "../../include/moonshine_hip.h"
+#include "context_extractor.h"
 #include "host_text_vad.h"
 #include "streaming_model.h"
 
@@ -63,6 +64,8 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   bool decode_incomplete_lines = true;
   bool use_speculative_decoding = true;  // streaming architectures (reference core/transcriber.h:191)
   std::vector<std::string> keyterms;     // contextual biasing (streaming architectures only)
+  std::string context;                   // free-text passage the key terms are picked from (reference :context option)
+  int32_t context_max_terms = 0;         // 0 = ContextExtractor::kDefaultMaxTerms
   float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
@@ -133,6 +136,10 @@ class Transcriber {
   // reference core/transcriber.cpp:250-288: compile the key terms (each in its mid-sentence and utterance-initial
   // spelling) into the biasing trie; drops every stream's speculative draft
   void set_keyterms(const std::vector<std::string>& keyterms);
+  // reference core/transcriber.cpp:217-248: pick the key terms out of a passage with ContextExtractor (a word
+  // qualifies when the loaded tokenizer needs >= 2 subwords for it), then set_keyterms
+  std::vector<std::string> keyterms_from_context(const std::string& context, int32_t max_terms);
+  void set_context(const std::string& context, int32_t max_terms);
 
  private:
   TranscriberStream* new_stream(int32_t id);

@@ -107,7 +107,7 @@ DECLARED_SYMBOLS = [
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
-    "msh_host_biaser_bonuses", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
+    "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",

@@ -174,3 +174,82 @@ class ContextBiaser:
             if c is not None:
                 best = max(best, self.bonus_for_depth(self.depth[c]))
         return best
+
+
+# --- ContextExtractor: key terms out of a free-text passage ---------------------------------------------
+# reference core/context-extractor.{h,cpp} (cited ``ce:<line>``)
+_PUNCT = [("’", "'"), ("‘", "'"), ("“", " "), ("”", " "), ("–", " "), ("—", " "),
+          ("…", " "), (" ", " ")]
+DEFAULT_MAX_TERMS = 200   # ce.h:36
+MIN_SUBWORDS = 2          # ce.h:43
+MIN_CHARACTERS = 3        # ce.h:48
+
+
+def strip_possessive(word: bytes) -> bytes:
+    """ce:102-110."""
+    if word.endswith(b"'s") or word.endswith(b"'S"):
+        return word[:-2]
+    if word.endswith(b"'"):
+        return word[:-1]
+    return word
+
+
+def candidate_words(text: str) -> list[bytes]:
+    """ce:112-150: letters (any byte >= 0x80 counts as one) and digits build a word, ' and - only inside one;
+    possessives stripped, words under three characters or holding a digit dropped; case kept."""
+    for a, b in _PUNCT:
+        text = text.replace(a, b)
+    data = text.encode("utf-8")
+    is_letter = lambda c: c >= 0x80 or (65 <= c <= 90) or (97 <= c <= 122)
+    is_digit = lambda c: 48 <= c <= 57
+    is_join = lambda c: c in (39, 45)
+    words, cur = [], bytearray()
+
+    def flush():
+        nonlocal cur
+        if not cur:
+            return
+        w = bytes(cur).strip(b"'-")
+        w = strip_possessive(w).strip(b"'-")
+        cur = bytearray()
+        if sum(1 for c in w if (c & 0xC0) != 0x80) < MIN_CHARACTERS:
+            return
+        if any(is_digit(c) for c in w):
+            return
+        words.append(w)
+
+    for c in data:
+        if is_letter(c) or is_digit(c):
+            cur.append(c)
+        elif is_join(c) and cur:
+            cur.append(c)
+        else:
+            flush()
+    flush()
+    return words
+
+
+def extract_terms(context: str, max_terms: int, subword_count) -> list[bytes]:
+    """ce:152-226: group case variants (ASCII fold), keep the majority spelling (earliest on a tie), require
+    >= 2 subwords of " " + term, rank by occurrences, then subwords, then first appearance; cap the list."""
+    limit = max_terms if max_terms > 0 else DEFAULT_MAX_TERMS
+    words = candidate_words(context)
+    forms: dict[bytes, list[int]] = {}
+    for i, w in enumerate(words):
+        if w not in forms:
+            forms[w] = [0, i]
+        forms[w][0] += 1
+    groups: dict[bytes, dict] = {}
+    for form, (count, first) in forms.items():
+        key = bytes(c + 32 if 65 <= c <= 90 else c for c in form)
+        g = groups.setdefault(key, {"term": None, "term_count": 0, "first": 0, "occ": 0})
+        g["occ"] += count
+        if g["term"] is None or count > g["term_count"] or (count == g["term_count"] and first < g["first"]):
+            g["term"], g["term_count"], g["first"] = form, count, first
+    cands = []
+    for g in groups.values():
+        sub = subword_count(b" " + g["term"])
+        if sub >= MIN_SUBWORDS:
+            cands.append((-g["occ"], -sub, g["first"], g["term"]))
+    cands.sort()
+    return [c[3] for c in cands[:limit]]

@@ -144,3 +144,81 @@ def test_cxx_biaser_matches_oracle(lib):
         want = np.zeros(V, np.float32)
         b.apply(want)
         np.testing.assert_allclose(cxx_bonuses(lib, seqs, boost, prefix), want, rtol=1e-6, atol=0)
+
+
+# ---- ContextExtractor: the reference's known-answer cases (core/context-extractor-test.cpp) ----
+COMMON = {"the", "and", "for", "with", "about", "some", "will", "have", "team", "meeting", "notes", "word", "here",
+          "chapter", "doctor", "prison", "wine", "shop", "spy", "said", "very"}
+
+
+def stub_subword_count(word: bytes) -> int:
+    bare = word.strip(b" \t").lower()
+    if not bare:
+        return 0
+    if bare.decode("utf-8", "replace") in COMMON:
+        return 1
+    return (len(bare) + 2) // 3
+
+
+def test_context_extractor_words_known_answers():
+    cw = lambda t: [w.decode() for w in br.candidate_words(t)]
+    assert cw("The meeting, with Defarge: ready?") == ["The", "meeting", "with", "Defarge", "ready"]
+    assert cw("a wine-shop, and Marie's can't") == ["wine-shop", "and", "Marie", "can't"]
+    assert cw("Defarge -- Manette") == ["Defarge", "Manette"]
+    assert cw("Tellson’s bank—Lorry waited") == ["Tellson", "bank", "Lorry", "waited"]
+    assert cw("an IPv6 route to 10 hosts in Kubernetes") == ["route", "hosts", "Kubernetes"]
+    w = cw("the Marquis St. Évrémonde")
+    assert "Marquis" in w and "Évrémonde" in w
+    assert cw("два дв") == ["два"]
+    assert br.strip_possessive(b"Tellson's") == b"Tellson" and br.strip_possessive(b"Jones'") == b"Jones"
+    assert br.strip_possessive(b"Defarge") == b"Defarge"
+    assert cw("Tellson's clerk and Jones' desk") == ["Tellson", "clerk", "and", "Jones", "desk"]
+
+
+def test_context_extractor_extract_known_answers():
+    ex = lambda t, m=0, f=stub_subword_count: [w.decode() for w in br.extract_terms(t, m, f)]
+    terms = ex("The team meeting notes said very little about Kubernetes.")
+    assert "Kubernetes" in terms and not {"meeting", "notes", "The"} & set(terms)
+    terms = ex("Defarge and Defarge and Defarge, with Manette.")
+    assert terms == ["Defarge", "Manette"]
+    terms = ex("Ceph and glomerulonephritis.")
+    assert terms.index("glomerulonephritis") < terms.index("Ceph")
+    terms = ex("Madame Defarge, madame Defarge, Madame Defarge, and MADAME.")
+    assert "Madame" in terms and "madame" not in terms and "MADAME" not in terms
+    assert terms.index("Madame") < terms.index("Defarge")
+    assert ex("Defarge Defarge Defarge Manette Manette Cruncher", 2) == ["Defarge", "Manette"]
+    many = "".join(f"zq{chr(a)}{chr(b)}vx " for a in range(97, 123) for b in range(97, 123))
+    assert len(ex(many, 0)) == br.DEFAULT_MAX_TERMS == len(ex(many, -1))
+    assert ex("") == [] and ex("   ,,,   ") == []
+    assert ex("Defarge and Manette", 0, lambda w: 0) == []
+
+
+def test_cxx_context_extractor_matches_oracle(lib):
+    from moonshine_amd.synth import encode_tokenizer_bin
+
+    lib.msh_host_context_terms.restype = C.c_int64
+    lib.msh_host_context_terms.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64]
+    # a BPE vocabulary: raw bytes, the marker, and a few merges so that common words are one token
+    vocab = bpe_vocab()
+    for piece in ["th", "the", "an", "and", "in", "er", "on", "at", "ng", "ing", "re", "De", "Def", "Ma", "Man"]:
+        vocab.append(piece.encode())
+    for piece in ["the", "and", "team", "with", "said"]:
+        vocab.append(br.SPACE + piece.encode())
+    vocab.append(br.SPACE)
+    blob = encode_tokenizer_bin(vocab)
+    count = lambda w: len(br.text_to_tokens_bpe(vocab, w))
+    passages = [
+        "The team meeting notes said very little about Kubernetes.",
+        "Defarge and Defarge and Defarge, with Manette. Madame Defarge, madame Defarge — Tellson’s bank.",
+        "Ceph and glomerulonephritis; an IPv6 route to 10 hosts, the wine-shop and Jones' desk, Évrémonde!",
+        "", "   ,,,   ", "the and the and with",
+    ]
+    for text in passages:
+        for cap in (0, 3):
+            want = [w.decode() for w in br.extract_terms(text, cap, count)]
+            raw = text.encode()
+            out = C.create_string_buffer(65536)
+            n = lib.msh_host_context_terms(blob, len(blob), raw, len(raw), cap, out, 65536)
+            assert n >= 0
+            got = out.raw[:n].decode().split("\n") if n else []
+            assert got == want, (text, cap, got, want)

@@ -157,8 +157,6 @@ def test_streaming_arch_options(model_dir, engine):
     assert m.last[0] == CFG.bos and len(m.last) > 1      # the closing update did decode
     m.close()
     t.close()
-    with pytest.raises(api.MoonshineError):      # the context extractor is not part of this build
-        api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "context": "some passage of text"})
     with pytest.raises(api.MoonshineError):      # offline weights directory for a streaming arch
         api.Transcriber(str(model_dir) + "_missing", api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
 
@@ -203,3 +201,42 @@ def test_streaming_arch_keyterms(model_dir, engine):
         engine.set_bias(None)
     t.close()
     plain_t.close()
+
+
+def test_streaming_arch_context(model_dir, engine):
+    """The `context` option / moonshine_transcriber_set_context: key terms picked out of a passage by the subword
+    count of the model's own tokenizer (reference transcriber.cpp:201-248), then compiled like explicit key terms."""
+    from oracle.biaser_ref import extract_terms, text_to_tokens_bpe
+
+    vocab = synthetic_vocab(CFG.vocab)
+
+    def count(word: bytes) -> int:
+        try:
+            return len(text_to_tokens_bpe(vocab, word))
+        except ValueError:
+            return 0
+
+    passage = "the qjx wvut and the qjx again; abcab's route to Évrémonde, 42 things"
+    terms = [w.decode() for w in extract_terms(passage, 0, count)]
+    assert "qjx" in terms and terms[0] == "qjx"
+    audio = make_audio(96, 16000 * 3)
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "context": passage, "keyterm_boost": "5.0"})
+    b = compile_terms(terms, 5.0)
+    engine.set_bias(b.children, b.depth, [float(b.bonus_for_depth(d)) for d in range(max(b.depth) + 2)])
+    try:
+        lines = t.transcribe_without_streaming(audio)
+        m = GlueMirror(engine)
+        assert lines[0].text_bytes == m.update(lines[0].audio_data, True)
+        m.close()
+        # runtime call with a cap of one term
+        lib = api.lib()
+        assert lib.moonshine_transcriber_set_context(t.handle, passage.encode(), 1) == 0
+        b1 = compile_terms(terms[:1], 5.0)
+        engine.set_bias(b1.children, b1.depth, [float(b1.bonus_for_depth(d)) for d in range(max(b1.depth) + 2)])
+        lines = t.transcribe_without_streaming(audio)
+        m = GlueMirror(engine)
+        assert lines[0].text_bytes == m.update(lines[0].audio_data, True)
+        m.close()
+    finally:
+        engine.set_bias(None)
+    t.close()

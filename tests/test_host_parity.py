@@ -162,6 +162,8 @@ def test_option_parsing_and_error_rules():
     # no model at all (skip_transcription): nothing to tokenize against, accepted (reference transcriber.cpp:266-277)
     assert lib.moonshine_transcriber_set_keyterms(t.handle, b"Kubernetes, etcd") == 0
     assert lib.moonshine_transcriber_set_keyterms(4242, b"x") == -2
+    assert lib.moonshine_transcriber_set_context(t.handle, b"Madame Defarge knits", 0) == 0   # no model: accepted, no terms
+    assert lib.moonshine_transcriber_set_context(4242, b"x", 0) == -2
     assert lib.moonshine_load_transcriber_from_memory(None, 0, None, 0, None, 0, None, 0, 1, None, 0, 30000) == -3
     t.close()
     t.close()  # double free is harmless
