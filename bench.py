@@ -249,6 +249,7 @@ def main():
     eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)
     prof = eng.profile()
     eng.profile_enable(False)
+    ev_overhead_ms = max(eng.profile_event_overhead_ms(500), 0.0)  # empty event pair: bookkeeping inside every scope
     prof = [p for p in prof if p["launches"] > 0]
     kernels = sorted((roofline_entry(p) | {"total_ms": round(p["ms"], 3)} for p in prof), key=lambda r: -r["total_ms"])
     # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (tools/gpu_final.sh), so
@@ -325,7 +326,10 @@ def main():
                                "inputs resident in HBM", "clips_per_gpu": B, "global_batch": world * B, "decode_steps": args.decode_steps,
                    "parallelism": f"utterance-sharded dp{world}"},
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
-            "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"], "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3)},
+            "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"], "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3),
+            # HIP-event time per launch includes the scope's own event bookkeeping (an EMPTY scope lasts
+            # `empty_event_scope_us`, an upper bound on it): the rocprofv3 kernel duration in profiles/ is ~2 us shorter
+            "empty_event_scope_us": round(ev_overhead_ms * 1e3, 2)},
         "cpu_baseline": cpu,
         "latency_ms": latency,
         "kernels": kernels,

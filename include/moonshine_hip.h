@@ -110,6 +110,9 @@ MSH_EXPORT int32_t msh_profile_count(msh_engine* e);
 MSH_EXPORT int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_entry* out);
 
 MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
+/* Average duration (ms) of an EMPTY profiling scope (two event records back to back on the engine stream): what every
+ * per-launch figure of msh_profile_get carries on top of the kernel's own run time.  Negative on error. */
+MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
 /* Developer hook: ms per launch of one tiled-GEMM configuration on synthetic operands (tools/gemm_microbench.py). */
 MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
                                           int32_t iters);

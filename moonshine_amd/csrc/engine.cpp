@@ -293,6 +293,26 @@ struct Engine::ProfScope {
   }
 };
 
+double Engine::profile_event_overhead_ms(int iters) {
+  MSH_HIP(hipSetDevice(device_));
+  if (iters <= 0) iters = 1;
+  std::vector<hipEvent_t> ev(2 * (size_t)iters);
+  for (auto& e : ev) e = get_event();
+  for (int i = 0; i < iters; ++i) {
+    MSH_HIP(hipEventRecord(ev[2 * i], stream_));
+    MSH_HIP(hipEventRecord(ev[2 * i + 1], stream_));
+  }
+  MSH_HIP(hipStreamSynchronize(stream_));
+  double total = 0;
+  for (int i = 0; i < iters; ++i) {
+    float ms = 0.f;
+    MSH_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    total += ms;
+  }
+  for (auto& e : ev) event_pool_.push_back(e);
+  return total / iters;
+}
+
 void Engine::prof_flush() {
   if (prof_pending_.empty()) return;
   MSH_HIP(hipStreamSynchronize(stream_));

@@ -82,6 +82,9 @@ class Engine {
   void profile_enable(bool on);
   void profile_reset();
   std::vector<ProfEntry> profile_get();
+  // average time between the two events of an EMPTY profiling scope on the engine stream: the part of every
+  // per-launch figure that is event / dispatch bookkeeping rather than kernel time
+  double profile_event_overhead_ms(int iters);
 
   hipStream_t stream() const { return stream_; }
   void synchronize();

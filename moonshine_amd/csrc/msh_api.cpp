@@ -198,6 +198,12 @@ int32_t msh_profile_get(msh_engine* e, int32_t index, msh_profile_entry* out) {
   return MSH_OK;
 }
 
+double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters) {
+  double v = -1.0;
+  guarded(e, [&] { v = e->eng->profile_event_overhead_ms(iters); });
+  return v;
+}
+
 float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl, int32_t iters) {
   try {
     return msh::gemm_microbench(M, N, K, lda, cfg, abl, iters);
