@@ -368,7 +368,7 @@ void Engine::plan_batch(const uint64_t* n_samples, uint32_t count, float mtps) {
     // rows: the clip's slot in every stream.  conv1 consumes samples [0, 64*L1 + 63) from a slot of
     // 384*rows samples; conv2/conv3 need 2*rows >= L2 and rows >= T.
     int rows = std::max({(64 * L1 + 63 + 383) / 384, (L2 + 1) / 2, T});
-    c.rows = round_up(rows, 4);
+    c.rows = round_up(rows, 8);  // 8: a clip starts on an 8-row boundary, so 8 consecutive keys never straddle clips
     c.row_start = (int)row;
     c.Tk = round_up(T, 8);
     c.kv_start = (int)kv;

@@ -169,7 +169,43 @@ struct EpiCrossKV {
     o.y = pack_bf16x2(x[2], x[3]);
     *reinterpret_cast<uint2*>(base) = o;
   }
+  // Paired form for kernels whose wave owns 32 consecutive keys (two 16-row tiles): lanes kg and kg^1 swap halves so
+  // that every lane stores 8 consecutive keys (16 bytes) and the four lanes of a column cover one full 64-byte
+  // sector.  With 8-byte stores the PMC pass showed 2.4 GB written per launch for 1.43 GB of K^T / V^T.
+  // Needs clip row_start and Tk to be multiples of 8 (plan_batch pads rows to 8).
+  static constexpr bool kPairedKeys = true;
+  struct KeyRow {  // per-lane row bookkeeping, looked up once per tile instead of once per column
+    int t, T, Tk;
+    long off;  // kv_start * D + t
+  };
+  __device__ KeyRow key_row(int m) const {
+    const ClipMeta cm = clips[row_clip[m]];
+    KeyRow k;
+    k.t = m - cm.row_start;
+    k.T = cm.T;
+    k.Tk = cm.Tk;
+    k.off = (long)cm.kv_start * D + k.t;
+    return k;
+  }
+  __device__ uint2 pack_keys4(const KeyRow& k, f32x4 v) const {  // this lane's 4 keys, zeroed past the frame count
+    uint2 o;
+    o.x = pack_bf16x2(k.t < k.T ? v[0] : 0.f, k.t + 1 < k.T ? v[1] : 0.f);
+    o.y = pack_bf16x2(k.t + 2 < k.T ? v[2] : 0.f, k.t + 3 < k.T ? v[3] : 0.f);
+    return o;
+  }
+  __device__ void store_keys8(const KeyRow& k, int n, uint4 v) const {  // k = first of 8 consecutive keys of one clip
+    if (k.t >= k.Tk) return;
+    const int layer = n / (2 * D);
+    const int r = n - layer * 2 * D;
+    const int which = r / D;
+    const int c = r - which * D;
+    *reinterpret_cast<uint4*>((which ? VT : KT) + layer * layer_stride + k.off + (long)c * k.Tk) = v;
+  }
 };
+template <class E, class = void>
+struct is_paired_keys : std::false_type {};
+template <class E>
+struct is_paired_keys<E, std::void_t<decltype(E::kPairedKeys)>> : std::true_type {};
 
 struct EpiDecQkv {
   float* q;         // [M][D]

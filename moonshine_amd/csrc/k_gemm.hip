@@ -472,6 +472,35 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
       uint2* stg = stage_lds + wave * (16 * StagedRow<TN>::ROWP);
 #pragma unroll
       for (int i = 0; i < 2; ++i) staged_store_tile<TN>(epi, stg, acc[i], m0 + i * 16, n0, M, N, lane);
+    } else if constexpr (!SWAP && is_paired_keys<Epi>::value) {
+      // rows m0 .. m0+31 are this wave's keys: lane (li, kg) holds keys kg*4..+3 of both 16-row tiles for column li
+      const int mr = m0 + kg * 4;
+      const bool rows_ok = m0 + 31 < M;  // M (total rows) is a multiple of 8; a ragged last tile takes the 4-key path
+      if (rows_ok) {
+        const auto klo = epi.key_row(mr), khi = epi.key_row(mr + 16);
+        // the 8-key run this lane stores: even kg -> keys kg*4.. of tile 0, odd kg -> keys (kg-1)*4.. of tile 1
+        const auto kst = epi.key_row((kg & 1) ? m0 + 16 + (kg - 1) * 4 : mr);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 16 + li;
+          const uint2 lo = epi.pack_keys4(klo, acc[0][j]), hi = epi.pack_keys4(khi, acc[1][j]);
+          const uint2 send = (kg & 1) ? lo : hi;  // even kg keeps tile 0, odd kg keeps tile 1
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16, 64);
+          recv.y = __shfl_xor(send.y, 16, 64);
+          if (n < N) epi.store_keys8(kst, n, (kg & 1) ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 16 + li;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 16 + kg * 4;
+            if (m < M && n < N) epi.m4(m, n, acc[i][j]);
+          }
+        }
+      }
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

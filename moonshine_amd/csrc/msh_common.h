@@ -64,7 +64,7 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
 // (so the strided conv-as-GEMM views have one uniform row stride over the batch).
 struct ClipMeta {
   int32_t row_start;  // first row in the [R, D] stream
-  int32_t rows;       // R_b (multiple of 4): padded frame count
+  int32_t rows;       // R_b (multiple of 8): padded frame count
   int32_t T;          // valid encoder frames (conv3 length)
   int32_t L1;         // valid conv1 frames
   int32_t L2;         // valid conv2 frames
