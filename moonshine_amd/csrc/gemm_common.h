@@ -46,14 +46,21 @@ struct EpiBiasGeluBf16 {
   bf16_t* out;
   long ldc;
   const float* bias;
-  __device__ uint2 pack4(int /*m*/, int n, f32x4 v) const {
+  struct RowCtx {};
+  struct ColCtx {};
+  __device__ RowCtx row_ctx(int) const { return RowCtx{}; }
+  __device__ ColCtx col_ctx(int) const { return ColCtx{}; }
+  __device__ void col_next16(ColCtx&) const {}
+  __device__ uint2 pack4(const RowCtx&, const ColCtx&, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     uint2 o;
     o.x = pack_bf16x2(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y));
     o.y = pack_bf16x2(gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
     return o;
   }
-  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(RowCtx{}, ColCtx{}, n, v);
+  }
 };
 
 struct EpiBiasGeluF32 {
@@ -92,20 +99,88 @@ struct EpiQkvRopeBf16 {
   __device__ Pre pre(int, int) const { return Pre{}; }
   __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
   static constexpr bool kStagedBf16 = true;
-  __device__ uint2 pack4(int m, int n, f32x4 v) const {
-    if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
-      int pos = row_pos[m];   // (rows past M are clamped by the caller's guard before the store, not here)
+  // RoPE factors of a tile's rows come from a per-wave LDS table (16 rows x [cos | sin] x 28 pairs, identity beyond
+  // rot_pairs) that the wave fills with coalesced loads before it packs the tile: reading the global cos / sin
+  // tables per accumulator group cost four scattered 4-byte loads per group, ~100 us of the 300 us kernel.
+  static constexpr bool kRowTable = true;
+  static constexpr int kTabRow = 56;  // floats per row: 28 cos + 28 sin
+  struct RowCtx {
+    const float* tab;  // this lane's row of the LDS table, or nullptr: factors come from the global tables
+    int pos;
+  };
+  // (the table holds 28 pairs per row: heads wider than 56 keep the global-table path)
+  __device__ bool tile_needs_table(int n0) const { return n0 < 2 * rp.hidden && rp.head_dim <= 56; }
+  __device__ void fill_row_table(float* tab, int mbase, int M, int lane) const {
+    for (int idx = lane; idx < 16 * kTabRow; idx += 64) {
+      const int r = idx / kTabRow, c = idx - r * kTabRow;
+      const int which = c >= 28, p = c - which * 28;
+      int m = mbase + r;
+      m = m < M ? m : M - 1;
+      int pos = row_pos[m];
       pos = pos < 0 ? 0 : pos;
-      const int d = (n % rp.hidden) % rp.head_dim;
-      rope4(v, d, pos, rp);
+      float v = which ? 0.f : 1.f;
+      if (p < rp.rot_pairs) v = (which ? rp.sin : rp.cos)[(long)pos * rp.rot_pairs + p];
+      tab[idx] = v;
+    }
+  }
+  __device__ RowCtx row_ctx_tab(const float* tab, int li) const { return RowCtx{tab + li * kTabRow, 0}; }
+  __device__ RowCtx row_ctx(int m) const {
+    const int pos = row_pos[m];
+    return RowCtx{nullptr, pos < 0 ? 0 : pos};
+  }
+  struct ColCtx {
+    int c, d;  // column within q / k / v, offset within its head
+  };
+  __device__ ColCtx col_ctx(int n) const {
+    const int c = n % rp.hidden;
+    return ColCtx{c, c % rp.head_dim};
+  }
+  __device__ void col_next16(ColCtx& k) const {  // head_dim >= 16
+    k.c += 16;
+    k.d += 16;
+    if (k.c >= rp.hidden) {
+      k.c -= rp.hidden;
+      k.d = k.c % rp.head_dim;
+    } else if (k.d >= rp.head_dim) {
+      k.d -= rp.head_dim;
+    }
+  }
+  __device__ uint2 pack4(const RowCtx& c, const ColCtx& k, int n, f32x4 v) const {
+    if (n < 2 * rp.hidden) {  // q and k are rotated, v passes through
+      const int d = k.d;
+      if (c.tab != nullptr) {
+        const int j0 = d >> 1;  // pairs j0, j0 + 1 (head_dim % 4 == 0)
+        const float c0 = c.tab[j0], c1 = c.tab[j0 + 1], s0 = c.tab[28 + j0], s1 = c.tab[28 + j0 + 1];
+        const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+        v[0] = x0 * c0 - x1 * s0;
+        v[1] = x1 * c0 + x0 * s0;
+        v[2] = x2 * c1 - x3 * s1;
+        v[3] = x3 * c1 + x2 * s1;
+      } else {
+        rope4(v, d, c.pos, rp);
+      }
     }
     uint2 o;
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
     return o;
   }
-  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {  // unstaged paths: factors straight from the global tables
+    if (n < 2 * rp.hidden) {
+      int pos = row_pos[m];
+      pos = pos < 0 ? 0 : pos;
+      rope4(v, (n % rp.hidden) % rp.head_dim, pos, rp);
+    }
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = o;
+  }
 };
+template <class E, class = void>
+struct has_row_table : std::false_type {};
+template <class E>
+struct has_row_table<E, std::void_t<decltype(E::kRowTable)>> : std::true_type {};
 
 struct EpiResidF32 {
   float* H;
@@ -408,11 +483,25 @@ struct StagedRow {
 // acc = the TN accumulators of one 16-row tile of this wave; stg = this wave's [16][ROWP] uint2 staging slab
 template <int TN, class Epi>
 __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restrict__ stg, const f32x4 (&acc)[TN],
-                                                  int mbase, int n0, int M, int N, int lane) {
+                                                  int mbase, int n0, int M, int N, int lane, float* rowtab = nullptr) {
   constexpr int ROWP = StagedRow<TN>::ROWP;
   const int li = lane & 15, kg = lane >> 4;
+  auto ctx = epi.row_ctx(mbase + li < M ? mbase + li : M - 1);  // per-row inputs, fetched once per tile
+  if constexpr (has_row_table<Epi>::value) {
+    if (rowtab != nullptr && epi.tile_needs_table(n0)) {
+      epi.fill_row_table(rowtab, mbase, M, lane);
+      __builtin_amdgcn_wave_barrier();
+      ctx = epi.row_ctx_tab(rowtab, li);
+    }
+  }
+  // per-column inputs advance by 16 columns per accumulator: no integer division inside the loop (the two runtime
+  // modulos per group that RoPE needs cost more than its arithmetic: ~100 us of the 300 us QKV kernel)
+  auto col = epi.col_ctx(n0 + kg * 4);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) stg[li * ROWP + j * 4 + kg] = epi.pack4(mbase + li, n0 + j * 16 + kg * 4, acc[j]);
+  for (int j = 0; j < TN; ++j) {
+    stg[li * ROWP + j * 4 + kg] = epi.pack4(ctx, col, n0 + j * 16 + kg * 4, acc[j]);
+    epi.col_next16(col);
+  }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int q0 = 0; q0 < 16 * TN * 2; q0 += 64) {

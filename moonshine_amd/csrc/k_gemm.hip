@@ -327,12 +327,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* _
   }
   if constexpr (is_staged_bf16<Epi>::value && SWAP && (ABL & 16) == 0) {
     // the pipeline ring is dead once every wave has read the last k-slice: reuse it as the store staging area
-    static_assert(NW * 16 * StagedRow<TN>::ROWP * 8 <= NSTAGE * STAGE_SLOTS * 16, "staging does not fit the ring");
+    constexpr int STG_BYTES = NW * 16 * StagedRow<TN>::ROWP * 8, TAB_BYTES = 16 * 56 * 4;  // per-wave 16-row RoPE table
+    static_assert(STG_BYTES + NW * TAB_BYTES <= NSTAGE * STAGE_SLOTS * 16, "staging does not fit the ring");
     __builtin_amdgcn_s_barrier();
     uint2* stg = reinterpret_cast<uint2*>(lds) + wave * (16 * StagedRow<TN>::ROWP);
+    float* rowtab = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + STG_BYTES) + wave * (TAB_BYTES / 4);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      staged_store_tile<TN>(epi, stg, acc[i], m0 + wave * 16 * TM + i * 16, n0, M, N, lane);
+      staged_store_tile<TN>(epi, stg, acc[i], m0 + wave * 16 * TM + i * 16, n0, M, N, lane, rowtab);
     return;
   }
 #pragma unroll
@@ -642,13 +644,20 @@ struct EpiBf16 {
   static constexpr bool kStagedBf16 = true;
   bf16_t* out;
   long ldc;
-  __device__ uint2 pack4(int, int, f32x4 v) const {
+  struct RowCtx {};
+  struct ColCtx {};
+  __device__ RowCtx row_ctx(int) const { return RowCtx{}; }
+  __device__ ColCtx col_ctx(int) const { return ColCtx{}; }
+  __device__ void col_next16(ColCtx&) const {}
+  __device__ uint2 pack4(const RowCtx&, const ColCtx&, int, f32x4 v) const {
     uint2 o;
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
     return o;
   }
-  __device__ void n4(int m, int n, f32x4 v) const { *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pack4(RowCtx{}, ColCtx{}, 0, v);
+  }
 };
 __global__ void fill_bf16_kernel(bf16_t* p, long n, unsigned seed) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
