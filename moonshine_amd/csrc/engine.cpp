@@ -58,8 +58,8 @@ Engine::~Engine() {
     (void)hipEventDestroy(r.b);
   }
   for (void* p : weight_allocs_) (void)hipFree(p);
-  DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x1n_, &x2_, &H_,
-                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &KT_, &VT_};
+  DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
+                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -135,11 +135,31 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload_bf16(r, &conv1_w_);
     expect_shape("model.encoder.conv2.weight", {2 * D, D, 7});
     w = st.to_f32("model.encoder.conv2.weight");
-    r.assign((size_t)2 * D * 7 * D, 0.f);
-    for (int n = 0; n < 2 * D; ++n)
-      for (int ch = 0; ch < D; ++ch)
-        for (int k = 0; k < 7; ++k) r[((size_t)n * 7 + k) * D + ch] = w[((size_t)n * D + ch) * 7 + k];
-    upload_bf16(r, &conv2_w_);
+    {
+      // GroupNorm(1 group) between conv1 and conv2 is folded into conv2 (EpiGnBiasGeluBf16): its scale gamma goes into
+      // the weights per input channel, its shift beta and the per-clip mean into two per-output-channel vectors.
+      // S1 sums the bf16-ROUNDED folded weights, i.e. exactly what the MFMA multiplies.
+      const std::vector<float> gam = st.to_f32("model.encoder.groupnorm.weight"), bet = st.to_f32("model.encoder.groupnorm.bias");
+      const std::vector<float> b2 = st.to_f32("model.encoder.conv2.bias");
+      r.assign((size_t)2 * D * 7 * D, 0.f);
+      std::vector<float> s1((size_t)2 * D, 0.f), s2((size_t)2 * D, 0.f);
+      for (int n = 0; n < 2 * D; ++n) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int ch = 0; ch < D; ++ch)
+          for (int k = 0; k < 7; ++k) {
+            const float wv = w[((size_t)n * D + ch) * 7 + k];
+            const float folded = wv * gam[ch];
+            r[((size_t)n * 7 + k) * D + ch] = folded;
+            a1 += (double)bf16_to_f32(f32_to_bf16(folded));
+            a2 += (double)wv * bet[ch];
+          }
+        s1[n] = (float)a1;
+        s2[n] = (float)(a2 + b2[n]);
+      }
+      upload_bf16(r, &conv2_w_);
+      upload(s1, &conv2_s1_);
+      upload(s2, &conv2_b2_);
+    }
     expect_shape("model.encoder.conv3.weight", {D, 2 * D, 3});
     w = st.to_f32("model.encoder.conv3.weight");
     r.assign((size_t)D * 3 * 2 * D, 0.f);
@@ -147,10 +167,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       for (int ch = 0; ch < 2 * D; ++ch)
         for (int k = 0; k < 3; ++k) r[((size_t)n * 3 + k) * 2 * D + ch] = w[((size_t)n * 2 * D + ch) * 3 + k];
     upload_bf16(r, &conv3_w_);
-    upload(st.to_f32("model.encoder.conv2.bias"), &conv2_b_);
     upload(st.to_f32("model.encoder.conv3.bias"), &conv3_b_);
-    upload(st.to_f32("model.encoder.groupnorm.weight"), &gn_w_);
-    upload(st.to_f32("model.encoder.groupnorm.bias"), &gn_b_);
     upload(st.to_f32("model.encoder.layer_norm.weight"), &enc_ln_);
   }
   auto fuse = [&](std::initializer_list<std::string> names) {
@@ -402,8 +419,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= audio_bf16_.reserve((384 * R + 512) * sizeof(bf16_t));
   moved |= row_pos_.reserve(R * sizeof(int));
   moved |= row_clip_.reserve(R * sizeof(int));
-  moved |= x1_.reserve((6 * R + 16) * D * sizeof(float));
-  moved |= x1n_.reserve((6 * R + 16) * D * sizeof(bf16_t));
+  moved |= x1_.reserve((6 * R + 16) * D * sizeof(bf16_t));
   moved |= x2_.reserve((2 * R + 8) * 2 * D * sizeof(bf16_t));
   moved |= H_.reserve(R * D * sizeof(float));
   moved |= Y_.reserve(R * D * sizeof(bf16_t));
@@ -414,6 +430,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   if (keep_enc_f32_) moved |= ENC32_.reserve(R * D * sizeof(float));
   moved |= gn_part_.reserve((size_t)count * 64 * sizeof(float2));
   moved |= gn_stats_.reserve(count * sizeof(float2));
+  moved |= gn_table_.reserve((size_t)count * 2 * D * sizeof(float));
   moved |= KT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
   moved |= VT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
   if (moved) ++ws_gen_;
@@ -464,18 +481,18 @@ void Engine::run_encoder() {
     build_row_meta(clips, (int)n_clips_, row_pos_.as<int>(), row_clip_.as<int>(), s);
   }
   {  // conv1 (k127, s64, no bias) + tanh: GEMM over the sample stream, row t = samples [64t, 64t+128)
-    ProfScope p(this, "conv1_tanh_gemm", 2.0 * sL1 * D * 127, sN * 2 + sL1 * D * 4);
-    gemm_tanh_f32(audio_bf16_.as<bf16_t>(), 64, conv1_w_, 6 * R, D, 128, x1_.as<float>(), s);
+    ProfScope p(this, "conv1_tanh_gemm", 2.0 * sL1 * D * 127, sN * 2 + sL1 * D * 2);
+    gemm_tanh_bf16(audio_bf16_.as<bf16_t>(), 64, conv1_w_, 6 * R, D, 128, x1_.as<bf16_t>(), s);
   }
-  {
-    ProfScope p(this, "groupnorm", 0, sL1 * D * (4 + 4 + 2));
-    groupnorm_stats(x1_.as<float>(), clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
-    groupnorm_apply(x1_.as<float>(), gn_stats_.as<float2>(), row_clip_.as<int>(), gn_w_, gn_b_, 6L * R, D,
-                    x1n_.as<bf16_t>(), s);
+  {  // GroupNorm(1 group): only the per-clip statistics are computed; the affine map is folded into conv2
+    ProfScope p(this, "groupnorm_stats", 0, sL1 * D * 2);
+    groupnorm_stats(x1_.as<bf16_t>(), clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
+    gn_fold_table(gn_stats_.as<float2>(), conv2_s1_, conv2_b2_, (int)n_clips_, 2 * D, gn_table_.as<float>(), s);
   }
-  {  // conv2 (k7, s3) + GELU: window of 7 channels-last frames is contiguous -> lda = 3D, K = 7D
+  {  // conv2 (k7, s3) + GroupNorm fold + GELU: window of 7 channels-last frames is contiguous -> lda = 3D, K = 7D
     ProfScope p(this, "conv2_gelu_gemm", 2.0 * sL2 * 2 * D * 7 * D, sL1 * D * 2 + sL2 * 2 * D * 2);
-    gemm_bias_gelu_bf16(x1n_.as<bf16_t>(), 3L * D, conv2_w_, conv2_b_, 2 * R, 2 * D, 7 * D, x2_.as<bf16_t>(), s);
+    gemm_gn_bias_gelu_bf16(x1_.as<bf16_t>(), 3L * D, conv2_w_, gn_table_.as<float>(), gn_stats_.as<float2>(),
+                           row_clip_.as<int>(), 2 * R, 2 * D, 7 * D, x2_.as<bf16_t>(), s);
   }
   {  // conv3 (k3, s2) + GELU -> residual stream H [R, D] fp32
     ProfScope p(this, "conv3_gelu_gemm", 2.0 * sT * D * 6 * D, sL2 * 2 * D * 2 + sT * D * 4);

@@ -107,7 +107,7 @@ class Engine {
 
   // weights
   bf16_t *conv1_w_ = nullptr, *conv2_w_ = nullptr, *conv3_w_ = nullptr;
-  float *conv2_b_ = nullptr, *conv3_b_ = nullptr, *gn_w_ = nullptr, *gn_b_ = nullptr, *enc_ln_ = nullptr;
+  float *conv2_s1_ = nullptr, *conv2_b2_ = nullptr, *conv3_b_ = nullptr, *enc_ln_ = nullptr;  // conv2_s1 / _b2: GroupNorm fold
   std::vector<EncLayerW> enc_;
   std::vector<DecLayerW> dec_;
   bf16_t *embed_bf16_ = nullptr, *embed_head_folded_ = nullptr, *cross_kv_w_ = nullptr;
@@ -124,8 +124,8 @@ class Engine {
   bool encoded_ = false, keep_enc_f32_ = false;
 
   // workspace (grow-only)
-  DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x1n_, x2_, H_, Y_, QKV_, AO_, Z_,
-      ENC_, ENC32_, gn_part_, gn_stats_, KT_, VT_;
+  DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, AO_, Z_,
+      ENC_, ENC32_, gn_part_, gn_stats_, gn_table_, KT_, VT_;
   int Smax_ = 0;
 
   // decode groups (own stream + buffers + captured step graph each); group 0 runs on stream_

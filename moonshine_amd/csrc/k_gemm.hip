@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 // bit 2 = no fragment reads, bit 3 = no epilogue stores, bit 4 = direct (unstaged) stores; ABL >> 8 = b + 1: workgroups whose id has bit b set start
 // ~10 us late (probe for co-resident workgroups running their main loops and epilogues in lockstep).
 template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
-__global__ __launch_bounds__(64 * NW) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
+__global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ W, int M, int N, int K,
                                                              int ntn, int nblocks, Epi epi) {
   constexpr int BM = 16 * NW * TM, BN = 16 * TN;
@@ -589,8 +589,12 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-void gemm_tanh_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiTanhF32{out, N}, s);
+void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s) {
+  launch_tiled<true>(A, lda, W, M, N, K, EpiTanhBf16{out, N}, s);
+}
+void gemm_gn_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* table, const float2* stats,
+                            const int* row_clip, int M, int N, int K, bf16_t* out, hipStream_t s) {
+  launch_tiled<true>(A, lda, W, M, N, K, EpiGnBiasGeluBf16{out, N, table, stats, row_clip}, s);
 }
 void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
                          bf16_t* out, hipStream_t s) {

@@ -43,20 +43,25 @@ __global__ __launch_bounds__(256) void build_row_meta_kernel(const ClipMeta* __r
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_CHUNKS = 64;
 
-__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x1,
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const bf16_t* __restrict__ x1,
                                                                 const ClipMeta* __restrict__ clips, int D,
                                                                 float2* __restrict__ partials) {
   __shared__ float2 red[4];
   const ClipMeta cm = clips[blockIdx.y];
-  const long n4 = (long)cm.L1 * D / 4;  // valid block is contiguous: rows [0, L1) x D
-  const float4* p = reinterpret_cast<const float4*>(x1 + 6L * cm.row_start * D);
-  const long per = (n4 + GN_CHUNKS - 1) / GN_CHUNKS;
-  const long lo = blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+  const long n8 = (long)cm.L1 * D / 8;  // valid block is contiguous: rows [0, L1) x D (D % 8 == 0)
+  const uint4* p = reinterpret_cast<const uint4*>(x1 + 6L * cm.row_start * D);
+  const long per = (n8 + GN_CHUNKS - 1) / GN_CHUNKS;
+  const long lo = blockIdx.x * per, hi = (lo + per < n8) ? lo + per : n8;
   float s = 0.f, ss = 0.f;
   for (long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float4 v = p[i];
-    s += (v.x + v.y) + (v.z + v.w);
-    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    const uint4 u = p[i];
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = __uint_as_float(w[k] << 16), b = __uint_as_float(w[k] & 0xffff0000u);
+      s += a + b;
+      ss += a * a + b * b;
+    }
   }
   s = wave_sum(s);
   ss = wave_sum(ss);
@@ -70,6 +75,13 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __r
     }
     partials[blockIdx.y * GN_CHUNKS + blockIdx.x] = a;
   }
+}
+
+__global__ void gn_fold_table_kernel(const float2* __restrict__ stats, const float* __restrict__ s1,
+                                     const float* __restrict__ b2, int N, float* __restrict__ table) {
+  const float2 st = stats[blockIdx.x];
+  const float c = st.x * st.y;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) table[(long)blockIdx.x * N + n] = b2[n] - c * s1[n];
 }
 
 __global__ void groupnorm_final_kernel(const float2* __restrict__ partials, const ClipMeta* __restrict__ clips,
@@ -86,26 +98,6 @@ __global__ void groupnorm_final_kernel(const float2* __restrict__ partials, cons
   double var = ss / n - mean * mean;
   var = var < 0.0 ? 0.0 : var;
   stats[b] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
-}
-
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x1,
-                                                              const float2* __restrict__ stats,
-                                                              const int* __restrict__ row_clip,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, long n4, int D4,
-                                                              bf16_t* __restrict__ out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const long r6 = i / D4;
-    const int c4 = (int)(i - r6 * D4);
-    const float2 st = stats[row_clip[r6 / 6]];
-    const float4 v = reinterpret_cast<const float4*>(x1)[i];
-    const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
-    const float4 b = reinterpret_cast<const float4*>(beta)[c4];
-    uint2 o;
-    o.x = pack_bf16x2((v.x - st.x) * st.y * g.x + b.x, (v.y - st.x) * st.y * g.y + b.y);
-    o.y = pack_bf16x2((v.z - st.x) * st.y * g.z + b.z, (v.w - st.x) * st.y * g.w + b.w);
-    reinterpret_cast<uint2*>(out)[i] = o;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,21 +296,18 @@ void build_row_meta(const ClipMeta* clips, int n_clips, int* row_pos, int* row_c
   hipLaunchKernelGGL(build_row_meta_kernel, dim3(2, n_clips), dim3(256), 0, s, clips, row_pos, row_clip);
 }
 
-void groupnorm_stats(const float* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
+void groupnorm_stats(const bf16_t* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
                      hipStream_t s) {
+  if ((D & 7) != 0) throw std::runtime_error("groupnorm_stats: width must be a multiple of 8");
   hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(GN_CHUNKS, n_clips), dim3(256), 0, s, x1, clips, D,
                      reinterpret_cast<float2*>(partials));
   hipLaunchKernelGGL(groupnorm_final_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, s,
                      reinterpret_cast<const float2*>(partials), clips, n_clips, D, stats);
 }
 
-void groupnorm_apply(const float* x1, const float2* stats, const int* row_clip, const float* gamma, const float* beta,
-                     long rows6, int D, bf16_t* out, hipStream_t s) {
-  const long n4 = rows6 * D / 4;
-  long blocks = (n4 + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x1, stats, row_clip, gamma, beta,
-                     n4, D / 4, out);
+void gn_fold_table(const float2* stats, const float* s1, const float* b2, int n_clips, int N, float* table,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(gn_fold_table_kernel, dim3(n_clips), dim3(256), 0, s, stats, s1, b2, N, table);
 }
 
 void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t* y, float* y_f32, hipStream_t s) {

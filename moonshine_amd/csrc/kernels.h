@@ -18,8 +18,15 @@ struct RopeParams {
 };
 
 // ---------------- tiled MFMA GEMM (large M): C = A[M,K](lda) * W[N,K]^T ----------------
-// conv1: out_f32[M,N] = tanh(acc)
-void gemm_tanh_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
+// conv1: out_bf16[M,N] = tanh(acc)
+void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s);
+// conv2 with the GroupNorm folded in (see EpiGnBiasGeluBf16): W = conv2 weight * gamma; table [clips][N] from
+// gn_fold_table; stats per clip {mean, rstd}; row m belongs to the clip of stream row m / 2
+void gemm_gn_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* table, const float2* stats,
+                            const int* row_clip, int M, int N, int K, bf16_t* out, hipStream_t s);
+// table[b][n] = b2[n] - mean_b * rstd_b * s1[n]
+void gn_fold_table(const float2* stats, const float* s1, const float* b2, int n_clips, int N, float* table,
+                   hipStream_t s);
 // out_bf16[M,N] = gelu(acc + bias)
 void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
                          bf16_t* out, hipStream_t s);
@@ -115,13 +122,9 @@ void pack_audio(const float* const* clip_ptrs, const ClipMeta* clips, int n_clip
                 hipStream_t s);
 // row_pos[m] = frame index within its clip (or -1 for padding rows), row_clip[m] = clip id
 void build_row_meta(const ClipMeta* clips, int n_clips, int* row_pos, int* row_clip, hipStream_t s);
-// GroupNorm(1 group) statistics per clip over the valid [L1, D] block of x1 (fp32) -> stats[b] = {mean, rstd}
-void groupnorm_stats(const float* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
+// GroupNorm(1 group) statistics per clip over the valid [L1, D] block of x1 (bf16) -> stats[b] = {mean, rstd}
+void groupnorm_stats(const bf16_t* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
                      hipStream_t s);
-// x1n_bf16 = (x1 - mean_b) * rstd_b * gamma[c] + beta[c]
-// (rows6 = 6 * R conv1 rows; row r6 belongs to the clip of stream row r6 / 6)
-void groupnorm_apply(const float* x1, const float2* stats, const int* row_clip, const float* gamma, const float* beta,
-                     long rows6, int D, bf16_t* out, hipStream_t s);
 // y_bf16[r,:] = LayerNorm(x[r,:]) * gamma   (no bias, eps 1e-5); optional fp32 copy
 void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t* y, float* y_f32, hipStream_t s);
 // decode bookkeeping after the logits of one step: first-max argmax per row, EOS / budget
