@@ -113,6 +113,10 @@ MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
 /* Average duration (ms) of an EMPTY profiling scope (two event records back to back on the engine stream): what every
  * per-launch figure of msh_profile_get carries on top of the kernel's own run time.  Negative on error. */
 MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
+/* Test hook: copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
+ * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]) to host memory; returns the buffer's
+ * size in bytes, -1 on error.  No reference counterpart (ORT owns these tensors there). */
+MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
 /* Developer hook: ms per launch of one tiled-GEMM configuration on synthetic operands (tools/gemm_microbench.py). */
 MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
                                           int32_t iters);

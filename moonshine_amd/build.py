@@ -25,6 +25,10 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
+# extra flags per source file ("packed-FP32 glitch")
+PER_FILE: dict[str, list[str]] = {f: ["-fno-slp-vectorize"] for f in ("k_gemm_dec.hip", "k_gemm.hip", "k_attn.hip", "k_misc.hip", "k_stream.hip")}
+
+
 def hipcc() -> str:
     for c in ("hipcc", "/opt/rocm/bin/hipcc"):
         p = shutil.which(c)
@@ -54,7 +58,7 @@ def _compile(src: str, force: bool, hdr_t: float) -> tuple[str, str]:
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
         return obj, ""
-    cmd = [hipcc(), f"--offload-arch={ARCH}", *COMMON, "-c", src, "-o", obj]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *COMMON, *PER_FILE.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x")
         cmd.insert(2, "hip")

@@ -580,6 +580,23 @@ struct Engine::DecodeGroup {
 
 void Engine::destroy_groups() { groups_.clear(); }
 
+size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
+  MSH_HIP(hipSetDevice(device_));
+  if (groups_.empty()) throw std::runtime_error("debug_read: no decode() yet");
+  DecodeGroup& g = *groups_[0];
+  const int dh = cfg_.head_dim();
+  const size_t cache = (size_t)cfg_.dec_layers * g.M * cfg_.heads * Smax_ * dh * sizeof(bf16_t);
+  const void* src = nullptr;
+  size_t size = 0;
+  if (name == "cache_k") src = g.cacheK.p, size = cache;
+  else if (name == "cache_v") src = g.cacheV.p, size = cache;
+  else if (name == "resid") src = g.dH.p, size = (size_t)g.M * cfg_.hidden * sizeof(float);
+  else throw std::invalid_argument("debug_read: unknown buffer " + name);
+  MSH_HIP(hipStreamSynchronize(g.stream));
+  if (dst != nullptr && bytes > 0) MSH_HIP(hipMemcpy(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost));
+  return size;
+}
+
 void Engine::decode_step_enqueue(DecodeGroup& g) {
   const int D = cfg_.hidden, F = cfg_.ffn, Hh = cfg_.heads, V = cfg_.vocab, dh = cfg_.head_dim();
   const int M = g.M;

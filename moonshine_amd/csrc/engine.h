@@ -85,6 +85,9 @@ class Engine {
   // average time between the two events of an EMPTY profiling scope on the engine stream: the part of every
   // per-launch figure that is event / dispatch bookkeeping rather than kernel time
   double profile_event_overhead_ms(int iters);
+  // test hook: bytes of a named decode buffer of the last decode() call ("cache_k", "cache_v", "resid"); copies
+  // min(bytes, size) to `dst` and returns the buffer's size
+  size_t debug_read(const std::string& name, void* dst, size_t bytes);
 
   hipStream_t stream() const { return stream_; }
   void synchronize();

@@ -703,7 +703,43 @@ void bench_launch(int abl, const bf16_t* A, long lda, const bf16_t* W, int M, in
 }
 }  // namespace
 
+// Probe: the same GEMM launched with `abl` bytes of extra dynamic LDS per workgroup, which moves the second
+// co-resident workgroup's pipeline ring up in the CU's 160 KB; returns the number of output elements that differ
+// from the launch without it.
+static float gemm_lds_placement_probe(int M, int N, int K, long lda, int dyn_lds, int iters) {
+  bf16_t *A = nullptr, *W = nullptr, *C = nullptr, *C2 = nullptr;
+  const long a_elems = (long)M * lda + K + 64;
+  MSH_HIP(hipMalloc(&A, a_elems * 2));
+  MSH_HIP(hipMalloc(&W, (long)N * K * 2));
+  MSH_HIP(hipMalloc(&C, (long)M * N * 2));
+  MSH_HIP(hipMalloc(&C2, (long)M * N * 2));
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+  constexpr int BM = 128, BN = 208;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN, nb = ntm * ntn;
+  hipLaunchKernelGGL((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), 0, 0, A, lda, W, M, N, K,
+                     ntn, nb, EpiBf16{C, N});
+  MSH_HIP(hipDeviceSynchronize());
+  std::vector<uint16_t> ref((size_t)M * N), got((size_t)M * N);
+  MSH_HIP(hipMemcpy(ref.data(), C, ref.size() * 2, hipMemcpyDeviceToHost));
+  long bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    MSH_HIP(hipMemset(C2, 0, (size_t)M * N * 2));
+    hipLaunchKernelGGL((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), dyn_lds, 0, A, lda, W, M,
+                       N, K, ntn, nb, EpiBf16{C2, N});
+    MSH_HIP(hipDeviceSynchronize());
+    MSH_HIP(hipMemcpy(got.data(), C2, got.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != got[i];
+  }
+  (void)hipFree(A);
+  (void)hipFree(W);
+  (void)hipFree(C);
+  (void)hipFree(C2);
+  return (float)bad;
+}
+
 float gemm_microbench(int M, int N, int K, long lda, int cfg, int abl, int iters) {
+  if (cfg == 10) return gemm_lds_placement_probe(M, N, K, lda, abl, iters);
   bf16_t *A = nullptr, *W = nullptr, *C = nullptr;
   const long a_elems = (long)M * lda + K + 64;
   MSH_HIP(hipMalloc(&A, a_elems * 2));

@@ -204,6 +204,12 @@ double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters) {
   return v;
 }
 
+int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) {
+  int64_t v = -1;
+  guarded(e, [&] { v = (int64_t)e->eng->debug_read(name ? name : "", dst, bytes); });
+  return v;
+}
+
 float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl, int32_t iters) {
   try {
     return msh::gemm_microbench(M, N, K, lda, cfg, abl, iters);

@@ -72,6 +72,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_profile_get": (i32, [vp, i32, P(ProfileEntry)]),
         "msh_synchronize": (i32, [vp]),
         "msh_profile_event_overhead_ms": (C.c_double, [vp, i32]),
+        "msh_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
         "msh_stream_create": (i32, [i32, C.c_char_p, C.c_char_p, i32, i32, P(vp)]),
         "msh_stream_create_from_memory": (i32, [i32, vp, u64, C.c_char_p, i32, i32, P(vp)]),
         "msh_stream_destroy": (None, [vp]),
@@ -106,7 +107,7 @@ DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
-    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms",
+    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_debug_read",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
@@ -238,6 +239,15 @@ class Engine:
 
     def synchronize(self):
         self._check(self.lib.msh_synchronize(self.h))
+
+    def debug_read(self, name: str) -> np.ndarray:
+        """Raw bytes of a decode buffer of the last decode() ("cache_k", "cache_v", "resid") -- test hook."""
+        size = int(self.lib.msh_debug_read(self.h, name.encode(), None, 0))
+        if size < 0:
+            raise MshError(-1, (self.lib.msh_last_error(self.h) or b"").decode())
+        out = np.empty(size, np.uint8)
+        self.lib.msh_debug_read(self.h, name.encode(), out.ctypes.data, size)
+        return out
 
 
 class StreamEngine:
