@@ -113,6 +113,20 @@ MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
 /* Average duration (ms) of an EMPTY profiling scope (two event records back to back on the engine stream): what every
  * per-launch figure of msh_profile_get carries on top of the kernel's own run time.  Negative on error. */
 MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
+/* ---- batches in flight (additive; the reference serialises calls on processing_mutex, core/moonshine-model.cpp:229) ----
+ * n lanes (1..8), each an engine with its own HIP stream, workspace and host thread, sharing this engine's weights: the
+ * encoder of one batch runs inside the idle gaps of another batch's decode loop.  n = 0 tears the lanes down.  The
+ * synchronous calls above keep using the engine itself and may be mixed with submitted batches. */
+MSH_EXPORT int32_t msh_set_batches_in_flight(msh_engine* e, int32_t n);
+/* Queue msh_transcribe_tokens for one batch; returns a ticket >= 0 or a negative msh error.  The clips and the output
+ * arrays must stay valid until msh_wait(ticket) returns (the pointer / length arrays themselves are copied). */
+MSH_EXPORT int64_t msh_submit_transcribe_tokens(msh_engine* e, const float* const* pcm, const uint64_t* n_samples,
+                                                uint32_t count, int32_t on_device, float max_tokens_per_second,
+                                                int32_t forced_steps, int32_t* tokens_out, int32_t* counts_out,
+                                                int32_t tokens_stride);
+/* Block until that batch is done; returns its status (msh_last_error has the message).  One wait per ticket. */
+MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
+
 /* Test hook: copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
  * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]) to host memory; returns the buffer's
  * size in bytes, -1 on error.  No reference counterpart (ORT owns these tensors there). */

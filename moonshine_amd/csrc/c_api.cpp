@@ -79,6 +79,8 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "use_speculative_decoding") o->use_speculative_decoding = parse_bool(v);
     else if (k == "max_streams") o->max_streams = parse_int32(v);                  // additive (streaming archs)
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
+    else if (k == "batch_clips") o->batch_clips = parse_int32(v);                   // additive (batch calls)
+    else if (k == "batches_in_flight") o->batches_in_flight = parse_int32(v);       // additive (batch calls)
     else if (k == "word_timestamps" || k == "identify_speakers") require_off(k, v);
     else if (k == "keyterms") {
       o->keyterms = parse_keyterms(v);

@@ -15,11 +15,9 @@ bool DevBuf::reserve(size_t bytes) {
   size_t want = bytes + bytes / 8 + 256;  // a little slack so ragged batches do not thrash
   void* np = nullptr;
   MSH_HIP(hipMalloc(&np, want));
-  // hipMemset on device memory is asynchronous to the host and runs on the null stream, which the engines'
-  // non-blocking streams do not wait for: without the sync the zero-fill can land AFTER the first kernel or copy
-  // that writes the new buffer (seen as a rare garbage-logits failure of the streaming tests).
-  MSH_HIP(hipMemset(np, 0, want));
-  MSH_HIP(hipDeviceSynchronize());
+  // The zero-fill must be complete before the first kernel or copy on an engine stream writes the new buffer (a plain
+  // hipMemset is asynchronous null-stream work those streams do not wait for: seen as rare garbage logits).
+  zero_blocking(np, want);
   if (p) MSH_HIP(hipFree(p));
   p = np;
   cap = want;
@@ -73,7 +71,7 @@ void Engine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
   MSH_HIP(hipMalloc(&p, src.size() * sizeof(float)));
   weight_allocs_.push_back(p);
-  MSH_HIP(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<float*>(p);
 }
 
@@ -83,7 +81,7 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   void* p = nullptr;
   MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
   weight_allocs_.push_back(p);
-  MSH_HIP(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
 }
 
@@ -97,6 +95,21 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
 //   q,k,v  3 x [D,D]   -> [3D][D] fused
 //   cross k,v of all decoder layers -> [L*2D][D] (one GEMM per batch)
 //   decoder fc1 [2F,D] -> rows interleaved (value_j, gate_j) so SwiGLU pairs sit in one lane
+void Engine::share_weights_from(const Engine& o) {
+  if (loaded_) throw std::runtime_error("weights already loaded");
+  if (!o.loaded_ || o.device_ != device_) throw std::runtime_error("share_weights_from: owner not loaded / other device");
+  cfg_ = o.cfg_;
+  conv1_w_ = o.conv1_w_, conv2_w_ = o.conv2_w_, conv3_w_ = o.conv3_w_;
+  conv2_s1_ = o.conv2_s1_, conv2_b2_ = o.conv2_b2_, conv3_b_ = o.conv3_b_, enc_ln_ = o.enc_ln_;
+  enc_ = o.enc_;
+  dec_ = o.dec_;
+  embed_bf16_ = o.embed_bf16_, embed_head_folded_ = o.embed_head_folded_, cross_kv_w_ = o.cross_kv_w_;
+  embed_f32_ = o.embed_f32_, dec_ln_ = o.dec_ln_;
+  rope_cos_ = o.rope_cos_, rope_sin_ = o.rope_sin_;
+  rope_max_pos_ = o.rope_max_pos_;
+  loaded_ = true;  // weight_allocs_ stays empty: the owner frees
+}
+
 // ------------------------------------------------------------------------------------------------
 void Engine::load_weights(const SafeTensors& st, int expect_arch) {
   MSH_HIP(hipSetDevice(device_));
@@ -545,8 +558,8 @@ void Engine::get_encoder_output(uint32_t clip, float* out) {
   if (!encoded_ || !keep_enc_f32_) throw std::runtime_error("encoder output not available (enable keep_encoder_f32)");
   const ClipMeta& c = clips_h_.at(clip);
   MSH_HIP(hipStreamSynchronize(stream_));
-  MSH_HIP(hipMemcpy(out, ENC32_.as<float>() + (long)c.row_start * cfg_.hidden,
-                    (size_t)c.T * cfg_.hidden * sizeof(float), hipMemcpyDeviceToHost));
+  copy_blocking(out, ENC32_.as<float>() + (long)c.row_start * cfg_.hidden,
+                    (size_t)c.T * cfg_.hidden * sizeof(float), hipMemcpyDeviceToHost);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,7 +606,7 @@ size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
   else if (name == "resid") src = g.dH.p, size = (size_t)g.M * cfg_.hidden * sizeof(float);
   else throw std::invalid_argument("debug_read: unknown buffer " + name);
   MSH_HIP(hipStreamSynchronize(g.stream));
-  if (dst != nullptr && bytes > 0) MSH_HIP(hipMemcpy(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost));
+  if (dst != nullptr && bytes > 0) copy_blocking(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost);
   return size;
 }
 
@@ -757,7 +770,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       for (int b = 0; b < M; ++b)
         for (int i = 0; i < stride && i < teacher_stride; ++i)
           t[(size_t)b * stride + i] = teacher[(size_t)(g.first + b) * teacher_stride + i];
-      MSH_HIP(hipMemcpy(g.teacher.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      copy_blocking(g.teacher.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     DecodeState& st = states[gi];
     st.tokens = g.tokens.as<int32_t>();

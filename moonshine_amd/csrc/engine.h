@@ -59,6 +59,8 @@ class Engine {
   ~Engine();
 
   void load_weights(const SafeTensors& st, int expect_arch /* -1 any, 0 tiny, 1 base */);
+  // Use the weight buffers of a loaded engine on the same device (read-only; `owner` must outlive this engine).
+  void share_weights_from(const Engine& owner);
   const ModelConfig& config() const { return cfg_; }
   bool loaded() const { return loaded_; }
 

@@ -9,10 +9,13 @@
 #include <string>
 
 #include "engine.h"
+#include "pipeline.h"
 #include "stream_engine.h"
 
 struct msh_engine {
   msh::Engine* eng = nullptr;
+  int device = 0;
+  std::unique_ptr<msh::BatchPipeline> pipe;  // batches in flight (msh_set_batches_in_flight)
   std::string last_error;
   std::vector<msh::ProfEntry> prof_cache;
 };
@@ -64,6 +67,7 @@ int32_t msh_create(int32_t device, msh_engine** out) {
     msh_engine* e = new msh_engine();
     try {
       e->eng = new msh::Engine(device);
+      e->device = device;
     } catch (...) {
       delete e;
       throw;
@@ -82,6 +86,7 @@ int32_t msh_create(int32_t device, msh_engine** out) {
 void msh_destroy(msh_engine* e) {
   if (e == nullptr) return;
   try {
+    e->pipe.reset();  // the lanes borrow the engine's weights
     delete e->eng;
   } catch (...) {
   }
@@ -202,6 +207,32 @@ double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters) {
   double v = -1.0;
   guarded(e, [&] { v = e->eng->profile_event_overhead_ms(iters); });
   return v;
+}
+
+int32_t msh_set_batches_in_flight(msh_engine* e, int32_t n) {
+  return guarded(e, [&] {
+    e->pipe.reset();
+    if (n > 0) e->pipe.reset(new msh::BatchPipeline(*e->eng, e->device, n));
+  });
+}
+
+int64_t msh_submit_transcribe_tokens(msh_engine* e, const float* const* pcm, const uint64_t* n_samples, uint32_t count,
+                                     int32_t on_device, float max_tokens_per_second, int32_t forced_steps,
+                                     int32_t* tokens_out, int32_t* counts_out, int32_t tokens_stride) {
+  int64_t ticket = -1;
+  const int32_t rc = guarded(e, [&] {
+    if (!e->pipe) throw std::invalid_argument("msh_submit_transcribe_tokens: call msh_set_batches_in_flight first");
+    ticket = e->pipe->submit(pcm, n_samples, count, on_device != 0, max_tokens_per_second, forced_steps, tokens_out,
+                             counts_out, tokens_stride);
+  });
+  return rc == MSH_OK ? ticket : (int64_t)rc;
+}
+
+int32_t msh_wait(msh_engine* e, int64_t ticket) {
+  return guarded(e, [&] {
+    if (!e->pipe) throw std::invalid_argument("msh_wait: no batches in flight");
+    e->pipe->wait(ticket);
+  });
 }
 
 int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) {

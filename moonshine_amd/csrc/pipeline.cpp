@@ -1,0 +1,87 @@
+#include "pipeline.h"
+
+#include <stdexcept>
+
+namespace msh {
+
+BatchPipeline::BatchPipeline(Engine& primary, int device, int lanes) : device_(device) {
+  if (lanes < 1 || lanes > 8) throw std::invalid_argument("batches in flight must be 1..8");
+  if (!primary.loaded()) throw std::runtime_error("batches in flight: load the weights first");
+  for (int i = 0; i < lanes; ++i) {
+    std::unique_ptr<Engine> e(new Engine(device));
+    e->share_weights_from(primary);
+    lanes_.push_back(std::move(e));
+  }
+  for (int i = 0; i < lanes; ++i) threads_.emplace_back([this, i] { worker(i); });
+}
+
+BatchPipeline::~BatchPipeline() {
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  for (std::thread& t : threads_) t.join();
+}
+
+int64_t BatchPipeline::submit(const float* const* pcm, const uint64_t* n_samples, uint32_t count, bool on_device, float mtps,
+                              int forced_steps, int32_t* tokens_out, int32_t* counts_out, int tokens_stride) {
+  if (count == 0 || pcm == nullptr || n_samples == nullptr) throw std::invalid_argument("submit: empty batch");
+  std::shared_ptr<Job> j(new Job());
+  j->pcm.assign(pcm, pcm + count);
+  j->n_samples.assign(n_samples, n_samples + count);
+  j->on_device = on_device;
+  j->mtps = mtps;
+  j->forced_steps = forced_steps;
+  j->tokens_out = tokens_out;
+  j->counts_out = counts_out;
+  j->tokens_stride = tokens_stride;
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    j->ticket = next_ticket_++;
+    jobs_[j->ticket] = j;
+    queue_.push_back(j);
+  }
+  cv_work_.notify_one();
+  return j->ticket;
+}
+
+void BatchPipeline::wait(int64_t ticket) {
+  std::shared_ptr<Job> j;
+  {
+    std::unique_lock<std::mutex> lock(mu_);
+    auto it = jobs_.find(ticket);
+    if (it == jobs_.end()) throw std::invalid_argument("wait: unknown ticket " + std::to_string(ticket));
+    j = it->second;
+    cv_done_.wait(lock, [&] { return j->done; });
+    jobs_.erase(ticket);
+  }
+  if (j->error) std::rethrow_exception(j->error);
+}
+
+void BatchPipeline::worker(int lane) {
+  Engine& eng = *lanes_[lane];
+  for (;;) {
+    std::shared_ptr<Job> j;
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      cv_work_.wait(lock, [&] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) return;  // stop requested and nothing left to do
+      j = queue_.front();
+      queue_.pop_front();
+    }
+    try {
+      eng.encode(j->pcm.data(), j->n_samples.data(), (uint32_t)j->pcm.size(), j->on_device, j->mtps);
+      eng.decode(j->forced_steps, nullptr, 0, nullptr, 0, j->tokens_out, j->counts_out, j->tokens_stride);
+    } catch (...) {
+      j->error = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      j->done = true;
+    }
+    cv_done_.notify_all();
+  }
+}
+
+}  // namespace msh

@@ -96,7 +96,7 @@ void StreamingEngine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
   MSH_HIP(hipMalloc(&p, std::max<size_t>(src.size(), 4) * sizeof(float)));
   allocs_.push_back(p);
-  MSH_HIP(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<float*>(p);
 }
 void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
@@ -105,7 +105,7 @@ void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   void* p = nullptr;
   MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
   allocs_.push_back(p);
-  MSH_HIP(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
 }
 
@@ -342,13 +342,10 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
   auto slab = [&](size_t bytes) {
     void* p = nullptr;
     MSH_HIP(hipMalloc(&p, bytes));
-    MSH_HIP(hipMemset(p, 0, bytes));
     allocs_.push_back(p);
+    zero_blocking(p, bytes);  // complete before anything on the engine stream touches the slab (see DevBuf::reserve)
     return p;
   };
-  struct SyncAtExit {  // the zero-fills above are asynchronous null-stream work (see DevBuf::reserve)
-    ~SyncAtExit() { (void)hipDeviceSynchronize(); }
-  } sync_at_exit;
   const size_t S = (size_t)max_slots_;
   conv1_buf_ = (bf16_t*)slab(S * 4 * De * 2);
   conv2_buf_ = (bf16_t*)slab(S * 4 * 2 * De * 2);
@@ -398,15 +395,15 @@ void StreamingEngine::get_memory(int slot, float* out) {
   const SlotHost& h = st(slot);
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamSynchronize(stream_));
-  MSH_HIP(hipMemcpy(out, memory_ + (size_t)slot * Mcap_ * cfg_.decoder_dim,
-                    (size_t)h.mem_len * cfg_.decoder_dim * sizeof(float), hipMemcpyDeviceToHost));
+  copy_blocking(out, memory_ + (size_t)slot * Mcap_ * cfg_.decoder_dim,
+                    (size_t)h.mem_len * cfg_.decoder_dim * sizeof(float), hipMemcpyDeviceToHost);
 }
 void StreamingEngine::get_features(int slot, float* out) {
   const SlotHost& h = st(slot);
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamSynchronize(stream_));
-  MSH_HIP(hipMemcpy(out, features_ + (size_t)slot * Mcap_ * cfg_.encoder_dim,
-                    (size_t)h.feat_count * cfg_.encoder_dim * sizeof(float), hipMemcpyDeviceToHost));
+  copy_blocking(out, features_ + (size_t)slot * Mcap_ * cfg_.encoder_dim,
+                    (size_t)h.feat_count * cfg_.encoder_dim * sizeof(float), hipMemcpyDeviceToHost);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,16 +61,65 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
     msh_profile_reset(engine);
     msh_profile_enable(engine, 1);
   }
-  if (msh_encode(engine, audio.data(), lens.data(), count, 0, max_tokens_per_second) != MSH_OK) {
-    MSH_LOGF("encoder failed: %s", error().c_str());
-    return 1;
-  }
-  const int32_t steps = msh_max_decode_steps(engine);
-  const int32_t stride = steps + 1;
-  std::vector<int32_t> tokens((size_t)count * stride), counts(count);
-  if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, tokens.data(), counts.data(), stride) != MSH_OK) {
-    MSH_LOGF("decoder failed: %s", error().c_str());
-    return 1;
+  const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
+  std::vector<int32_t> tokens, counts(count);
+  int32_t stride = 0;
+  if (count <= chunk || batches_in_flight <= 1 || log_ort_run) {
+    // one sub-batch after the other on the engine itself
+    std::vector<std::vector<int32_t>> parts;
+    std::vector<int32_t> strides;
+    for (uint32_t lo = 0; lo < count; lo += chunk) {
+      const uint32_t n = std::min(chunk, count - lo);
+      if (msh_encode(engine, audio.data() + lo, lens.data() + lo, n, 0, max_tokens_per_second) != MSH_OK) {
+        MSH_LOGF("encoder failed: %s", error().c_str());
+        return 1;
+      }
+      const int32_t st = msh_max_decode_steps(engine) + 1;
+      parts.emplace_back((size_t)n * st);
+      strides.push_back(st);
+      if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, parts.back().data(), counts.data() + lo, st) != MSH_OK) {
+        MSH_LOGF("decoder failed: %s", error().c_str());
+        return 1;
+      }
+    }
+    size_t p = 0;
+    for (uint32_t lo = 0; lo < count; lo += chunk, ++p)
+      for (uint32_t i = lo; i < std::min(count, lo + chunk); ++i)
+        (*out_texts)[i] = tokenizer->tokens_to_text(parts[p].data() + (size_t)(i - lo) * strides[p], (size_t)counts[i]);
+  } else {
+    if (!lanes_ready) {
+      if (msh_set_batches_in_flight(engine, batches_in_flight) != MSH_OK) {
+        MSH_LOGF("batches in flight: %s", error().c_str());
+        return 1;
+      }
+      lanes_ready = true;
+    }
+    // rows wide enough for the step budget of the longest clip (the engine's rule: ceil(seconds * tokens/s)) + BOS
+    size_t longest = 0;
+    for (uint64_t n : lens) longest = std::max<size_t>(longest, (size_t)n);
+    stride = (int32_t)ceilf((float)longest / 16000.0f * max_tokens_per_second) + 2;
+    tokens.assign((size_t)count * stride, 0);
+    std::vector<int64_t> tickets;
+    bool failed = false;
+    for (uint32_t lo = 0; lo < count; lo += chunk) {
+      const uint32_t n = std::min(chunk, count - lo);
+      const int64_t t = msh_submit_transcribe_tokens(engine, audio.data() + lo, lens.data() + lo, n, 0, max_tokens_per_second, -1,
+                                                     tokens.data() + (size_t)lo * stride, counts.data() + lo, stride);
+      if (t < 0) {
+        MSH_LOGF("submit failed: %s", error().c_str());
+        failed = true;
+        break;
+      }
+      tickets.push_back(t);
+    }
+    for (int64_t t : tickets)  // every queued sub-batch is waited for, also after a failure: they write into `tokens`
+      if (msh_wait(engine, t) != MSH_OK) {
+        MSH_LOGF("sub-batch failed: %s", error().c_str());
+        failed = true;
+      }
+    if (failed) return 1;
+    for (uint32_t i = 0; i < count; ++i)
+      (*out_texts)[i] = tokenizer->tokens_to_text(tokens.data() + (size_t)i * stride, (size_t)counts[i]);
   }
   if (log_ort_run) {
     const int32_t n = msh_profile_count(engine);
@@ -81,8 +130,6 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
     }
     msh_profile_enable(engine, 0);
   }
-  for (uint32_t i = 0; i < count; ++i)
-    (*out_texts)[i] = tokenizer->tokens_to_text(tokens.data() + (size_t)i * stride, (size_t)counts[i]);
   return 0;
 }
 
@@ -197,6 +244,8 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
     throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
                              "does not decode through a path that can apply it.");
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
+  model_->batch_clips = opt_.batch_clips;
+  model_->batches_in_flight = opt_.batches_in_flight;
   if (opt_.model_source == TranscriberOptions::FILES) {
     if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
     if (!is_dir_or_file(opt_.model_path))

@@ -31,6 +31,11 @@ struct MoonshineModel {
   std::mutex processing_mutex;
   float max_tokens_per_second = 6.5f;  // reference core/moonshine-model.h:49
   bool log_ort_run = false;            // here: print per-kernel-group timings after each call
+  // additive: a call with more than batch_clips clips is cut into sub-batches of that size and batches_in_flight of them
+  // run on the GPU at once (include/moonshine_hip.h, msh_set_batches_in_flight); 1 = one sub-batch after the other
+  int batch_clips = 256;
+  int batches_in_flight = 2;
+  bool lanes_ready = false;
   std::string last_result;
 
   MoonshineModel(bool log_ort_run, float max_tokens_per_second, int device);
@@ -69,6 +74,8 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
+  int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call
+  int batches_in_flight = 2;             // additive: sub-batches on the GPU at once (1 = strictly one after the other)
   bool return_audio_data = true;
   bool log_output_text = false;
   bool log_ort_run = false;

@@ -73,6 +73,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_synchronize": (i32, [vp]),
         "msh_profile_event_overhead_ms": (C.c_double, [vp, i32]),
         "msh_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
+        "msh_set_batches_in_flight": (i32, [vp, i32]),
+        "msh_submit_transcribe_tokens": (C.c_int64, [vp, vp, vp, C.c_uint32, i32, C.c_float, i32, vp, vp, i32]),
+        "msh_wait": (i32, [vp, C.c_int64]),
         "msh_stream_create": (i32, [i32, C.c_char_p, C.c_char_p, i32, i32, P(vp)]),
         "msh_stream_create_from_memory": (i32, [i32, vp, u64, C.c_char_p, i32, i32, P(vp)]),
         "msh_stream_destroy": (None, [vp]),
@@ -108,6 +111,7 @@ DECLARED_SYMBOLS = [
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_debug_read",
+    "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
@@ -239,6 +243,37 @@ class Engine:
 
     def synchronize(self):
         self._check(self.lib.msh_synchronize(self.h))
+
+    # -- batches in flight ------------------------------------------------------------------------
+    def set_batches_in_flight(self, n: int):
+        self._check(self.lib.msh_set_batches_in_flight(self.h, n))
+
+    def submit_transcribe_tokens(self, clips=None, max_tokens_per_second: float = 6.5, forced_steps: int = -1,
+                                 device_ptrs=None, max_steps: int | None = None):
+        """Queue one batch on the lanes; returns a ticket for wait_tokens().  max_steps bounds the token rows when the
+        reference budget applies (forced_steps < 0): ceil(longest clip in s * max_tokens_per_second)."""
+        n = len(device_ptrs) if device_ptrs is not None else len(clips)
+        ptrs, lens, keep = self._clip_args(clips if clips is not None else [None] * n, device_ptrs)
+        if forced_steps >= 0:
+            steps = forced_steps
+        elif max_steps is not None:
+            steps = max_steps
+        else:
+            longest = max(int(l) for l in lens)
+            steps = max(1, int(np.ceil(longest / 16000.0 * max_tokens_per_second))) + 1  # >= the engine's own budget
+        stride = steps + 1
+        tokens = np.full((n, stride), -1, np.int32)
+        counts = np.zeros(n, np.int32)
+        t = self.lib.msh_submit_transcribe_tokens(self.h, ptrs, lens, n, 1 if device_ptrs is not None else 0,
+                                                  max_tokens_per_second, forced_steps, tokens.ctypes.data, counts.ctypes.data, stride)
+        if t < 0:
+            raise MshError(int(t), (self.lib.msh_last_error(self.h) or b"").decode())
+        return (int(t), tokens, counts, keep, ptrs, lens)
+
+    def wait_tokens(self, ticket) -> list[list[int]]:
+        t, tokens, counts = ticket[0], ticket[1], ticket[2]
+        self._check(self.lib.msh_wait(self.h, t))
+        return [tokens[i, : counts[i]].tolist() for i in range(tokens.shape[0])]
 
     def debug_read(self, name: str) -> np.ndarray:
         """Raw bytes of a decode buffer of the last decode() ("cache_k", "cache_v", "resid") -- test hook."""

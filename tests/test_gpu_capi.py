@@ -82,6 +82,20 @@ def test_batch_call_equals_single_calls(tiny):
     assert batch[4][0].text_bytes == b""
 
 
+def test_batch_call_in_sub_batches_with_two_in_flight(tiny_dir, tiny):
+    """Additive options batch_clips / batches_in_flight: a 23-clip call cut into sub-batches of 4 with two of them on the
+    GPU at once returns exactly the transcripts of the uncut call, and so does the strictly serial cut (in flight = 1)."""
+    clips = [make_audio(200 + i, 12000 + 3517 * ((5 * i) % 17)) for i in range(23)]
+    want = [[l.text_bytes for l in t] for t in tiny.transcribe_batch_without_streaming(clips)]
+    for opts in ({"batch_clips": "4", "batches_in_flight": "2"}, {"batch_clips": "4", "batches_in_flight": "1"},
+                 {"batch_clips": "1", "batches_in_flight": "3"}):
+        t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", **opts})
+        for _ in range(2):
+            got = [[l.text_bytes for l in r] for r in t.transcribe_batch_without_streaming(clips)]
+            assert got == want, opts
+        t.close()
+
+
 def test_other_sample_rate_goes_through_the_resampler(tiny, engine):
     vocab = synthetic_vocab(ARCHS["tiny"].vocab)
     x = make_audio(31, 72000)  # pretend 24 kHz

@@ -288,3 +288,35 @@ def test_fused_argmax_lm_head_matches_logits_path(tmp_path_factory):
     e.encode(many)
     p9, _ = e.decode(forced_steps=9, want_logits=1)
     assert f9 == p9
+
+
+def test_batches_in_flight_match_synchronous_calls(base):
+    """include/moonshine_hip.h msh_submit_transcribe_tokens / msh_wait: six ragged batches on three lanes (encoders and
+    decode loops of different batches overlap on the GPU) must return exactly the ids of the synchronous call, in both
+    the reference stopping rule (EOS / per-clip budget) and the forced-steps mode; bad tickets are errors."""
+    from moonshine_amd.hip_api import MshError
+
+    e, _, _ = base
+    batches = []
+    for b in range(6):
+        n = 3 + 5 * b
+        batches.append([make_audio(100 * b + i, 16000 + 2377 * ((7 * i + b) % 23)) for i in range(n)])
+    want_free = [e.transcribe_tokens(c) for c in batches]
+    want_forced = [e.transcribe_tokens(c, forced_steps=9) for c in batches]
+    e.set_batches_in_flight(3)
+    try:
+        for _ in range(2):  # second round reuses warmed lanes (captured graphs, grown workspaces)
+            tickets = [e.submit_transcribe_tokens(c) for c in batches] + [e.submit_transcribe_tokens(c, forced_steps=9) for c in batches]
+            got = [e.wait_tokens(t) for t in tickets]
+            assert got[:6] == want_free
+            assert got[6:] == want_forced
+        with pytest.raises(MshError):
+            e.wait_tokens((12345, np.zeros((1, 1), np.int32), np.zeros(1, np.int32)))
+        # the synchronous path keeps working next to the lanes
+        t = e.submit_transcribe_tokens(batches[5])
+        assert e.transcribe_tokens(batches[0]) == want_free[0]
+        assert e.wait_tokens(t) == want_free[5]
+    finally:
+        e.set_batches_in_flight(0)
+    with pytest.raises(MshError):
+        e.submit_transcribe_tokens(batches[0])
