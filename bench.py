@@ -238,7 +238,10 @@ def main():
     serial_ref = step()  # primary engine: allocates its workspace, captures its decode graph (also used by the profiling pass)
     if F > 1:
         eng.set_batches_in_flight(F)
-        run_steps(2 * F)  # every lane allocates and captures before the timed region
+        # every lane allocates its workspace and captures its decode graph before the timed region -- and before any
+        # torch / RCCL call runs next to it (legacy-stream work is not allowed while another thread captures)
+        for t in [eng.submit_transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps) for _ in range(3 * F)]:
+            eng.wait_tokens(t)
     if args.warmup > 0:
         run_steps(args.warmup)
     if dist is not None:
