@@ -361,7 +361,10 @@ def main():
                    "batches_in_flight": F},
         "serial_steps": serial,
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
-            "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"], "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3),
+            "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"],
+            # HIP events around every launch of one extra step that runs ALONE on the GPU (no other batch in flight):
+            # the kernel's own speed; with batches in flight the same launches stretch (profiles/*_inflight.csv)
+            "measured_in": "serial profiling step", "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3),
             # HIP-event time per launch includes the scope's own event bookkeeping (an EMPTY scope lasts
             # `empty_event_scope_us`, an upper bound on it): the rocprofv3 kernel duration in profiles/ is ~2 us shorter
             "empty_event_scope_us": round(ev_overhead_ms * 1e3, 2)},
