@@ -15,6 +15,11 @@ Extra objects in the line:
   latency_ms    p50 end-to-end latency of a single 10 s clip (batch 1), encode / decode split.
 """
 import argparse
+import os
+
+# hardware queues for concurrent streams: must be in the environment before the HIP runtime initialises (first torch.cuda
+# call); libmoonshine.so sets the same default when it is loaded first (moonshine_amd/csrc/msh_api.cpp)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import json
 import os
 import statistics
@@ -40,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU (engine lanes with their own stream / workspace; 1 = strictly serial steps)")
     ap.add_argument("--decode-steps", type=int, default=65, help="forced decode steps (ceil(10 s * 6.5 tok/s))")
     ap.add_argument("--arch", default="base")

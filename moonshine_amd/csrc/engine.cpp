@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include <mutex>
+
 #include <math.h>
 #include <string.h>
 
@@ -8,6 +10,44 @@
 #include <algorithm>
 
 namespace msh {
+
+namespace {
+struct UtilStreams {
+  std::mutex mu;
+  std::map<int, hipStream_t> by_device;
+  hipStream_t get() {  // call with mu held
+    int dev = 0;
+    MSH_HIP(hipGetDevice(&dev));
+    auto it = by_device.find(dev);
+    if (it != by_device.end()) return it->second;
+    hipStream_t s = nullptr;
+    MSH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    by_device[dev] = s;
+    return s;
+  }
+};
+UtilStreams& util_streams() {
+  static UtilStreams* u = new UtilStreams();  // never destroyed: the HIP runtime may already be gone at exit
+  return *u;
+}
+}  // namespace
+
+void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return;
+  UtilStreams& u = util_streams();
+  std::lock_guard<std::mutex> lock(u.mu);
+  hipStream_t s = u.get();
+  MSH_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+  MSH_HIP(hipStreamSynchronize(s));
+}
+void zero_blocking(void* p, size_t bytes) {
+  if (bytes == 0) return;
+  UtilStreams& u = util_streams();
+  std::lock_guard<std::mutex> lock(u.mu);
+  hipStream_t s = u.get();
+  MSH_HIP(hipMemsetAsync(p, 0, bytes, s));
+  MSH_HIP(hipStreamSynchronize(s));
+}
 
 // ------------------------------------------------------------------------------------------------
 bool DevBuf::reserve(size_t bytes) {
@@ -39,6 +79,13 @@ Engine::Engine(int device) : device_(device) {
   if (device < 0 || device >= n) throw HipError("invalid device index " + std::to_string(device));
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  {
+    // first command now, not at the first encode(): HIP binds a stream to its hardware queue lazily and round-robin, so
+    // engines (lanes) created one after the other get consecutive queues only if each touches its stream right away
+    MSH_HIP(hipMalloc(&stream_probe_, 256));
+    MSH_HIP(hipMemsetAsync(stream_probe_, 0, 256, stream_));
+    MSH_HIP(hipStreamSynchronize(stream_));
+  }
   const char* ng = getenv("MSH_NO_GRAPH");
   if (ng != nullptr && ng[0] == '1') use_graph_ = false;
   const char* dg = getenv("MSH_DEC_GROUPS");
@@ -50,6 +97,7 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamSynchronize(stream_);
   groups_.clear();
   if (enc_done_) (void)hipEventDestroy(enc_done_);
+  if (stream_probe_) (void)hipFree(stream_probe_);
   for (hipEvent_t ev : event_pool_) (void)hipEventDestroy(ev);
   for (auto& r : prof_pending_) {
     (void)hipEventDestroy(r.a);

@@ -106,6 +106,7 @@ class Engine {
 
   int device_;
   hipStream_t stream_ = nullptr;
+  void* stream_probe_ = nullptr;
   ModelConfig cfg_;
   bool loaded_ = false;
   std::vector<void*> weight_allocs_;

@@ -30,29 +30,13 @@ struct HipError : std::runtime_error {
 // Blocking copies / zero-fills that stay OFF the legacy (null) stream: hipMemcpy / hipMemset / hipDeviceSynchronize
 // touch it, and the legacy stream may not be used while ANOTHER host thread captures a decode-step graph on its own
 // stream ("operation would make the legacy stream depend on a capturing blocking stream") -- which is exactly what
-// several engines or lanes in one process do.  Each call runs on a short-lived non-blocking stream and waits for it,
-// so the result is visible to every later launch on any stream.
-struct UtilStream {
-  hipStream_t s = nullptr;
-  UtilStream() { MSH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
-  ~UtilStream() {
-    if (s) (void)hipStreamDestroy(s);
-  }
-  UtilStream(const UtilStream&) = delete;
-  UtilStream& operator=(const UtilStream&) = delete;
-};
-inline void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-  if (bytes == 0) return;
-  UtilStream u;
-  MSH_HIP(hipMemcpyAsync(dst, src, bytes, kind, u.s));
-  MSH_HIP(hipStreamSynchronize(u.s));
-}
-inline void zero_blocking(void* p, size_t bytes) {
-  if (bytes == 0) return;
-  UtilStream u;
-  MSH_HIP(hipMemsetAsync(p, 0, bytes, u.s));
-  MSH_HIP(hipStreamSynchronize(u.s));
-}
+// several engines or lanes in one process do.  They run on ONE long-lived non-blocking utility stream per device
+// (serialised by a mutex) and wait for it, so the result is visible to every later launch on any stream.  One stream,
+// not one per call: HIP hands streams their hardware queue round-robin out of a small pool (GPU_MAX_HW_QUEUES, 4 by
+// default), and a churn of short-lived streams made two engine lanes land on the same queue, i.e. run one after the
+// other (profiles/r03e_kernel_trace: lanes on queues 3, 4, 4).
+void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+void zero_blocking(void* p, size_t bytes);
 
 // ---- bf16 <-> fp32 (round-to-nearest-even), usable on host and device ----
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {

@@ -20,6 +20,8 @@ CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2_${TAG} -- $CMD2 > /tmp/prof2_${TAG}.log 2>&1)
 f=$(find /tmp/prof2_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_inflight.csv && head -4 "$f" | cut -c1-160
+f=$(find /tmp/prof2_${TAG} -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && cut -d, -f1-20 "$f" | gzip -9 > gpurun_out/${TAG}_kernel_trace_inflight.csv.gz && ls -la gpurun_out/${TAG}_kernel_trace_inflight.csv.gz
 pass() { # name counters...
   local name=$1; shift
   (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /tmp/pmc_${TAG}_$name.log 2>&1)
@@ -32,7 +34,7 @@ import csv, glob, collections, json, re
 GROUPS = {  # bench.py kernel group -> kernel-name pattern
     "dec_cross_attention": r"dec_cross_attention_kernel", "dec_self_attention": r"dec_self_attention_kernel",
     "enc_attention": r"enc_attention_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
-    "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiBiasGeluBf16",
+    "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiGnBiasGeluBf16", "enc_fc1_gelu_gemm": r"gemm_astat_kernel.*EpiBiasGeluBf16",
 }
 out = {}
 for name in ("fetch", "write"):
