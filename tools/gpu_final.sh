@@ -21,7 +21,15 @@ CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency"
 f=$(find /tmp/prof2_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_inflight.csv && head -4 "$f" | cut -c1-160
 f=$(find /tmp/prof2_${TAG} -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && cut -d, -f1-20 "$f" | gzip -9 > gpurun_out/${TAG}_kernel_trace_inflight.csv.gz && ls -la gpurun_out/${TAG}_kernel_trace_inflight.csv.gz
+[ -n "$f" ] && python - "$f" gpurun_out/${TAG}_kernel_trace_inflight.csv.gz <<'PYT'
+import csv, gzip, re, sys
+with open(sys.argv[1]) as src, gzip.open(sys.argv[2], "wt") as dst:
+    w = csv.writer(dst)
+    w.writerow(["queue", "start_ns", "end_ns", "kernel"])
+    for r in csv.DictReader(src):
+        name = re.sub(r"msh::\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:80]
+        w.writerow([r["Queue_Id"], r["Start_Timestamp"], r["End_Timestamp"], name])
+PYT
 pass() { # name counters...
   local name=$1; shift
   (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /tmp/pmc_${TAG}_$name.log 2>&1)
