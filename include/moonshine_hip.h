@@ -160,6 +160,18 @@ MSH_EXPORT int64_t msh_host_text_to_tokens(const uint8_t* tokenizer_bin, uint64_
  *                           of the given tokenizer; the chosen terms come back joined by '\n'. */
 MSH_EXPORT int64_t msh_host_context_terms(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* context,
                                           uint64_t context_len, int32_t max_terms, char* out, uint64_t out_cap);
+/* Word alignment (reference core/word-alignment.cpp): the host code the transcriber runs on the device's cross-attention.
+ * msh_host_dtw           : dtw (:12-88); returns the path length, indices into text_idx / time_idx (cap entries each).
+ * msh_host_median_filter : median_filter (:98-153) in place over [rows][row_len].
+ * msh_host_align_words   : align_words (:181-394) on att [heads_total][n_steps][frames]; word texts joined by '\n' into
+ *                          text_out, (start, end, confidence) triples into times_out; returns the word count. */
+MSH_EXPORT int64_t msh_host_dtw(const float* cost, int32_t n_text, int32_t n_time, int32_t* text_idx, int32_t* time_idx,
+                                uint64_t cap);
+MSH_EXPORT int32_t msh_host_median_filter(float* data, uint64_t rows, int32_t row_len, int32_t width);
+MSH_EXPORT int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const float* att,
+                                        int32_t heads_total, int32_t n_steps, int32_t frames, const int32_t* tokens,
+                                        uint64_t n_tokens, float seconds_per_frame, char* text_out, uint64_t text_cap,
+                                        float* times_out, uint64_t max_words);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

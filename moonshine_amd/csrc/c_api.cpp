@@ -19,6 +19,7 @@
 #include "context_biaser.h"
 #include "context_extractor.h"
 #include "transcriber.h"
+#include "word_alignment.h"
 
 using namespace msh_host;
 
@@ -374,6 +375,46 @@ int64_t msh_host_context_terms(const uint8_t* tokenizer_bin, uint64_t tokenizer_
     std::string joined;
     for (size_t i = 0; i < terms.size(); ++i) joined += (i ? "\n" : "") + terms[i];
     return copy_out(joined, out, out_cap);
+  } catch (const std::exception& e) {
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_dtw(const float* cost, int32_t n_text, int32_t n_time, int32_t* text_idx, int32_t* time_idx, uint64_t cap) {
+  if (cost == nullptr || n_text <= 0 || n_time <= 0) return MSH_ERR_INVALID_ARGUMENT;
+  std::vector<int> a, b;
+  dtw_path(cost, n_text, n_time, &a, &b);
+  for (size_t i = 0; i < a.size() && i < cap; ++i) {
+    if (text_idx) text_idx[i] = a[i];
+    if (time_idx) time_idx[i] = b[i];
+  }
+  return (int64_t)a.size();
+}
+
+int32_t msh_host_median_filter(float* data, uint64_t rows, int32_t row_len, int32_t width) {
+  if (data == nullptr || row_len <= 0) return MSH_ERR_INVALID_ARGUMENT;
+  median_filter_rows(data, (size_t)rows, row_len, width);
+  return MSH_OK;
+}
+
+int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const float* att, int32_t heads_total,
+                             int32_t n_steps, int32_t frames, const int32_t* tokens, uint64_t n_tokens,
+                             float seconds_per_frame, char* text_out, uint64_t text_cap, float* times_out, uint64_t max_words) {
+  try {
+    BinTokenizer tok(tokenizer_bin, (size_t)tokenizer_size);
+    const std::vector<TranscriberWord> words = align_words(att, heads_total, n_steps, frames, std::vector<int32_t>(tokens, tokens + n_tokens),
+                                                           seconds_per_frame, tok);
+    std::string joined;
+    for (size_t i = 0; i < words.size(); ++i) {
+      joined += (i ? "\n" : "") + words[i].text;
+      if (times_out != nullptr && i < max_words) {
+        times_out[3 * i] = words[i].start;
+        times_out[3 * i + 1] = words[i].end;
+        times_out[3 * i + 2] = words[i].confidence;
+      }
+    }
+    if (copy_out(joined, text_out, text_cap) < 0) return MSH_ERR_INVALID_ARGUMENT;
+    return (int64_t)words.size();
   } catch (const std::exception& e) {
     return MSH_ERR_INVALID_ARGUMENT;
   }

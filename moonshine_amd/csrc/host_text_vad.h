@@ -17,6 +17,7 @@ class BinTokenizer {
   BinTokenizer(const uint8_t* data, size_t size, const std::string& space_marker = "\xE2\x96\x81");
   static BinTokenizer* from_file(const std::string& path);
   size_t vocab_size() const { return tokens_.size(); }
+  const std::string& token_bytes(size_t id) const { return tokens_[id]; }
   // ids -> text: concatenate, skip `<...>` specials, marker -> ' ', trim spaces/tabs
   // (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).  Throws on an id with no bytes.
   std::string tokens_to_text(const int32_t* ids, size_t count, bool skip_specials = true) const;

@@ -174,10 +174,12 @@ class DecoderState:
         return self.self_k[0].shape[1]
 
 
-def decoder_forward(w: dict, cfg: ArchConfig, st: DecoderState, tokens) -> np.ndarray:
+def decoder_forward(w: dict, cfg: ArchConfig, st: DecoderState, tokens, cross_probs: list | None = None) -> np.ndarray:
     """MoonshineDecoder.forward hf:639-711 + tied LM head hf:858-: feed ``tokens``
     (n >= 1 ids) at positions past_len .. past_len+n-1, append to the self cache,
-    return logits [n, V]."""
+    return logits [n, V].  ``cross_probs``: if a list, one [H, n, T] array of cross-attention
+    probabilities per layer is appended (the ``cross_attentions.{l}`` outputs of the reference's
+    attention-exporting decoder, core/moonshine-model.cpp:480-500)."""
     H = cfg.heads
     ids = np.asarray(tokens, dtype=np.int64).reshape(-1)
     n = ids.shape[0]
@@ -201,6 +203,8 @@ def decoder_forward(w: dict, cfg: ArchConfig, st: DecoderState, tokens) -> np.nd
         q = _heads(y @ w[p + "encoder_attn.q_proj.weight"].T, H)
         ck, cv = st.cross[l]
         a = attention(q, ck, cv)
+        if cross_probs is not None:
+            cross_probs.append(softmax_f32(np.einsum("hqd,hkd->hqk", q, ck).astype(F32) * F32(cfg.head_dim ** -0.5)))
         h = r + a @ w[p + "encoder_attn.o_proj.weight"].T
         r = h
         y = layer_norm_nobias(h, w[p + "final_layernorm.weight"])
@@ -226,6 +230,7 @@ def greedy_decode(
     ignore_eos: bool = False,
     return_logits: bool = False,
     teacher: list[int] | None = None,
+    return_cross_attention: bool = False,
 ):
     """The decode loop of MoonshineModel::transcribe ref:370-517: start from BOS,
     one token per step, first-max argmax, stop after appending EOS or after
@@ -235,8 +240,12 @@ def greedy_decode(
     tokens = [cfg.bos]
     logits_all = []
     cur = cfg.bos
+    cross = []  # per step: [L][H, 1, T]
     for i in range(max_len):
-        logits = decoder_forward(w, cfg, st, [cur])[0]
+        probs = [] if return_cross_attention else None
+        logits = decoder_forward(w, cfg, st, [cur], probs)[0]
+        if return_cross_attention:
+            cross.append(np.stack([p[:, 0, :] for p in probs]))  # [L, H, T]
         if return_logits:
             logits_all.append(logits)
         nxt = argmax_first(logits)
@@ -244,6 +253,10 @@ def greedy_decode(
         if nxt == cfg.eos and not ignore_eos:
             break
         cur = nxt if teacher is None else teacher[i + 1] if i + 1 < len(teacher) else nxt
+    if return_cross_attention:
+        # [L*H, steps, T]: the layout align_words takes (core/moonshine-model.cpp:616-640)
+        att = np.stack(cross, axis=2).reshape(cfg.dec_layers * cfg.heads, len(cross), -1).astype(F32)
+        return (tokens, np.stack(logits_all), att) if return_logits else (tokens, att)
     if return_logits:
         return tokens, np.stack(logits_all) if logits_all else np.zeros((0, cfg.vocab), F32)
     return tokens
