@@ -81,7 +81,7 @@ struct transcript_line_t {
   const struct speaker_span_t *speaker_spans; /* always NULL / 0 here (no diarizer) */
   uint64_t speaker_span_count;
   uint32_t last_transcription_latency_ms;
-  const struct transcript_word_t *words;      /* always NULL / 0 here (no word timestamps yet) */
+  const struct transcript_word_t *words;      /* word_timestamps option (offline architectures); NULL / 0 otherwise */
   uint64_t word_count;
 };
 

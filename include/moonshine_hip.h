@@ -113,6 +113,16 @@ MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
 /* Average duration (ms) of an EMPTY profiling scope (two event records back to back on the engine stream): what every
  * per-launch figure of msh_profile_get carries on top of the kernel's own run time.  Negative on error. */
 MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
+/* ---- word timestamps: the decoder's cross-attention ----
+ * Replaces the `cross_attentions.{l}` outputs of the reference's attention-exporting decoder graph
+ * (decoder_with_attention.ort, core/moonshine-model.cpp:480-500, buffer layout :616-640).  With the capture on, every
+ * msh_decode keeps the cross-attention probabilities of all layers, heads and steps (eager decode, one extra kernel per
+ * layer and step).  msh_get_cross_attention: dims3 = {layers*heads, steps, frames} of clip `clip` (steps = ids generated,
+ * frames = encoder frames T); if `out` holds cap_floats >= their product it receives the fp32 block
+ * [layers*heads][steps][frames] -- the layout align_words takes.  Returns the element count or a negative msh error. */
+MSH_EXPORT int32_t msh_set_capture_cross_attention(msh_engine* e, int32_t on);
+MSH_EXPORT int64_t msh_get_cross_attention(msh_engine* e, uint32_t clip, float* out, uint64_t cap_floats, int32_t* dims3);
+
 /* ---- batches in flight (additive; the reference serialises calls on processing_mutex, core/moonshine-model.cpp:229) ----
  * n lanes (1..8), each an engine with its own HIP stream, workspace and host thread, sharing this engine's weights: the
  * encoder of one batch runs inside the idle gaps of another batch's decode loop.  n = 0 tears the lanes down.  The

@@ -121,6 +121,7 @@ class TranscriptLine:
     has_text_changed: bool
     audio_data: np.ndarray | None
     last_transcription_latency_ms: int
+    words: list = None  # [(text bytes, start s, end s, confidence)] with the word_timestamps option, else []
 
 
 def _options(options: dict | None):
@@ -143,7 +144,8 @@ def _parse(tp) -> list[TranscriptLine]:
         out.append(TranscriptLine(
             text=None if l.text is None else l.text.decode("utf-8", errors="replace"), text_bytes=l.text, start_time=l.start_time,
             duration=l.duration, line_id=l.id, is_complete=bool(l.is_complete), is_updated=bool(l.is_updated), is_new=bool(l.is_new),
-            has_text_changed=bool(l.has_text_changed), audio_data=audio, last_transcription_latency_ms=l.last_transcription_latency_ms))
+            has_text_changed=bool(l.has_text_changed), audio_data=audio, last_transcription_latency_ms=l.last_transcription_latency_ms,
+            words=[(C.cast(l.words[k].text, C.c_char_p).value, float(l.words[k].start), float(l.words[k].end), float(l.words[k].confidence)) for k in range(l.word_count)]))
     return out
 
 

@@ -82,7 +82,8 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
     else if (k == "batch_clips") o->batch_clips = parse_int32(v);                   // additive (batch calls)
     else if (k == "batches_in_flight") o->batches_in_flight = parse_int32(v);       // additive (batch calls)
-    else if (k == "word_timestamps" || k == "identify_speakers") require_off(k, v);
+    else if (k == "word_timestamps") o->word_timestamps = parse_bool(v);
+    else if (k == "identify_speakers") require_off(k, v);
     else if (k == "keyterms") {
       o->keyterms = parse_keyterms(v);
     } else if (k == "keyterm_boost") {

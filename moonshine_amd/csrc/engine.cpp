@@ -105,7 +105,7 @@ Engine::~Engine() {
   }
   for (void* p : weight_allocs_) (void)hipFree(p);
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
-                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_};
+                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -471,6 +471,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   MSH_HIP(hipSetDevice(device_));
   if (!loaded_) throw std::runtime_error("no weights loaded");
   encoded_ = false;
+  cross_counts_.clear();  // a new batch invalidates the captured attention of the previous one
   plan_batch(n_samples, count, mtps);
   const int D = cfg_.hidden, F = cfg_.ffn, L = cfg_.dec_layers;
   const long R = R_;
@@ -693,7 +694,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       const char* e = getenv("MSH_NO_FUSED_CROSSQ");
       return !(e != nullptr && e[0] == '1');
     }();
-    if (fuse_q && D <= 512 && M < 64) {  // latency-bound regime only (see k_attn.hip)
+    if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
       ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * 2 + w_dd + M * D * 4.0);
       dec_cross_attention_fused_q(dH, W.wq_c, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
@@ -703,6 +704,9 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
         dec_gemm_ln_f32(dH, W.wq_c, M, D, D, dq, s);
       }
+      if (capture_cross_)
+        dec_cross_attention_probs(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, clips, pos, M, D, Hh, cfg_.dec_layers, l,
+                                  cross_smax_, cross_tcap_, cross_probs_.as<float>() + (size_t)g.first * cfg_.dec_layers * Hh * cross_smax_ * cross_tcap_, s);
       ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
       dec_cross_attention(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
                           clips, M, D, Hh, dao, s);
@@ -754,9 +758,18 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
                                 std::to_string(stride));
   if (teacher != nullptr && teacher_stride < 1) throw std::invalid_argument("decode: bad teacher stride");
   Smax_ = round_up(steps, 8);
+  if (capture_cross_) {
+    int tmax = 0;
+    for (const ClipMeta& c : clips_h_) tmax = std::max(tmax, c.T);
+    if (tmax > 2048) throw std::invalid_argument("word timestamps: clip longer than 2048 encoder frames");
+    cross_tcap_ = round_up(tmax, 4);
+    cross_smax_ = Smax_;
+    cross_probs_.reserve((size_t)Mtot * cfg_.dec_layers * Hh * cross_smax_ * cross_tcap_ * sizeof(float));
+    cross_counts_.clear();
+  }
 
   // ---- groups ----
-  const bool eager = prof_on_ || logits_out != nullptr || !use_graph_;
+  const bool eager = prof_on_ || logits_out != nullptr || !use_graph_ || capture_cross_;
   int ngroups = 1;
   if (!eager) {
     ngroups = dec_groups_ > 0 ? dec_groups_ : 1;  // measured: extra streams only add per-kernel fixed cost
@@ -918,8 +931,33 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       MSH_HIP(hipStreamSynchronize(g.stream));
     }
   }
+  if (capture_cross_) {
+    cross_counts_.resize(Mtot);
+    for (int gi = 0; gi < ngroups; ++gi) {
+      DecodeGroup& g = *groups_[gi];
+      MSH_HIP(hipMemcpyAsync(cross_counts_.data() + g.first, g.counts.p, (size_t)g.M * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+      MSH_HIP(hipStreamSynchronize(g.stream));
+    }
+  }
   prof_flush();
   return steps_run;
+}
+
+void Engine::get_cross_attention(uint32_t clip, float* out, size_t cap, int dims[3]) {
+  MSH_HIP(hipSetDevice(device_));
+  if (cross_counts_.empty() || clip >= cross_counts_.size())
+    throw std::runtime_error("cross-attention not captured (set_capture_cross_attention before decode)");
+  const int LH = cfg_.dec_layers * cfg_.heads, steps = cross_counts_[clip] - 1, T = clips_h_.at(clip).T;
+  dims[0] = LH, dims[1] = steps, dims[2] = T;
+  if (out == nullptr || steps <= 0) return;
+  if (cap < (size_t)LH * steps * T) throw std::invalid_argument("get_cross_attention: output buffer too small");
+  // device rows are [clip][layer*head][Smax][Tcap]: one strided 2-D copy per (layer, head)
+  const float* src = cross_probs_.as<float>() + (size_t)clip * LH * cross_smax_ * cross_tcap_;
+  for (int lh = 0; lh < LH; ++lh)
+    MSH_HIP(hipMemcpy2DAsync(out + (size_t)lh * steps * T, (size_t)T * sizeof(float), src + (size_t)lh * cross_smax_ * cross_tcap_,
+                             (size_t)cross_tcap_ * sizeof(float), (size_t)T * sizeof(float), (size_t)steps, hipMemcpyDeviceToHost,
+                             stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
 }
 
 }  // namespace msh

@@ -80,6 +80,13 @@ class Engine {
   void get_encoder_output(uint32_t clip, float* out);  // [T][D] fp32 (needs keep_encoder_f32)
   void set_keep_encoder_f32(bool v) { keep_enc_f32_ = v; }
 
+  // Word timestamps: keep the cross-attention probabilities of every decode step of the next decode() calls (eager
+  // decode, one extra kernel per layer and step).  get_cross_attention copies clip `clip`'s [layers*heads][steps][T]
+  // fp32 block (steps = tokens generated, T = encoder frames) to `out` if it holds `cap` >= that many floats, and
+  // returns the three dimensions.
+  void set_capture_cross_attention(bool on) { capture_cross_ = on; }
+  void get_cross_attention(uint32_t clip, float* out, size_t cap, int dims[3]);
+
   // per-kernel-group timing with HIP events on the engine stream
   void profile_enable(bool on);
   void profile_reset();
@@ -128,6 +135,10 @@ class Engine {
   long kv_keys_ = 0;  // sum of Tk
   int max_rows_ = 0, max_steps_ = 0;
   bool encoded_ = false, keep_enc_f32_ = false;
+  bool capture_cross_ = false;
+  DevBuf cross_probs_;                // [clips][layers][heads][Smax][Tcap] fp32 (capture_cross_)
+  int cross_tcap_ = 0, cross_smax_ = 0;
+  std::vector<int32_t> cross_counts_;  // tokens per clip (incl. BOS) of the captured decode
 
   // workspace (grow-only)
   DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, AO_, Z_,

@@ -506,7 +506,61 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-attention PROBABILITIES of one decode step, for word timestamps (the `cross_attentions.{l}` outputs of the
+// reference's attention-exporting decoder, core/moonshine-model.cpp:480-500): one workgroup per (clip, head), plain
+// two-pass softmax over the clip's T valid frames, written to out[clip][layer][head][pos][0..T).  Runs only when the
+// capture is switched on; the regular kernel above never materialises the probabilities.
+// ------------------------------------------------------------------------------------------------
+constexpr int PROBS_TMAX = 2048;
+__global__ __launch_bounds__(256) void dec_cross_probs_kernel(const float* __restrict__ q, const bf16_t* __restrict__ KT,
+                                                              const ClipMeta* __restrict__ clips,
+                                                              const int* __restrict__ pos_ptr, int D, int heads, int dh,
+                                                              int layers, int layer, int Smax, int Tcap,
+                                                              float* __restrict__ out) {
+  __shared__ float sc[PROBS_TMAX];
+  __shared__ float red[4];
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const ClipMeta cm = clips[b];
+  const int T = cm.T < PROBS_TMAX ? cm.T : PROBS_TMAX, Tk = cm.Tk;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const float* qp = q + (long)b * D + h * dh;
+  const bf16_t* kp = KT + (long)cm.kv_start * D + (long)(h * dh) * Tk;
+  const float scale = rsqrtf((float)dh);
+  float mloc = -INFINITY;
+  for (int key = tid; key < T; key += 256) {
+    float acc = 0.f;
+    for (int d = 0; d < dh; ++d) acc += qp[d] * bf16_to_f32(kp[(long)d * Tk + key]);
+    acc *= scale;
+    sc[key] = acc;
+    mloc = fmaxf(mloc, acc);
+  }
+  mloc = wave_max(mloc);
+  if ((tid & 63) == 0) red[wave] = mloc;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float lsum = 0.f;
+  for (int key = tid; key < T; key += 256) {
+    const float p = expf(sc[key] - mx);
+    sc[key] = p;
+    lsum += p;
+  }
+  lsum = wave_sum(lsum);
+  if ((tid & 63) == 0) red[wave] = lsum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  float* o = out + ((((long)b * layers + layer) * heads + h) * Smax + *pos_ptr) * Tcap;
+  for (int key = tid; key < T; key += 256) o[key] = sc[key] * inv;
+}
+
 }  // namespace
+
+void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta* clips, const int* pos_ptr, int M, int D,
+                               int heads, int layers, int layer, int Smax, int Tcap, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(dec_cross_probs_kernel, dim3(M * heads), dim3(256), 0, s, q, KT, clips, pos_ptr, D, heads, D / heads,
+                     layers, layer, Smax, Tcap, out);
+}
 
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows, int D, int heads,
                    hipStream_t s) {

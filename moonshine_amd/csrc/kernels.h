@@ -113,6 +113,10 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
 
 // same with the query projection fused in: H = fp32 residual stream [M,D], Wq = cross-q weight [D,D] with the
 // LayerNorm scale folded in (replaces dec_gemm_ln_f32 + dec_cross_attention)
+// cross-attention probabilities of the current step (word timestamps): out[clip][layer][head][pos][Tcap] fp32, frames
+// [0, T) of the row written; T <= 2048
+void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta* clips, const int* pos_ptr, int M, int D,
+                               int heads, int layers, int layer, int Smax, int Tcap, float* out, hipStream_t s);
 void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t* KT, const bf16_t* VT,
                                  const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s);
 

@@ -246,6 +246,18 @@ int32_t msh_wait(msh_engine* e, int64_t ticket) {
   });
 }
 
+int32_t msh_set_capture_cross_attention(msh_engine* e, int32_t on) {
+  return guarded(e, [&] { e->eng->set_capture_cross_attention(on != 0); });
+}
+
+int64_t msh_get_cross_attention(msh_engine* e, uint32_t clip, float* out, uint64_t cap_floats, int32_t* dims3) {
+  int d[3] = {0, 0, 0};
+  const int32_t rc = guarded(e, [&] { e->eng->get_cross_attention(clip, out, (size_t)cap_floats, d); });
+  if (rc != MSH_OK) return rc;
+  if (dims3 != nullptr) dims3[0] = d[0], dims3[1] = d[1], dims3[2] = d[2];
+  return (int64_t)d[0] * d[1] * d[2];
+}
+
 int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) {
   int64_t v = -1;
   guarded(e, [&] { v = (int64_t)e->eng->debug_read(name ? name : "", dst, bytes); });

@@ -51,10 +51,13 @@ int MoonshineModel::load_from_memory(const uint8_t* weights, size_t weights_size
 }
 
 int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, const std::vector<size_t>& n_samples,
-                                     std::vector<std::string>* out_texts) {
+                                     std::vector<std::string>* out_texts, std::vector<std::vector<TranscriberWord>>* out_words) {
   std::lock_guard<std::mutex> lock(processing_mutex);
   const uint32_t count = (uint32_t)audio.size();
   out_texts->assign(count, std::string());
+  const bool want_words = word_timestamps && out_words != nullptr;
+  if (out_words != nullptr) out_words->assign(count, {});
+  if (msh_set_capture_cross_attention(engine, want_words ? 1 : 0) != MSH_OK) return 1;
   if (count == 0) return 0;
   std::vector<uint64_t> lens(n_samples.begin(), n_samples.end());
   if (log_ort_run) {
@@ -64,7 +67,7 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
   const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
   std::vector<int32_t> tokens, counts(count);
   int32_t stride = 0;
-  if (count <= chunk || batches_in_flight <= 1 || log_ort_run) {
+  if (count <= chunk || batches_in_flight <= 1 || log_ort_run || want_words) {
     // one sub-batch after the other on the engine itself
     std::vector<std::vector<int32_t>> parts;
     std::vector<int32_t> strides;
@@ -80,6 +83,25 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
       if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, parts.back().data(), counts.data() + lo, st) != MSH_OK) {
         MSH_LOGF("decoder failed: %s", error().c_str());
         return 1;
+      }
+      if (want_words) {  // the attention of this sub-batch is only on the device until the next decode
+        std::vector<float> att;
+        for (uint32_t i = 0; i < n; ++i) {
+          int32_t dims[3] = {0, 0, 0};
+          const int64_t need = msh_get_cross_attention(engine, i, nullptr, 0, dims);
+          if (need < 0) {
+            MSH_LOGF("cross-attention not available: %s", error().c_str());
+            return 1;
+          }
+          if (need == 0 || counts[lo + i] < 2) continue;
+          att.resize((size_t)need);
+          if (msh_get_cross_attention(engine, i, att.data(), (uint64_t)att.size(), dims) < 0) return 1;
+          const int32_t* row = parts.back().data() + (size_t)i * st;
+          const std::vector<int32_t> ids(row, row + counts[lo + i]);
+          // seconds per encoder frame: clip duration / frames (reference core/moonshine-model.cpp:636)
+          const float spf = ((float)lens[lo + i] / 16000.0f) / (float)dims[2];
+          (*out_words)[lo + i] = align_words(att.data(), dims[0], dims[1], dims[2], ids, spf, *tokenizer);
+        }
       }
     }
     size_t p = 0;
@@ -175,9 +197,15 @@ void TranscriptOutput::add_or_update(TranscriberLine& line) {
 void TranscriptOutput::rebuild() {
   std::lock_guard<std::mutex> lock(mutex);
   c_lines.clear();
+  c_words.assign(order.size(), {});
+  size_t li = 0;
   for (uint64_t id : order) {
     const TranscriberLine& l = lines[id];
     transcript_line_t c{};
+    std::vector<transcript_word_t>& cw = c_words[li++];
+    for (const TranscriberWord& w : l.words) cw.push_back(transcript_word_t{w.text.c_str(), w.start, w.end, w.confidence});
+    c.words = cw.empty() ? nullptr : cw.data();
+    c.word_count = cw.size();
     c.text = l.has_text ? l.text.c_str() : nullptr;
     c.audio_data = l.audio.empty() ? nullptr : l.audio.data();
     c.audio_data_count = l.audio.size();
@@ -246,6 +274,7 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
   model_->batch_clips = opt_.batch_clips;
   model_->batches_in_flight = opt_.batches_in_flight;
+  model_->word_timestamps = opt_.word_timestamps;
   if (opt_.model_source == TranscriberOptions::FILES) {
     if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
     if (!is_dir_or_file(opt_.model_path))
@@ -289,6 +318,8 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
 // (the reference's holds frontend / encoder / adapter / cross_kv / decoder_kv .ort graphs next to the same
 // json and tokenizer, core/moonshine-streaming-model.cpp:233-300).
 void Transcriber::load_streaming_model() {
+  if (opt_.word_timestamps)  // the reference swaps in decoder_kv_with_attention.ort here (core/transcriber.cpp:327-345)
+    throw std::runtime_error("option 'word_timestamps' is only implemented for the non-streaming architectures in the MI355X build");
   const int frames = (int)ceilf(opt_.max_stream_seconds * 50.0f);
   streaming_model_.reset(new MoonshineStreamingModel(opt_.device, opt_.max_streams, frames));
   if (opt_.model_source == TranscriberOptions::FILES) {
@@ -527,6 +558,7 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
   std::vector<const float*> ptrs;
   std::vector<size_t> lens;
   std::vector<std::string> texts;
+  std::vector<std::vector<TranscriberWord>> words;
   uint32_t latency_ms = 0;
   const bool streaming = streaming_model_ != nullptr;
   for (size_t si = 0; si < streams.size(); ++si) {
@@ -578,7 +610,8 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
   } else if (!jobs.empty()) {
     std::lock_guard<std::mutex> lock(model_mutex_);
     const auto t0 = std::chrono::steady_clock::now();
-    if (model_->transcribe_batch(ptrs, lens, &texts) != 0) throw std::runtime_error("Failed to transcribe: " + model_->error());
+    if (model_->transcribe_batch(ptrs, lens, &texts, opt_.word_timestamps ? &words : nullptr) != 0)
+      throw std::runtime_error("Failed to transcribe: " + model_->error());
     latency_ms = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   }
   size_t job = 0;
@@ -601,6 +634,15 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
           if (opt_.log_output_text && !streaming) MSH_LOGF("Transcribed text: '%s'", texts[job].c_str());
           line.text = streaming ? texts[job] : sanitize_utf8(texts[job]);
           line.latency_ms = latency_ms;
+          // words only for finished lines: an open segment is re-transcribed on the next update anyway (reference
+          // core/transcriber.cpp:1103-1117); times become absolute by adding the segment start
+          if (job < words.size() && seg.is_complete) {
+            line.words = words[job];
+            for (TranscriberWord& w : line.words) {
+              w.start += seg.start_time;
+              w.end += seg.start_time;
+            }
+          }
           ++job;
         }
       }

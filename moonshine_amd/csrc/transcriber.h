@@ -22,6 +22,7 @@
 #include "context_extractor.h"
 #include "host_text_vad.h"
 #include "streaming_model.h"
+#include "word_alignment.h"
 
 namespace msh_host {
 
@@ -36,6 +37,9 @@ struct MoonshineModel {
   int batch_clips = 256;
   int batches_in_flight = 2;
   bool lanes_ready = false;
+  // word timestamps (reference core/moonshine-model.cpp:600-645): with this on, transcribe_batch also keeps the device's
+  // cross-attention and fills out_words[i] through align_words (times relative to the clip start)
+  bool word_timestamps = false;
   std::string last_result;
 
   MoonshineModel(bool log_ort_run, float max_tokens_per_second, int device);
@@ -49,7 +53,7 @@ struct MoonshineModel {
   int transcribe(const float* audio, size_t n_samples, char** out_text);
   // Many clips -> texts in one GPU batch (no reference counterpart).
   int transcribe_batch(const std::vector<const float*>& audio, const std::vector<size_t>& n_samples,
-                       std::vector<std::string>* out_texts);
+                       std::vector<std::string>* out_texts, std::vector<std::vector<TranscriberWord>>* out_words = nullptr);
   std::string error() const;
 };
 
@@ -74,6 +78,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
+  bool word_timestamps = false;          // reference core/transcriber.h (word_timestamps): offline architectures here
   int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call
   int batches_in_flight = 2;             // additive: sub-batches on the GPU at once (1 = strictly one after the other)
   bool return_audio_data = true;
@@ -91,12 +96,14 @@ struct TranscriberLine {
   bool is_complete = false, just_updated = false, is_new = false, has_text_changed = false;
   uint64_t id = 0;
   uint32_t latency_ms = 0;
+  std::vector<TranscriberWord> words;  // word_timestamps option; absolute times (segment start added)
 };
 
 struct TranscriptOutput {
   std::map<uint64_t, TranscriberLine> lines;
   std::vector<uint64_t> order;
   std::vector<transcript_line_t> c_lines;
+  std::vector<std::vector<transcript_word_t>> c_words;  // per line, pointing into the lines' word texts
   transcript_t transcript{nullptr, 0};
   std::mutex mutex;
   void clear_update_flags();

@@ -73,6 +73,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_synchronize": (i32, [vp]),
         "msh_profile_event_overhead_ms": (C.c_double, [vp, i32]),
         "msh_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
+        "msh_set_capture_cross_attention": (i32, [vp, i32]),
+        "msh_get_cross_attention": (C.c_int64, [vp, C.c_uint32, vp, C.c_uint64, vp]),
         "msh_set_batches_in_flight": (i32, [vp, i32]),
         "msh_submit_transcribe_tokens": (C.c_int64, [vp, vp, vp, C.c_uint32, i32, C.c_float, i32, vp, vp, i32]),
         "msh_wait": (i32, [vp, C.c_int64]),
@@ -111,7 +113,7 @@ DECLARED_SYMBOLS = [
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_debug_read",
-    "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait",
+    "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
@@ -243,6 +245,23 @@ class Engine:
 
     def synchronize(self):
         self._check(self.lib.msh_synchronize(self.h))
+
+    # -- word timestamps -------------------------------------------------------------------------
+    def set_capture_cross_attention(self, on: bool = True):
+        self._check(self.lib.msh_set_capture_cross_attention(self.h, 1 if on else 0))
+
+    def cross_attention(self, clip: int) -> np.ndarray:
+        """[layers*heads, steps, frames] fp32 cross-attention probabilities of the last decode() for one clip."""
+        dims = (C.c_int32 * 3)()
+        n = int(self.lib.msh_get_cross_attention(self.h, clip, None, 0, dims))
+        if n < 0:
+            raise MshError(n, (self.lib.msh_last_error(self.h) or b"").decode())
+        out = np.zeros((dims[0], dims[1], dims[2]), np.float32)
+        if n > 0:
+            n = int(self.lib.msh_get_cross_attention(self.h, clip, out.ctypes.data, out.size, dims))
+            if n < 0:
+                raise MshError(n, (self.lib.msh_last_error(self.h) or b"").decode())
+        return out
 
     # -- batches in flight ------------------------------------------------------------------------
     def set_batches_in_flight(self, n: int):

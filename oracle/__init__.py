@@ -23,6 +23,8 @@ Modules and what pins them:
                      multi-token decoder, speculative decode_full)   MoonshineStreaming, tests/golden/make_golden_streaming.py
   biaser_ref.py      ContextBiaser + tokenizer text -> ids        <- the known-answer cases of the reference's
                                                                      context-biaser-test.cpp / bin-tokenizer-test.cpp
+  word_align_ref.py  DTW, median filter, align_words (word timestamps) <- scipy.ndimage.median_filter(mode="mirror") and a brute-force
+                                                                     search over all monotone paths (tests/test_word_alignment.py)
   host_ref.py        tokenizer.bin, tokens_to_text, sanitize_text, VAD (threshold 0), resampler, step budgets
                      (byte / integer rules restated from the cited C++; the reference holds no fixtures for them)
 Unpinned everywhere: agreement with the shipped int8 ``.ort`` graphs themselves (absent from the checkout).

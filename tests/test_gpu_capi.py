@@ -96,6 +96,53 @@ def test_batch_call_in_sub_batches_with_two_in_flight(tiny_dir, tiny):
         t.close()
 
 
+def test_word_timestamps_option(tiny_dir, engine):
+    """Option word_timestamps (reference core/word-alignment-test.cpp:12-70): every finished line carries words whose
+    times are those of the oracle's align_words applied to the engine's own cross-attention and ids (exact), shifted by
+    the segment start; the reference's properties hold; the batch call fills every clip; without the option no words."""
+    from oracle import word_align_ref as wa
+
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "word_timestamps": "true"})
+    clips = [make_audio(400 + i, n) for i, n in enumerate([48000, 31000 + 300, 80000])]
+    try:
+        single = [t.transcribe_without_streaming(c) for c in clips]
+        batch = t.transcribe_batch_without_streaming(clips)
+    finally:
+        t.close()
+    engine.set_capture_cross_attention(True)
+    try:
+        for c, lines, blines in zip(clips, single, batch):
+            assert len(lines) == 1 and lines[0].is_complete
+            seg = c[: (len(c) // 512) * 512]
+            toks = engine.transcribe_tokens([seg])[0]
+            att = engine.cross_attention(0)
+            spf = float(np.float32(np.float32(len(seg)) / np.float32(16000.0)) / np.float32(att.shape[2]))
+            want = wa.align_words(att, toks, spf, vocab, host_ref.tokens_to_text)
+            got = lines[0].words
+            assert [w[0] for w in got] == [w["text"] for w in want]
+            np.testing.assert_allclose([w[1] for w in got], [w["start"] for w in want], rtol=0, atol=1e-6)
+            np.testing.assert_allclose([w[2] for w in got], [w["end"] for w in want], rtol=0, atol=1e-6)
+            assert got == blines[0].words
+            prev = -1.0
+            for _, start, end, conf in got:
+                assert end >= start >= prev and 0.0 <= conf <= 1.0 and end <= len(seg) / 16000 + 1e-3
+                prev = start
+    finally:
+        engine.set_capture_cross_attention(False)
+    assert any(len(l[0].words) > 0 for l in single)
+
+
+def test_word_timestamps_off_by_default_and_refused_for_streaming_archs(tiny, tmp_path_factory):
+    assert tiny.transcribe_without_streaming(make_audio(410, 32000))[0].words == []
+    from moonshine_amd.synth import STREAMING_ARCHS, write_streaming_model_dir
+
+    d = str(tmp_path_factory.mktemp("ws"))
+    write_streaming_model_dir(d, STREAMING_ARCHS["micro_streaming"], seed=5)
+    with pytest.raises(api.MoonshineError):
+        api.Transcriber(d, api.ARCH_TINY_STREAMING, {"word_timestamps": "true"})
+
+
 def test_other_sample_rate_goes_through_the_resampler(tiny, engine):
     vocab = synthetic_vocab(ARCHS["tiny"].vocab)
     x = make_audio(31, 72000)  # pretend 24 kHz

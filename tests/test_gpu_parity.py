@@ -320,3 +320,43 @@ def test_batches_in_flight_match_synchronous_calls(base):
         e.set_batches_in_flight(0)
     with pytest.raises(MshError):
         e.submit_transcribe_tokens(batches[0])
+
+
+# stated tolerance for cross-attention probabilities (softmax outputs in [0, 1]; bf16 GEMM operands upstream, bf16 K,
+# fp32 scores and softmax): max-abs 5e-3 (observed 2.0e-3 on 22-frame clips, where single probabilities reach 0.13)
+ATT_MAXABS = 5e-3
+
+
+@pytest.mark.parametrize("arch", ["micro", "base"])
+def test_cross_attention_capture_vs_oracle(arch, micro, base):
+    """msh_set_capture_cross_attention / msh_get_cross_attention: the probabilities of every layer, head and step,
+    in the [layers*heads][steps][frames] layout align_words takes (reference core/moonshine-model.cpp:616-640),
+    against the oracle run on the SAME token sequence; ragged batch, EOS ignored."""
+    e, w, cfg = micro if arch == "micro" else base
+    lens = [16000, 30011, 9000] if arch == "micro" else [40000, 23456]
+    steps = 9 if arch == "micro" else 6
+    clips = [make_audio(300 + i, n) for i, n in enumerate(lens)]
+    e.set_capture_cross_attention(True)
+    try:
+        toks = e.transcribe_tokens(clips, forced_steps=steps)
+        for i, c in enumerate(clips):
+            att = e.cross_attention(i)
+            enc = ref.encoder_forward(w, cfg, c)
+            _, want = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, teacher=toks[i], return_cross_attention=True)
+            assert att.shape == want.shape == (cfg.dec_layers * cfg.heads, steps, enc.shape[0])
+            np.testing.assert_allclose(att.sum(-1), 1.0, atol=1e-4)
+            assert float(np.abs(att - want).max()) <= ATT_MAXABS
+        # the capture does not change the ids, and switching it off restores the graph-replayed path
+        assert e.transcribe_tokens(clips, forced_steps=steps) == toks
+    finally:
+        e.set_capture_cross_attention(False)
+    assert e.transcribe_tokens(clips, forced_steps=steps) == toks
+    from moonshine_amd.hip_api import MshError
+
+    e2_toks = e.transcribe_tokens(clips[:1], forced_steps=2)
+    assert len(e2_toks[0]) == 3
+    e.set_capture_cross_attention(True)
+    e.encode(clips[:1])
+    with pytest.raises(MshError):  # nothing decoded since the capture was switched on
+        e.cross_attention(0)
+    e.set_capture_cross_attention(False)
