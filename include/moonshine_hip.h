@@ -113,6 +113,10 @@ MSH_EXPORT int32_t msh_synchronize(msh_engine* e);
 /* Average duration (ms) of an EMPTY profiling scope (two event records back to back on the engine stream): what every
  * per-launch figure of msh_profile_get carries on top of the kernel's own run time.  Negative on error. */
 MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
+/* Average ms per launch of the decode cross-attention kernel (the HBM-bound kernel that dominates a decode step),
+ * launched back to back over the cross K/V of every layer of the batch encoded + decoded last, `rounds` sweeps between
+ * one pair of HIP events: the kernel's own duration, free of per-launch event bookkeeping.  < 0 on error. */
+MSH_EXPORT double msh_profile_cross_attention_ms(msh_engine* e, int32_t rounds);
 /* ---- word timestamps: the decoder's cross-attention ----
  * Replaces the `cross_attentions.{l}` outputs of the reference's attention-exporting decoder graph
  * (decoder_with_attention.ort, core/moonshine-model.cpp:480-500, buffer layout :616-640).  With the capture on, every

@@ -642,6 +642,33 @@ struct Engine::DecodeGroup {
 
 void Engine::destroy_groups() { groups_.clear(); }
 
+double Engine::profile_cross_attention_ms(int rounds) {
+  MSH_HIP(hipSetDevice(device_));
+  if (!encoded_ || groups_.empty() || groups_[0]->M != (int)n_clips_)
+    throw std::runtime_error("profile_cross_attention: encode and decode a batch first");
+  if (rounds <= 0) rounds = 1;
+  DecodeGroup& g = *groups_[0];
+  const int D = cfg_.hidden, L = cfg_.dec_layers;
+  MSH_HIP(hipStreamSynchronize(g.stream));
+  hipEvent_t a = get_event(), b = get_event();
+  auto sweep = [&] {
+    for (int l = 0; l < L; ++l)
+      dec_cross_attention(g.dq.as<float>(), KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
+                          clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
+  };
+  sweep();  // warm
+  MSH_HIP(hipEventRecord(a, stream_));
+  for (int r = 0; r < rounds; ++r) sweep();
+  MSH_HIP(hipEventRecord(b, stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  float ms = 0.f;
+  MSH_HIP(hipEventElapsedTime(&ms, a, b));
+  event_pool_.push_back(a);
+  event_pool_.push_back(b);
+  return (double)ms / ((double)rounds * L);
+}
+
+
 size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
   MSH_HIP(hipSetDevice(device_));
   if (groups_.empty()) throw std::runtime_error("debug_read: no decode() yet");

@@ -94,6 +94,10 @@ class Engine {
   // average time between the two events of an EMPTY profiling scope on the engine stream: the part of every
   // per-launch figure that is event / dispatch bookkeeping rather than kernel time
   double profile_event_overhead_ms(int iters);
+  // The decode cross-attention kernel launched back to back over the cross K/V of all layers (`rounds` sweeps, so every
+  // launch streams its own 2*D*keys bytes from HBM like a real step does) between ONE pair of HIP events: average ms per
+  // launch without per-launch event bookkeeping.  Needs a batch that was encoded and decoded at least once.
+  double profile_cross_attention_ms(int rounds);
   // test hook: bytes of a named decode buffer of the last decode() call ("cache_k", "cache_v", "resid"); copies
   // min(bytes, size) to `dst` and returns the buffer's size
   size_t debug_read(const std::string& name, void* dst, size_t bytes);

@@ -264,6 +264,12 @@ int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t byte
   return v;
 }
 
+double msh_profile_cross_attention_ms(msh_engine* e, int32_t rounds) {
+  double v = -1.0;
+  guarded(e, [&] { v = e->eng->profile_cross_attention_ms(rounds); });
+  return v;
+}
+
 float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl, int32_t iters) {
   try {
     return msh::gemm_microbench(M, N, K, lda, cfg, abl, iters);
