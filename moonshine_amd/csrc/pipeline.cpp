@@ -17,10 +17,17 @@ BatchPipeline::BatchPipeline(Engine& primary, int device, int lanes) : device_(d
 
 BatchPipeline::~BatchPipeline() {
   {
+    // batches still queued are cancelled (their output arrays may be gone with the caller); running ones finish
     std::lock_guard<std::mutex> lock(mu_);
     stop_ = true;
+    for (const std::shared_ptr<Job>& j : queue_) {
+      j->error = std::make_exception_ptr(std::runtime_error("batch cancelled: the lanes were torn down"));
+      j->done = true;
+    }
+    queue_.clear();
   }
   cv_work_.notify_all();
+  cv_done_.notify_all();
   for (std::thread& t : threads_) t.join();
 }
 
