@@ -133,6 +133,24 @@ def test_word_timestamps_option(tiny_dir, engine):
     assert any(len(l[0].words) > 0 for l in single)
 
 
+def test_reference_word_timestamp_test_flow_as_a_c_program(tiny_dir, tmp_path):
+    """tests/c/word_timestamps_flow.c is the reference's core/word-alignment-test.cpp flow compiled by gcc against
+    include/moonshine-c-api.h and linked to libmoonshine.so -- the drop-in boundary exercised from C, not ctypes."""
+    import subprocess
+
+    from moonshine_amd.build import LIB
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "wt_flow")
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(here, "..", "include"), os.path.join(here, "c", "word_timestamps_flow.c"), "-o", exe,
+                    LIB, f"-Wl,-rpath,{os.path.dirname(LIB)}"], check=True)
+    pcm = tmp_path / "clip.f32"
+    make_audio(420, 16000 * 5).astype(np.float32).tofile(pcm)
+    r = subprocess.run([exe, tiny_dir[0], str(pcm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("words: ")
+
+
 def test_word_timestamps_off_by_default_and_refused_for_streaming_archs(tiny, tmp_path_factory):
     assert tiny.transcribe_without_streaming(make_audio(410, 32000))[0].words == []
     from moonshine_amd.synth import STREAMING_ARCHS, write_streaming_model_dir

@@ -290,3 +290,21 @@ def test_reference_resampler_known_answer(out_rate):
         assert abs(out.max() - audio.max()) <= 0.005 * abs(audio.max())
         assert abs(out.min() - audio.min()) <= 0.005 * abs(audio.min())
     assert abs(out.mean() - audio.mean()) <= 1e-3
+
+
+def test_c_program_links_against_the_public_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """tests/c/word_timestamps_flow.c (the reference's word-timestamp test flow) builds with plain gcc against
+    include/moonshine-c-api.h + libmoonshine.so; on a box without a GPU the load is refused with an error code -- there
+    is no CPU fallback behind the C API."""
+    import torch
+
+    from moonshine_amd.build import LIB
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "wt_flow")
+    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", INCLUDE, os.path.join(here, "c", "word_timestamps_flow.c"), "-o", exe, LIB,
+                    f"-Wl,-rpath,{os.path.dirname(LIB)}"], check=True)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by tests/test_gpu_capi.py")
+    r = subprocess.run([exe, str(tmp_path), str(tmp_path / "none.f32")], capture_output=True, text=True)
+    assert r.returncode == 1 and "REQUIRE failed" in r.stderr and "handle >= 0" in r.stderr
