@@ -32,6 +32,11 @@ UtilStreams& util_streams() {
 }
 }  // namespace
 
+std::mutex& device_structure_mutex() {
+  static std::mutex* m = new std::mutex();
+  return *m;
+}
+
 void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return;
   UtilStreams& u = util_streams();
@@ -54,6 +59,7 @@ bool DevBuf::reserve(size_t bytes) {
   if (bytes <= cap && p != nullptr) return false;
   size_t want = bytes + bytes / 8 + 256;  // a little slack so ragged batches do not thrash
   void* np = nullptr;
+  std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
   MSH_HIP(hipMalloc(&np, want));
   // The zero-fill must be complete before the first kernel or copy on an engine stream writes the new buffer (a plain
   // hipMemset is asynchronous null-stream work those streams do not wait for: seen as rare garbage logits).
@@ -64,6 +70,7 @@ bool DevBuf::reserve(size_t bytes) {
   return true;
 }
 void DevBuf::release() {
+  std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
   if (p) (void)hipFree(p);
   p = nullptr;
   cap = 0;
@@ -82,7 +89,10 @@ Engine::Engine(int device) : device_(device) {
   {
     // first command now, not at the first encode(): HIP binds a stream to its hardware queue lazily and round-robin, so
     // engines (lanes) created one after the other get consecutive queues only if each touches its stream right away
-    MSH_HIP(hipMalloc(&stream_probe_, 256));
+    {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      MSH_HIP(hipMalloc(&stream_probe_, 256));
+    }
     MSH_HIP(hipMemsetAsync(stream_probe_, 0, 256, stream_));
     MSH_HIP(hipStreamSynchronize(stream_));
   }
@@ -97,7 +107,12 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamSynchronize(stream_);
   groups_.clear();
   if (enc_done_) (void)hipEventDestroy(enc_done_);
-  if (stream_probe_) (void)hipFree(stream_probe_);
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    if (stream_probe_) (void)hipFree(stream_probe_);
+    for (void* p : weight_allocs_) (void)hipFree(p);
+    weight_allocs_.clear();
+  }
   for (hipEvent_t ev : event_pool_) (void)hipEventDestroy(ev);
   for (auto& r : prof_pending_) {
     (void)hipEventDestroy(r.a);
@@ -117,7 +132,10 @@ void Engine::synchronize() {
 
 void Engine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
-  MSH_HIP(hipMalloc(&p, src.size() * sizeof(float)));
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    MSH_HIP(hipMalloc(&p, src.size() * sizeof(float)));
+  }
   weight_allocs_.push_back(p);
   copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<float*>(p);
@@ -127,7 +145,10 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   std::vector<bf16_t> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
   void* p = nullptr;
-  MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  }
   weight_allocs_.push_back(p);
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
@@ -886,6 +907,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
           g.graph = nullptr;
         }
         hipGraph_t gr = nullptr;
+        std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
         MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
         decode_step_enqueue(g);
         if (g.fused_argmax)

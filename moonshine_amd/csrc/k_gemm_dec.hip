@@ -408,12 +408,34 @@ static bool use_dec64(int M) {
   return thr > 0 && M >= thr;
 }
 
+// Narrow outputs (N = decoder width) at streaming batch sizes give too few 16 x 32 tiles to occupy the chip (M = 64,
+// N = 640: 80 workgroups on 256 CUs, each streaming its whole K x 32 weight slice alone): halve the tile width then.
+// The per-element summation order does not depend on the tile width, so results are bit-identical.
+static bool few_tiles(int M, int N) {
+  static const int thr = [] {
+    const char* e = getenv("MSH_DEC_NARROW_TILES");
+    return e ? atoi(e) : 192;
+  }();
+  return ((M + 15) / 16) * ((N + 31) / 32) < thr;
+}
+// One row tile (M <= 16, the single-clip latency case): 16-column tiles double the workgroups that share a GEMM's weight
+// stream (o-proj 13 -> 26, qkv 39 -> 78, fc1 104 -> 208); measured p50 of a 10 s clip 20.8 -> 19.0 ms (decode 19.4 -> 17.6).
+static bool narrow_small_batch(int M) {
+  static const int thr = [] {
+    const char* e = getenv("MSH_DEC_NARROW_M");
+    return e ? atoi(e) : 16;
+  }();
+  return M <= thr;
+}
+
 void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
   EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 3 * D, D, epi, s)) return;
   if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
     launch_dec<4, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+  else if (narrow_small_batch(M))
+    launch_dec<1, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
   else
     launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
 }
@@ -431,6 +453,8 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
   if (M >= dec_tm2_threshold() && launch_dec_tm2<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
   if (M >= 96)
     launch_dec<4, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+  else if (narrow_small_batch(M))
+    launch_dec<1, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
   else
     launch_dec<2, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
 }
@@ -445,7 +469,10 @@ void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bia
     }();
     if (fc2_tm2 && K > N && M >= dec_tm2_threshold() && launch_dec_tm2<2, false>(A, lda, W, M, N, K, epi, s)) return;
   }
-  launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
+  if (narrow_small_batch(M))
+    launch_dec<1, false>(A, lda, nullptr, W, M, N, K, epi, s);
+  else
+    launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
 }
 // ---- bf16-input small-batch GEMMs of the streaming decoder (row-based passes with M <= 256) ----
 // Same split-K kernel, LayerNorm done by the caller; K covers the streaming widths (320 / 640 tiny / assumed-medium,
@@ -486,6 +513,7 @@ bool small_ln_gemm_stream_qkv(const float* H, const bf16_t* Wf, int M, int D, bf
   return launch_dec_ln<2>(H, Wf, M, 3 * D, D, EpiStreamQkv{q_out, cacheK, cacheV, row_slot, row_pos, rp, layer, L, Scap}, s);
 }
 bool small_ln_gemm_bf16(const float* H, const bf16_t* Wf, int M, int N, int D, bf16_t* out, hipStream_t s) {
+  if (few_tiles(M, N)) return launch_dec_ln<1>(H, Wf, M, N, D, EpiAct{out, nullptr, N, nullptr, 0}, s);
   return launch_dec_ln<2>(H, Wf, M, N, D, EpiAct{out, nullptr, N, nullptr, 0}, s);
 }
 bool small_ln_gemm_swiglu(const float* H, const bf16_t* Wf, const float* bias, int M, int N, int D, bf16_t* z,
@@ -509,6 +537,7 @@ bool small_gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const fl
 }
 bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                           hipStream_t s) {
+  if (few_tiles(M, N)) return launch_dec_bf16<1>(A, lda, W, M, N, K, EpiResidF32{H, N, bias}, s);
   return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiResidF32{H, N, bias}, s);
 }
 bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {

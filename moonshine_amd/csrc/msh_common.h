@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -35,6 +36,11 @@ struct HipError : std::runtime_error {
 // not one per call: HIP hands streams their hardware queue round-robin out of a small pool (GPU_MAX_HW_QUEUES, 4 by
 // default), and a churn of short-lived streams made two engine lanes land on the same queue, i.e. run one after the
 // other (profiles/r03e_kernel_trace: lanes on queues 3, 4, 4).
+// Device allocation / release and graph capture never run at the same time in one process: hipMalloc / hipFree
+// synchronise the whole device behind the scenes, and doing that from one host thread while another is between
+// hipStreamBeginCapture and hipStreamEndCapture is where a (rare) crash of the multi-lane tests pointed.  Both sides
+// take this mutex; it is only ever contended while engines warm up.
+std::mutex& device_structure_mutex();
 void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 void zero_blocking(void* p, size_t bytes);
 

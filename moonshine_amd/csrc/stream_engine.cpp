@@ -78,7 +78,10 @@ StreamingEngine::StreamingEngine(int device, int max_slots, int max_memory_frame
 StreamingEngine::~StreamingEngine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  for (void* p : allocs_) (void)hipFree(p);
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    for (void* p : allocs_) (void)hipFree(p);
+  }
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
@@ -94,7 +97,10 @@ void StreamingEngine::synchronize() {
 
 void StreamingEngine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
-  MSH_HIP(hipMalloc(&p, std::max<size_t>(src.size(), 4) * sizeof(float)));
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    MSH_HIP(hipMalloc(&p, std::max<size_t>(src.size(), 4) * sizeof(float)));
+  }
   allocs_.push_back(p);
   copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<float*>(p);
@@ -103,7 +109,10 @@ void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   std::vector<bf16_t> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
   void* p = nullptr;
-  MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  }
   allocs_.push_back(p);
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
@@ -341,7 +350,10 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
   // per-slot state slabs
   auto slab = [&](size_t bytes) {
     void* p = nullptr;
-    MSH_HIP(hipMalloc(&p, bytes));
+    {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      MSH_HIP(hipMalloc(&p, bytes));
+    }
     allocs_.push_back(p);
     zero_blocking(p, bytes);  // complete before anything on the engine stream touches the slab (see DevBuf::reserve)
     return p;
