@@ -434,7 +434,7 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 3 * D, D, epi, s)) return;
   if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
     launch_dec<4, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
-  else if (narrow_small_batch(M))
+  else if (narrow_small_batch(M) || few_tiles(M, 3 * D))
     launch_dec<1, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
   else
     launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
@@ -442,7 +442,10 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
 void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
   EpiF32 epi{out, N};
   if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, N, D, epi, s)) return;
-  launch_dec<2, true>(H, D, nullptr, W, M, N, D, epi, s);
+  if (few_tiles(M, N))
+    launch_dec<1, true>(H, D, nullptr, W, M, N, D, epi, s);
+  else
+    launch_dec<2, true>(H, D, nullptr, W, M, N, D, epi, s);
 }
 void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int M, int F, int D, bf16_t* z,
                         hipStream_t s) {
@@ -469,7 +472,7 @@ void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bia
     }();
     if (fc2_tm2 && K > N && M >= dec_tm2_threshold() && launch_dec_tm2<2, false>(A, lda, W, M, N, K, epi, s)) return;
   }
-  if (narrow_small_batch(M))
+  if (narrow_small_batch(M) || few_tiles(M, N))
     launch_dec<1, false>(A, lda, nullptr, W, M, N, K, epi, s);
   else
     launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
