@@ -174,6 +174,12 @@ MSH_EXPORT int64_t msh_host_text_to_tokens(const uint8_t* tokenizer_bin, uint64_
  *                           of the given tokenizer; the chosen terms come back joined by '\n'. */
 MSH_EXPORT int64_t msh_host_context_terms(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const char* context,
                                           uint64_t context_len, int32_t max_terms, char* out, uint64_t out_cap);
+/* WAV files either side of the path (reference core/moonshine-utils/debug-utils.cpp:52-190 load_wav_data, :192-250
+ * save_wav_data -- what its tests, benchmark and the save_input_wav_path option use): 16-bit PCM only, samples / 32768,
+ * the channel count is ignored (interleaved samples stay interleaved), a data chunk longer than the file is clamped.
+ * msh_host_load_wav returns the sample count (copies min(count, out_cap) floats if out != NULL) or a negative error. */
+MSH_EXPORT int64_t msh_host_load_wav(const char* path, float* out, uint64_t out_cap, int32_t* sample_rate);
+MSH_EXPORT int32_t msh_host_save_wav(const char* path, const float* samples, uint64_t count, int32_t sample_rate);
 /* Word alignment (reference core/word-alignment.cpp): the host code the transcriber runs on the device's cross-attention.
  * msh_host_dtw           : dtw (:12-88); returns the path length, indices into text_idx / time_idx (cap entries each).
  * msh_host_median_filter : median_filter (:98-153) in place over [rows][row_len].

@@ -421,6 +421,21 @@ int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t tokenizer_si
   }
 }
 
+int64_t msh_host_load_wav(const char* path, float* out, uint64_t out_cap, int32_t* sample_rate) {
+  if (path == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  std::vector<float> samples;
+  int32_t rate = 0;
+  if (!load_wav(path, &samples, &rate)) return MSH_ERR_INVALID_ARGUMENT;
+  if (sample_rate != nullptr) *sample_rate = rate;
+  if (out != nullptr) memcpy(out, samples.data(), sizeof(float) * (samples.size() < out_cap ? samples.size() : (size_t)out_cap));
+  return (int64_t)samples.size();
+}
+
+int32_t msh_host_save_wav(const char* path, const float* samples, uint64_t count, int32_t sample_rate) {
+  if (path == nullptr || (samples == nullptr && count > 0)) return MSH_ERR_INVALID_ARGUMENT;
+  return save_wav(path, samples, (size_t)count, sample_rate) ? MSH_OK : MSH_ERR_INVALID_ARGUMENT;
+}
+
 int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap) {
   if (text == nullptr && n > 0) return MSH_ERR_INVALID_ARGUMENT;
   return copy_out(sanitize_utf8(std::string(text ? text : "", (size_t)n)), out, out_cap);

@@ -116,7 +116,7 @@ DECLARED_SYMBOLS = [
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_debug_read",
     "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
-    "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
+    "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",

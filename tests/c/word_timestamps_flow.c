@@ -1,13 +1,14 @@
 /* The flow of the reference's core/word-alignment-test.cpp ("non-streaming-transcribe-with-word-timestamps") as a plain C
  * program against include/moonshine-c-api.h + libmoonshine.so: load a transcriber with word_timestamps on, transcribe one
  * clip, check what that test REQUIREs of every word.  Differences: the model directory and the clip are synthetic (the
- * shipped tiny-en model and beckett.wav are not available), so the clip comes from a raw float32 file, vad_threshold is 0,
- * and "end > start" is relaxed to ">=" (random weights can put two words on one frame).
- * usage: word_timestamps_flow <model dir> <raw f32 pcm file> */
+ * shipped tiny-en model and beckett.wav are not available; the WAV is read with msh_host_load_wav, this library's
+ * load_wav_data), vad_threshold is 0, and "end > start" is relaxed to ">=" (random weights can put two words on one frame).
+ * usage: word_timestamps_flow <model dir> <16-bit PCM wav> */
 #include <stdio.h>
 #include <stdlib.h>
 
 #include "moonshine-c-api.h"
+#include "moonshine_hip.h"
 
 #define REQUIRE(c)                                                     \
   do {                                                                 \
@@ -27,18 +28,17 @@ int main(int argc, char** argv) {
   int32_t handle = moonshine_load_transcriber_from_files(argv[1], MOONSHINE_MODEL_ARCH_TINY, options, 3, moonshine_get_version());
   REQUIRE(handle >= 0);
 
-  FILE* f = fopen(argv[2], "rb");
-  REQUIRE(f != NULL);
-  fseek(f, 0, SEEK_END);
-  long bytes = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  size_t n = (size_t)bytes / sizeof(float);
+  /* Load WAV file (reference: load_wav_data) */
+  int32_t sample_rate = 0;
+  int64_t count = msh_host_load_wav(argv[2], NULL, 0, &sample_rate);
+  REQUIRE(count > 0);
+  size_t n = (size_t)count;
   float* pcm = (float*)malloc(n * sizeof(float));
-  REQUIRE(pcm != NULL && fread(pcm, sizeof(float), n, f) == n);
-  fclose(f);
+  REQUIRE(pcm != NULL);
+  REQUIRE(msh_host_load_wav(argv[2], pcm, n, &sample_rate) == count);
 
   struct transcript_t* transcript = NULL;
-  int32_t err = moonshine_transcribe_without_streaming(handle, pcm, n, 16000, 0, &transcript);
+  int32_t err = moonshine_transcribe_without_streaming(handle, pcm, n, sample_rate, 0, &transcript);
   REQUIRE(err == 0);
   REQUIRE(transcript != NULL);
   REQUIRE(transcript->line_count > 0);

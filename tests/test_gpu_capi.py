@@ -144,8 +144,12 @@ def test_reference_word_timestamp_test_flow_as_a_c_program(tiny_dir, tmp_path):
     exe = str(tmp_path / "wt_flow")
     subprocess.run(["gcc", "-O1", "-I", os.path.join(here, "..", "include"), os.path.join(here, "c", "word_timestamps_flow.c"), "-o", exe,
                     LIB, f"-Wl,-rpath,{os.path.dirname(LIB)}"], check=True)
-    pcm = tmp_path / "clip.f32"
-    make_audio(420, 16000 * 5).astype(np.float32).tofile(pcm)
+    import wave
+
+    pcm = tmp_path / "clip.wav"
+    with wave.open(str(pcm), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.clip(make_audio(420, 16000 * 5) * 32768.0, -32768, 32767).astype("<i2").tobytes())
     r = subprocess.run([exe, tiny_dir[0], str(pcm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("words: ")

@@ -306,5 +306,80 @@ def test_c_program_links_against_the_public_header_and_fails_loudly_without_a_gp
                     f"-Wl,-rpath,{os.path.dirname(LIB)}"], check=True)
     if torch.cuda.is_available():
         pytest.skip("GPU present: the run itself is covered by tests/test_gpu_capi.py")
-    r = subprocess.run([exe, str(tmp_path), str(tmp_path / "none.f32")], capture_output=True, text=True)
+    r = subprocess.run([exe, str(tmp_path), str(tmp_path / "none.wav")], capture_output=True, text=True)
     assert r.returncode == 1 and "REQUIRE failed" in r.stderr and "handle >= 0" in r.stderr
+
+
+def _wav_bytes(samples_i16: np.ndarray, rate: int, channels: int = 1, fmt: int = 1, bits: int = 16, extra_chunks=(), fmt_extra: bytes = b"",
+               claim_data_bytes: int | None = None) -> bytes:
+    import struct
+
+    data = samples_i16.astype("<i2").tobytes() if bits == 16 else samples_i16.astype("u1").tobytes()
+    fmt_chunk = struct.pack("<HHIIHH", fmt, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits) + fmt_extra
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_chunk)) + fmt_chunk
+    for cid, payload in extra_chunks:
+        body += cid + struct.pack("<I", len(payload)) + payload
+    body += b"data" + struct.pack("<I", len(data) if claim_data_bytes is None else claim_data_bytes) + data
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_wav_reader_and_writer(tmp_path):
+    """msh_host_load_wav / msh_host_save_wav against the rules of the reference's load_wav_data / save_wav_data
+    (core/moonshine-utils/debug-utils.cpp:52-250): 16-bit PCM only, sample / 32768, channels left interleaved, chunks
+    before `data` skipped, a data size larger than the file clamped; and against Python's own `wave` module."""
+    import wave
+
+    lib = load_library()
+    lib.msh_host_load_wav.restype = C.c_int64
+    lib.msh_host_load_wav.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.msh_host_save_wav.restype = C.c_int32
+    lib.msh_host_save_wav.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32]
+
+    def load(path):
+        rate = C.c_int32(0)
+        n = lib.msh_host_load_wav(str(path).encode(), None, 0, C.byref(rate))
+        if n < 0:
+            return None, 0
+        out = np.zeros(n, np.float32)
+        assert lib.msh_host_load_wav(str(path).encode(), out.ctypes.data, n, C.byref(rate)) == n
+        return out, rate.value
+
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-32768, 32768, 4001, dtype=np.int64).astype(np.int16)
+    pcm[:3] = [-32768, 32767, 0]
+    # a file written by Python's wave module
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(22050); w.writeframes(pcm.tobytes())
+    got, rate = load(p)
+    assert rate == 22050
+    np.testing.assert_array_equal(got, pcm.astype(np.float32) / np.float32(32768.0))
+    # LIST chunk before the data, extended fmt chunk, stereo (left interleaved)
+    p2 = tmp_path / "b.wav"
+    p2.write_bytes(_wav_bytes(pcm[:4000], 48000, channels=2, extra_chunks=[(b"LIST", b"x" * 26)], fmt_extra=b"\x00\x00"))
+    got, rate = load(p2)
+    assert rate == 48000 and got.shape[0] == 4000
+    np.testing.assert_array_equal(got, pcm[:4000].astype(np.float32) / np.float32(32768.0))
+    # the header claims more data than the file holds: clamped to what is there
+    p3 = tmp_path / "c.wav"
+    p3.write_bytes(_wav_bytes(pcm[:100], 16000, claim_data_bytes=1 << 30))
+    got, _ = load(p3)
+    assert got.shape[0] == 100
+    # refused: 8-bit, float format, not RIFF, no data chunk, empty data, missing file
+    bad = {"d.wav": _wav_bytes(pcm[:10], 16000, bits=8), "e.wav": _wav_bytes(pcm[:10], 16000, fmt=3), "f.wav": b"RIFX" + b"\0" * 60,
+           "g.wav": _wav_bytes(pcm[:10], 16000)[:36], "h.wav": _wav_bytes(pcm[:0], 16000)}
+    for name, blob in bad.items():
+        (tmp_path / name).write_bytes(blob)
+        assert load(tmp_path / name)[0] is None, name
+    assert load(tmp_path / "missing.wav")[0] is None
+    # writer: clamp to [-1, 1], truncate towards zero after x 32768, readable by `wave`, round-trips through the reader
+    x = np.asarray([0.0, 0.5, -0.5, 1.0, -1.0, 1.5, -2.0, 0.99999, 1e-6, -3.0517578125e-05], np.float32)
+    p4 = tmp_path / "out.wav"
+    assert lib.msh_host_save_wav(str(p4).encode(), x.ctypes.data, len(x), 16000) == 0
+    with wave.open(str(p4), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, len(x))
+        raw = np.frombuffer(w.readframes(len(x)), "<i2")
+    want = np.clip(x.astype(np.float32) * np.float32(32768.0), -32768.0, 32767.0).astype(np.int16)  # astype truncates towards zero
+    np.testing.assert_array_equal(raw, want)
+    got, rate = load(p4)
+    np.testing.assert_array_equal(got, want.astype(np.float32) / np.float32(32768.0))
