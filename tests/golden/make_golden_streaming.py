@@ -174,5 +174,11 @@ def run_case(name, arch, seed, seconds, update_chunks, n_greedy, audio_index):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    run_case("micro_2s", "micro_streaming", 11, 2.4, 5, 12, 3)
-    run_case("tiny_3s", "tiny_streaming", 5, 3.2, 8, 10, 4)
+    only = sys.argv[1:]
+    cases = [("micro_2s", "micro_streaming", 11, 2.4, 5, 12, 3),
+             ("tiny_3s", "tiny_streaming", 5, 3.2, 8, 10, 4),
+             # the dims bench.py's streaming workload (BASELINE config 5) runs at
+             ("medium_2s", "medium_streaming", 7, 2.4, 6, 8, 5)]
+    for case in cases:
+        if not only or case[0] in only:
+            run_case(*case)

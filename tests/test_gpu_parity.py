@@ -360,3 +360,66 @@ def test_cross_attention_capture_vs_oracle(arch, micro, base):
     with pytest.raises(MshError):  # nothing decoded since the capture was switched on
         e.cross_attention(0)
     e.set_capture_cross_attention(False)
+
+
+def test_base_batch256_benchmark_path_vs_oracle(base):
+    """The configuration bench.py quotes (BASELINE config 3: base, 256 x 10 s, 65 forced steps) on the path it
+    runs -- hipGraph replay, 64-column / 32-row decode GEMM tiles (M >= 96 / 128), tiled LM head with the argmax
+    fused into its epilogue -- against the ORACLE, not against the engine itself:
+      * ids: for clips spread over the batch (first / last rows, both sides of the 16-row MFMA tile and 128-row LM-head
+        tile boundaries) the oracle is teacher-forced with the GPU's own ids (no cascade); wherever its top-1 margin
+        exceeds 0.1 its first-max argmax must be the GPU's next id (reference loop core/moonshine-model.cpp:380-517);
+      * logits: a second pass at the SAME batch with the logits materialised (eager, same GEMM instantiations, LM head
+        without the argmax epilogue) must give max-abs <= 5e-2 on those clips and EXACTLY the ids of the fused path
+        for all 256 clips."""
+    e, w, cfg = base
+    n, steps, logit_steps = 256, 65, 12
+    clips = [make_audio(1234 + i, 160000) for i in range(n)]
+    toks = e.transcribe_tokens(clips, forced_steps=steps)          # graph + fused argmax
+    assert all(len(t) == steps + 1 and t[0] == cfg.bos for t in toks)
+    teacher = np.asarray(toks, np.int32)
+    e.encode(clips)
+    toks_eager, logits = e.decode(forced_steps=steps, teacher=teacher, want_logits=logit_steps)
+    assert toks_eager == toks                                      # fused (max, first index) epilogue == argmax of logits
+    picked = [0, 15, 16, 127, 128, 255]
+    checked = flips = 0
+    worst = 0.0
+    for b in picked:
+        enc = ref.encoder_forward(w, cfg, clips[b])
+        o_toks, o_logits = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, return_logits=True, teacher=toks[b])
+        for i in range(steps):
+            top2 = np.partition(o_logits[i], -2)[-2:]
+            if float(top2[1] - top2[0]) > MARGIN:
+                assert toks[b][i + 1] == o_toks[i + 1], (b, i, float(top2[1] - top2[0]))
+                checked += 1
+            elif toks[b][i + 1] != o_toks[i + 1]:
+                flips += 1
+            if i < logit_steps:
+                worst = max(worst, float(np.abs(logits[i, b] - o_logits[i]).max()))
+    assert worst <= LOGIT_MAXABS, worst
+    assert checked >= len(picked) * steps // 2, (checked, flips)   # the check must not be vacuous
+    print(f"batch-256 parity: {checked} ids checked against the oracle, {flips} near-tie flips, logits max-abs {worst:.3e}")
+
+
+def test_batches_in_flight_soak_base_256(base):
+    """Soak test of the overlapped mode bench.py quotes: 56 base batches of 256 x 10 s on 4 lanes (encoder GEMMs of one
+    batch next to the decode kernels of three others), every one bit-equal to the ids of the serial pass.  The device
+    code is built without packed-FP32 instructions (build.py checks the disassembly): with them a few
+    clips per batch used to differ."""
+    e, _, cfg = base
+    steps = 65
+    batches = [[make_audio(5000 + 300 * b + i, 160000) for i in range(256)] for b in range(4)]
+    want = [e.transcribe_tokens(c, forced_steps=steps) for c in batches]
+    assert want[0] != want[1]
+    e.set_batches_in_flight(4)
+    try:
+        bad = []
+        for rnd in range(2):
+            tickets = [(k % 4, e.submit_transcribe_tokens(batches[k % 4], forced_steps=steps)) for k in range(28)]
+            for k, (b, t) in enumerate(tickets):
+                got = e.wait_tokens(t)
+                if got != want[b]:
+                    bad.append((rnd, k, sum(g != w_ for g, w_ in zip(got, want[b]))))
+        assert not bad, f"(round, submission, differing clips): {bad}"
+    finally:
+        e.set_batches_in_flight(0)

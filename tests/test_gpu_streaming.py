@@ -68,7 +68,7 @@ def oracle_state(w, cfg, audio, chunks_per_update):
     return st
 
 
-@pytest.mark.parametrize("name", ["micro_2s", "tiny_3s"])
+@pytest.mark.parametrize("name", ["micro_2s", "tiny_3s", "medium_2s"])
 def test_stream_matches_reference_graphs(tmp_path, name):
     g = np.load(os.path.join(GOLD, f"golden_stream_{name}.npz"))
     eng, cfg, w = make_engine(tmp_path, str(g["arch"]), int(g["seed"]))
@@ -369,4 +369,57 @@ def test_decode_full_with_context_biaser(tmp_path):
     eng.decoder_reset([s])
     (back,), _ = eng.decode_full([s])
     assert back == plain
+    eng.close()
+
+
+def test_medium_dims_batch64_vs_oracle_and_golden(tmp_path):
+    """BASELINE config 5's shape -- the (assumed) medium dims bench.py's streaming workload runs at, 64 streams in one
+    batch, speculative decode_full -- against the oracle on three streams spread over the batch and against the golden
+    vectors made from the reference's own graph modules on stream 0 (tests/golden/golden_stream_medium_2s.npz).  The
+    oracle is teacher-forced with the engine's ids, so every position with a clear margin is checked (no cascade)."""
+    g = np.load(os.path.join(GOLD, "golden_stream_medium_2s.npz"))
+    eng, cfg, w = make_engine(tmp_path, "medium_streaming", int(g["seed"]), max_slots=64, max_frames=256)
+    n, upd = 64, int(g["update_chunks"])
+    n_chunks = int(g["n_samples"]) // 1280
+    audios = [make_audio(int(g["audio_index"]) + 100 * i, n_chunks * 1280) for i in range(n)]
+    slots = [eng.open() for _ in range(n)]
+    c = 0
+    prev = [[] for _ in range(n)]
+    accepted_total = 0
+    while c < n_chunks:
+        k = min(upd, n_chunks - c)
+        got = eng.process_audio(slots, [a[c * 1280:(c + k) * 1280] for a in audios])
+        assert got.tolist() == [4 * k] * n
+        c += k
+        eng.encode(slots, [c >= n_chunks] * n)
+        # the Transcriber's update: reset, decode the whole line again with the previous hypothesis as the draft
+        eng.decoder_reset(slots)
+        toks, acc = eng.decode_full(slots, drafts=[p if p else None for p in prev])
+        accepted_total += int(acc.sum())
+        prev = toks
+    assert eng.memory_len(slots[0]) == int(g["mem_lens"][-1])
+    # stream 0 is the golden's audio: features / memory against the reference graph modules
+    f0, m0 = eng.features(slots[0]), eng.memory(slots[0])
+    assert relrms(f0, g["features"]) < RELRMS and relrms(m0, g["memory"]) < 2 * RELRMS
+    # speculative result == plain greedy on the same engine (the spec == greedy invariant of speculative-decode-bench.cpp:486)
+    eng.decoder_reset(slots)
+    plain, acc0 = eng.decode_full(slots)
+    assert plain == prev and acc0.tolist() == [0] * n
+    checked = 0
+    for i in (0, 31, 63):
+        st = oracle_state(w, cfg, audios[i], upd)
+        assert relrms(eng.features(slots[i]), st.features) < RELRMS
+        assert relrms(eng.memory(slots[i]), st.memory) < 2 * RELRMS
+        st.decoder_reset()
+        lg = sr.decode_tokens(w, cfg, st, [cfg.bos] + plain[i])          # teacher-forced wide pass
+        for t, tok in enumerate(plain[i]):
+            top = np.sort(lg[t])[-2:]
+            if top[1] - top[0] > MARGIN:
+                assert int(np.argmax(lg[t])) == tok, (i, t)
+                checked += 1
+        # logits of the engine's wide pass on the same tokens
+        eng.decoder_reset([slots[i]])
+        got_lg = eng.decode_tokens([slots[i]], [[cfg.bos] + plain[i]])[0]
+        assert np.abs(got_lg - lg).max() < LOGIT_MAXABS
+    assert checked >= 6
     eng.close()

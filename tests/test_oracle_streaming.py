@@ -37,7 +37,7 @@ def drive(g, cfg, w):
     return st, mem_lens, windows
 
 
-@pytest.mark.parametrize("name", ["micro_2s", "tiny_3s"])
+@pytest.mark.parametrize("name", ["micro_2s", "tiny_3s", "medium_2s"])
 def test_oracle_matches_reference_graphs(name):
     g = load(name)
     cfg = STREAMING_ARCHS[str(g["arch"])]

@@ -1,0 +1,249 @@
+"""Fuzz-diff of libmoonshine.so's host byte / integer / sample helpers (msh_host_*, the code the MI355X Transcriber
+runs) against the REFERENCE's own sources compiled into oracle/_ref/libmoonshine_ref_host.so (oracle/build_ref.py,
+oracle/ref_shim.cpp): resampler.cpp, bin-tokenizer.cpp, word-alignment.cpp, context-biaser.cpp, context-extractor.cpp,
+debug-utils.cpp (WAV).  Same arguments into both libraries; results must be byte-identical (floats bit-identical).
+
+The reference library is test infrastructure: built here when /root/reference exists, shipped prebuilt to the GPU box
+(where these CPU tests do not run anyway).  No reference library -> the tests are skipped, not passed.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from moonshine_amd.hip_api import load_library
+from moonshine_amd.synth import encode_tokenizer_bin, synthetic_vocab
+from oracle.build_ref import build_ref, ref_library_path
+
+SPACE = "▁".encode()
+vp, u64, i32, i64, f32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.c_float
+
+SIGS = {
+    "tokens_to_text": (i64, [vp, u64, vp, u64, vp, u64]),
+    "text_to_tokens": (i64, [vp, u64, vp, u64, C.c_char_p, i32, vp, u64]),
+    "biaser_bonuses": (i64, [vp, vp, u64, f32, vp, u64, vp, u64]),
+    "context_terms": (i64, [vp, u64, vp, u64, i32, vp, u64]),
+    "dtw": (i64, [vp, i32, i32, vp, vp, u64]),
+    "median_filter": (i32, [vp, u64, i32, i32]),
+    "align_words": (i64, [vp, u64, vp, i32, i32, i32, vp, u64, f32, vp, u64, vp, u64]),
+    "load_wav": (i64, [C.c_char_p, vp, u64, vp]),
+    "save_wav": (i32, [C.c_char_p, vp, u64, i32]),
+    "resample": (i64, [vp, u64, f32, f32, vp, u64]),
+}
+
+
+class Pair:
+    """The same function in both libraries."""
+
+    def __init__(self, ours, ref):
+        self.fns = {}
+        for name, (res, args) in SIGS.items():
+            a, b = getattr(ours, "msh_host_" + name), getattr(ref, "ref_host_" + name)
+            for f in (a, b):
+                f.restype, f.argtypes = res, args
+            self.fns[name] = (a, b)
+
+    def both(self, name, make_args):
+        """make_args() builds a fresh argument tuple + a function returning the observable outputs."""
+        out = []
+        for f in self.fns[name]:
+            args, observe = make_args()
+            rc = f(*args)
+            out.append((rc, observe(rc)))
+        return out
+
+
+@pytest.fixture(scope="module")
+def pair():
+    path = build_ref() or ref_library_path()
+    if path is None:
+        pytest.skip("no oracle/_ref library (reference sources absent and nothing prebuilt)")
+    return Pair(load_library(), C.CDLL(path))
+
+
+def bpe_vocab(rng, n_pieces=600):
+    """Control tokens, the 256 raw bytes, the word marker, then random 'merged' pieces over a small alphabet -- the
+    layout the reference's BPE encoder needs (bin-tokenizer-test.cpp:17-45)."""
+    v = [b"<unk>", b"<s>", b"</s>"] + [bytes([i]) for i in range(256)] + [SPACE]
+    alpha = b"abcdefghij"
+    seen = set(v)
+    while len(v) < 260 + n_pieces:
+        n = int(rng.integers(2, 6))
+        p = bytes(rng.choice(list(alpha), n).tolist())
+        if rng.random() < 0.3:
+            p = SPACE + p
+        if p not in seen:
+            seen.add(p)
+            v.append(p)
+    return v
+
+
+def arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def test_resampler_bit_identical(pair):
+    rng = np.random.default_rng(0)
+    rates = [(48000, 16000), (44100, 16000), (22050, 16000), (24000, 16000), (8000, 16000), (11025, 16000), (16000, 16000),
+             (16000, 48000), (32000, 16000), (96000, 16000), (12345, 16000)]
+    for k in range(120):
+        ir, orate = rates[k % len(rates)]
+        n = int(rng.integers(0, 6000)) if k % 7 else int(rng.integers(0, 4))
+        x = arr(rng.standard_normal(n) * 0.3, np.float32)
+
+        def mk():
+            out = np.full(n * 8 + 64, np.nan, np.float32)
+            return (x.ctypes.data, n, float(ir), float(orate), out.ctypes.data, out.size), lambda rc: out[:max(rc, 0)].tobytes()
+
+        a, b = pair.both("resample", mk)
+        assert a == b, (ir, orate, n)
+
+
+def test_tokenizer_decode_and_encode_identical(pair):
+    rng = np.random.default_rng(1)
+    vocabs = [synthetic_vocab(4096), bpe_vocab(rng), [b"<unk>", b"<s>", b"</s>", b"_", b"a", b"b", b"ab", b"_ab", b"abb"]]
+    for vi, vocab in enumerate(vocabs):
+        blob = encode_tokenizer_bin(vocab)
+        for trial in range(150):
+            ids = arr(rng.integers(0, len(vocab), int(rng.integers(0, 30))), np.int32)
+
+            def mk():
+                buf = C.create_string_buffer(1 << 15)
+                return (blob, len(blob), ids.ctypes.data, len(ids), C.addressof(buf), len(buf)), lambda rc: buf.raw[:max(rc, 0)]
+
+            a, b = pair.both("tokens_to_text", mk)
+            assert a == b, (vi, ids.tolist())
+        # text -> ids, both encodings; texts are built from the vocabulary's own alphabet, raw bytes and the marker
+        alpha = b"abcdefghij _" if vi else b"abcdefghijklmnopqrstuvwxyz "
+        marker = b"_" if vi == 2 else SPACE
+        for trial in range(200):
+            n = int(rng.integers(0, 24))
+            text = bytes(rng.choice(list(alpha), n).tolist()) if n else b""
+            if trial % 9 == 0:
+                text += "é中".encode() + bytes([int(rng.integers(1, 256))])
+            for bpe in (0, 1):
+                def mk():
+                    out = np.full(256, -7, np.int32)
+                    return (blob, len(blob), text, len(text), marker, bpe, out.ctypes.data, out.size), lambda rc: out[:max(rc, 0)].tolist()
+
+                a, b = pair.both("text_to_tokens", mk)
+                assert (a[0] < 0) == (b[0] < 0), (vi, text, bpe, a, b)
+                if a[0] >= 0:
+                    assert a == b, (vi, text, bpe)
+
+
+def test_context_biaser_identical(pair):
+    rng = np.random.default_rng(2)
+    V = 300
+    for trial in range(150):
+        n_seqs = int(rng.integers(0, 9))
+        seqs = [rng.integers(0, 12 if trial % 2 else V, int(rng.integers(1, 6))).tolist() for _ in range(n_seqs)]
+        flat = arr([t for s in seqs for t in s] or [0], np.int32)
+        lens = arr([len(s) for s in seqs] or [0], np.int32)
+        prefix = arr(rng.integers(0, 12 if trial % 2 else V, int(rng.integers(0, 8))), np.int32)
+        boost = float(rng.choice([0.5, 2.0, 4.0]))
+        base = arr(rng.standard_normal(V), np.float32)
+
+        def mk():
+            out = base.copy()
+            return (flat.ctypes.data, lens.ctypes.data, n_seqs, boost, prefix.ctypes.data, len(prefix), out.ctypes.data, V), lambda rc: out.tobytes()
+
+        a, b = pair.both("biaser_bonuses", mk)
+        assert a == b, (seqs, prefix.tolist(), boost)
+
+
+def test_context_extractor_identical(pair):
+    rng = np.random.default_rng(3)
+    vocab = bpe_vocab(rng, 900)
+    blob = encode_tokenizer_bin(vocab)
+    words = ["abc", "Kubernetes", "ab", "jig", "Abe", "cafe", "hidea", "bad", "IPv6", "x", "gadj", "beef's", "dig-ace", "école", "façade",
+             "BACH", "the", "decaf", "jab", "abcdefghij"]
+    seps = [" ", ", ", ". ", "\n", "; ", " - ", "  ", "! ", " (", ") "]
+    for trial in range(80):
+        n = int(rng.integers(0, 60))
+        text = "".join(words[int(rng.integers(len(words)))] + seps[int(rng.integers(len(seps)))] for _ in range(n)).encode()
+        max_terms = int(rng.choice([0, -1, 1, 3, 10, 200]))
+
+        def mk():
+            buf = C.create_string_buffer(1 << 15)
+            return (blob, len(blob), text, len(text), max_terms, C.addressof(buf), len(buf)), lambda rc: buf.raw[:max(rc, 0)]
+
+        a, b = pair.both("context_terms", mk)
+        assert a == b, (text, max_terms)
+
+
+def test_dtw_and_median_filter_identical(pair):
+    rng = np.random.default_rng(4)
+    for trial in range(120):
+        n, m = int(rng.integers(1, 24)), int(rng.integers(1, 80))
+        cost = arr(rng.standard_normal((n, m)) if trial % 3 else np.round(rng.standard_normal((n, m))), np.float32)   # ties too
+
+        def mk():
+            ti, tj = np.full(n + m + 4, -1, np.int32), np.full(n + m + 4, -1, np.int32)
+            return (cost.ctypes.data, n, m, ti.ctypes.data, tj.ctypes.data, ti.size), lambda rc: (ti.tolist(), tj.tolist())
+
+        a, b = pair.both("dtw", mk)
+        assert a == b, (n, m)
+    for trial in range(120):
+        rows, w = int(rng.integers(1, 6)), int(rng.integers(1, 40))
+        width = int(rng.choice([1, 3, 5, 7, 9]))
+        x = arr(rng.standard_normal((rows, w)), np.float32)
+
+        def mk():
+            d = x.copy()
+            return (d.ctypes.data, rows, w, width), lambda rc: d.tobytes()
+
+        a, b = pair.both("median_filter", mk)
+        assert a == b, (rows, w, width)
+
+
+def test_align_words_identical(pair):
+    rng = np.random.default_rng(5)
+    vocab = synthetic_vocab(2048)
+    blob = encode_tokenizer_bin(vocab)
+    for trial in range(60):
+        heads, steps, frames = int(rng.integers(1, 9)), int(rng.integers(1, 20)), int(rng.integers(2, 120))
+        att = rng.random((heads, steps, frames)).astype(np.float32) ** 4
+        # a moving ridge, as real cross-attention has
+        for s in range(steps):
+            att[:, s, min(frames - 1, s * frames // steps)] += 1.0
+        att /= att.sum(-1, keepdims=True)
+        att = arr(att, np.float32)
+        body = rng.integers(259, 2048, steps - 1).tolist() if steps > 1 else []
+        toks = arr([1] + body + ([2] if trial % 2 else []), np.int32)[: steps + 1]
+        spf = float(rng.choice([0.02, 0.024, 0.0241]))
+
+        def mk():
+            text = C.create_string_buffer(1 << 14)
+            times = np.full(3 * 64, np.nan, np.float32)
+            return ((blob, len(blob), att.ctypes.data, heads, steps, frames, toks.ctypes.data, len(toks), spf, C.addressof(text), len(text),
+                     times.ctypes.data, 64), lambda rc: (text.value, times[: 3 * max(rc, 0)].tobytes()))
+
+        a, b = pair.both("align_words", mk)
+        assert a == b, (heads, steps, frames, toks.tolist())
+
+
+def test_wav_io_identical(pair, tmp_path):
+    rng = np.random.default_rng(6)
+    for trial in range(12):
+        n = int(rng.integers(0, 5000))
+        x = arr(np.clip(rng.standard_normal(n) * 0.5, -1.2, 1.2), np.float32)     # includes clipping
+        rate = int(rng.choice([16000, 44100, 8000]))
+        paths = [str(tmp_path / f"ours_{trial}.wav").encode(), str(tmp_path / f"ref_{trial}.wav").encode()]
+        rcs = [f(p, x.ctypes.data, n, rate) for f, p in zip(pair.fns["save_wav"], paths)]
+        assert rcs[0] == rcs[1] == 0
+        assert open(paths[0], "rb").read() == open(paths[1], "rb").read()
+        # each loader on the OTHER writer's file
+        res = []
+        for f, p in zip(pair.fns["load_wav"], paths[::-1]):
+            out = np.full(n + 16, np.nan, np.float32)
+            r = C.c_int32(0)
+            cnt = f(p, out.ctypes.data, out.size, C.addressof(r))
+            res.append((cnt, r.value, out[:max(cnt, 0)].tobytes()))
+        assert res[0] == res[1] and res[0][0] == n and res[0][1] == rate
+    # malformed files: both refuse
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    r = C.c_int32(0)
+    assert all(f(str(bad).encode(), None, 0, C.addressof(r)) < 0 for f in pair.fns["load_wav"])
