@@ -152,6 +152,81 @@ MOONSHINE_EXPORT int32_t moonshine_transcribe_batch_without_streaming(
     int32_t transcriber_handle, const float *const *audio_data, const uint64_t *audio_lengths, uint64_t count,
     int32_t sample_rate, uint32_t flags, struct transcript_t **out_transcripts);
 
+/* ---- out of scope for this engine, exported as stubs (reference core/moonshine-c-api.h:758-1258) ----
+ * Sentence embeddings, text to speech, grapheme-to-phoneme, model catalogs and download manifests are not part of the
+ * MI355X transcription build.  The reference's bindings bind every symbol of the header when they load the library
+ * (language-bindings/python/src/moonshine_voice/moonshine_api.py:972-1121), so the symbols exist: each call returns
+ * MOONSHINE_ERROR_UNKNOWN and clears its outputs.  Prototypes are the reference's, byte for byte. */
+#define MOONSHINE_EMBEDDING_MODEL_ARCH_GEMMA_300M (0)
+struct moonshine_speech_clip_t { /* reference h:833-851 */
+  float *audio_data;
+  uint64_t audio_length;
+  float start_time;
+  float speech_duration;
+  int32_t is_complete;
+  char *transcript;
+};
+MOONSHINE_EXPORT int32_t moonshine_create_embedding_model(const char *model_path, uint32_t model_arch,
+                                                          const char *model_variant);
+MOONSHINE_EXPORT int32_t moonshine_create_embedding_model_from_memory(
+    uint32_t model_arch, const char *model_variant, const char **filenames, uint64_t filenames_count,
+    const uint8_t **memory, const uint64_t *memory_sizes, const struct moonshine_option_t *options,
+    uint64_t options_count, int32_t moonshine_version);
+MOONSHINE_EXPORT void moonshine_free_embedding_model(int32_t embedding_model_handle);
+MOONSHINE_EXPORT int32_t moonshine_calculate_embedding(int32_t embedding_model_handle, const char *sentence,
+                                                       float **out_embedding, uint64_t *out_embedding_size,
+                                                       const char *model_name);
+MOONSHINE_EXPORT void moonshine_free_embedding(float *embedding);
+MOONSHINE_EXPORT int32_t moonshine_calculate_embedding_distance(int32_t embedding_model_handle,
+                                                                const float *embedding_a, const float *embedding_b,
+                                                                uint64_t embedding_size, float *out_similarity);
+MOONSHINE_EXPORT int32_t moonshine_extract_speech_clip(const float *audio_data, uint64_t audio_length,
+                                                       int32_t sample_rate, int32_t tts_synthesizer_handle,
+                                                       const struct moonshine_option_t *options,
+                                                       uint64_t options_count, struct moonshine_speech_clip_t *out_clip);
+MOONSHINE_EXPORT int32_t moonshine_create_tts_synthesizer_from_files(const char *language, const char **filenames,
+                                                                     uint64_t filenames_count,
+                                                                     const struct moonshine_option_t *options,
+                                                                     uint64_t options_count, int32_t moonshine_version);
+MOONSHINE_EXPORT int32_t moonshine_create_tts_synthesizer_from_memory(
+    const char *language, const char **filenames, const uint64_t filenames_count, const uint8_t **memory,
+    const uint64_t *memory_sizes, const struct moonshine_option_t *options, uint64_t options_count,
+    int32_t moonshine_version);
+MOONSHINE_EXPORT void moonshine_free_tts_synthesizer(int32_t tts_synthesizer_handle);
+MOONSHINE_EXPORT int32_t moonshine_get_g2p_dependencies(const char *languages, const struct moonshine_option_t *options,
+                                                        uint64_t options_count, char **out_dependencies_json);
+MOONSHINE_EXPORT int32_t moonshine_get_tts_dependencies(const char *languages, const struct moonshine_option_t *options,
+                                                        uint64_t options_count, char **out_dependencies_json);
+MOONSHINE_EXPORT int32_t moonshine_get_tts_voices(const char *languages, const struct moonshine_option_t *options,
+                                                  uint64_t options_count, char **out_voices_json);
+MOONSHINE_EXPORT int32_t moonshine_get_stt_dependencies(const char *language, const struct moonshine_option_t *options,
+                                                        uint64_t options_count, char **out_dependencies_json);
+MOONSHINE_EXPORT int32_t moonshine_get_embedding_dependencies(const char *model_name,
+                                                              const struct moonshine_option_t *options,
+                                                              uint64_t options_count, char **out_dependencies_json);
+MOONSHINE_EXPORT int32_t moonshine_get_diarization_dependencies(char **out_dependencies_json);
+MOONSHINE_EXPORT int32_t moonshine_get_stt_catalog(char **out_catalog_json);
+MOONSHINE_EXPORT int32_t moonshine_get_embedding_catalog(char **out_catalog_json);
+MOONSHINE_EXPORT int32_t moonshine_text_to_speech(int32_t tts_synthesizer_handle, const char *text,
+                                                  const struct moonshine_option_t *options, uint64_t options_count,
+                                                  float **out_audio_data, uint64_t *out_audio_data_size,
+                                                  int32_t *out_sample_rate);
+MOONSHINE_EXPORT int32_t moonshine_phonemes_to_speech(int32_t tts_synthesizer_handle, const char *phonemes,
+                                                      const struct moonshine_option_t *options, uint64_t options_count,
+                                                      float **out_audio_data, uint64_t *out_audio_data_size,
+                                                      int32_t *out_sample_rate);
+MOONSHINE_EXPORT int32_t moonshine_create_grapheme_to_phonemizer_from_files(
+    const char *language, const char **filenames, uint64_t filenames_count, const struct moonshine_option_t *options,
+    uint64_t options_count, int32_t moonshine_version);
+MOONSHINE_EXPORT int32_t moonshine_create_grapheme_to_phonemizer_from_memory(
+    const char *language, const char **filenames, const uint64_t filenames_count, const uint8_t **memory,
+    const uint64_t *memory_sizes, const struct moonshine_option_t *options, uint64_t options_count,
+    int32_t moonshine_version);
+MOONSHINE_EXPORT void moonshine_free_grapheme_to_phonemizer(int32_t grapheme_to_phonemizer_handle);
+MOONSHINE_EXPORT int32_t moonshine_text_to_phonemes(int32_t grapheme_to_phonemizer_handle, const char *text,
+                                                    const struct moonshine_option_t *options, uint64_t options_count,
+                                                    const char **out_phonemes, uint64_t *out_phonemes_count);
+
 #ifdef __cplusplus
 }
 #endif

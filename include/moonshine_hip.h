@@ -132,6 +132,12 @@ MSH_EXPORT int64_t msh_get_cross_attention(msh_engine* e, uint32_t clip, float* 
  * encoder of one batch runs inside the idle gaps of another batch's decode loop.  n = 0 tears the lanes down.  The
  * synchronous calls above keep using the engine itself and may be mixed with submitted batches. */
 MSH_EXPORT int32_t msh_set_batches_in_flight(msh_engine* e, int32_t n);
+/* Lanes overlap only when their HIP streams sit on different hardware queues, and HIP sizes its queue pool from the
+ * environment variable GPU_MAX_HW_QUEUES (default 4) when the runtime initialises.  The library never touches the
+ * environment by itself: either the host exports GPU_MAX_HW_QUEUES (>= lanes + 3; 8 is what bench.py uses) or it calls
+ * this BEFORE the first GPU call of the process (msh_create, or any HIP call of the host).  Later calls have no effect
+ * on an initialised runtime.  The transcriber load option `hw_queues` calls it. */
+MSH_EXPORT int32_t msh_set_hw_queues(int32_t n);
 /* Queue msh_transcribe_tokens for one batch; returns a ticket >= 0 or a negative msh error.  The clips and the output
  * arrays must stay valid until msh_wait(ticket) returns (the pointer / length arrays themselves are copied). */
 MSH_EXPORT int64_t msh_submit_transcribe_tokens(msh_engine* e, const float* const* pcm, const uint64_t* n_samples,
@@ -192,6 +198,20 @@ MSH_EXPORT int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t t
                                         int32_t heads_total, int32_t n_steps, int32_t frames, const int32_t* tokens,
                                         uint64_t n_tokens, float seconds_per_frame, char* text_out, uint64_t text_cap,
                                         float* times_out, uint64_t max_words);
+/* Voice activity detection (reference core/silero-vad.cpp:78-173, core/voice-activity-detector.cpp:125-199), as the
+ * Transcriber's streams run it -- host code, no GPU:
+ * msh_host_silero_probabilities : Silero VAD over whole 512-sample hops of 16 kHz audio from a fresh state; weights = a
+ *                                 safetensors blob (tools/convert_silero_vad.py); probs[i] = SileroVad::predict of hop i;
+ *                                 state_out (nullable) receives the final [2][128] LSTM state.  Returns the hop count.
+ * msh_host_vad_segments         : VoiceActivityDetector start / process_audio (in `chunk`-sample calls) / stop; weights
+ *                                 may be NULL when threshold == 0.  bounds[3i..3i+2] = (start sample, sample count,
+ *                                 is_complete) of segment i at 16 kHz.  Returns the segment count. */
+MSH_EXPORT int64_t msh_host_silero_probabilities(const uint8_t* weights, uint64_t weights_size, const float* audio,
+                                                 uint64_t n_samples, float* probs, uint64_t cap, float* state_out);
+MSH_EXPORT int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window,
+                                         int32_t hop, uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap,
+                                         const float* audio, uint64_t n_samples, int32_t sample_rate, uint64_t chunk,
+                                         int64_t* bounds, uint64_t max_segments);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

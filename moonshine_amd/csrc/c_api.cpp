@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -70,6 +71,7 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "vad_hop_size") o->vad_hop_size = parse_int32(v);
     else if (k == "vad_look_behind_sample_count") o->vad_look_behind_sample_count = parse_size(v);
     else if (k == "vad_max_segment_duration") o->vad_max_segment_duration = parse_float(v);
+    else if (k == "vad_model_path") o->vad_model_path = v;                          // additive: Silero weights (safetensors)
     else if (k == "max_tokens_per_second") o->max_tokens_per_second = parse_float(v);
     else if (k == "decode_incomplete_lines") o->decode_incomplete_lines = parse_bool(v);
     else if (k == "return_audio_data") o->return_audio_data = parse_bool(v);
@@ -82,6 +84,9 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
     else if (k == "batch_clips") o->batch_clips = parse_int32(v);                   // additive (batch calls)
     else if (k == "batches_in_flight") o->batches_in_flight = parse_int32(v);       // additive (batch calls)
+    else if (k == "hw_queues") {                                                    // additive: see msh_set_hw_queues
+      if (msh_set_hw_queues(parse_int32(v)) != MSH_OK) throw std::runtime_error("option 'hw_queues' must be 1..64");
+    }
     else if (k == "word_timestamps") o->word_timestamps = parse_bool(v);
     else if (k == "identify_speakers") require_off(k, v);
     else if (k == "keyterms") {
@@ -107,17 +112,20 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
 }
 
 std::mutex g_map_mutex;
-std::map<int32_t, Transcriber*> g_transcribers;
+// Handles own their transcriber through a shared_ptr: a call in flight keeps it alive, so moonshine_free_transcriber
+// racing another thread's call (the reference documents the API as thread-safe, moonshine-c-api.h:64-67) ends with the
+// object destroyed by whoever finishes last -- never under a running call.
+std::map<int32_t, std::shared_ptr<Transcriber>> g_transcribers;
 int32_t g_next_handle = 0;
 
 int32_t register_transcriber(Transcriber* t) {
   std::lock_guard<std::mutex> lock(g_map_mutex);
   const int32_t h = g_next_handle++;
-  g_transcribers[h] = t;
+  g_transcribers[h].reset(t);
   return h;
 }
 
-Transcriber* lookup(int32_t handle) {
+std::shared_ptr<Transcriber> lookup(int32_t handle) {
   std::lock_guard<std::mutex> lock(g_map_mutex);
   auto it = g_transcribers.find(handle);
   return (handle < 0 || it == g_transcribers.end()) ? nullptr : it->second;
@@ -125,7 +133,8 @@ Transcriber* lookup(int32_t handle) {
 
 template <class F>
 int32_t with_transcriber(int32_t handle, const char* what, F&& f) {
-  Transcriber* t = lookup(handle);
+  const std::shared_ptr<Transcriber> keep = lookup(handle);  // alive until this call returns
+  Transcriber* t = keep.get();
   if (t == nullptr) {
     MSH_LOGF("Moonshine transcriber handle is invalid: handle %d", handle);
     return MOONSHINE_ERROR_INVALID_HANDLE;
@@ -221,9 +230,9 @@ int32_t moonshine_load_transcriber_from_memory_files(const char** filenames, con
   for (uint64_t i = 0; i < file_count; ++i) {
     if (filenames[i] == nullptr) return MOONSHINE_ERROR_INVALID_ARGUMENT;
     const std::string key(filenames[i]);
-    if (key != "model.safetensors" && key != "tokenizer.bin") {
+    if (key != "model.safetensors" && key != "tokenizer.bin" && key != "streaming_config.json" && key != "silero_vad.safetensors") {
       MSH_LOGF("moonshine_load_transcriber_from_memory_files(): '%s' is not a model asset this loader recognizes. "
-               "Canonical filenames: model.safetensors, tokenizer.bin",
+               "Canonical filenames: model.safetensors, tokenizer.bin, streaming_config.json, silero_vad.safetensors",
                key.c_str());
       return MOONSHINE_ERROR_INVALID_ARGUMENT;
     }
@@ -233,15 +242,15 @@ int32_t moonshine_load_transcriber_from_memory_files(const char** filenames, con
 }
 
 void moonshine_free_transcriber(int32_t handle) {
-  Transcriber* t = nullptr;
+  std::shared_ptr<Transcriber> t;
   {
     std::lock_guard<std::mutex> lock(g_map_mutex);
     auto it = g_transcribers.find(handle);
     if (it == g_transcribers.end()) return;
-    t = it->second;
+    t = std::move(it->second);
     g_transcribers.erase(it);
   }
-  delete t;
+  t.reset();  // destroyed here unless a call on another thread still holds it
 }
 
 int32_t moonshine_transcribe_without_streaming(int32_t handle, float* audio_data, uint64_t audio_length,
@@ -434,6 +443,56 @@ int64_t msh_host_load_wav(const char* path, float* out, uint64_t out_cap, int32_
 int32_t msh_host_save_wav(const char* path, const float* samples, uint64_t count, int32_t sample_rate) {
   if (path == nullptr || (samples == nullptr && count > 0)) return MSH_ERR_INVALID_ARGUMENT;
   return save_wav(path, samples, (size_t)count, sample_rate) ? MSH_OK : MSH_ERR_INVALID_ARGUMENT;
+}
+
+// Silero VAD + segmenter, exactly as the Transcriber's streams run them (tests; bindings that want segments only)
+int64_t msh_host_silero_probabilities(const uint8_t* weights, uint64_t weights_size, const float* audio, uint64_t n_samples,
+                                      float* probs, uint64_t cap, float* state_out) {
+  try {
+    if (weights == nullptr || (audio == nullptr && n_samples > 0)) return MSH_ERR_INVALID_ARGUMENT;
+    std::shared_ptr<SileroWeights> w(new SileroWeights());
+    w->load_memory(weights, (size_t)weights_size);
+    SileroVad vad(w);
+    const uint64_t hops = n_samples / SileroVad::kHop;
+    for (uint64_t i = 0; i < hops; ++i) {
+      const float p = vad.predict(audio + i * SileroVad::kHop);
+      if (probs != nullptr && i < cap) probs[i] = p;
+    }
+    if (state_out != nullptr) memcpy(state_out, vad.state(), sizeof(float) * 2 * SileroVad::kState);
+    return (int64_t)hops;
+  } catch (const std::exception& e) {
+    MSH_LOGF("silero_probabilities failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
+int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window, int32_t hop,
+                              uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap, const float* audio,
+                              uint64_t n_samples, int32_t sample_rate, uint64_t chunk, int64_t* bounds, uint64_t max_segments) {
+  try {
+    std::shared_ptr<SileroWeights> w;
+    if (weights != nullptr && weights_size > 0) {
+      w.reset(new SileroWeights());
+      w->load_memory(weights, (size_t)weights_size);
+    }
+    VoiceActivityDetector vad(threshold, window, hop, (size_t)look_behind, (size_t)max_segment, w, (size_t)hard_cap);
+    vad.start();
+    if (chunk == 0) chunk = n_samples ? n_samples : 1;
+    for (uint64_t off = 0; off < n_samples; off += chunk)
+      vad.process_audio(audio + off, (size_t)(n_samples - off < chunk ? n_samples - off : chunk), sample_rate);
+    vad.stop();
+    const std::vector<VadSegment>& segs = vad.segments();
+    for (size_t i = 0; i < segs.size() && i < max_segments; ++i) {
+      // start / end in samples of the 16 kHz stream (times are sample counts / 16000 in the detector), + completeness
+      bounds[3 * i] = (int64_t)llroundf(segs[i].start_time * kSampleRate);
+      bounds[3 * i + 1] = (int64_t)segs[i].audio.size();
+      bounds[3 * i + 2] = segs[i].is_complete ? 1 : 0;
+    }
+    return (int64_t)segs.size();
+  } catch (const std::exception& e) {
+    MSH_LOGF("vad_segments failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
 }
 
 int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap) {

@@ -164,14 +164,22 @@ std::string sanitize_utf8(const std::string& text) {
 }
 
 // ---------------------------------------------------------------------------------------------
-VoiceActivityDetector::VoiceActivityDetector(float threshold, int32_t /*window_size*/, int32_t hop_size,
-                                             size_t look_behind, size_t max_segment)
-    : threshold_(threshold), hop_(hop_size), look_behind_(look_behind), max_segment_(max_segment) {
-  if (threshold > 0.0f)
-    throw std::runtime_error(
-        "vad_threshold > 0 needs the Silero VAD model, which is not part of the MI355X build yet; "
-        "load the transcriber with the option vad_threshold=0 (segments are then split by length only)");
+VoiceActivityDetector::VoiceActivityDetector(float threshold, int32_t window_size, int32_t hop_size, size_t look_behind,
+                                             size_t max_segment, std::shared_ptr<const SileroWeights> silero,
+                                             size_t hard_cap)
+    : threshold_(threshold), hop_(hop_size), look_behind_(look_behind), max_segment_(max_segment), hard_cap_(hard_cap) {
   if (hop_size <= 0) throw std::runtime_error("vad_hop_size must be positive");
+  if (threshold > 0.0f) {
+    if (!silero)
+      throw std::runtime_error(
+          "vad_threshold > 0 needs the Silero VAD weights: pass the option vad_model_path=<silero_vad.safetensors> "
+          "(tools/convert_silero_vad.py writes it from the published model) or put silero_vad.safetensors into the "
+          "model directory; vad_threshold=0 treats all audio as speech");
+    if (hop_size != SileroVad::kHop)
+      throw std::runtime_error("vad_hop_size must be 512 when vad_threshold > 0 (the Silero model's window)");
+    silero_.reset(new SileroVad(std::move(silero)));
+  }
+  prob_window_.assign((size_t)(window_size > 0 ? window_size : 1), 0.f);
   look_buf_.assign(look_behind_, 0.f);
 }
 
@@ -183,6 +191,10 @@ void VoiceActivityDetector::start() {
   remainder_.clear();
   look_buf_.assign(look_behind_, 0.f);
   prev_voice_ = false;
+  forced_cut_ = false;
+  prob_window_.assign(prob_window_.size(), 0.f);
+  prob_index_ = 0;
+  if (silero_) silero_->reset();
 }
 
 void VoiceActivityDetector::stop() {
@@ -229,14 +241,25 @@ void VoiceActivityDetector::process_hop(const float* hop) {
     std::move(look_buf_.begin() + hop_, look_buf_.end(), look_buf_.begin());
     std::copy(hop, hop + hop_, look_buf_.end() - hop_);
   }
-  // threshold 0: probability 1, scaled by the max-length fade once the segment passes 2/3 of the cap
+  // threshold 0: probability 1; otherwise Silero's probability averaged over the last `window` hops (a ring that
+  // starts at zero, reference :139-151).  Either is scaled by the max-length fade once the segment passes 2/3 of the cap.
   float p = 1.0f;
+  if (silero_) {
+    prob_window_[prob_index_] = silero_->predict(hop);
+    prob_index_ = (prob_index_ + 1) % prob_window_.size();
+    float sum = 0.0f;  // std::accumulate(..., 0.0f) in the reference: fp32, in ring order
+    for (float v : prob_window_) sum += v;
+    p = sum / (float)prob_window_.size();
+  }
   const size_t fade = (max_segment_ * 2) / 3;
   if (max_segment_ && cur_.size() > fade) p = p * ((float)(cur_.size() - fade) / (float)fade);
-  const bool voice = p > threshold_;
+  bool voice = p > threshold_;
+  bool cut = false;
+  if (voice && prev_voice_ && hard_cap_ && cur_.size() + 2 * (size_t)hop_ > hard_cap_) voice = false, cut = true;  // engine capacity
   const float now = (float)processed_ / kSampleRate;
   if (voice && !prev_voice_) {
-    const size_t lb = std::min(look_behind_, processed_);
+    const size_t lb = forced_cut_ ? std::min((size_t)hop_, look_buf_.size()) : std::min(look_behind_, processed_);
+    forced_cut_ = false;
     cur_.assign(look_buf_.end() - lb, look_buf_.end());
     VadSegment s;
     s.audio = cur_;
@@ -252,6 +275,7 @@ void VoiceActivityDetector::process_hop(const float* hop) {
     s.is_complete = true;
     s.just_updated = true;
     cur_.clear();  // (the reference's resize() of the look-behind buffer here is a no-op: it keeps its contents)
+    forced_cut_ = cut;
   } else if (voice && prev_voice_) {
     cur_.insert(cur_.end(), hop, hop + hop_);
     VadSegment& s = segments_.back();

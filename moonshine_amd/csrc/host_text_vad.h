@@ -8,6 +8,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "silero_vad.h"
+
 namespace msh_host {
 
 // tokenizer.bin = concatenated length-prefixed byte strings, one per id
@@ -50,12 +52,22 @@ struct VadSegment {
 };
 
 // Segmenter with the reference's state machine (reference core/voice-activity-detector.cpp:69-199):
-// whole hops only, look-behind on voice start, max-segment fade.  The speech probability itself comes
-// from Silero in the reference; this build only supports threshold == 0 ("always voice"), which is what
-// the reference's own evaluation / benchmark scripts use (scripts/eval-librispeech.py:381-388).
+// whole hops only, look-behind on voice start, max-segment fade.  threshold == 0 means "always voice" (what the
+// reference's own evaluation / benchmark scripts use, scripts/eval-librispeech.py:381-388); threshold > 0 runs
+// Silero VAD on every hop (silero_vad.h) and smooths its probability over the last `window_size` hops (:139-151).
+//
+// Two deliberate differences from the reference:
+//  * every detector owns its Silero context / LSTM state, reset by start(); the reference shares ONE global
+//    SileroVad between all detectors of the process and never resets it (voice-activity-detector.cpp:22,35-37), so
+//    its probabilities depend on whatever audio any stream saw before.  The first stream of a process is identical.
+//  * `hard_cap` (samples, 0 = none): a segment that would grow beyond it is closed and the next hop opens a new one
+//    without look-behind.  The reference has no such cap (with threshold 0 its fade factor stays positive, so a
+//    segment never ends, Appendix A.2 of SURVEY.md); the engine behind this build has a finite position table and
+//    token budget, and the Transcriber passes that capacity here instead of failing on long audio.
 class VoiceActivityDetector {
  public:
-  VoiceActivityDetector(float threshold, int32_t window_size, int32_t hop_size, size_t look_behind, size_t max_segment);
+  VoiceActivityDetector(float threshold, int32_t window_size, int32_t hop_size, size_t look_behind, size_t max_segment,
+                        std::shared_ptr<const SileroWeights> silero = nullptr, size_t hard_cap = 0);
   void start();
   void stop();
   bool is_active() const { return active_; }
@@ -67,8 +79,11 @@ class VoiceActivityDetector {
   void process_hop(const float* hop);
   float threshold_;
   int32_t hop_;
-  size_t look_behind_, max_segment_;
-  bool active_ = false, prev_voice_ = false;
+  size_t look_behind_, max_segment_, hard_cap_;
+  std::unique_ptr<SileroVad> silero_;
+  std::vector<float> prob_window_;
+  size_t prob_index_ = 0;
+  bool active_ = false, prev_voice_ = false, forced_cut_ = false;
   size_t processed_ = 0;
   std::vector<float> look_buf_, cur_, remainder_;
   std::vector<VadSegment> segments_;

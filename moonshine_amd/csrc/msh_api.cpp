@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "engine.h"
+#include "host_utils.h"
 #include "pipeline.h"
 #include "stream_engine.h"
 
@@ -31,11 +32,19 @@ namespace {
 // HIP binds streams to hardware queues out of a pool of GPU_MAX_HW_QUEUES (4 by default), by least use.  An engine with
 // N lanes needs N + 3 streams that really run concurrently (lanes, the engine's own stream, the utility stream, the
 // legacy stream of the host framework); with 4 queues two lanes can share one and then simply alternate (measured:
-// 2 lanes 47.4k audio-s/s = no overlap at all, against 59.8k on separate queues).  The pool size is read when the HIP
-// runtime initialises, so the default is raised when this library is loaded -- unless the user already set it.
-struct HwQueueDefault {
-  HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queue_default;
+// 2 lanes 47.4k audio-s/s = no overlap at all, against 59.8k on separate queues).  The pool size is read once, when the
+// HIP runtime initialises.  A drop-in library must not change the process environment behind the host's back, so this
+// is an explicit call (msh_set_hw_queues / the load option `hw_queues`) -- or the host exports the variable itself.
+bool hw_queue_note_given = false;
+void note_hw_queues(int lanes) {
+  if (lanes < 2 || hw_queue_note_given) return;
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  if (e != nullptr && atoi(e) >= lanes + 3) return;
+  hw_queue_note_given = true;
+  MSH_LOGF("%d batches in flight want %d HIP hardware queues; GPU_MAX_HW_QUEUES is %s: lanes may share a queue and "
+           "serialise.  Export GPU_MAX_HW_QUEUES=8 or call msh_set_hw_queues(8) before the first GPU call.",
+           lanes, lanes + 3, e ? e : "unset (4)");
+}
 
 thread_local std::string g_create_error;
 
@@ -220,8 +229,14 @@ double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters) {
   return v;
 }
 
+int32_t msh_set_hw_queues(int32_t n) {
+  if (n < 1 || n > 64) return MSH_ERR_INVALID_ARGUMENT;
+  return setenv("GPU_MAX_HW_QUEUES", std::to_string(n).c_str(), 1) == 0 ? MSH_OK : MSH_ERR_UNKNOWN;
+}
+
 int32_t msh_set_batches_in_flight(msh_engine* e, int32_t n) {
   return guarded(e, [&] {
+    note_hw_queues(n);
     e->pipe.reset();
     if (n > 0) e->pipe.reset(new msh::BatchPipeline(*e->eng, e->device, n));
   });

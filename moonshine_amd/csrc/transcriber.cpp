@@ -253,10 +253,14 @@ bool is_dir_or_file(const std::string& p) {
 Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   std::random_device rd;  // random 64-bit base for line ids (reference core/transcriber.cpp:112-117)
   next_line_id_ = ((uint64_t)rd() << 32) | (uint64_t)rd();
+  load_vad_model();  // before the model: a transcriber that could never segment audio must not load (reference default 0.5)
   if (opt_.model_source == TranscriberOptions::NONE) return;
   if (opt_.model_arch > MOONSHINE_MODEL_ARCH_MEDIUM_STREAMING)
     throw std::runtime_error("Invalid model architecture: " + std::to_string(opt_.model_arch));
+  if (!(opt_.max_tokens_per_second > 0.0f)) throw std::runtime_error("max_tokens_per_second must be positive");
   if (is_streaming_arch(opt_.model_arch)) {
+    // one line = one device slot sized for max_stream_seconds of memory frames
+    vad_hard_cap_ = (size_t)(opt_.max_stream_seconds * kSampleRate);
     load_streaming_model();
     // compiled last: this needs the tokenizer the load just brought up (reference core/transcriber.cpp:201-213)
     if (!opt_.context.empty()) {
@@ -271,6 +275,10 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   if (!opt_.keyterms.empty() || !opt_.context.empty())
     throw std::runtime_error("Key-term biasing requires one of the streaming model architectures; the loaded model "
                              "does not decode through a path that can apply it.");
+  {  // offline engine limits: 504 decode steps (include/moonshine_hip.h) and 8192 encoder frames of 384 samples
+    const double by_steps = 504.0 / (double)opt_.max_tokens_per_second, by_frames = 8192.0 * 384.0 / kSampleRate;
+    vad_hard_cap_ = (size_t)((by_steps < by_frames ? by_steps : by_frames) * kSampleRate);
+  }
   model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
   model_->batch_clips = opt_.batch_clips;
   model_->batches_in_flight = opt_.batches_in_flight;
@@ -514,23 +522,47 @@ void Transcriber::transcribe_segments_with_streaming_model(std::vector<Streaming
   }
 }
 
+// Silero weights for vad_threshold > 0 (the reference's default): option vad_model_path, else silero_vad.safetensors
+// in the model directory / among the memory files.  Missing weights fail the LOAD with the explanation, not the first
+// transcribe call.
+void Transcriber::load_vad_model() {
+  if (!(opt_.vad_threshold > 0.0f)) return;
+  static const char* kName = "silero_vad.safetensors";
+  std::shared_ptr<SileroWeights> w(new SileroWeights());
+  auto mem = opt_.memory_files.find(kName);
+  if (!opt_.vad_model_path.empty()) {
+    w->load_file(opt_.vad_model_path);
+  } else if (mem != opt_.memory_files.end() && mem->second.first != nullptr) {
+    w->load_memory(mem->second.first, mem->second.second);
+  } else if (opt_.model_source == TranscriberOptions::FILES && !opt_.model_path.empty() &&
+             file_exists(join_path(opt_.model_path, kName))) {
+    w->load_file(join_path(opt_.model_path, kName));
+  } else {
+    throw std::runtime_error(
+        "vad_threshold=" + std::to_string(opt_.vad_threshold) + " (the default is 0.5) needs the Silero VAD weights: pass the "
+        "option vad_model_path=<silero_vad.safetensors> (tools/convert_silero_vad.py writes it from the published model) or "
+        "put silero_vad.safetensors into the model directory; vad_threshold=0 treats all audio as speech");
+  }
+  silero_ = std::move(w);
+}
+
 TranscriberStream* Transcriber::new_stream(int32_t id) {
   const int32_t window = (int32_t)ceilf((opt_.vad_window_duration * kSampleRate) / opt_.vad_hop_size);
   const size_t max_seg = (size_t)roundf(opt_.vad_max_segment_duration * kSampleRate);
   TranscriberStream* s = new TranscriberStream();
   s->vad.reset(new VoiceActivityDetector(opt_.vad_threshold, window, opt_.vad_hop_size, opt_.vad_look_behind_sample_count,
-                                         max_seg));
+                                         max_seg, silero_, vad_hard_cap_));
   s->id = id;
   return s;
 }
 
-TranscriberStream* Transcriber::find_stream(int32_t id) {
+std::shared_ptr<TranscriberStream> Transcriber::find_stream(int32_t id) {
   std::lock_guard<std::mutex> lock(streams_mutex_);
   auto it = streams_.find(id);
   if (it == streams_.end())
     throw std::runtime_error("Stream with ID " + std::to_string(id) + " not found in " + std::to_string(streams_.size()) +
                              " streams");
-  return it->second.get();
+  return it->second;
 }
 
 void Transcriber::save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush) {
@@ -695,7 +727,21 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     streams.push_back(s);
   }
   std::vector<transcript_t*> outs(count, nullptr);
-  update_from_segments(streams, segs, outs.data());
+  // A streaming architecture keeps one device slot per line being decoded (max_streams of them): larger batches run in
+  // waves of that size, and a wave's slots are handed back before the next one starts.  The transcripts stay.
+  const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) : std::max<uint64_t>(count, 1);
+  for (uint64_t w0 = 0; w0 < count; w0 += wave) {
+    const uint64_t w1 = std::min(count, w0 + wave);
+    std::vector<TranscriberStream*> sub(streams.begin() + w0, streams.begin() + w1);
+    std::vector<std::vector<VadSegment>> sub_segs(segs.begin() + w0, segs.begin() + w1);
+    update_from_segments(sub, sub_segs, outs.data() + w0);
+    if (streaming_model_)
+      for (TranscriberStream* s : sub)
+        if (s->sstate != nullptr && s->sowner != nullptr) {
+          s->sowner->free_state(s->sstate);
+          s->sstate = nullptr;
+        }
+  }
   if (out != nullptr)
     for (uint64_t i = 0; i < count; ++i) out[i] = outs[i];
 }
@@ -713,7 +759,8 @@ void Transcriber::free_stream(int32_t id) {
 }
 
 void Transcriber::start_stream(int32_t id) {
-  TranscriberStream* s = find_stream(id);
+  const std::shared_ptr<TranscriberStream> keep = find_stream(id);
+  TranscriberStream* s = keep.get();
   std::lock_guard<std::mutex> ol(s->out.mutex);
   s->out.lines.clear();
   s->out.order.clear();
@@ -723,31 +770,40 @@ void Transcriber::start_stream(int32_t id) {
 }
 
 void Transcriber::stop_stream(int32_t id) {
-  TranscriberStream* s = find_stream(id);
+  const std::shared_ptr<TranscriberStream> keep = find_stream(id);
+  TranscriberStream* s = keep.get();
   s->vad->stop();
   save_input(s, nullptr, 0, 0, true);
 }
 
 void Transcriber::add_audio_to_stream(int32_t id, const float* audio, uint64_t n, int32_t sample_rate) {
-  TranscriberStream* s = find_stream(id);
+  const std::shared_ptr<TranscriberStream> keep = find_stream(id);
+  TranscriberStream* s = keep.get();
   if (!s->vad->is_active())
     throw std::runtime_error("Adding new audio for stream with ID " + std::to_string(id) +
                              " but VAD is not active. Did you call start_stream()?");
   save_input(s, audio, n, sample_rate, false);
   std::vector<float> in(audio, audio + n);
   std::vector<float> r = resample(in, (float)sample_rate, (float)kSampleRate);
+  std::lock_guard<std::mutex> al(s->audio_mutex);
   s->new_audio.insert(s->new_audio.end(), r.begin(), r.end());
 }
 
 // reference core/transcriber.cpp:775-891: only re-run the model when enough new audio has arrived
 // (or on FORCE_UPDATE); otherwise hand back the cached transcript with cleared update flags.
 void Transcriber::transcribe_stream(int32_t id, uint32_t flags, transcript_t** out) {
-  TranscriberStream* s = find_stream(id);
-  const size_t n = s->new_audio.size();
-  const bool has_new = n > 0;
-  const bool long_enough = (float)n / (float)kSampleRate >= opt_.transcription_interval;
-  const bool force = (flags & MOONSHINE_FLAG_FORCE_UPDATE) != 0;
-  if (!((long_enough || force) && has_new)) {
+  const std::shared_ptr<TranscriberStream> keep = find_stream(id);
+  TranscriberStream* s = keep.get();
+  std::vector<float> fresh;  // the audio this update consumes; add_audio may keep appending meanwhile
+  {
+    std::lock_guard<std::mutex> al(s->audio_mutex);
+    const size_t n = s->new_audio.size();
+    const bool has_new = n > 0;
+    const bool long_enough = (float)n / (float)kSampleRate >= opt_.transcription_interval;
+    const bool force = (flags & MOONSHINE_FLAG_FORCE_UPDATE) != 0;
+    if ((long_enough || force) && has_new) fresh.swap(s->new_audio);
+  }
+  if (fresh.empty()) {
     s->out.clear_update_flags();
     if (!s->vad->is_active()) s->out.mark_all_complete();
     if (out != nullptr) *out = &s->out.transcript;
@@ -756,7 +812,7 @@ void Transcriber::transcribe_stream(int32_t id, uint32_t flags, transcript_t** o
   std::vector<std::vector<VadSegment>> segs(1);
   {
     std::lock_guard<std::mutex> vl(s->vad_mutex);
-    s->vad->process_audio(s->new_audio.data(), n, kSampleRate);
+    s->vad->process_audio(fresh.data(), fresh.size(), kSampleRate);
     for (const VadSegment& seg : s->vad->segments()) {
       VadSegment c;
       c.start_time = seg.start_time;
@@ -767,7 +823,6 @@ void Transcriber::transcribe_stream(int32_t id, uint32_t flags, transcript_t** o
       segs[0].push_back(std::move(c));
     }
   }
-  s->new_audio.clear();
   transcript_t* one = nullptr;
   update_from_segments({s}, segs, &one);
   if (out != nullptr) *out = one;

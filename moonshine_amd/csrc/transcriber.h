@@ -69,6 +69,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   int32_t vad_hop_size = 512;
   size_t vad_look_behind_sample_count = 8192;
   float vad_max_segment_duration = 15.0f;
+  std::string vad_model_path;            // additive: Silero VAD weights (safetensors); default <model_path>/silero_vad.safetensors
   float max_tokens_per_second = 6.5f;
   bool decode_incomplete_lines = true;
   bool use_speculative_decoding = true;  // streaming architectures (reference core/transcriber.h:191)
@@ -116,7 +117,8 @@ struct TranscriberStream {
   std::unique_ptr<VoiceActivityDetector> vad;
   std::mutex vad_mutex;
   TranscriptOutput out;
-  std::vector<float> new_audio;
+  std::vector<float> new_audio;  // guarded by audio_mutex: add_audio (audio callback thread) vs transcribe_stream
+  std::mutex audio_mutex;
   std::vector<float> saved_input;
   int32_t saved_rate = 0;
   int32_t id = -1;
@@ -158,7 +160,7 @@ class Transcriber {
  private:
   TranscriberStream* new_stream(int32_t id);
   void load_streaming_model();
-  TranscriberStream* find_stream(int32_t id);
+  std::shared_ptr<TranscriberStream> find_stream(int32_t id);  // the caller's copy keeps the stream alive against free_stream
   // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs
   void update_from_segments(const std::vector<TranscriberStream*>& streams,
                             const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs);
@@ -173,7 +175,10 @@ class Transcriber {
   // segment of each of several streams, as one GPU batch
   void transcribe_segments_with_streaming_model(std::vector<StreamingJob>& jobs);
 
+  void load_vad_model();
   TranscriberOptions opt_;
+  std::shared_ptr<const SileroWeights> silero_;  // shared by every stream's detector (each keeps its own state)
+  size_t vad_hard_cap_ = 0;                      // longest segment (samples) the engine behind this transcriber takes
   std::unique_ptr<MoonshineModel> model_;
   std::unique_ptr<MoonshineStreamingModel> streaming_model_;
   ContextBiaser context_biaser_;
@@ -181,7 +186,7 @@ class Transcriber {
   std::mutex model_mutex_, batch_mutex_, streams_mutex_;
   std::unique_ptr<TranscriberStream> batch_stream_;
   std::vector<std::unique_ptr<TranscriberStream>> batch_streams_;  // one per clip of the last batch call
-  std::map<int32_t, std::unique_ptr<TranscriberStream>> streams_;
+  std::map<int32_t, std::shared_ptr<TranscriberStream>> streams_;
   std::atomic<uint64_t> next_line_id_;
   int32_t next_stream_id_ = 1;
 };

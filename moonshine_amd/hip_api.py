@@ -99,6 +99,9 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_host_tokens_to_text": (C.c_int64, [vp, u64, vp, u64, vp, u64]),
         "msh_host_sanitize_utf8": (C.c_int64, [vp, u64, vp, u64]),
         "msh_host_resample": (C.c_int64, [vp, u64, f32, f32, vp, u64]),
+        "msh_set_hw_queues": (i32, [i32]),
+        "msh_host_silero_probabilities": (C.c_int64, [vp, u64, vp, u64, vp, u64, vp]),
+        "msh_host_vad_segments": (C.c_int64, [vp, u64, f32, C.c_int32, C.c_int32, u64, u64, u64, vp, u64, C.c_int32, u64, vp, u64]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -116,7 +119,7 @@ DECLARED_SYMBOLS = [
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_debug_read",
     "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
-    "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
+    "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_set_hw_queues", "msh_host_silero_probabilities", "msh_host_vad_segments", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# lanes ("batches in flight") overlap only on separate HIP hardware queues; the pool size is read from the environment when
+# the HIP runtime initialises, and the library leaves the environment to its host (include/moonshine_hip.h msh_set_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -215,3 +215,58 @@ def test_log_ort_run_option_reports_kernel_groups(tiny_dir, capfd):
     err = capfd.readouterr().err
     assert "dec_cross_attention" in err and "enc_attention" in err
     t.close()
+
+
+def test_audio_longer_than_the_engine_capacity_is_cut_not_refused(tiny_dir, engine):
+    """with vad_threshold=0 the reference's fade never ends a segment, so a long file
+    reached the engine as ONE clip and failed on its 504-step budget -- on every later call too.  The detector now gets
+    the engine's capacity (504 steps / max_tokens_per_second) as a hard cap: 100 s at 6.5 tok/s = two lines, the second
+    starting where the first ended, each transcribed like a clip of its own."""
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "vad_max_segment_duration": "100000"})
+    audio = make_audio(21, 100 * 16000)
+    lines = t.transcribe_without_streaming(audio)
+    assert len(lines) == 2 and all(l.is_complete for l in lines)
+    assert lines[0].start_time == 0.0 and abs(lines[1].start_time - lines[0].duration) < 1e-3
+    total = sum(len(l.audio_data) for l in lines)
+    assert total == (len(audio) // 512) * 512
+    cap = int(504 / 6.5 * 16000)
+    assert all(len(l.audio_data) <= cap for l in lines)
+    for l in lines:
+        want, _ = _expected_text(engine, vocab, np.ascontiguousarray(l.audio_data))
+        assert l.text_bytes == want
+    # and the transcriber is still usable afterwards
+    assert len(t.transcribe_without_streaming(make_audio(22, 32000))) == 1
+    t.close()
+
+
+def test_default_vad_threshold_needs_silero_weights_at_load_and_works_with_them(tiny_dir, tmp_path, engine):
+    """The reference's default options (vad_threshold 0.5): without Silero weights the LOAD fails with the explanation;
+    with silero_vad.safetensors next to the model the default options work and every line is the transcription of its
+    VAD segment (reference core/voice-activity-detector.cpp:125-199, core/silero-vad.cpp:78-173)."""
+    import shutil
+
+    from moonshine_amd.synth import save_safetensors
+    from oracle import silero_ref as sr
+
+    with pytest.raises(api.MoonshineError):
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {})
+    d = str(tmp_path / "with_vad")
+    shutil.copytree(tiny_dir[0], d)
+    w = sr.make_weights(2)
+    save_safetensors(os.path.join(d, "silero_vad.safetensors"), w)
+    t = api.Transcriber(d, api.ARCH_TINY, {})
+    n = int(12.0 * 16000)
+    a = make_audio(7, n)
+    env = (np.sin(np.arange(n) / 16000 * 2 * np.pi * 0.7) > 0).astype(np.float32)
+    audio = (a * (0.05 + 3.0 * env)).astype(np.float32)
+    lines = t.transcribe_without_streaming(audio)
+    vad = sr.SileroRef(w)
+    want = sr.vad_segments(vad.predict, audio, 0.5, 16, 512, 8192, 15 * 16000)
+    assert len(lines) == len(want) >= 2
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    for l, (s, cnt, _) in zip(lines, want):
+        np.testing.assert_array_equal(l.audio_data, audio[s:s + cnt])
+        text, _ = _expected_text(engine, vocab, audio[s:s + cnt])
+        assert l.text_bytes == text
+    t.close()

@@ -121,6 +121,13 @@ def test_streaming_arch_one_shot_and_batch(model_dir, engine):
     batch = t.transcribe_batch_without_streaming(clips)
     assert [b[0].text_bytes for b in batch] == [s[0].text_bytes for s in single]
     t.close()
+    # a batch larger than the device's slot pool (max_streams) runs in waves of that size: same transcripts
+    t3 = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "max_streams": "3"})
+    many = [clips[i % len(clips)] for i in range(11)]
+    got = t3.transcribe_batch_without_streaming(many)
+    assert [g[0].text_bytes for g in got] == [single[i % len(clips)][0].text_bytes for i in range(11)]
+    assert len(t3.transcribe_batch_without_streaming(many[:7])) == 7     # and again: the slots were handed back
+    t3.close()
 
 
 def test_streaming_arch_options(model_dir, engine):

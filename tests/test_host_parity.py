@@ -150,7 +150,7 @@ def test_option_parsing_and_error_rules():
     assert e.value.code == -1
     with pytest.raises(api.MoonshineError):  # bools accept only true/false/1/0
         _load_skip({"return_audio_data": "yes"})
-    with pytest.raises(api.MoonshineError):  # Silero is not part of this build: must fail loudly, not fall back
+    with pytest.raises(api.MoonshineError):  # vad_threshold > 0 without Silero weights fails the LOAD (no silent fallback)
         api.Transcriber("", api.ARCH_BASE, {"skip_transcription": "true", "vad_threshold": "0.5"}).transcribe_without_streaming(np.zeros(1000, np.float32))
     t = _load_skip({"VAD_HOP_SIZE": "256", "Log_Api_Calls": "false"})  # names are case-insensitive
     assert len(t.transcribe_without_streaming(np.zeros(1024, np.float32))) == 1
@@ -383,3 +383,27 @@ def test_wav_reader_and_writer(tmp_path):
     np.testing.assert_array_equal(raw, want)
     got, rate = load(p4)
     np.testing.assert_array_equal(got, want.astype(np.float32) / np.float32(32768.0))
+
+
+def test_reference_python_binding_binds_every_symbol_unedited():
+    """The reference's own ctypes binding resolves EVERY function of moonshine-c-api.h when it loads the library
+    (language-bindings/python/src/moonshine_voice/moonshine_api.py:860-1121), including the TTS / G2P / embedding /
+    catalog calls that are out of scope here and exported as MOONSHINE_ERROR_UNKNOWN stubs.  Loading our libmoonshine.so
+    through that unedited module must work.  Needs /root/reference (build container only)."""
+    src = "/root/reference/language-bindings/python/src"
+    if not os.path.isdir(src):
+        pytest.skip("reference checkout not present")
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "import moonshine_voice.moonshine_api as m\n"
+        "l = m._MoonshineLib()._lib\n"
+        "assert l.moonshine_get_version() == 30000\n"
+        "out = ctypes.c_void_p()\n"
+        "assert l.moonshine_get_stt_catalog(ctypes.byref(out)) == -1 and not out.value\n"
+        "assert l.moonshine_create_tts_synthesizer_from_files(b'en', None, 0, None, 0, 30000) == -1\n"
+        "print('bound', l._name)\n" % src
+    )
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(LIB_PATH) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp", env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "bound libmoonshine.so" in r.stdout
