@@ -117,6 +117,12 @@ MSH_EXPORT double msh_profile_event_overhead_ms(msh_engine* e, int32_t iters);
  * launched back to back over the cross K/V of every layer of the batch encoded + decoded last, `rounds` sweeps between
  * one pair of HIP events: the kernel's own duration, free of per-launch event bookkeeping.  < 0 on error. */
 MSH_EXPORT double msh_profile_cross_attention_ms(msh_engine* e, int32_t rounds);
+/* Marginal cost of every decode kernel group the way the decode loop runs it: for each group a hipGraph of `reps` decode
+ * steps holding ONLY that group's launches (same arguments as the real step of the batch decoded last) is replayed and
+ * timed as a whole; the result is added to the profile table as entries named "chain_<group>" (ms / launches = us per
+ * launch inside a dependent chain).  HIP-event scopes (msh_profile_enable) add ~4.8 us per launch and rocprofv3 reports
+ * >= 4.3 us for an empty kernel, so neither resolves kernels of 2-6 us.  Leaves the decode state undefined. */
+MSH_EXPORT int32_t msh_profile_decode_chain(msh_engine* e, int32_t reps);
 /* ---- word timestamps: the decoder's cross-attention ----
  * Replaces the `cross_attentions.{l}` outputs of the reference's attention-exporting decoder graph
  * (decoder_with_attention.ort, core/moonshine-model.cpp:480-500, buffer layout :616-640).  With the capture on, every

@@ -154,6 +154,25 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   *dst = reinterpret_cast<bf16_t*>(p);
 }
 
+// bf16 upload of a [rows][K] matrix in the MFMA-fragment-major order of the decode GEMMs (kernels.h fm16)
+void Engine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst) {
+  if ((rows & 15) != 0 || (K & 31) != 0 || src.size() != (size_t)rows * K)
+    throw std::runtime_error("decode weight [" + std::to_string(rows) + ", " + std::to_string(K) +
+                             "] cannot be packed for the MFMA decode kernels (rows % 16, K % 32)");
+  std::vector<bf16_t> tmp(src.size());
+  const int ks = K >> 5;
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < K; ++k) tmp[(size_t)fm16(r, k, ks)] = f32_to_bf16(src[(size_t)r * K + k]);
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+  }
+  weight_allocs_.push_back(p);
+  copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+  *dst = reinterpret_cast<bf16_t*>(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weights.  Tensor names / shapes: HuggingFace MoonshineForConditionalGeneration state_dict
 // (transformers modeling_moonshine.py:520-540 stem, :265-274 attention, :74-75 / :89-90 MLPs,
@@ -287,7 +306,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     // copy of the head with the final LayerNorm scale folded in, for the LN-fused small-batch head GEMM
     for (int v = 0; v < V; ++v)
       for (int d = 0; d < D; ++d) e[(size_t)v * D + d] *= g[d];
-    upload_bf16(e, &embed_head_folded_);
+    upload_bf16_fm(e, V, D, &embed_head_folded_);
   }
   dec_.resize(c.dec_layers);
   std::vector<float> cross;
@@ -302,12 +321,18 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
         for (int d = 0; d < D; ++d) w[(size_t)r * D + d] *= gam[d];
       return w;
     };
-    upload_bf16(fold(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
-                     p + "input_layernorm.weight", 3 * D),
-                &L.wqkv);
-    upload_bf16(fuse({p + "self_attn.o_proj.weight"}), &L.wo);
-    upload_bf16(fold(fuse({p + "encoder_attn.q_proj.weight"}), p + "post_attention_layernorm.weight", D), &L.wq_c);
-    upload_bf16(fuse({p + "encoder_attn.o_proj.weight"}), &L.wo_c);
+    // decode weights go to the device in MFMA-fragment-major order (kernels.h); the cross-q weight additionally in
+    // row-major for the small-batch kernel that fuses the query projection into the attention
+    upload_bf16_fm(fold(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
+                        p + "input_layernorm.weight", 3 * D),
+                   3 * D, D, &L.wqkv);
+    upload_bf16_fm(fuse({p + "self_attn.o_proj.weight"}), D, D, &L.wo);
+    {
+      const std::vector<float> wq = fold(fuse({p + "encoder_attn.q_proj.weight"}), p + "post_attention_layernorm.weight", D);
+      upload_bf16_fm(wq, D, D, &L.wq_c);
+      upload_bf16(wq, &L.wq_c_rm);
+    }
+    upload_bf16_fm(fuse({p + "encoder_attn.o_proj.weight"}), D, D, &L.wo_c);
     std::vector<float> kv = fuse({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"});
     cross.insert(cross.end(), kv.begin(), kv.end());
     expect_shape(p + "mlp.fc1.weight", {2 * F, D});
@@ -320,9 +345,9 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       bi[2 * j] = b[j];
       bi[2 * j + 1] = b[F + j];
     }
-    upload_bf16(fold(wi, p + "final_layernorm.weight", 2 * F), &L.fc1);
+    upload_bf16_fm(fold(wi, p + "final_layernorm.weight", 2 * F), 2 * F, D, &L.fc1);
     upload(bi, &L.b1);
-    upload_bf16(st.to_f32(p + "mlp.fc2.weight"), &L.fc2);
+    upload_bf16_fm(st.to_f32(p + "mlp.fc2.weight"), D, F, &L.fc2);
     upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
     upload(st.to_f32(p + "input_layernorm.weight"), &L.ln1);
     upload(st.to_f32(p + "post_attention_layernorm.weight"), &L.ln2);
@@ -648,6 +673,8 @@ struct Engine::DecodeGroup {
   int first = 0, M = 0;
   DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher, pval, pidx;
   bool fused_argmax = false;  // LM head writes per-tile (max, index) pairs instead of logits
+  DecodeState state{};        // of the last decode() (profile_decode_chain replays its kernels)
+  bool has_state = false;
   hipGraphExec_t graph = nullptr;
   std::string key;
   uint64_t gen = 0;
@@ -703,7 +730,18 @@ size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
   else if (name == "resid") src = g.dH.p, size = (size_t)g.M * cfg_.hidden * sizeof(float);
   else throw std::invalid_argument("debug_read: unknown buffer " + name);
   MSH_HIP(hipStreamSynchronize(g.stream));
-  if (dst != nullptr && bytes > 0) copy_blocking(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost);
+  if (dst != nullptr && bytes > 0) {
+    if (name == "resid") {  // the device keeps the residual stream fragment-major (kernels.h fm32): hand back [clips][hidden]
+      const int D = cfg_.hidden;
+      std::vector<float> fm((size_t)round_up(g.M, 16) * D), rm((size_t)g.M * D);
+      copy_blocking(fm.data(), src, fm.size() * sizeof(float), hipMemcpyDeviceToHost);
+      for (int m = 0; m < g.M; ++m)
+        for (int k = 0; k < D; ++k) rm[(size_t)m * D + k] = fm[(size_t)fm32(m, k, D >> 5)];
+      memcpy(dst, rm.data(), std::min(bytes, size));
+    } else {
+      copy_blocking(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost);
+    }
+  }
   return size;
 }
 
@@ -722,62 +760,70 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
   double sT = 0;
   for (int b = 0; b < M; ++b) sT += clips_h_[g.first + b].T;
   const double w_dd = 2.0 * D * D;  // bytes of a [D, D] bf16 weight
+  // chain profiling (profile_decode_chain): enqueue only the kernel group `step_only_`
+  auto on = [&](int id) { return step_only_ < 0 || step_only_ == id; };
   for (int l = 0; l < cfg_.dec_layers; ++l) {
     const DecLayerW& W = dec_[l];
     bf16_t* cK = g.cacheK.as<bf16_t>() + l * cache_layer;
     bf16_t* cV = g.cacheV.as<bf16_t>() + l * cache_layer;
-    {
+    if (on(0)) {
       ProfScope p(this, "dec_qkv_gemm", 2.0 * M * D * 3 * D, 3 * w_dd + M * D * 4.0 * 2);
       dec_gemm_qkv(dH, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
     }
-    {
-      ProfScope p(this, "dec_self_attention", 0, 0);
+    if (on(1)) {
+      // q (fp32) + the cached K / V rows of every (clip, head) up to the current position + the bf16 output
+      ProfScope p(this, "dec_self_attention", 0, M * D * 6.0 + 2.0 * M * D * 2.0 * 33);
       dec_self_attention(dq, cK, cV, pos, M, D, Hh, Smax_, dao, s);
     }
-    {
+    if (on(2)) {
       ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
-      dec_gemm_resid(dao, D, W.wo, nullptr, M, D, D, dH, s);
+      dec_gemm_resid(dao, W.wo, nullptr, M, D, D, dH, s);
     }
     static const bool fuse_q = [] {
       const char* e = getenv("MSH_NO_FUSED_CROSSQ");
       return !(e != nullptr && e[0] == '1');
     }();
+    const bf16_t* KTl = KT_.as<bf16_t>() + (size_t)l * D * kv_keys_;
+    const bf16_t* VTl = VT_.as<bf16_t>() + (size_t)l * D * kv_keys_;
     if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
-      ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * 2 + w_dd + M * D * 4.0);
-      dec_cross_attention_fused_q(dH, W.wq_c, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
-                                  VT_.as<bf16_t>() + (size_t)l * D * kv_keys_, clips, M, D, Hh, dao, s);
+      if (on(4)) {
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * 2 + w_dd + M * D * 4.0);
+        dec_cross_attention_fused_q(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, dao, s);
+      }
     } else {
-      {
+      if (on(3)) {
         ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D, w_dd + M * D * 8.0);
         dec_gemm_ln_f32(dH, W.wq_c, M, D, D, dq, s);
       }
-      if (capture_cross_)
-        dec_cross_attention_probs(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, clips, pos, M, D, Hh, cfg_.dec_layers, l,
-                                  cross_smax_, cross_tcap_, cross_probs_.as<float>() + (size_t)g.first * cfg_.dec_layers * Hh * cross_smax_ * cross_tcap_, s);
-      ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
-      dec_cross_attention(dq, KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
-                          clips, M, D, Hh, dao, s);
+      if (capture_cross_ && on(4))
+        dec_cross_attention_probs(dq, KTl, clips, pos, M, D, Hh, cfg_.dec_layers, l, cross_smax_, cross_tcap_,
+                                  cross_probs_.as<float>() + (size_t)g.first * cfg_.dec_layers * Hh * cross_smax_ * cross_tcap_, s);
+      if (on(4)) {
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
+        dec_cross_attention(dq, KTl, VTl, clips, M, D, Hh, dao, s);
+      }
     }
-    {
+    if (on(5)) {
       ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
-      dec_gemm_resid(dao, D, W.wo_c, nullptr, M, D, D, dH, s);
+      dec_gemm_resid(dao, W.wo_c, nullptr, M, D, D, dH, s);
     }
-    {
+    if (on(6)) {
       ProfScope p(this, "dec_fc1_swiglu_gemm", 2.0 * M * D * 2 * F, 2.0 * 2 * F * D + M * (D * 4.0 + F * 2.0));
       dec_gemm_ln_swiglu(dH, W.fc1, W.b1, M, F, D, dz, s);
     }
-    {
+    if (on(7)) {
       ProfScope p(this, "dec_fc2_resid_gemm", 2.0 * M * D * F, 2.0 * F * D + M * (F * 2.0 + D * 8.0));
-      dec_gemm_resid(dz, F, W.fc2, W.b2, M, D, F, dH, s);
+      dec_gemm_resid(dz, W.fc2, W.b2, M, D, F, dH, s);
     }
   }
   if (M >= 128) {  // batch large enough for the LDS-tiled MFMA kernel: final LN once, then [M,D] x [V,D]^T
-    {
+    if (on(8)) {
       ProfScope p(this, "dec_final_layernorm", 0, M * D * 6.0);
-      layernorm_bf16(dH, dec_ln_, M, D, g.dy.as<bf16_t>(), nullptr, s);
+      dec_final_layernorm(dH, dec_ln_, M, D, g.dy.as<bf16_t>(), s);
     }
-    if (g.fused_argmax) {
+    if (!on(9)) {
+    } else if (g.fused_argmax) {
       // nobody reads the logits: reduce every 128 x 208 tile to (max, first index) per row in the GEMM epilogue
       ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)gemm_argmax_tiles(V) * 8);
       gemm_argmax_partials(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.pval.as<float>(), g.pidx.as<int>(), s);
@@ -785,10 +831,82 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
       gemm_logits_f32(g.dy.as<bf16_t>(), D, embed_bf16_, M, V, D, g.logits.as<float>(), s);
     }
-  } else {
+  } else if (on(9)) {
     ProfScope p(this, "dec_lm_head_gemm", 2.0 * M * D * V, 2.0 * V * D + M * (double)V * 4);
     dec_gemm_logits(dH, embed_head_folded_, M, V, D, g.logits.as<float>(), s);
   }
+}
+
+// Per-launch cost of every decode kernel group INSIDE a dependent chain of a replayed hipGraph -- the way the decode
+// loop runs them.  HIP-event scopes add ~4.8 us to every launch and rocprofv3 reports >= 4.3 us even for an empty kernel
+// (its per-dispatch instrumentation), so neither can resolve kernels whose real marginal cost is 2-6 us.  For each group
+// a graph of `reps` decode steps containing ONLY that group's launches (8 layers x its launches per layer, same
+// arguments as the real step) is captured and replayed; ms / launches of the "chain_*" entries is the marginal cost.
+// The decode state is garbage afterwards (residuals accumulate): encode + decode again before using results.
+void Engine::profile_decode_chain(int reps) {
+  MSH_HIP(hipSetDevice(device_));
+  if (!encoded_ || groups_.empty() || groups_[0]->M != (int)n_clips_ || !groups_[0]->has_state)
+    throw std::runtime_error("profile_decode_chain: encode and decode a batch first");
+  if (prof_on_) throw std::runtime_error("profile_decode_chain: switch the event profiler off first");
+  if (reps < 1) reps = 1;
+  DecodeGroup& g = *groups_[0];
+  const int V = cfg_.vocab, D = cfg_.hidden;
+  static const char* names[] = {"dec_qkv_gemm", "dec_self_attention", "dec_proj_resid_gemm", "dec_crossq_gemm",
+                                "dec_cross_attention", "dec_proj_resid_gemm#cross", "dec_fc1_swiglu_gemm", "dec_fc2_resid_gemm",
+                                "dec_final_layernorm", "dec_lm_head_gemm", "dec_argmax_advance", "empty_step"};
+  MSH_HIP(hipStreamSynchronize(g.stream));
+  hipEvent_t a = get_event(), b = get_event();
+  for (int id = 0; id < 12; ++id) {
+    int launches = 0;
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ge = nullptr;
+    {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+      for (int r = 0; r < reps; ++r) {
+        if (id < 10) {
+          step_only_ = id;
+          decode_step_enqueue(g);
+          step_only_ = -1;
+        } else if (id == 10) {
+          if (g.fused_argmax)
+            decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), g.M,
+                                    clips_d_.as<ClipMeta>() + g.first, g.state, embed_f32_, D, g.dH.as<float>(), g.stream);
+          else
+            decode_advance(g.logits.as<float>(), g.M, V, clips_d_.as<ClipMeta>() + g.first, g.state, embed_f32_, D,
+                           g.dH.as<float>(), g.stream);
+        }
+      }
+      MSH_HIP(hipStreamEndCapture(g.stream, &gr));
+      size_t n_nodes = 0;
+      MSH_HIP(hipGraphGetNodes(gr, nullptr, &n_nodes));
+      launches = (int)n_nodes;
+      MSH_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+      MSH_HIP(hipGraphDestroy(gr));
+    }
+    if (launches > 0) {
+      MSH_HIP(hipGraphLaunch(ge, g.stream));  // warm
+      MSH_HIP(hipEventRecord(a, g.stream));
+      MSH_HIP(hipGraphLaunch(ge, g.stream));
+      MSH_HIP(hipGraphLaunch(ge, g.stream));
+      MSH_HIP(hipEventRecord(b, g.stream));
+      MSH_HIP(hipStreamSynchronize(g.stream));
+      float ms = 0.f;
+      MSH_HIP(hipEventElapsedTime(&ms, a, b));
+      const std::string name = std::string("chain_") + names[id];
+      auto it = prof_idx_.find(name);
+      if (it == prof_idx_.end()) {
+        prof_idx_[name] = (int)prof_.size();
+        prof_.push_back(ProfEntry{name, 0, 0, 0, 0});
+        it = prof_idx_.find(name);
+      }
+      prof_[it->second].ms += ms;
+      prof_[it->second].launches += 2ull * launches;
+    }
+    MSH_HIP(hipGraphExecDestroy(ge));
+  }
+  event_pool_.push_back(a);
+  event_pool_.push_back(b);
 }
 
 int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride, float* logits_out,
@@ -851,10 +969,11 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     g.M = (int)((long)Mtot * (gi + 1) / ngroups) - g.first;
     const int M = g.M;
     bool moved = false;
-    moved |= g.dH.reserve((size_t)M * D * sizeof(float));
+    const size_t M16 = (size_t)round_up(M, 16);  // the FM buffers hold whole 16-row MFMA tiles (kernels.h)
+    moved |= g.dH.reserve(M16 * D * sizeof(float));
     moved |= g.dq.reserve((size_t)M * D * sizeof(float));
-    moved |= g.dao.reserve((size_t)M * D * sizeof(bf16_t));
-    moved |= g.dz.reserve((size_t)M * F * sizeof(bf16_t));
+    moved |= g.dao.reserve(M16 * D * sizeof(bf16_t));
+    moved |= g.dz.reserve(M16 * F * sizeof(bf16_t));
     moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
     moved |= g.logits.reserve((size_t)M * V * sizeof(float));
     moved |= g.pval.reserve((size_t)M * gemm_argmax_tiles(V) * sizeof(float));
@@ -922,6 +1041,8 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       }
     }
     g.n_active_h = M;
+    g.state = st;
+    g.has_state = true;
   }
 
   int steps_run = 0;

@@ -42,7 +42,8 @@ struct EncLayerW {
 };
 struct DecLayerW {
   float *ln1, *ln2, *ln3, *b1, *b2;
-  bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;
+  bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;  // MFMA-fragment-major (kernels.h fm16)
+  bf16_t* wq_c_rm;                              // cross-q again, row-major (fused-q attention kernel, small batches)
 };
 
 struct ProfEntry {
@@ -98,6 +99,8 @@ class Engine {
   // launch streams its own 2*D*keys bytes from HBM like a real step does) between ONE pair of HIP events: average ms per
   // launch without per-launch event bookkeeping.  Needs a batch that was encoded and decoded at least once.
   double profile_cross_attention_ms(int rounds);
+  // marginal cost of every decode kernel group inside a replayed hipGraph chain: fills "chain_*" profile entries
+  void profile_decode_chain(int reps);
   // test hook: bytes of a named decode buffer of the last decode() call ("cache_k", "cache_v", "resid"); copies
   // min(bytes, size) to `dst` and returns the buffer's size
   size_t debug_read(const std::string& name, void* dst, size_t bytes);
@@ -114,6 +117,7 @@ class Engine {
   void decode_step_enqueue(DecodeGroup& g);
   void upload(const std::vector<float>& src, float** dst);
   void upload_bf16(const std::vector<float>& src, bf16_t** dst);
+  void upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst);
 
   int device_;
   hipStream_t stream_ = nullptr;
@@ -158,6 +162,7 @@ class Engine {
 
   // profiling
   bool prof_on_ = false;
+  int step_only_ = -1;  // decode_step_enqueue: enqueue only this kernel group (profile_decode_chain)
   struct ProfRec {
     int idx;
     hipEvent_t a, b;

@@ -265,6 +265,52 @@ struct EpiResidF32 {
   }
 };
 
+// Decode-kernel form of the residual epilogue: whether there is a bias is a template parameter, so `pre` is straight-line
+// code (a runtime `bias != nullptr` test put a branch -- and with it a vmcnt(0) -- into the kernel's load phase).
+template <bool BIAS>
+struct EpiDecResid {
+  float* H;
+  long ldc;
+  const float* bias;
+  struct Pre {
+    float4 h, b;
+  };
+  __device__ Pre pre(int m, int n) const {
+    Pre p;
+    p.h = *reinterpret_cast<const float4*>(H + (long)m * ldc + n);
+    if constexpr (BIAS) p.b = *reinterpret_cast<const float4*>(bias + n);
+    else p.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    *reinterpret_cast<float4*>(H + (long)m * ldc + n) =
+        make_float4(p.h.x + p.b.x + v[0], p.h.y + p.b.y + v[1], p.h.z + p.b.z + v[2], p.h.w + p.b.w + v[3]);
+  }
+};
+
+// The same on the fragment-major residual stream of the offline decoder (kernels.h fm32): H is FM fp32 [M16][N],
+// ksteps = N / 32.  A lane's 4 consecutive columns are contiguous in FM as well (n % 4 == 0).
+template <bool BIAS>
+struct EpiDecResidFm {
+  float* H;
+  int ksteps;
+  const float* bias;
+  struct Pre {
+    float4 h, b;
+  };
+  __device__ Pre pre(int m, int n) const {
+    Pre p;
+    p.h = *reinterpret_cast<const float4*>(H + fm32(m, n, ksteps));
+    if constexpr (BIAS) p.b = *reinterpret_cast<const float4*>(bias + n);
+    else p.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    return p;
+  }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    *reinterpret_cast<float4*>(H + fm32(m, n, ksteps)) =
+        make_float4(p.h.x + p.b.x + v[0], p.h.y + p.b.y + v[1], p.h.z + p.b.z + v[2], p.h.w + p.b.w + v[3]);
+  }
+};
+
 // cross K/V, all decoder layers in one GEMM: n = layer*2D + which*D + c  ->  K^T/V^T[layer][clip][c][t]
 struct EpiCrossKV {
   bf16_t* KT;
@@ -341,21 +387,21 @@ struct EpiDecQkv {
     float c0, s0, c1, s1;
   };
   __device__ Pre pre(int /*m*/, int n) const {
+    // straight-line: the factor loads are unconditional (index clamped into the table row) and the identity is
+    // selected afterwards for v columns and for pairs beyond rot_pairs -- no branch in the kernel's load phase
     Pre p;
     p.pos = *pos_ptr;
     const int d = (n % rp.hidden) % rp.head_dim, j0 = d >> 1;
-    p.c0 = p.c1 = 1.f;
-    p.s0 = p.s1 = 0.f;
-    if (n < 2 * rp.hidden) {  // q / k: rotation factors of the lane's two pairs (identity beyond rot_pairs)
-      if (j0 < rp.rot_pairs) {
-        p.c0 = rp.cos[(long)p.pos * rp.rot_pairs + j0];
-        p.s0 = rp.sin[(long)p.pos * rp.rot_pairs + j0];
-      }
-      if (j0 + 1 < rp.rot_pairs) {
-        p.c1 = rp.cos[(long)p.pos * rp.rot_pairs + j0 + 1];
-        p.s1 = rp.sin[(long)p.pos * rp.rot_pairs + j0 + 1];
-      }
-    }
+    const int ja = j0 < rp.rot_pairs ? j0 : rp.rot_pairs - 1, jb = j0 + 1 < rp.rot_pairs ? j0 + 1 : rp.rot_pairs - 1;
+    const float* cr = rp.cos + (long)p.pos * rp.rot_pairs;
+    const float* sr = rp.sin + (long)p.pos * rp.rot_pairs;
+    const float c0 = cr[ja], s0 = sr[ja], c1 = cr[jb], s1 = sr[jb];
+    const bool rot = n < 2 * rp.hidden;   // q / k are rotated, v passes through
+    const bool r0 = rot && j0 < rp.rot_pairs, r1 = rot && j0 + 1 < rp.rot_pairs;
+    p.c0 = r0 ? c0 : 1.f;
+    p.s0 = r0 ? s0 : 0.f;
+    p.c1 = r1 ? c1 : 1.f;
+    p.s1 = r1 ? s1 : 0.f;
     return p;
   }
   __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
@@ -427,6 +473,22 @@ struct EpiSwiGLU {
     const float val0 = v[0] + b.x, gate0 = v[1] + b.y, val1 = v[2] + b.z, gate1 = v[3] + b.w;
     uint32_t o = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
     *reinterpret_cast<uint32_t*>(z + (long)m * ldz + (n >> 1)) = o;
+  }
+};
+
+// SwiGLU writing the fragment-major bf16 activation of the offline decoder's fc2 (kernels.h fm16): z is FM [M16][F],
+// ksteps = F / 32; the lane's two outputs (columns n/2, n/2 + 1) share one 16-byte chunk.
+struct EpiSwiGLUFm {
+  bf16_t* z;
+  int ksteps;
+  const float* bias;
+  struct Pre {
+    float4 b;
+  };
+  __device__ Pre pre(int, int n) const { return Pre{*reinterpret_cast<const float4*>(bias + n)}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre& p) const {
+    const float val0 = v[0] + p.b.x, gate0 = v[1] + p.b.y, val1 = v[2] + p.b.z, gate1 = v[3] + p.b.w;
+    *reinterpret_cast<uint32_t*>(z + fm16(m, n >> 1, ksteps)) = pack_bf16x2(silu_f(gate0) * val0, silu_f(gate1) * val1);
   }
 };
 

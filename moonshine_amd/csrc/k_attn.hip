@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
     uint2 o;
     o.x = pack_bf16x2(t.x * inv, t.y * inv);
     o.y = pack_bf16x2(t.z * inv, t.w * inv);
-    *reinterpret_cast<uint2*>(out + (long)b * D + h * DH + lane * 4) = o;
+    *reinterpret_cast<uint2*>(out + fm16(b, h * DH + lane * 4, D >> 5)) = o;   // FM: the o-proj GEMM's A operand
   }
 }
 
@@ -386,10 +386,10 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
   if constexpr (FUSEQ) {
     const int k0q = lane * 8;
     const bool act = k0q < D;  // D / 8 lanes hold the row
-    const float* x = q + (long)b * D + k0q;
     float xv[8];
-    if (act) {
-      const float4 a = *reinterpret_cast<const float4*>(x), c4 = *reinterpret_cast<const float4*>(x + 4);
+    if (act) {   // the residual stream is FM (kernels.h fm32): columns k0q..k0q+3 and k0q+4..k0q+7 are two float4 halves
+      const float4 a = *reinterpret_cast<const float4*>(q + fm32(b, k0q, D >> 5));
+      const float4 c4 = *reinterpret_cast<const float4*>(q + fm32(b, k0q + 4, D >> 5));
       xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = c4.x; xv[5] = c4.y; xv[6] = c4.z; xv[7] = c4.w;
     } else {
 #pragma unroll
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
     float acc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
-    out[(long)b * D + h * DH + wave * DQ + lane] = f32_to_bf16(acc / l);
+    out[fm16(b, h * DH + wave * DQ + lane, D >> 5)] = f32_to_bf16(acc / l);   // FM: the o-proj GEMM's A operand
   }
 }
 

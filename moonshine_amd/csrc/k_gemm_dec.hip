@@ -6,140 +6,214 @@
 namespace msh {
 namespace {
 
+// Developer instrumentation (tools/dec_gemm_timeline.hip builds this file with MSH_TIMELINE): wave-level time stamps
+// (100 MHz s_memrealtime, comparable across CUs) at the phase boundaries of gemm_dec_kernel.  Compiled out otherwise.
+#ifdef MSH_TIMELINE
+__device__ unsigned long long* g_timeline = nullptr;   // [blocks][4 waves][8 points]
+#define MSH_TL(i)                                                                                          \
+  do {                                                                                                     \
+    if (lane == 0 && g_timeline != nullptr)                                                                \
+      g_timeline[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();            \
+  } while (0)
+#else
+#define MSH_TL(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Decode GEMM (M = batch rows): fragment-direct, split-K inside the workgroup.
 //
 // A workgroup owns one 16 x (16*TN) output tile; its 4 waves split the K loop (wave w takes the 32-wide
-// k-steps w, w+4, ...), each loading its MFMA fragments straight from global memory -- all loads of a
-// wave are independent and issued up front, so the kernel costs about one memory round trip instead of a
-// K/32-long dependent chain.  Partial tiles are summed through LDS in a fixed order (deterministic).
-// LN = true: A is the fp32 residual stream [M][K]; LayerNorm (no bias, eps 1e-5, exact two-pass) is
-// fused into the fragment build: row sums are combined across the 4 waves through LDS.  The LayerNorm
-// scale gamma is folded into W at load time (W' = W * diag(gamma)), so the kernel only normalises.
+// k-steps w, w+4, ...), each loading its MFMA fragments straight from global memory.  The kernel is written
+// so that it has exactly ONE memory round trip on its critical path:
+//   * every load of a wave (W fragments, A fragments, the epilogue's residual / bias / RoPE factors) is issued
+//     up front and UNCONDITIONALLY -- a k-step or an output tile that does not exist for this wave (KS or the
+//     tile count not a multiple of 4), a row beyond M or a column beyond N is clamped to a valid address and
+//     its contribution zeroed / its result dropped.  The first version guarded those loads with `if (s < KS)`
+//     on the (runtime) wave index: hipcc turned that into a branchy CFG with `s_waitcnt vmcnt(0)` between the
+//     load groups -- two to three serialised round trips per kernel (4.8 us for a GEMM whose chain floor,
+//     tools/launch_floor.hip, is 1.7 us).
+//   * LN = true: A is the fp32 residual stream [M][K]; LayerNorm (no bias, eps 1e-5) is fused into the
+//     fragment build with ONE cross-wave exchange: shifted single-pass moments (d = x - x[row][0], so a large
+//     common offset cannot cancel catastrophically), sum(d) and sum(d^2) combined through LDS in a fixed order.
+//     The LayerNorm scale gamma is folded into W at load time (W' = W * diag(gamma)).
+// Partial tiles are summed through LDS in a fixed order (deterministic, independent of TN / TM).
 // ------------------------------------------------------------------------------------------------
-template <int KS, int TN, bool LN, class Epi, int TM = 1>
+// FM = true: W, A and (through the epilogue) the outputs are in the MFMA-fragment-major layouts of kernels.h: every
+// wave-level load is one contiguous 1 KiB run.  FM = false: row-major operands (the streaming decoder's path).
+template <int KS, int TN, bool LN, class Epi, int TM = 1, bool FM = false>
 __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
                                                        const float* __restrict__ gamma,
                                                        const bf16_t* __restrict__ W, int M, int N, int n_tiles,
                                                        Epi epi) {
   // TM = 2: the workgroup owns 32 rows (two MFMA row tiles) and every W fragment it loads feeds two MFMAs -- the
-  // weights are re-read M/32 instead of M/16 times.  At M = 256 these GEMMs are bound by exactly that L2 -> CU
-  // re-read traffic (fc1: 832 workgroups x 66 KB = 55 MB per launch at ~4 TB/s), not by HBM or latency.
+  // weights are re-read M/32 instead of M/16 times.
   constexpr int K = 32 * KS;
-  constexpr int KW = (KS + 3) / 4;  // k-steps per wave (upper bound)
+  constexpr int KW = (KS + 3) / 4;   // k-steps per wave (upper bound)
+  constexpr int KFULL = KS / 4;      // k-steps i < KFULL exist for every wave
   __shared__ __attribute__((aligned(16))) float4 part[4][TM * TN][64];
-  __shared__ float stat[2][4][16 * TM];
+  __shared__ float2 stat[4][16 * TM];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = (blockIdx.x / n_tiles) * (16 * TM), n0 = (blockIdx.x % n_tiles) * (16 * TN);
+  MSH_TL(0);
   int gm[TM];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     gm[t] = m0 + t * 16 + li;
     gm[t] = gm[t] < M ? gm[t] : M - 1;
   }
-
-  // ---- issue every load of this wave first ----
-  uint4 wreg[KW][TN];
+  // k-step i of this wave: s = wave + 4 i (wave-uniform); a step past KS reads step KS - 1 again and is masked
+  int ks[KW];
+  bool kv[KW];
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
     const int s = wave + 4 * i;
-    if (s < KS) {
+    kv[i] = i < KFULL ? true : s < KS;
+    ks[i] = kv[i] ? s : KS - 1;
+  }
+
+  // ---- every load of this wave, unconditionally ----
+  uint4 wreg[KW][TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int gn = n0 + j * 16 + li;
-        gn = gn < N ? gn : N - 1;
-        wreg[i][j] = *reinterpret_cast<const uint4*>(W + (long)gn * K + s * 32 + kg * 8);
-      }
+  for (int j = 0; j < TN; ++j) {
+    if constexpr (FM) {
+      int tn = (n0 >> 4) + j;                     // N is a multiple of 16 (checked by the launcher)
+      tn = tn < (N >> 4) ? tn : (N >> 4) - 1;
+#pragma unroll
+      for (int i = 0; i < KW; ++i)
+        wreg[i][j] = *reinterpret_cast<const uint4*>(W + (((long)tn * KS + ks[i]) * 64 + lane) * 8);
+    } else {
+      int gn = n0 + j * 16 + li;
+      gn = gn < N ? gn : N - 1;
+      const bf16_t* wrow = W + (long)gn * K + kg * 8;
+#pragma unroll
+      for (int i = 0; i < KW; ++i) wreg[i][j] = *reinterpret_cast<const uint4*>(wrow + ks[i] * 32);
     }
   }
-  // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors): fetched now so
-  // that the kernel has ONE memory round trip on its critical path, not one per dependent stage
-  constexpr int NT = TM * TN;            // output tiles of the workgroup
-  constexpr int NE = (NT + 3) / 4;
-  typename Epi::Pre epre[NE];
+  float xv[LN ? TM : 1][LN ? KW : 1][8];
+  float x0[LN ? TM : 1];
+  uint4 araw[LN ? 1 : TM][LN ? 1 : KW];
+  int mt[TM];   // FM: row tile of (m0, t), clamped to the last tile that holds a valid row
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int o = wave + 4 * e, t = o / TN, j = o - t * TN;
-    const int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
-    if (o < NT && m < M && n < N) epre[e] = epi.pre(m, n);
+  for (int t = 0; t < TM; ++t) {
+    mt[t] = (m0 >> 4) + t;
+    mt[t] = mt[t] <= ((M - 1) >> 4) ? mt[t] : ((M - 1) >> 4);
   }
-  bf16x8 afrag[TM][KW];
   if constexpr (LN) {
-    float xv[TM][KW][8];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm[t] * lda + kg * 8;
-      float sum = 0.f;
+      if constexpr (FM) {
+        const float* xt = reinterpret_cast<const float*>(Aptr) + (long)mt[t] * KS * 512;
+        x0[t] = xt[li * 4];   // element (row, 0): k-step 0, half 0, lane = row % 16
 #pragma unroll
-      for (int i = 0; i < KW; ++i) {
-        const int s = wave + 4 * i;
-        if (s < KS) {
-          const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
-          const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
+        for (int i = 0; i < KW; ++i) {
+          const float* xf = xt + ((long)ks[i] * 128 + lane) * 4;
+          const float4 a = *reinterpret_cast<const float4*>(xf);
+          const float4 b = *reinterpret_cast<const float4*>(xf + 256);
           xv[t][i][0] = a.x; xv[t][i][1] = a.y; xv[t][i][2] = a.z; xv[t][i][3] = a.w;
           xv[t][i][4] = b.x; xv[t][i][5] = b.y; xv[t][i][6] = b.z; xv[t][i][7] = b.w;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sum += xv[t][i][e];
         }
-      }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
-      if (kg == 0) stat[0][wave][t * 16 + li] = sum;
-    }
-    __syncthreads();
-    float mean[TM];
+      } else {
+        const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm[t] * lda;
+        x0[t] = x[0];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int r = t * 16 + li;
-      mean[t] = ((stat[0][0][r] + stat[0][1][r]) + (stat[0][2][r] + stat[0][3][r])) * (1.0f / (float)K);
-      float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < KW; ++i) {
-        if (wave + 4 * i < KS) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = xv[t][i][e] - mean[t];
-            sq += d * d;
-          }
-        }
-      }
-      sq += __shfl_xor(sq, 16);
-      sq += __shfl_xor(sq, 32);
-      if (kg == 0) stat[1][wave][r] = sq;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int r = t * 16 + li;
-      const float var = ((stat[1][0][r] + stat[1][1][r]) + (stat[1][2][r] + stat[1][3][r])) * (1.0f / (float)K);
-      const float rstd = rsqrtf(var + 1e-5f);
-#pragma unroll
-      for (int i = 0; i < KW; ++i) {
-        const int s = wave + 4 * i;
-        if (s < KS) {
-          uint4 q;
-          q.x = pack_bf16x2((xv[t][i][0] - mean[t]) * rstd, (xv[t][i][1] - mean[t]) * rstd);
-          q.y = pack_bf16x2((xv[t][i][2] - mean[t]) * rstd, (xv[t][i][3] - mean[t]) * rstd);
-          q.z = pack_bf16x2((xv[t][i][4] - mean[t]) * rstd, (xv[t][i][5] - mean[t]) * rstd);
-          q.w = pack_bf16x2((xv[t][i][6] - mean[t]) * rstd, (xv[t][i][7] - mean[t]) * rstd);
-          afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
+        for (int i = 0; i < KW; ++i) {
+          const float4 a = *reinterpret_cast<const float4*>(x + kg * 8 + ks[i] * 32);
+          const float4 b = *reinterpret_cast<const float4*>(x + kg * 8 + ks[i] * 32 + 4);
+          xv[t][i][0] = a.x; xv[t][i][1] = a.y; xv[t][i][2] = a.z; xv[t][i][3] = a.w;
+          xv[t][i][4] = b.x; xv[t][i][5] = b.y; xv[t][i][6] = b.z; xv[t][i][7] = b.w;
         }
       }
     }
   } else {
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm[t] * lda + kg * 8;
+      if constexpr (FM) {
+        const bf16_t* at = reinterpret_cast<const bf16_t*>(Aptr) + (long)mt[t] * KS * 512;
 #pragma unroll
-      for (int i = 0; i < KW; ++i) {
-        const int s = wave + 4 * i;
-        if (s < KS) {
-          uint4 q = *reinterpret_cast<const uint4*>(a + s * 32);
-          afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
-        }
+        for (int i = 0; i < KW; ++i) araw[t][i] = *reinterpret_cast<const uint4*>(at + ((long)ks[i] * 64 + lane) * 8);
+      } else {
+        const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm[t] * lda + kg * 8;
+#pragma unroll
+        for (int i = 0; i < KW; ++i) araw[t][i] = *reinterpret_cast<const uint4*>(a + ks[i] * 32);
       }
     }
+  }
+  // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors)
+  constexpr int NT = TM * TN;            // output tiles of the workgroup
+  constexpr int NE = (NT + 3) / 4;
+  typename Epi::Pre epre[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    int o = wave + 4 * e;
+    o = o < NT ? o : NT - 1;
+    const int t = o / TN, j = o - t * TN;
+    int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
+    m = m < M ? m : M - 1;
+    n = n < N ? n : N - 4;
+    epre[e] = epi.pre(m, n);
+  }
+  // nothing below may be scheduled above this point and no load above may sink below it: without the fence hipcc
+  // moved the W loads behind the first LayerNorm arithmetic (= behind a wait for the A loads): a second round trip
+  __builtin_amdgcn_sched_barrier(0);
+  MSH_TL(1);
+
+  bf16x8 afrag[TM][KW];
+  if constexpr (LN) {
+    // shifted single-pass moments: d = x - x0 (x0 = the row's first element)
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        const float keep = kv[i] ? 1.0f : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (xv[t][i][e] - x0[t]) * keep;
+          xv[t][i][e] = d;
+          sum += d;
+          sq += d * d;
+        }
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      if (kg == 0) stat[wave][t * 16 + li] = make_float2(sum, sq);
+    }
+    MSH_TL(2);
+    __syncthreads();
+    MSH_TL(3);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int r = t * 16 + li;
+      const float2 s0 = stat[0][r], s1 = stat[1][r], s2 = stat[2][r], s3 = stat[3][r];
+      const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * (1.0f / (float)K);
+      float var = ((s0.y + s1.y) + (s2.y + s3.y)) * (1.0f / (float)K) - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        const float scale = kv[i] ? rstd : 0.0f;   // a masked k-step contributes exact zeros
+        uint4 q;
+        q.x = pack_bf16x2((xv[t][i][0] - mean) * scale, (xv[t][i][1] - mean) * scale);
+        q.y = pack_bf16x2((xv[t][i][2] - mean) * scale, (xv[t][i][3] - mean) * scale);
+        q.z = pack_bf16x2((xv[t][i][4] - mean) * scale, (xv[t][i][5] - mean) * scale);
+        q.w = pack_bf16x2((xv[t][i][6] - mean) * scale, (xv[t][i][7] - mean) * scale);
+        afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int i = 0; i < KW; ++i) {
+        uint4 q = araw[t][i];
+        if (i >= KFULL) {  // wave-uniform select, no branch
+          q.x = kv[i] ? q.x : 0u; q.y = kv[i] ? q.y : 0u; q.z = kv[i] ? q.z : 0u; q.w = kv[i] ? q.w : 0u;
+        }
+        afrag[t][i] = *reinterpret_cast<bf16x8*>(&q);
+      }
   }
 
   f32x4 acc[TM][TN];
@@ -148,38 +222,37 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < KW; ++i) {
-    if (wave + 4 * i < KS) {
+  for (int i = 0; i < KW; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
-          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[t][i],
-                                                               acc[t][j], 0, 0, 0);
-    }
-  }
+      for (int t = 0; t < TM; ++t)
+        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wreg[i][j]), afrag[t][i],
+                                                             acc[t][j], 0, 0, 0);
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       part[wave][t * TN + j][lane] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+  MSH_TL(4);
   __syncthreads();
+  MSH_TL(5);
   // the waves finish the output tiles round-robin: fixed summation order
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int o = wave + 4 * e;
-    if (o < NT) {
-      const int t = o / TN, j = o - t * TN;
-      const float4 p0 = part[0][o][lane], p1 = part[1][o][lane], p2 = part[2][o][lane], p3 = part[3][o][lane];
-      f32x4 v;
-      v[0] = (p0.x + p1.x) + (p2.x + p3.x);
-      v[1] = (p0.y + p1.y) + (p2.y + p3.y);
-      v[2] = (p0.z + p1.z) + (p2.z + p3.z);
-      v[3] = (p0.w + p1.w) + (p2.w + p3.w);
-      const int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
-      if (m < M && n < N) epi.n4p(m, n, v, epre[e]);
-    }
+    const int oc = o < NT ? o : NT - 1;
+    const int t = oc / TN, j = oc - t * TN;
+    const float4 p0 = part[0][oc][lane], p1 = part[1][oc][lane], p2 = part[2][oc][lane], p3 = part[3][oc][lane];
+    f32x4 v;
+    v[0] = (p0.x + p1.x) + (p2.x + p3.x);
+    v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+    v[2] = (p0.z + p1.z) + (p2.z + p3.z);
+    v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+    const int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
+    if (o < NT && m < M && n < N) epi.n4p(m, n, v, epre[e]);
   }
+  MSH_TL(6);
 }
 
 template <int KS, int TN, bool LN, class Epi, int TM = 1>
@@ -226,187 +299,30 @@ void launch_dec(const void* A, long lda, const float* gamma, const bf16_t* W, in
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Decode GEMM for larger batches (M >= 64): A fragments resident in registers, W streamed by LDS-DMA.
-//
-// A workgroup owns a 64 x (16*TN) tile: wave w holds the MFMA A fragments of its own 16 rows for the
-// whole K = 32*KS (LayerNorm fused: the row is normalised in registers, two-pass, gamma folded into W),
-// so the only operand that moves during the k-loop is the W slice -- TN KiB per 32-wide k-step, fetched
-// once per workgroup by `global_load_lds` into a 6-deep ring and shared by the 4 waves.  Compared with
-// gemm_dec_kernel (16-row tiles, W fragments loaded per wave) the weights are re-read M/64 instead of
-// M/16 times and the LayerNorm is recomputed N/(16*TN) / 4 times less often.
-// ------------------------------------------------------------------------------------------------
-template <int KS, int TN, bool LN, class Epi>
-__global__ __launch_bounds__(256) void gemm_dec64_kernel(const void* __restrict__ Aptr, long lda,
-                                                         const bf16_t* __restrict__ W, int M, int N, int n_tiles,
-                                                         Epi epi) {
-  constexpr int K = 32 * KS;
-  constexpr int NST = 6;                      // ring depth (k-slices)
-  constexpr int AHEAD = NST - 1;
-  constexpr int PW = (TN + 3) / 4;            // 1-KiB pieces a wave issues per k-slice (upper bound)
-  __shared__ __attribute__((aligned(16))) uint4 lds[NST * TN * 64];
-  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = (blockIdx.x / n_tiles) * 64 + wave * 16, n0 = (blockIdx.x % n_tiles) * (16 * TN);
-  const int m = m0 + li;
-  const int gm = m < M ? m : M - 1;
-  const int my_pieces = (TN - wave + 3) / 4;  // wave-uniform, 0 when TN < 4 and wave >= TN
 
-  // epilogue inputs first (oldest loads), then the A rows, then the DMA prologue
-  typename Epi::Pre epre[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + j * 16 + kg * 4;
-    if (m < M && n < N) epre[j] = epi.pre(m, n);
-  }
-  float xv[LN ? KS : 1][8];
-  uint4 araw[LN ? 1 : KS];
-  if constexpr (LN) {
-    const float* x = reinterpret_cast<const float*>(Aptr) + (long)gm * lda + kg * 8;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(x + s * 32);
-      const float4 b = *reinterpret_cast<const float4*>(x + s * 32 + 4);
-      xv[s][0] = a.x; xv[s][1] = a.y; xv[s][2] = a.z; xv[s][3] = a.w;
-      xv[s][4] = b.x; xv[s][5] = b.y; xv[s][6] = b.z; xv[s][7] = b.w;
-    }
-  } else {
-    const bf16_t* a = reinterpret_cast<const bf16_t*>(Aptr) + (long)gm * lda + kg * 8;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) araw[s] = *reinterpret_cast<const uint4*>(a + s * 32);
-  }
-  const bf16_t* src[PW];
-  unsigned dst[PW];
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
-#pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    const int p = wave + 4 * i;               // column tile this wave fetches
-    const int r = lane >> 2, pos = lane & 3, row = p * 16 + r;
-    int gn = n0 + row;
-    gn = gn < N ? gn : N - 1;
-    src[i] = W + (long)gn * K + ((pos ^ swz(row)) << 3);
-    dst[i] = lds_base + (unsigned)p * 1024u;
-  }
-  auto issue = [&](int kt) {
-    const unsigned sb = (unsigned)(kt % NST) * (TN * 1024u);
-#pragma unroll
-    for (int i = 0; i < PW; ++i)
-      if (i < my_pieces) dma16(src[i] + (kt << 5), dst[i] + sb);
-  };
-#pragma unroll
-  for (int s = 0; s < AHEAD; ++s)
-    if (s < KS) issue(s);
-
-  bf16x8 afr[KS];
-  if constexpr (LN) {
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += xv[s][e];
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / (float)K);
-    float sq = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = xv[s][e] - mean;
-        sq += d * d;
-      }
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.0f / (float)K) + 1e-5f);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      uint4 t;
-      t.x = pack_bf16x2((xv[s][0] - mean) * rstd, (xv[s][1] - mean) * rstd);
-      t.y = pack_bf16x2((xv[s][2] - mean) * rstd, (xv[s][3] - mean) * rstd);
-      t.z = pack_bf16x2((xv[s][4] - mean) * rstd, (xv[s][5] - mean) * rstd);
-      t.w = pack_bf16x2((xv[s][6] - mean) * rstd, (xv[s][7] - mean) * rstd);
-      afr[s] = *reinterpret_cast<bf16x8*>(&t);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) afr[s] = *reinterpret_cast<bf16x8*>(&araw[s]);
-  }
-
-  f32x4 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // every compiler-issued load above is older than the DMAs, and vector-memory ops retire in order: a
-  // counted wait that leaves only this wave's newest DMA pieces outstanding therefore covers them too
-#pragma unroll
-  for (int kt = 0; kt < KS; ++kt) {
-    const int inflight = (kt + AHEAD - 1 < KS ? AHEAD - 1 : KS - 1 - kt);  // compile-time after unrolling
-    if (my_pieces == PW) {
-      switch (inflight) {
-        case 4: wait_vmcnt<4 * PW>(); break;
-        case 3: wait_vmcnt<3 * PW>(); break;
-        case 2: wait_vmcnt<2 * PW>(); break;
-        case 1: wait_vmcnt<PW>(); break;
-        default: wait_vmcnt<0>(); break;
-      }
-    } else {
-      switch (inflight) {
-        case 4: wait_vmcnt<4 * (PW - 1)>(); break;
-        case 3: wait_vmcnt<3 * (PW - 1)>(); break;
-        case 2: wait_vmcnt<2 * (PW - 1)>(); break;
-        case 1: wait_vmcnt<(PW - 1)>(); break;
-        default: wait_vmcnt<0>(); break;
-      }
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kt + AHEAD < KS) issue(kt + AHEAD);
-    const uint4* st = lds + (kt % NST) * (TN * 64);
-    uint4 bfr[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = j * 16 + li;
-      bfr[j] = st[row * 4 + (kg ^ swz(row))];
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&bfr[j]), afr[kt], acc[j], 0, 0, 0);
-  }
-  wait_vmcnt<0>();
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + j * 16 + kg * 4;
-    if (m < M && n < N) epi.n4p(m, n, acc[j], epre[j]);
-  }
-}
-
-template <int KS, int TN, bool LN, class Epi>
-void launch_dec64_cfg(const void* A, long lda, const bf16_t* W, int M, int N, Epi epi, hipStream_t s) {
-  const int m_tiles = (M + 63) / 64, n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  hipLaunchKernelGGL((gemm_dec64_kernel<KS, TN, LN, Epi>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, W, M, N,
-                     n_tiles, epi);
-}
-
-// register-resident A needs K <= 416 (13 fragments): the hidden size of every supported model
-template <int TN, bool LN, class Epi>
-bool launch_dec64(const void* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+// FM operands (offline decoder): K = D or F of the offline architectures
+template <int TN, bool LN, class Epi, int TM = 1>
+void launch_fm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  if ((N & 15) != 0) throw std::runtime_error("gemm_dec (FM): N must be a multiple of 16");
+  const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
+#define MSH_FM_CASE(KK)                                                                                              \
+  case KK:                                                                                                           \
+    hipLaunchKernelGGL((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, \
+                       (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
+    return;
   switch (K) {
-    case 416: launch_dec64_cfg<13, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
-    case 288: launch_dec64_cfg<9, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
-    case 64: launch_dec64_cfg<2, TN, LN, Epi>(A, lda, W, M, N, epi, s); return true;
-    default: return false;
+    MSH_FM_CASE(416)
+    MSH_FM_CASE(1664)
+    MSH_FM_CASE(288)
+    MSH_FM_CASE(1152)
+    MSH_FM_CASE(64)
+    MSH_FM_CASE(256)
+    default: throw std::runtime_error("gemm_dec (FM): unsupported K " + std::to_string(K));
   }
+#undef MSH_FM_CASE
 }
 
 }  // namespace
-
-// Batch threshold for the 64-row register-resident-A kernel.  Off by default (MSH_DEC64_M=0): on MI355X it
-// measured slower than the split-K kernel at M = 256 (qkv 23 vs 12 us) -- kept for further work.
-static bool use_dec64(int M) {
-  static int thr = [] {
-    const char* e = getenv("MSH_DEC64_M");
-    return e ? atoi(e) : 0;
-  }();
-  return thr > 0 && M >= thr;
-}
 
 // Narrow outputs (N = decoder width) at streaming batch sizes give too few 16 x 32 tiles to occupy the chip (M = 64,
 // N = 640: 80 workgroups on 256 CUs, each streaming its whole K x 32 weight slice alone): halve the tile width then.
@@ -428,54 +344,53 @@ static bool narrow_small_batch(int M) {
   return M <= thr;
 }
 
+// ---- offline decoder: FM operands.  Tile shapes by batch: a GEMM wants >= ~200 workgroups (all 256 CUs pulling their
+// share of the weights) but no second round of workgroups; the per-element summation order does not depend on the tile
+// shape, so ids are identical across batch sizes. ----
 void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
   EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
-  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 3 * D, D, epi, s)) return;
   if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
-    launch_dec<4, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+    launch_fm<4, true>(H, W, M, 3 * D, D, epi, s);
   else if (narrow_small_batch(M) || few_tiles(M, 3 * D))
-    launch_dec<1, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+    launch_fm<1, true>(H, W, M, 3 * D, D, epi, s);
   else
-    launch_dec<2, true>(H, D, nullptr, W, M, 3 * D, D, epi, s);
+    launch_fm<2, true>(H, W, M, 3 * D, D, epi, s);
 }
 void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
   EpiF32 epi{out, N};
-  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, N, D, epi, s)) return;
   if (few_tiles(M, N))
-    launch_dec<1, true>(H, D, nullptr, W, M, N, D, epi, s);
+    launch_fm<1, true>(H, W, M, N, D, epi, s);
   else
-    launch_dec<2, true>(H, D, nullptr, W, M, N, D, epi, s);
+    launch_fm<2, true>(H, W, M, N, D, epi, s);
 }
 void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int M, int F, int D, bf16_t* z,
                         hipStream_t s) {
-  EpiSwiGLU epi{z, F, bias};
-  if (use_dec64(M) && launch_dec64<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
+  EpiSwiGLUFm epi{z, F / 32, bias};
   // 32-row workgroups pay off only where there are many column tiles (r01t, M = 256: fc1 14.1 -> 12.4 us, but
   // qkv 9.8 -> 11.1 and cross-q 7.9 -> 11.1 us with half as many workgroups in flight)
-  if (M >= dec_tm2_threshold() && launch_dec_tm2<4, true>(H, D, W, M, 2 * F, D, epi, s)) return;
-  if (M >= 96)
-    launch_dec<4, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+  if (M >= dec_tm2_threshold())
+    launch_fm<4, true, EpiSwiGLUFm, 2>(H, W, M, 2 * F, D, epi, s);
+  else if (M >= 96)
+    launch_fm<4, true>(H, W, M, 2 * F, D, epi, s);
   else if (narrow_small_batch(M))
-    launch_dec<1, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+    launch_fm<1, true>(H, W, M, 2 * F, D, epi, s);
   else
-    launch_dec<2, true>(H, D, nullptr, W, M, 2 * F, D, epi, s);
+    launch_fm<2, true>(H, W, M, 2 * F, D, epi, s);
 }
-void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
-                    hipStream_t s) {
-  EpiResidF32 epi{H, N, bias};
-  if (use_dec64(M) && launch_dec64<4, false>(A, lda, W, M, N, K, epi, s)) return;  // K = D only
-  {
-    static const bool fc2_tm2 = [] {
-      const char* e = getenv("MSH_DEC_FC2_TM2");
-      return e != nullptr && e[0] == '1';
-    }();
-    if (fc2_tm2 && K > N && M >= dec_tm2_threshold() && launch_dec_tm2<2, false>(A, lda, W, M, N, K, epi, s)) return;
-  }
+template <bool BIAS>
+static void dec_gemm_resid_t(const bf16_t* A, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
+                             hipStream_t s) {
+  EpiDecResidFm<BIAS> epi{H, N / 32, bias};
   if (narrow_small_batch(M) || few_tiles(M, N))
-    launch_dec<1, false>(A, lda, nullptr, W, M, N, K, epi, s);
+    launch_fm<1, false>(A, W, M, N, K, epi, s);
   else
-    launch_dec<2, false>(A, lda, nullptr, W, M, N, K, epi, s);
+    launch_fm<2, false>(A, W, M, N, K, epi, s);
+}
+void dec_gemm_resid(const bf16_t* A, const bf16_t* W, const float* bias, int M, int N, int K, float* H, hipStream_t s) {
+  if ((N & 31) != 0) throw std::runtime_error("dec_gemm_resid: the residual width must be a multiple of 32");
+  if (bias != nullptr) dec_gemm_resid_t<true>(A, W, bias, M, N, K, H, s);
+  else dec_gemm_resid_t<false>(A, W, bias, M, N, K, H, s);
 }
 // ---- bf16-input small-batch GEMMs of the streaming decoder (row-based passes with M <= 256) ----
 // Same split-K kernel, LayerNorm done by the caller; K covers the streaming widths (320 / 640 tiny / assumed-medium,
@@ -540,15 +455,19 @@ bool small_gemm_swiglu_bf16(const bf16_t* A, long lda, const bf16_t* W, const fl
 }
 bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                           hipStream_t s) {
-  if (few_tiles(M, N)) return launch_dec_bf16<1>(A, lda, W, M, N, K, EpiResidF32{H, N, bias}, s);
-  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiResidF32{H, N, bias}, s);
+  if (bias != nullptr) {
+    if (few_tiles(M, N)) return launch_dec_bf16<1>(A, lda, W, M, N, K, EpiDecResid<true>{H, N, bias}, s);
+    return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiDecResid<true>{H, N, bias}, s);
+  }
+  if (few_tiles(M, N)) return launch_dec_bf16<1>(A, lda, W, M, N, K, EpiDecResid<false>{H, N, bias}, s);
+  return launch_dec_bf16<2>(A, lda, W, M, N, K, EpiDecResid<false>{H, N, bias}, s);
 }
 bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   return launch_dec_bf16<4>(A, lda, W, M, N, K, EpiF32{out, N}, s);
 }
 
 void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s) {
-  launch_dec<4, true>(H, D, nullptr, E, M, V, D, EpiF32{logits, V}, s);
+  launch_fm<4, true>(H, E, M, V, D, EpiF32{logits, V}, s);
 }
 
 }  // namespace msh

@@ -102,7 +102,8 @@ __global__ void groupnorm_final_kernel(const float2* __restrict__ partials, cons
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (two-pass mean / variance, eps 1e-5).
-template <int NCH>  // float4 chunks per lane
+// FMIN: x is the decode path's fragment-major residual stream (kernels.h fm32); the output stays row-major.
+template <int NCH, bool FMIN = false>  // float4 chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         int rows, int D, bf16_t* __restrict__ y,
                                                         float* __restrict__ y32) {
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    v[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FMIN)
+      v[i] = c < D4 ? *reinterpret_cast<const float4*>(x + fm32(row, 4 * c, D >> 5)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+      v[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) / (float)D;
@@ -157,7 +161,7 @@ __global__ void decode_begin_kernel(int M, DecodeState st, int bos, const float*
       *st.n_active = M;
     }
   }
-  for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)b * D + d] = embed[(long)bos * D + d];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) H[fm32(b, d, D >> 5)] = embed[(long)bos * D + d];   // H is FM
 }
 
 // Loop bookkeeping of reference core/moonshine-model.cpp:511-516 for clip b once its token is chosen: append, stop
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const float* __res
     }
     __syncthreads();
     const int nt = next_tok;
-    for (int d = tid; d < D; d += 1024) H[(long)b * D + d] = embed[(long)nt * D + d];
+    for (int d = tid; d < D; d += 1024) H[fm32(b, d, D >> 5)] = embed[(long)nt * D + d];
   }
   if (b == 0 && tid == 0) *st.pos += 1;
 }
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void decode_advance_partials_kernel(const floa
     }
     __syncthreads();
     const int nt = next_tok;
-    for (int d = tid; d < D; d += 256) H[(long)b * D + d] = embed[(long)nt * D + d];
+    for (int d = tid; d < D; d += 256) H[fm32(b, d, D >> 5)] = embed[(long)nt * D + d];
   }
   if (b == 0 && tid == 0) *st.pos += 1;
 }
@@ -318,6 +322,17 @@ void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t*
     case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
     case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
     default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
+  }
+}
+
+void dec_final_layernorm(const float* H, const float* gamma, int M, int D, bf16_t* y, hipStream_t s) {
+  const int nch = (D / 4 + 63) / 64;
+  dim3 grid((M + 3) / 4);
+  if ((D & 31) != 0 || nch > 4) throw std::runtime_error("dec_final_layernorm: unsupported width");
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
+    default: hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
   }
 }
 

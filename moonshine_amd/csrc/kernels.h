@@ -17,6 +17,23 @@ struct RopeParams {
   int hidden;  // D = heads * head_dim
 };
 
+// ---------------- MFMA-fragment-major ("FM") layouts of the offline decode path ----------------
+// The decode GEMMs load their MFMA operands straight from global memory, one 16 x 32 bf16 fragment (16 rows x 64 bytes)
+// per wave instruction.  With row-major operands that is sixteen half-used 128-byte lines per instruction, and the
+// timeline of the kernels (tools/dec_gemm_timeline.hip) showed the waves spending 1-4.7 us just ISSUING their loads.
+// In FM order the 64 lanes of a fragment are contiguous, so every wave-level load is one 1 KiB run (8 full lines):
+//   bf16 [R][K]:  element (r, k) at (((r/16) * K/32 + k/32) * 64 + lane) * 8 + k%8,   lane = r%16 + 16 * ((k/8) % 4)
+//   fp32 [R][K]:  the lane's 8 values as two float4 halves, each half 1 KiB contiguous per fragment:
+//                 ((((r/16) * K/32 + k/32) * 2 + (k/4)%2) * 64 + lane) * 4 + k%4
+// Decode weights are repacked to FM at load; the residual stream H (fp32), the attention outputs and the MLP
+// activations (bf16) live in FM between the decode kernels.  R is padded to a multiple of 16, K is a multiple of 32.
+__host__ __device__ inline long fm16(int r, int k, int ksteps) {
+  return ((((long)(r >> 4) * ksteps + (k >> 5)) * 64) + ((r & 15) + 16 * ((k >> 3) & 3))) * 8 + (k & 7);
+}
+__host__ __device__ inline long fm32(int r, int k, int ksteps) {
+  return (((((long)(r >> 4) * ksteps + (k >> 5)) * 2 + ((k >> 2) & 1)) * 64) + ((r & 15) + 16 * ((k >> 3) & 3))) * 4 + (k & 3);
+}
+
 // ---------------- tiled MFMA GEMM (large M): C = A[M,K](lda) * W[N,K]^T ----------------
 // conv1: out_bf16[M,N] = tanh(acc)
 void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s);
@@ -47,6 +64,9 @@ void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int
 // ---------------- decode GEMMs (M = batch rows; k_gemm_dec.hip) ----------------
 // "LN" variants take the fp32 residual stream H and fuse LayerNorm (no bias, eps 1e-5) into the A-fragment
 // build; the LayerNorm scale gamma must already be folded into W (W' = W * diag(gamma), done at load).
+// The dec_* functions below work on FM operands (see above): every W is FM bf16 [N][K], H is FM fp32 [M16][D], the bf16
+// activations `A` / `z` are FM [M16][K] (M16 = M rounded up to 16 rows, which the buffers must hold); q, the logits and
+// the self-attention cache keep their row-major layouts.
 // q/k/v for one decoder layer: q_f32[M,D] (rope), k (rope) / v appended to the self cache
 // [M][H][Smax][dh] at position *pos_ptr.
 void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
@@ -57,8 +77,9 @@ void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float
 void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int M, int F, int D, bf16_t* z,
                         hipStream_t s);
 // H_f32[M,N] += A_bf16[M,K] * W^T (+ bias)
-void dec_gemm_resid(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
-                    hipStream_t s);
+void dec_gemm_resid(const bf16_t* A, const bf16_t* W, const float* bias, int M, int N, int K, float* H, hipStream_t s);
+// dy_bf16[M,D] (row-major, for the tiled LM head) = LayerNorm(H) * gamma, H in FM
+void dec_final_layernorm(const float* H, const float* gamma, int M, int D, bf16_t* y, hipStream_t s);
 // logits_f32[M,V] = LN(H) * E'^T  (E' = tied embedding with the final LayerNorm scale folded in)
 void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s);
 // logits_f32[M,N] = A_bf16[M,K] * W^T with the tiled kernel (LM head at batch >= 128, after layernorm_bf16)
@@ -104,14 +125,14 @@ void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int
 // encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
 void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,
                    hipStream_t s);
-// decode self-attention: q [M,D] f32, cache [M][H][Smax][dh] bf16, keys 0..*pos_ptr -> out [M,D] bf16
+// decode self-attention: q [M,D] f32, cache [M][H][Smax][dh] bf16, keys 0..*pos_ptr -> out [M16,D] bf16 in FM
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
                         int heads, int Smax, bf16_t* out, hipStream_t s);
-// decode cross-attention: q [M,D] f32, K^T/V^T of one layer -> out [M,D] bf16
+// decode cross-attention: q [M,D] f32, K^T/V^T of one layer -> out [M16,D] bf16 in FM
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                          int heads, bf16_t* out, hipStream_t s);
 
-// same with the query projection fused in: H = fp32 residual stream [M,D], Wq = cross-q weight [D,D] with the
+// same with the query projection fused in: H = fp32 residual stream (FM), Wq = cross-q weight [D,D] ROW-MAJOR with the
 // LayerNorm scale folded in (replaces dec_gemm_ln_f32 + dec_cross_attention)
 // cross-attention probabilities of the current step (word timestamps): out[clip][layer][head][pos][Tcap] fp32, frames
 // [0, T) of the row written; T <= 2048

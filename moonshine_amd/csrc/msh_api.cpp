@@ -279,6 +279,10 @@ int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t byte
   return v;
 }
 
+int32_t msh_profile_decode_chain(msh_engine* e, int32_t reps) {
+  return guarded(e, [&] { e->eng->profile_decode_chain(reps); });
+}
+
 double msh_profile_cross_attention_ms(msh_engine* e, int32_t rounds) {
   double v = -1.0;
   guarded(e, [&] { v = e->eng->profile_cross_attention_ms(rounds); });

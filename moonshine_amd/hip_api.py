@@ -73,6 +73,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_synchronize": (i32, [vp]),
         "msh_profile_event_overhead_ms": (C.c_double, [vp, i32]),
         "msh_profile_cross_attention_ms": (C.c_double, [vp, i32]),
+        "msh_profile_decode_chain": (i32, [vp, i32]),
         "msh_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
         "msh_set_capture_cross_attention": (i32, [vp, i32]),
         "msh_get_cross_attention": (C.c_int64, [vp, C.c_uint32, vp, C.c_uint64, vp]),
@@ -116,7 +117,7 @@ DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
-    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_debug_read",
+    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_profile_decode_chain", "msh_debug_read",
     "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_set_hw_queues", "msh_host_silero_probabilities", "msh_host_vad_segments", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
@@ -246,6 +247,10 @@ class Engine:
 
     def profile_event_overhead_ms(self, iters: int = 200) -> float:
         return float(self.lib.msh_profile_event_overhead_ms(self.h, iters))
+
+    def profile_decode_chain(self, reps: int = 8):
+        """Adds "chain_<kernel group>" entries to profile(): per-launch cost inside a replayed hipGraph chain."""
+        self._check(self.lib.msh_profile_decode_chain(self.h, reps))
 
     def profile_cross_attention_ms(self, rounds: int = 20) -> float:
         v = float(self.lib.msh_profile_cross_attention_ms(self.h, rounds))
