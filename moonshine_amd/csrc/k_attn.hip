@@ -235,9 +235,37 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decode self-attention: one wave per (clip, head)
+// Decode self-attention: one wave per (clip, head), keys in blocks of KB staged through LDS.
+//
+// The cache rows of a (clip, head) are one contiguous run of S x dh bf16.  The first version had every lane fetch "its"
+// key row with thirteen 8-byte loads at a 104-byte stride (64 cache lines per wave instruction) and spent its 8.6 us
+// issuing ~45 such loads per wave.  Here the wave copies the K and V runs of a key block to its private LDS slab with
+// LDS-DMA (`global_load_lds_dwordx4`: 1 KiB of consecutive bytes per instruction, 8 + 8 instructions for a 72-key block
+// at dh = 52) and computes from LDS: scores with lane = key (row stride 26 dwords: at most 2-way bank conflicts), fp32
+// softmax in the exp2 domain (online across key blocks, so any S <= Smax works; a 65-step decode is ONE block), P.V with
+// lane = (key group, 4-dim piece) and a fixed-order reduction.  The output row goes to the FM activation buffer the
+// o-proj GEMM reads (kernels.h fm16).
 // ------------------------------------------------------------------------------------------------
-constexpr int SELF_SMAX = 512;
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long)(lds_char_t*)(p); }
+// 16 bytes per ACTIVE lane from gsrc (per lane) to LDS at lds_base (wave-uniform) + 16 * lane
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+template <int DH>
+struct SelfAttnCfg {
+  static constexpr int KB = 72;                           // keys per block: a 10 s clip's 65 steps fit in one
+  static constexpr int TILE_BYTES = KB * DH * 2;
+  static constexpr int NCH = (TILE_BYTES + 1023) / 1024;  // 1 KiB DMA pieces per tile
+  static constexpr int TILE_PAD = NCH * 1024;
+  static constexpr int PIECES = DH / 4, G = 64 / PIECES;
+};
 
 template <int DH>
 __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __restrict__ q,
@@ -245,71 +273,89 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
                                                                  const bf16_t* __restrict__ cacheV,
                                                                  const int* __restrict__ pos_ptr, int M, int D,
                                                                  int heads, int Smax, bf16_t* __restrict__ out) {
-  __shared__ float sc[4][SELF_SMAX];
-  __shared__ float4 red[4][64 / (DH / 4)][DH / 4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  using C = SelfAttnCfg<DH>;
+  constexpr int KB = C::KB, NCH = C::NCH, PIECES = C::PIECES, G = C::G;
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[4][2][C::TILE_PAD];
+  __shared__ float sc[4][KB + 8];
+  __shared__ float4 red[4][G][PIECES];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + wave;
-  if (pair >= M * heads) return;
+  if (pair >= M * heads) return;   // wave-uniform; the waves of a workgroup never synchronise with each other
   const int b = pair / heads, h = pair - b * heads;
   const int S = *pos_ptr + 1;
   const float* qp = q + (long)b * D + h * DH;
-  const bf16_t* kp = cacheK + (long)pair * Smax * DH;
-  const bf16_t* vp = cacheV + (long)pair * Smax * DH;
+  const unsigned char* kp = reinterpret_cast<const unsigned char*>(cacheK + (long)pair * Smax * DH);
+  const unsigned char* vp = reinterpret_cast<const unsigned char*>(cacheV + (long)pair * Smax * DH);
+  const long run_bytes = (long)S * DH * 2;   // only the rows written so far are fetched (S <= Smax rows exist)
   const float c = rsqrtf((float)DH) * kLog2e;
+  const unsigned kt = __builtin_amdgcn_readfirstlane(lds_addr(&tiles[wave][0][0]));
+  const unsigned vt = __builtin_amdgcn_readfirstlane(lds_addr(&tiles[wave][1][0]));
+  const bf16_t* Kl = reinterpret_cast<const bf16_t*>(&tiles[wave][0][0]);
+  const bf16_t* Vl = reinterpret_cast<const bf16_t*>(&tiles[wave][1][0]);
 
-  float qreg[DH];
+  auto stage = [&](int k0) {   // keys [k0, k0 + KB) of K and V -> LDS (nothing beyond row S - 1 is read)
+    const long base = (long)k0 * DH * 2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const long off = base + i * 1024 + lane * 16;
+      if (i * 1024 + lane * 16 < C::TILE_BYTES && off < run_bytes) {
+        lds_dma16(kp + off, kt + i * 1024);
+        lds_dma16(vp + off, vt + i * 1024);
+      }
+    }
+  };
+  stage(0);
+  float qreg[DH];   // every lane holds the whole query (same address in all lanes: one request per load)
 #pragma unroll
   for (int d = 0; d < DH; d += 4) {
-    float4 t = *reinterpret_cast<const float4*>(qp + d);
-    qreg[d] = t.x; qreg[d + 1] = t.y; qreg[d + 2] = t.z; qreg[d + 3] = t.w;
+    const float4 t = *reinterpret_cast<const float4*>(qp + d);
+    qreg[d] = t.x * c; qreg[d + 1] = t.y * c; qreg[d + 2] = t.z * c; qreg[d + 3] = t.w * c;
   }
-  // PV mapping: lane = (key group g, 8-byte piece of the head dim).  The first NPRE V rows of each group
-  // (enough for the 66 keys of a 10 s clip) are requested now, so they arrive during the score phase
-  // instead of adding a third dependent memory round trip after the softmax.
-  constexpr int PIECES = DH / 4, G = 64 / PIECES, NPRE = 17;
   const int g = lane / PIECES, piece = lane - g * PIECES;
-  uint2 vpre[NPRE];
-  if (g < G) {
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int s = g + G * i;
-      vpre[i] = s < S ? *reinterpret_cast<const uint2*>(vp + (long)s * DH + piece * 4) : make_uint2(0u, 0u);
-    }
-  }
-  float mloc = -INFINITY;
-  for (int s = lane; s < S; s += 64) {
-    const bf16_t* kr = kp + (long)s * DH;
-    uint2 kraw[DH / 4];  // the whole key row is requested before the first use: one round trip
-#pragma unroll
-    for (int d = 0; d < DH; d += 4) kraw[d / 4] = *reinterpret_cast<const uint2*>(kr + d);
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; d += 4) {
-      const uint2 u = kraw[d / 4];
-      acc += qreg[d] * bf_lo(u.x) + qreg[d + 1] * bf_hi(u.x) + qreg[d + 2] * bf_lo(u.y) + qreg[d + 3] * bf_hi(u.y);
-    }
-    acc *= c;
-    sc[wave][s] = acc;
-    mloc = fmaxf(mloc, acc);
-  }
-  const float mx = wave_max(mloc);
-  float lsum = 0.f;
-  for (int s = lane; s < S; s += 64) {
-    const float p = __builtin_amdgcn_exp2f(sc[wave][s] - mx);
-    sc[wave][s] = p;
-    lsum += p;
-  }
-  lsum = wave_sum(lsum);
-  __builtin_amdgcn_wave_barrier();
-  // PV: lane = (key group g, 8-byte piece of the head dim); group g walks keys g, g+G, ... with
-  // independent loads, then the G partial rows are summed through LDS in a fixed order.
+  float m_run = -INFINITY, l_run = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g < G) {
+#pragma unroll 1
+  for (int k0 = 0; k0 < S; k0 += KB) {
+    if (k0 > 0) stage(k0);   // (the previous block's LDS reads are complete: their values were consumed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int nk = S - k0 < KB ? S - k0 : KB;
+    // scores: lane = key (and key + 64 for the block's tail)
+    float s0 = -INFINITY, s1 = -INFINITY;
+    if (lane < nk) {
+      const uint2* kr = reinterpret_cast<const uint2*>(Kl + lane * DH);
+      float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int s = g + G * i;
-      if (s < S) {
-        const uint2 u = vpre[i];
+      for (int d = 0; d < DH; d += 4) {
+        const uint2 u = kr[d >> 2];
+        a += qreg[d] * bf_lo(u.x) + qreg[d + 1] * bf_hi(u.x) + qreg[d + 2] * bf_lo(u.y) + qreg[d + 3] * bf_hi(u.y);
+      }
+      s0 = a;
+    }
+    if (lane + 64 < nk) {
+      const uint2* kr = reinterpret_cast<const uint2*>(Kl + (lane + 64) * DH);
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; d += 4) {
+        const uint2 u = kr[d >> 2];
+        a += qreg[d] * bf_lo(u.x) + qreg[d + 1] * bf_hi(u.x) + qreg[d + 2] * bf_lo(u.y) + qreg[d + 3] * bf_hi(u.y);
+      }
+      s1 = a;
+    }
+    const float m_new = fmaxf(m_run, wave_max(fmaxf(s0, s1)));
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first block: exp2(-inf) = 0
+    m_run = m_new;
+    const float p0 = __builtin_amdgcn_exp2f(s0 - m_new), p1 = __builtin_amdgcn_exp2f(s1 - m_new);   // masked keys: 0
+    sc[wave][lane] = p0;
+    if (lane < KB - 64) sc[wave][lane + 64] = p1;
+    l_run = l_run * alpha + wave_sum(p0 + p1);
+    __builtin_amdgcn_wave_barrier();
+    // P.V: lane = (key group g, 4-dim piece); group g walks keys g, g + G, ...
+    acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+    if (g < G) {
+#pragma unroll 6
+      for (int s = g; s < nk; s += G) {
+        const uint2 u = *reinterpret_cast<const uint2*>(Vl + s * DH + piece * 4);
         const float p = sc[wave][s];
         acc.x += p * bf_lo(u.x);
         acc.y += p * bf_hi(u.x);
@@ -317,17 +363,9 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
         acc.w += p * bf_hi(u.y);
       }
     }
-#pragma unroll 4
-    for (int s = g + G * NPRE; s < S; s += G) {
-      const uint2 u = *reinterpret_cast<const uint2*>(vp + (long)s * DH + piece * 4);
-      const float p = sc[wave][s];
-      acc.x += p * bf_lo(u.x);
-      acc.y += p * bf_hi(u.x);
-      acc.z += p * bf_lo(u.y);
-      acc.w += p * bf_hi(u.y);
-    }
-    red[wave][g][piece] = acc;
+    __builtin_amdgcn_wave_barrier();
   }
+  if (g < G) red[wave][g][piece] = acc;
   __builtin_amdgcn_wave_barrier();
   if (lane < PIECES) {
     float4 t = red[wave][0][lane];
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
       const float4 r = red[wave][k][lane];
       t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
     }
-    const float inv = 1.0f / lsum;
+    const float inv = 1.0f / l_run;
     uint2 o;
     o.x = pack_bf16x2(t.x * inv, t.y * inv);
     o.y = pack_bf16x2(t.z * inv, t.w * inv);
@@ -591,7 +629,6 @@ void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
                         int heads, int Smax, bf16_t* out, hipStream_t s) {
   const int dh = D / heads;
-  if (Smax > SELF_SMAX) throw std::runtime_error("dec_self_attention: Smax > 512");
   dim3 grid((M * heads + 3) / 4);
   switch (dh) {
     case 52: hipLaunchKernelGGL(dec_self_attention_kernel<52>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;

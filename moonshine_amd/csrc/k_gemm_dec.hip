@@ -9,11 +9,11 @@ namespace {
 // Developer instrumentation (tools/dec_gemm_timeline.hip builds this file with MSH_TIMELINE): wave-level time stamps
 // (100 MHz s_memrealtime, comparable across CUs) at the phase boundaries of gemm_dec_kernel.  Compiled out otherwise.
 #ifdef MSH_TIMELINE
-__device__ unsigned long long* g_timeline = nullptr;   // [blocks][4 waves][8 points]
+__device__ unsigned long long* g_timeline = nullptr;   // [blocks][8 waves][8 points]
 #define MSH_TL(i)                                                                                          \
   do {                                                                                                     \
     if (lane == 0 && g_timeline != nullptr)                                                                \
-      g_timeline[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();            \
+      g_timeline[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();            \
   } while (0)
 #else
 #define MSH_TL(i) do { } while (0)
@@ -40,18 +40,20 @@ __device__ unsigned long long* g_timeline = nullptr;   // [blocks][4 waves][8 po
 // ------------------------------------------------------------------------------------------------
 // FM = true: W, A and (through the epilogue) the outputs are in the MFMA-fragment-major layouts of kernels.h: every
 // wave-level load is one contiguous 1 KiB run.  FM = false: row-major operands (the streaming decoder's path).
-template <int KS, int TN, bool LN, class Epi, int TM = 1, bool FM = false>
-__global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
+// NW = waves per workgroup (4 or 8): the K loop is split NW ways.  With 8 waves every wave issues half as many loads,
+// which is what the first microsecond of these kernels consists of (tools/dec_gemm_timeline.hip).
+template <int KS, int TN, bool LN, class Epi, int TM = 1, bool FM = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_dec_kernel(const void* __restrict__ Aptr, long lda,
                                                        const float* __restrict__ gamma,
                                                        const bf16_t* __restrict__ W, int M, int N, int n_tiles,
                                                        Epi epi) {
   // TM = 2: the workgroup owns 32 rows (two MFMA row tiles) and every W fragment it loads feeds two MFMAs -- the
   // weights are re-read M/32 instead of M/16 times.
   constexpr int K = 32 * KS;
-  constexpr int KW = (KS + 3) / 4;   // k-steps per wave (upper bound)
-  constexpr int KFULL = KS / 4;      // k-steps i < KFULL exist for every wave
-  __shared__ __attribute__((aligned(16))) float4 part[4][TM * TN][64];
-  __shared__ float2 stat[4][16 * TM];
+  constexpr int KW = (KS + NW - 1) / NW;   // k-steps per wave (upper bound)
+  constexpr int KFULL = KS / NW;           // k-steps i < KFULL exist for every wave
+  __shared__ __attribute__((aligned(16))) float4 part[NW][TM * TN][64];
+  __shared__ float2 stat[NW][16 * TM];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = (blockIdx.x / n_tiles) * (16 * TM), n0 = (blockIdx.x % n_tiles) * (16 * TN);
@@ -62,12 +64,12 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
     gm[t] = m0 + t * 16 + li;
     gm[t] = gm[t] < M ? gm[t] : M - 1;
   }
-  // k-step i of this wave: s = wave + 4 i (wave-uniform); a step past KS reads step KS - 1 again and is masked
+  // k-step i of this wave: s = wave + NW i (wave-uniform); a step past KS reads step KS - 1 again and is masked
   int ks[KW];
   bool kv[KW];
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
-    const int s = wave + 4 * i;
+    const int s = wave + NW * i;
     kv[i] = i < KFULL ? true : s < KS;
     ks[i] = kv[i] ? s : KS - 1;
   }
@@ -141,11 +143,11 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
   }
   // inputs of the epilogue this wave will run at the end (residual, bias, RoPE factors)
   constexpr int NT = TM * TN;            // output tiles of the workgroup
-  constexpr int NE = (NT + 3) / 4;
+  constexpr int NE = (NT + NW - 1) / NW;
   typename Epi::Pre epre[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
-    int o = wave + 4 * e;
+    int o = wave + NW * e;
     o = o < NT ? o : NT - 1;
     const int t = o / TN, j = o - t * TN;
     int m = m0 + t * 16 + li, n = n0 + j * 16 + kg * 4;
@@ -187,7 +189,11 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       const int r = t * 16 + li;
-      const float2 s0 = stat[0][r], s1 = stat[1][r], s2 = stat[2][r], s3 = stat[3][r];
+      float2 s0 = stat[0][r], s1 = stat[1][r], s2 = stat[2][r], s3 = stat[3][r];
+      if constexpr (NW == 8) {
+        const float2 s4 = stat[4][r], s5 = stat[5][r], s6 = stat[6][r], s7 = stat[7][r];
+        s0.x += s4.x; s0.y += s4.y; s1.x += s5.x; s1.y += s5.y; s2.x += s6.x; s2.y += s6.y; s3.x += s7.x; s3.y += s7.y;
+      }
       const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * (1.0f / (float)K);
       float var = ((s0.y + s1.y) + (s2.y + s3.y)) * (1.0f / (float)K) - mean * mean;
       var = var > 0.f ? var : 0.f;
@@ -240,10 +246,17 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(const void* __restrict__ 
   // the waves finish the output tiles round-robin: fixed summation order
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
-    const int o = wave + 4 * e;
+    const int o = wave + NW * e;
     const int oc = o < NT ? o : NT - 1;
     const int t = oc / TN, j = oc - t * TN;
-    const float4 p0 = part[0][oc][lane], p1 = part[1][oc][lane], p2 = part[2][oc][lane], p3 = part[3][oc][lane];
+    float4 p0 = part[0][oc][lane], p1 = part[1][oc][lane], p2 = part[2][oc][lane], p3 = part[3][oc][lane];
+    if constexpr (NW == 8) {
+      const float4 p4 = part[4][oc][lane], p5 = part[5][oc][lane], p6 = part[6][oc][lane], p7 = part[7][oc][lane];
+      p0.x += p4.x; p0.y += p4.y; p0.z += p4.z; p0.w += p4.w;
+      p1.x += p5.x; p1.y += p5.y; p1.z += p5.z; p1.w += p5.w;
+      p2.x += p6.x; p2.y += p6.y; p2.z += p6.z; p2.w += p6.w;
+      p3.x += p7.x; p3.y += p7.y; p3.z += p7.z; p3.w += p7.w;
+    }
     f32x4 v;
     v[0] = (p0.x + p1.x) + (p2.x + p3.x);
     v[1] = (p0.y + p1.y) + (p2.y + p3.y);
@@ -261,18 +274,6 @@ void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
   hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W,
                      M, N, n_tiles, epi);
-}
-// 32-row workgroups for the K = D GEMMs of large batches (see gemm_dec_kernel); false if K has no such instance
-template <int TN, bool LN, class Epi>
-bool launch_dec_tm2(const void* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
-  switch (K) {
-    case 416: launch_dec_cfg<13, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
-    case 288: launch_dec_cfg<9, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
-    case 64: launch_dec_cfg<2, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
-    case 1664: launch_dec_cfg<52, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
-    case 1152: launch_dec_cfg<36, TN, LN, Epi, 2>(A, lda, nullptr, W, M, N, epi, s); return true;
-    default: return false;
-  }
 }
 static int dec_tm2_threshold() {
   static int thr = [] {
@@ -301,13 +302,13 @@ void launch_dec(const void* A, long lda, const float* gamma, const bf16_t* W, in
 
 
 // FM operands (offline decoder): K = D or F of the offline architectures
-template <int TN, bool LN, class Epi, int TM = 1>
+template <int TN, bool LN, class Epi, int TM = 1, int NW = 4>
 void launch_fm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((N & 15) != 0) throw std::runtime_error("gemm_dec (FM): N must be a multiple of 16");
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
 #define MSH_FM_CASE(KK)                                                                                              \
   case KK:                                                                                                           \
-    hipLaunchKernelGGL((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, \
+    hipLaunchKernelGGL((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
                        (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
     return;
   switch (K) {
@@ -350,7 +351,10 @@ static bool narrow_small_batch(int M) {
 void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
   EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
-  if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
+  // (timeline, M = 256: 96-column tiles = 208 workgroups, one round on 256 CUs, finish 0.4 us before 64-column tiles)
+  if (M >= 192 && (3 * D) % 96 == 0)
+    launch_fm<6, true>(H, W, M, 3 * D, D, epi, s);
+  else if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
     launch_fm<4, true>(H, W, M, 3 * D, D, epi, s);
   else if (narrow_small_batch(M) || few_tiles(M, 3 * D))
     launch_fm<1, true>(H, W, M, 3 * D, D, epi, s);
@@ -369,7 +373,10 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
   EpiSwiGLUFm epi{z, F / 32, bias};
   // 32-row workgroups pay off only where there are many column tiles (r01t, M = 256: fc1 14.1 -> 12.4 us, but
   // qkv 9.8 -> 11.1 and cross-q 7.9 -> 11.1 us with half as many workgroups in flight)
-  if (M >= dec_tm2_threshold())
+  // (timeline, M = 256: 32 x 128 tiles = 208 workgroups in one round beat 32 x 64 = 416 in two by 0.4 us)
+  if (M >= 192 && (2 * F) % 128 == 0)
+    launch_fm<8, true, EpiSwiGLUFm, 2>(H, W, M, 2 * F, D, epi, s);
+  else if (M >= dec_tm2_threshold())
     launch_fm<4, true, EpiSwiGLUFm, 2>(H, W, M, 2 * F, D, epi, s);
   else if (M >= 96)
     launch_fm<4, true>(H, W, M, 2 * F, D, epi, s);

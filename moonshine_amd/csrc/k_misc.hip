@@ -249,17 +249,18 @@ __global__ __launch_bounds__(256) void decode_advance_partials_kernel(const floa
   __shared__ int bi[4];
   __shared__ int next_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (st.finished[b] == 0) {
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int i = tid; i < ntn; i += 256) {
-      const float v = pval[(long)b * ntn + i];
-      const int ix = pidx[(long)b * ntn + i];
-      if (v > best || (v == best && ix < besti)) {
-        best = v;
-        besti = ix;
-      }
+  // the partial maxima are fetched before the "finished" flag is known: one memory round trip instead of two
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < ntn; i += 256) {
+    const float v = pval[(long)b * ntn + i];
+    const int ix = pidx[(long)b * ntn + i];
+    if (v > best || (v == best && ix < besti)) {
+      best = v;
+      besti = ix;
     }
+  }
+  if (st.finished[b] == 0) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       const float ov = __shfl_xor(best, o);

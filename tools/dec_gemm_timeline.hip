@@ -17,12 +17,12 @@ using namespace msh;
 static void report(const char* name, const std::vector<unsigned long long>& t, int blocks) {
   // per point: min / median / max over waves, relative to the earliest start of the launch (10 ns ticks -> us)
   unsigned long long t0 = ~0ull;
-  for (int b = 0; b < blocks * 4; ++b) t0 = std::min(t0, t[(size_t)b * 8]);
+  for (int b = 0; b < blocks * 8; ++b) if (t[(size_t)b * 8] != 0) t0 = std::min(t0, t[(size_t)b * 8]);
   printf("%-28s blocks %4d |", name, blocks);
   static const char* pt[] = {"start", "loads issued", "LN sums", "LN sync", "mfma+lds", "sync", "stored"};
   for (int p = 0; p < 7; ++p) {
     std::vector<double> v;
-    for (int b = 0; b < blocks * 4; ++b) {
+    for (int b = 0; b < blocks * 8; ++b) {
       const unsigned long long x = t[(size_t)b * 8 + p];
       if (x != 0) v.push_back((double)(x - t0) * 0.01);
     }
@@ -49,12 +49,15 @@ int main() {
   RopeParams rp{rope, rope + 8192 * 23, 23, 52, D};
   unsigned long long* tl;
   const int max_blocks = 4096;
-  CK(hipMalloc(&tl, (size_t)max_blocks * 32 * 8));
+  CK(hipMalloc(&tl, (size_t)max_blocks * 64 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &tl, sizeof(tl)));
-  std::vector<unsigned long long> host((size_t)max_blocks * 32);
+  std::vector<unsigned long long> host((size_t)max_blocks * 64);
   struct Case { const char* name; int blocks; int id; } cases[] = {
       {"o-proj  N=416 K=416", 16 * 13, 0}, {"cross-q N=416 K=416 LN", 16 * 13, 1}, {"qkv N=1248 K=416 LN", 16 * 20, 2},
-      {"fc1 N=3328 K=416 LN tm2", 8 * 52, 3}, {"fc2 N=416 K=1664", 16 * 13, 4}};
+      {"fc1 N=3328 K=416 LN tm2", 8 * 52, 3}, {"fc2 N=416 K=1664", 16 * 13, 4},
+      {"o-proj nw8", 16 * 13, 10}, {"cross-q nw8", 16 * 13, 11}, {"qkv tn4 nw8", 16 * 20, 12}, {"fc1 tm2 tn4 nw8", 8 * 52, 13},
+      {"fc1 tm2 tn8 nw4", 8 * 26, 14}, {"fc1 tm2 tn8 nw8", 8 * 26, 15}, {"fc2 tn2 nw8", 16 * 13, 16}, {"qkv tn6 nw8", 16 * 13, 17},
+      {"fc1 tm1 tn8 nw8", 16 * 26, 18}};
   for (auto& c : cases) {
     auto launch = [&] {
       switch (c.id) {
@@ -63,11 +66,20 @@ int main() {
         case 2: dec_gemm_qkv(H, W, M, D, pos, rp, q, cK, cV, 72, s); break;
         case 3: dec_gemm_ln_swiglu(H, W, bias, M, F, D, z, s); break;
         case 4: dec_gemm_resid(z, W, bias, M, D, F, H, s); break;
+        case 10: launch_fm<2, false, EpiDecResidFm<false>, 1, 8>(ao, W, M, D, D, EpiDecResidFm<false>{H, D / 32, nullptr}, s); break;
+        case 11: launch_fm<2, true, EpiF32, 1, 8>(H, W, M, D, D, EpiF32{q, D}, s); break;
+        case 12: launch_fm<4, true, EpiDecQkv, 1, 8>(H, W, M, 3 * D, D, EpiDecQkv{q, cK, cV, pos, rp, 72}, s); break;
+        case 13: launch_fm<4, true, EpiSwiGLUFm, 2, 8>(H, W, M, 2 * F, D, EpiSwiGLUFm{z, F / 32, bias}, s); break;
+        case 14: launch_fm<8, true, EpiSwiGLUFm, 2, 4>(H, W, M, 2 * F, D, EpiSwiGLUFm{z, F / 32, bias}, s); break;
+        case 15: launch_fm<8, true, EpiSwiGLUFm, 2, 8>(H, W, M, 2 * F, D, EpiSwiGLUFm{z, F / 32, bias}, s); break;
+        case 16: launch_fm<2, false, EpiDecResidFm<true>, 1, 8>(z, W, M, D, F, EpiDecResidFm<true>{H, D / 32, bias}, s); break;
+        case 17: launch_fm<6, true, EpiDecQkv, 1, 8>(H, W, M, 3 * D, D, EpiDecQkv{q, cK, cV, pos, rp, 72}, s); break;
+        case 18: launch_fm<8, true, EpiSwiGLUFm, 1, 8>(H, W, M, 2 * F, D, EpiSwiGLUFm{z, F / 32, bias}, s); break;
       }
     };
     for (int i = 0; i < 20; ++i) launch();   // warm; the last launch's stamps are what is read back
     CK(hipStreamSynchronize(s));
-    CK(hipMemsetAsync(tl, 0, (size_t)max_blocks * 32 * 8, s));
+    CK(hipMemsetAsync(tl, 0, (size_t)max_blocks * 64 * 8, s));
     for (int i = 0; i < 8; ++i) launch();
     CK(hipStreamSynchronize(s));
     CK(hipMemcpy(host.data(), tl, host.size() * 8, hipMemcpyDeviceToHost));
