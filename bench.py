@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--arch", default="base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the short config-5 (streaming) run inside the default bench")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (clips in pinned host memory) run")
     ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--workload", default="offline", choices=["offline", "streaming"],
                     help="offline = BASELINE.json configs[2] (default); streaming = configs[4] (speculative streaming decode)")
@@ -61,6 +63,23 @@ def parse():
 
 
 def main_streaming(args):
+    import torch
+
+    from moonshine_amd import dist as msd
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rank, world = msd.init_from_env("nccl", dev)
+    dist = torch.distributed if world > 1 else None
+    line = run_streaming(args, args.steps, args.warmup, local_rank, rank, world, dev, dist)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
     """BASELINE.json configs[4]: `--streams` concurrent 10 s streams per GPU, fed in `--update-ms` pieces.  Every
     update runs the reference Transcriber's flow for a growing line (core/transcriber.cpp:1311-1487): new whole
     1280-sample chunks through the frontend, window encoder + adapter + cross K/V, decoder reset, then
@@ -73,11 +92,6 @@ def main_streaming(args):
     from moonshine_amd.hip_api import StreamEngine
     from moonshine_amd.synth import STREAMING_ARCHS, make_audio, write_streaming_model_dir
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    rank, world = msd.init_from_env("nccl", dev)
-    dist = torch.distributed if world > 1 else None
     cfg = STREAMING_ARCHS[args.stream_arch]
     S = args.streams
     with tempfile.TemporaryDirectory() as d:
@@ -122,7 +136,7 @@ def main_streaming(args):
             last = toks
         return last
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     for k in stats:
         stats[k] = 0
@@ -130,23 +144,22 @@ def main_streaming(args):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         final_tokens = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = msd.max_over_ranks(time.perf_counter() - t0, world, dev)
+    eng.close()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    value = world * S * CLIP_SECONDS * args.steps / elapsed
-    k = args.steps
+        return None
+    value = world * S * CLIP_SECONDS * steps / elapsed
+    k = steps
     line = {
         "metric": "audio-seconds/sec (RTF^-1), streaming Moonshine with speculative decode, 10 s streams",
-        "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(value, 1), "unit": "audio-seconds/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic (white-noise streams; random weights; medium_streaming dims are ASSUMED -- the reference does not "
                 "hold the medium model's dimensions)",
@@ -154,15 +167,13 @@ def main_streaming(args):
                                f"{args.update_ms} ms updates, frontend + window encoder + speculative decode_full per update; audio "
                                "arrives from host memory every update", "streams_per_gpu": S, "updates_per_stream": n_upd,
                    "parallelism": f"stream-sharded dp{world}"},
-        "streaming": {"ms_per_update": round(elapsed / args.steps / n_upd * 1e3, 3),
+        "streaming": {"ms_per_update": round(elapsed / steps / n_upd * 1e3, 3),
                       "frontend_ms_per_step": round(stats["frontend_ms"] / k, 2), "encode_ms_per_step": round(stats["encode_ms"] / k, 2),
                       "decode_ms_per_step": round(stats["decode_ms"] / k, 2),
                       "draft_acceptance": round(stats["accepted"] / max(stats["draft"], 1), 4),
                       "tokens_per_final_line": round(sum(len(t) for t in final_tokens) / S, 2)},
     }
-    print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    return line
 
 
 def roofline_entry(p):
@@ -273,6 +284,31 @@ def main():
         dts = msd.max_over_ranks(time.perf_counter() - ts, world, dev)
         serial = {"value": round(world * B * CLIP_SECONDS * 3 / dts, 1), "ms_per_step": round(dts / 3 * 1e3, 3), "steps": 3}
 
+    # ---- PCIe-inclusive: the same steps with the clips handed over as HOST buffers (what the C API's batch call gets),
+    # here in pinned memory so that each lane's host->device copies are asynchronous DMA and overlap the other lanes' work.
+    # Never `value`: the contract quotes throughput with inputs resident in HBM. ----
+    pcie = None
+    if not args.no_pcie and world == 1:
+        pin = torch.from_numpy(np.stack(host)).pin_memory()
+        host_clips = [pin[i].numpy() for i in range(B)]
+        k = max(4, min(args.steps, 12))
+        warm = [eng.submit_transcribe_tokens(host_clips, forced_steps=args.decode_steps) for _ in range(max(F, 1))] if F > 1 else []
+        for t in warm:
+            eng.wait_tokens(t)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        if F > 1:
+            for t in [eng.submit_transcribe_tokens(host_clips, forced_steps=args.decode_steps) for _ in range(k)]:
+                last = eng.wait_tokens(t)
+        else:
+            for _ in range(k):
+                last = eng.transcribe_tokens(host_clips, forced_steps=args.decode_steps)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        pcie = {"value": round(B * CLIP_SECONDS * k / dtp, 1), "ms_per_step": round(dtp / k * 1e3, 3), "steps": k,
+                "host_buffers": "pinned", "bytes_per_step": int(B * CLIP_SAMPLES * 4), "ids_match_resident": last == serial_ref}
+        del pin
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -324,13 +360,12 @@ def main():
                 kr["traffic"] = round(pmc[kr["kernel"]]["traffic_bytes_per_launch"], 1)
     dominant = dict(kernels[0])
     prof_total = sum(p["ms"] for p in prof)
-    per_scope_ms = dominant["ms_per_launch"]
+    per_scope_ms = dominant.get("ms_per_launch_event_scope", dominant["ms_per_launch"])
+    sweep_ms = None
     if dominant["kernel"] == "dec_cross_attention" and dominant.get("algorithmic_bytes_per_launch"):
-        # the per-launch figure above carries the event bookkeeping of its scope (an EMPTY scope lasts ~5 us); time the
-        # kernel itself: back-to-back launches over the cross K/V of all layers between one event pair
-        ms = eng.profile_cross_attention_ms(25)
-        ach = dominant["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e9
-        dominant.update(ms_per_launch=round(ms, 5), achieved=round(ach, 1), frac=round(ach / dominant["peak"], 4))
+        # a second, independent timing of the same kernel: back-to-back launches over the cross K/V of all layers between
+        # one event pair on the engine's stream (no graph).  `ms_per_launch` stays the in-graph chain figure.
+        sweep_ms = round(eng.profile_cross_attention_ms(25), 5)
 
     # ---- batch-1 latency (p50), encode / decode split ----
     latency = None
@@ -354,12 +389,30 @@ def main():
                    # BASELINE.json configs[1] (batch = 1, one 10 s clip) as a rate
                    "audio_seconds_per_sec": round(CLIP_SECONDS / (statistics.median(tot) * 1e-3), 1)}
 
-    # ---- CPU baseline: the numpy oracle on this box's host cores (rank 0, N = 1 only) ----
+    # ---- CPU baseline on this box's host cores (rank 0, N = 1 only).  The reference's own CPU path (ONNX Runtime + int8
+    # .ort graphs) is not buildable, so two stand-ins are timed on a bounded sample and the FASTER one
+    # is `cpu_baseline`: (a) HuggingFace Moonshine fp32 eager, batched, all cores (the stand-in SURVEY section 8d names);
+    # (b) the numpy oracle, one clip at a time. ----
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import moonshine_ref as ref  # checker / baseline only, never on the GPU path
+    if world == 1 and not args.no_cpu_baseline and args.cpu_clips > 0:
+        from oracle import hf_baseline  # checker / baseline only, never on the GPU path
+        from oracle import moonshine_ref as ref
 
-        n_clips = args.cpu_clips
+        cands = []
+        cores = os.cpu_count() or 1
+        try:
+            threads = min(cores, 64)
+            nb, per = 48, 16   # three batches of 16: ~15 s of wall time on a 64-thread host
+            toks_hf, dt = hf_baseline.run(cfg, w, host[:nb], args.decode_steps, per, threads)
+            cands.append({"value": round(nb * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": threads,
+                          "host_cores_visible": cores, "kind": "port",
+                          "sample": f"{nb} clips x 10 s in batches of {per}, {args.decode_steps} forced decode steps, HuggingFace "
+                                    f"MoonshineForConditionalGeneration fp32 eager (torch {threads} threads), {dt:.1f} s of wall time; "
+                                    "stand-in for the reference's CPU-ORT int8 path, which cannot be built here",
+                          "clips_with_ids_equal_to_gpu": sum(int(a == list(b)) for a, b in zip(toks_hf, serial_ref[:nb]))})
+        except Exception as e:  # transformers missing / incompatible: keep the numpy port
+            print(f"HF CPU baseline skipped: {e}", file=sys.stderr)
+        n_clips = min(args.cpu_clips, 3)
         ref.transcribe_tokens(w, cfg, host[0][:32000], ignore_eos=True)  # warm BLAS threads
         t0 = time.perf_counter()
         for i in range(n_clips):
@@ -371,11 +424,29 @@ def main():
 
             blas_threads = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
         except Exception:
-            blas_threads = os.cpu_count()
-        cpu = {"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": blas_threads,
-               "host_cores_visible": os.cpu_count(),
-               "kind": "port", "sample": f"{n_clips} clips x 10 s, {args.decode_steps} forced decode steps, batch 1, "
-               f"numpy fp32 oracle (multi-threaded BLAS), {dt:.1f} s of CPU time"}
+            blas_threads = cores
+        cands.append({"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": blas_threads,
+                      "host_cores_visible": cores, "kind": "port",
+                      "sample": f"{n_clips} clips x 10 s, {args.decode_steps} forced decode steps, batch 1, numpy fp32 oracle "
+                                f"(multi-threaded BLAS), {dt:.1f} s of CPU time"})
+        cands.sort(key=lambda c: -c["value"])
+        cpu = dict(cands[0])
+        cpu["other_cpu_baselines"] = cands[1:]
+        # the >= 100x target of BASELINE.json is judged against whichever CPU number was measured; a large ratio says
+        # nothing about kernel quality (the roofline fraction does)
+        cpu["gpu_over_cpu"] = {"overlapped": round(value / cpu["value"], 1),
+                               "serial": round(serial["value"] / cpu["value"], 1) if serial else None}
+
+    # ---- BASELINE config 5 (streaming, speculative decode) as a short sub-run, so that it is driver-measured too ----
+    streaming = None
+    if world == 1 and not args.no_streaming:
+        try:
+            eng.set_batches_in_flight(0)
+            sl = run_streaming(args, 2, 1, local_rank, rank, world, dev, None)
+            streaming = {"value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"], "steps": sl["steps"],
+                         "workload": sl["config"]["workload"], "data": sl["data"], **sl["streaming"]}
+        except Exception as e:
+            print(f"streaming sub-run failed: {e}", file=sys.stderr)
 
     line = {
         "metric": "audio-seconds/sec (RTF^-1), Moonshine-base 10 s @ 16 kHz clips",
@@ -398,11 +469,15 @@ def main():
                    # the timed region still contains exactly `steps` complete passes
                    "batches_in_flight": F, "ids_match_serial_pass": ids_match},
         "serial_steps": serial,
+        "pcie_inclusive": pcie,
+        "streaming_config5": streaming,
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
             "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"],
-            # HIP events around every launch of one extra step that runs ALONE on the GPU (no other batch in flight):
-            # the kernel's own speed; with batches in flight the same launches stretch (profiles/*_inflight.csv)
-            "measured_in": "25 back-to-back sweeps over the 8 layers' cross K/V between one HIP-event pair, GPU otherwise idle",
+            # measured live with HIP events around a replayed hipGraph that holds only this kernel's launches of 4 decode
+            # steps (8 layers each, the real step's arguments), GPU otherwise idle; with batches in flight the same
+            # launches stretch (profiles/*_inflight.csv).  rocprofv3's kernel duration of the same launches is in profiles/.
+            "measured_in": dominant.get("timed_in", "HIP-event scope around every launch"),
+            "ms_per_launch_back_to_back_sweep": sweep_ms,
             "ms_per_launch_with_event_scope": per_scope_ms,
             # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s is the spec figure, a float4 copy measures 6.29 TB/s (79 %)
             "measured_copy_peak": 6290.0, "frac_of_measured_copy_peak": round(dominant["achieved"] / 6290.0, 4) if dominant["unit"] == "GB/s" else None, "share_of_profiled_time": round(dominant["total_ms"] / prof_total, 3),

@@ -1,0 +1,69 @@
+"""TEST / BENCH INFRASTRUCTURE ONLY (never on the product path): the CPU baseline SURVEY.md section 8d names as the runnable
+stand-in for the reference's CPU-ORT path -- HuggingFace ``MoonshineForConditionalGeneration`` in fp32 eager mode on the
+host cores, holding the same synthetic weights, fed the same clips, greedy for the same forced number of steps.
+
+The reference's own transcriber (ONNX Runtime 1.23.2 + int8 .ort graphs) cannot run here: neither the runtime library nor
+the graphs are in the checkout.  HF Moonshine is the float definition the reference names as its
+oracle (docs/models/accuracy.md:14-19), so this is "the same arithmetic in fp32 on a tuned CPU BLAS" -- slower per FLOP
+than int8 ORT kernels, which is stated next to the number wherever it is quoted.
+
+``run(cfg, weights, clips, steps, batch, threads)`` -> (token lists, seconds).  Clips of one call must have equal length
+(they are batched without an attention mask, like the reference's fixed batch of one).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+
+def build_hf(cfg, w):
+    import torch
+    from transformers import MoonshineConfig, MoonshineForConditionalGeneration
+
+    hcfg = MoonshineConfig(
+        vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.ffn,
+        encoder_num_hidden_layers=cfg.enc_layers, decoder_num_hidden_layers=cfg.dec_layers,
+        encoder_num_attention_heads=cfg.heads, decoder_num_attention_heads=cfg.heads)
+    hcfg._attn_implementation = "eager"
+    m = MoonshineForConditionalGeneration(hcfg).eval()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in k or "inv_freq" in k for k in missing), missing
+    return m
+
+
+def greedy(model, cfg, clips: np.ndarray, steps: int) -> list[list[int]]:
+    """clips [B, n] fp32 -> B token lists (BOS + `steps` ids, EOS ignored): encoder once, then one decoder call per
+    step on the KV cache -- the loop of reference core/moonshine-model.cpp:380-517 with a batch dimension."""
+    import torch
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+
+    with torch.no_grad():
+        x = torch.from_numpy(np.ascontiguousarray(clips))
+        enc_out = model.model.encoder(x)
+        past = EncoderDecoderCache(DynamicCache(config=model.config), DynamicCache(config=model.config))
+        B = x.shape[0]
+        cur = torch.full((B, 1), cfg.bos, dtype=torch.long)
+        toks = [cur]
+        for _ in range(steps):
+            out = model(decoder_input_ids=cur, encoder_outputs=enc_out, past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            cur = out.logits[:, -1].argmax(dim=-1, keepdim=True)   # lowest index among ties, like the reference scan
+            toks.append(cur)
+        return torch.cat(toks, dim=1).tolist()
+
+
+def run(cfg, w, clips: list[np.ndarray], steps: int, batch: int, threads: int):
+    import torch
+
+    torch.set_num_threads(max(1, threads))
+    model = build_hf(cfg, w)
+    greedy(model, cfg, np.stack(clips[:1])[:, :32000], 2)   # warm up the thread pool / allocator
+    out = []
+    t0 = time.perf_counter()
+    for i in range(0, len(clips), batch):
+        out += greedy(model, cfg, np.stack(clips[i:i + batch]), steps)
+    return out, time.perf_counter() - t0
