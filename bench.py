@@ -227,7 +227,7 @@ def main():
     # every rank's shard is resident in its own HBM, which is where the timed region starts.
     B = args.batch
     host = np.stack([make_audio(i, CLIP_SAMPLES) for i in range(world * B)]) if rank == 0 else None
-    audio, lens = msd.scatter_clips(list(host) if rank == 0 else None, world, rank, dev)
+    audio, lens, plan = msd.scatter_clips(list(host) if rank == 0 else None, world, rank, dev)
     assert audio.shape[0] == B and all(n == CLIP_SAMPLES for n in lens)
     torch.cuda.synchronize()
     ptrs = [(audio[i].data_ptr(), CLIP_SAMPLES) for i in range(B)]
@@ -236,7 +236,7 @@ def main():
     def step():
         toks = eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)
         # gather of the ids: the only collective on the path
-        return msd.gather_tokens(toks, world * B, world, rank, dev)
+        return msd.gather_tokens(toks, plan, world, rank, dev)
 
     F = max(1, args.in_flight)
 
@@ -248,7 +248,7 @@ def main():
             return out
         tickets = [eng.submit_transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps) for _ in range(k)]
         for t in tickets:
-            out = msd.gather_tokens(eng.wait_tokens(t), world * B, world, rank, dev)
+            out = msd.gather_tokens(eng.wait_tokens(t), plan, world, rank, dev)
         return out
 
     serial_ref = step()  # primary engine: allocates its workspace, captures its decode graph (also used by the profiling pass)

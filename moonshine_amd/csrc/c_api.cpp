@@ -82,7 +82,12 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "use_speculative_decoding") o->use_speculative_decoding = parse_bool(v);
     else if (k == "max_streams") o->max_streams = parse_int32(v);                  // additive (streaming archs)
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
-    else if (k == "batch_clips") o->batch_clips = parse_int32(v);                   // additive (batch calls)
+    else if (k == "batch_clips" || k == "max_batch_size") o->batch_clips = parse_int32(v);  // additive (batch calls; SURVEY 8b names it max_batch_size)
+    else if (k == "num_gpus") o->num_gpus = parse_int32(v);                         // additive: shard batch calls over GPUs device .. device+n-1 (-1 = all)
+    else if (k == "devices") {                                                      // additive: explicit GPU list, e.g. "0,1,2,3"
+      o->device_ids.clear();
+      for (const std::string& t : parse_keyterms(v)) o->device_ids.push_back(parse_int32(t));
+    }
     else if (k == "batches_in_flight") o->batches_in_flight = parse_int32(v);       // additive (batch calls)
     else if (k == "hw_queues") {                                                    // additive: see msh_set_hw_queues
       if (msh_set_hw_queues(parse_int32(v)) != MSH_OK) throw std::runtime_error("option 'hw_queues' must be 1..64");

@@ -6,6 +6,8 @@
 #include <chrono>
 #include <random>
 #include <stdexcept>
+#include <thread>
+#include <algorithm>
 
 #include "host_utils.h"
 
@@ -14,16 +16,27 @@ namespace msh_host {
 // ------------------------------------------------------------------------------------------------
 // MoonshineModel
 // ------------------------------------------------------------------------------------------------
-MoonshineModel::MoonshineModel(bool log_run, float mtps, int device) : max_tokens_per_second(mtps), log_ort_run(log_run) {
-  const int32_t rc = msh_create(device, &engine);
-  if (rc != MSH_OK) {
-    const std::string why = msh_last_error(nullptr);
-    throw std::runtime_error("cannot create the MI355X engine (status " + std::to_string(rc) + "): " + why);
+MoonshineModel::MoonshineModel(bool log_run, float mtps, const std::vector<int>& device_ids)
+    : max_tokens_per_second(mtps), log_ort_run(log_run) {
+  if (device_ids.empty()) throw std::runtime_error("no GPU selected");
+  for (int dev : device_ids) {
+    DeviceShard d;
+    d.device = dev;
+    const int32_t rc = msh_create(dev, &d.engine);
+    if (rc != MSH_OK) {
+      const std::string why = msh_last_error(nullptr);
+      for (DeviceShard& o : devices) msh_destroy(o.engine);
+      devices.clear();
+      throw std::runtime_error("cannot create the MI355X engine on device " + std::to_string(dev) + " (status " +
+                               std::to_string(rc) + "): " + why);
+    }
+    devices.push_back(d);
   }
+  engine = devices[0].engine;
 }
 
 MoonshineModel::~MoonshineModel() {
-  msh_destroy(engine);
+  for (DeviceShard& d : devices) msh_destroy(d.engine);
   delete tokenizer;
 }
 
@@ -31,10 +44,11 @@ std::string MoonshineModel::error() const { return msh_last_error(engine); }
 
 int MoonshineModel::load(const char* weights_path, const char* tokenizer_path, int32_t model_type) {
   if (weights_path == nullptr || tokenizer_path == nullptr) return 1;
-  if (msh_load_weights_file(engine, weights_path, model_type) != MSH_OK) {
-    MSH_LOGF("Failed to load weights from '%s': %s", weights_path, error().c_str());
-    return 1;
-  }
+  for (DeviceShard& d : devices)   // replicated weights: every device reads the file itself, nothing is broadcast
+    if (msh_load_weights_file(d.engine, weights_path, model_type) != MSH_OK) {
+      MSH_LOGF("Failed to load weights from '%s' on device %d: %s", weights_path, d.device, msh_last_error(d.engine));
+      return 1;
+    }
   tokenizer = BinTokenizer::from_file(tokenizer_path);
   return 0;
 }
@@ -42,11 +56,77 @@ int MoonshineModel::load(const char* weights_path, const char* tokenizer_path, i
 int MoonshineModel::load_from_memory(const uint8_t* weights, size_t weights_size, const uint8_t* tokenizer_data,
                                      size_t tokenizer_size, int32_t model_type) {
   if (weights == nullptr || tokenizer_data == nullptr) return 1;
-  if (msh_load_weights_memory(engine, weights, weights_size, model_type) != MSH_OK) {
-    MSH_LOGF("Failed to load weights from memory: %s", error().c_str());
-    return 1;
-  }
+  for (DeviceShard& d : devices)
+    if (msh_load_weights_memory(d.engine, weights, weights_size, model_type) != MSH_OK) {
+      MSH_LOGF("Failed to load weights from memory on device %d: %s", d.device, msh_last_error(d.engine));
+      return 1;
+    }
   tokenizer = new BinTokenizer(tokenizer_data, tokenizer_size);
+  return 0;
+}
+
+int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx, const std::vector<const float*>& audio,
+                              const std::vector<uint64_t>& lens, std::vector<std::vector<int32_t>>* ids) {
+  const uint32_t count = (uint32_t)idx.size();
+  if (count == 0) return 0;
+  std::vector<const float*> pcm(count);
+  std::vector<uint64_t> n(count);
+  size_t longest = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    pcm[i] = audio[idx[i]];
+    n[i] = lens[idx[i]];
+    longest = std::max<size_t>(longest, (size_t)n[i]);
+  }
+  const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
+  // rows wide enough for the step budget of the longest clip (the engine's rule: ceil(seconds * tokens/s)) + BOS
+  const int32_t stride = (int32_t)ceilf((float)longest / 16000.0f * max_tokens_per_second) + 2;
+  std::vector<int32_t> tokens((size_t)count * stride, 0), counts(count, 0);
+  if (count <= chunk || batches_in_flight <= 1) {
+    for (uint32_t lo = 0; lo < count; lo += chunk) {  // one sub-batch after the other on the engine itself
+      const uint32_t m = std::min(chunk, count - lo);
+      if (msh_encode(d.engine, pcm.data() + lo, n.data() + lo, m, 0, max_tokens_per_second) != MSH_OK) {
+        MSH_LOGF("encoder failed on device %d: %s", d.device, msh_last_error(d.engine));
+        return 1;
+      }
+      if (msh_max_decode_steps(d.engine) + 1 > stride) {
+        MSH_LOGF("internal: step budget %d above the token row width %d", msh_max_decode_steps(d.engine), stride);
+        return 1;
+      }
+      if (msh_decode(d.engine, -1, nullptr, 0, nullptr, 0, tokens.data() + (size_t)lo * stride, counts.data() + lo, stride) != MSH_OK) {
+        MSH_LOGF("decoder failed on device %d: %s", d.device, msh_last_error(d.engine));
+        return 1;
+      }
+    }
+  } else {
+    if (!d.lanes_ready) {
+      if (msh_set_batches_in_flight(d.engine, batches_in_flight) != MSH_OK) {
+        MSH_LOGF("batches in flight on device %d: %s", d.device, msh_last_error(d.engine));
+        return 1;
+      }
+      d.lanes_ready = true;
+    }
+    std::vector<int64_t> tickets;
+    bool failed = false;
+    for (uint32_t lo = 0; lo < count; lo += chunk) {
+      const uint32_t m = std::min(chunk, count - lo);
+      const int64_t t = msh_submit_transcribe_tokens(d.engine, pcm.data() + lo, n.data() + lo, m, 0, max_tokens_per_second, -1,
+                                                     tokens.data() + (size_t)lo * stride, counts.data() + lo, stride);
+      if (t < 0) {
+        MSH_LOGF("submit failed on device %d: %s", d.device, msh_last_error(d.engine));
+        failed = true;
+        break;
+      }
+      tickets.push_back(t);
+    }
+    for (int64_t t : tickets)  // every queued sub-batch is waited for, also after a failure: they write into `tokens`
+      if (msh_wait(d.engine, t) != MSH_OK) {
+        MSH_LOGF("sub-batch failed on device %d: %s", d.device, msh_last_error(d.engine));
+        failed = true;
+      }
+    if (failed) return 1;
+  }
+  for (uint32_t i = 0; i < count; ++i)
+    (*ids)[idx[i]].assign(tokens.begin() + (size_t)i * stride, tokens.begin() + (size_t)i * stride + counts[i]);
   return 0;
 }
 
@@ -60,17 +140,14 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
   if (msh_set_capture_cross_attention(engine, want_words ? 1 : 0) != MSH_OK) return 1;
   if (count == 0) return 0;
   std::vector<uint64_t> lens(n_samples.begin(), n_samples.end());
-  if (log_ort_run) {
-    msh_profile_reset(engine);
-    msh_profile_enable(engine, 1);
-  }
-  const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
-  std::vector<int32_t> tokens, counts(count);
-  int32_t stride = 0;
-  if (count <= chunk || batches_in_flight <= 1 || log_ort_run || want_words) {
-    // one sub-batch after the other on the engine itself
-    std::vector<std::vector<int32_t>> parts;
-    std::vector<int32_t> strides;
+  std::vector<std::vector<int32_t>> ids(count);
+  if (log_ort_run || want_words) {
+    // diagnostic / word-timestamp calls: one sub-batch after the other on the first device
+    if (log_ort_run) {
+      msh_profile_reset(engine);
+      msh_profile_enable(engine, 1);
+    }
+    const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
     for (uint32_t lo = 0; lo < count; lo += chunk) {
       const uint32_t n = std::min(chunk, count - lo);
       if (msh_encode(engine, audio.data() + lo, lens.data() + lo, n, 0, max_tokens_per_second) != MSH_OK) {
@@ -78,12 +155,12 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
         return 1;
       }
       const int32_t st = msh_max_decode_steps(engine) + 1;
-      parts.emplace_back((size_t)n * st);
-      strides.push_back(st);
-      if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, parts.back().data(), counts.data() + lo, st) != MSH_OK) {
+      std::vector<int32_t> part((size_t)n * st), counts(n);
+      if (msh_decode(engine, -1, nullptr, 0, nullptr, 0, part.data(), counts.data(), st) != MSH_OK) {
         MSH_LOGF("decoder failed: %s", error().c_str());
         return 1;
       }
+      for (uint32_t i = 0; i < n; ++i) ids[lo + i].assign(part.begin() + (size_t)i * st, part.begin() + (size_t)i * st + counts[i]);
       if (want_words) {  // the attention of this sub-batch is only on the device until the next decode
         std::vector<float> att;
         for (uint32_t i = 0; i < n; ++i) {
@@ -93,65 +170,65 @@ int MoonshineModel::transcribe_batch(const std::vector<const float*>& audio, con
             MSH_LOGF("cross-attention not available: %s", error().c_str());
             return 1;
           }
-          if (need == 0 || counts[lo + i] < 2) continue;
+          if (need == 0 || counts[i] < 2) continue;
           att.resize((size_t)need);
           if (msh_get_cross_attention(engine, i, att.data(), (uint64_t)att.size(), dims) < 0) return 1;
-          const int32_t* row = parts.back().data() + (size_t)i * st;
-          const std::vector<int32_t> ids(row, row + counts[lo + i]);
           // seconds per encoder frame: clip duration / frames (reference core/moonshine-model.cpp:636)
           const float spf = ((float)lens[lo + i] / 16000.0f) / (float)dims[2];
-          (*out_words)[lo + i] = align_words(att.data(), dims[0], dims[1], dims[2], ids, spf, *tokenizer);
+          (*out_words)[lo + i] = align_words(att.data(), dims[0], dims[1], dims[2], ids[lo + i], spf, *tokenizer);
         }
       }
     }
-    size_t p = 0;
-    for (uint32_t lo = 0; lo < count; lo += chunk, ++p)
-      for (uint32_t i = lo; i < std::min(count, lo + chunk); ++i)
-        (*out_texts)[i] = tokenizer->tokens_to_text(parts[p].data() + (size_t)(i - lo) * strides[p], (size_t)counts[i]);
+    if (log_ort_run) {
+      const int32_t n = msh_profile_count(engine);
+      for (int32_t i = 0; i < n; ++i) {
+        msh_profile_entry pe;
+        if (msh_profile_get(engine, i, &pe) == MSH_OK)
+          MSH_LOGF("kernel group %-24s %8.3f ms over %llu launches", pe.name, pe.ms, (unsigned long long)pe.launches);
+      }
+      msh_profile_enable(engine, 0);
+    }
   } else {
-    if (!lanes_ready) {
-      if (msh_set_batches_in_flight(engine, batches_in_flight) != MSH_OK) {
-        MSH_LOGF("batches in flight: %s", error().c_str());
-        return 1;
+    // Sharding: clips are independent end to end, so the only "communication" is handing out
+    // pointers and collecting ids.  The clip list is sorted by length (longest first) and dealt to the devices in
+    // snake order -- every device gets the same mix of lengths, hence the same amount of audio within one clip -- and
+    // each device cuts its share, still sorted, into sub-batches of batch_clips: clips of similar length end up in the
+    // same sub-batch, so little is wasted on padding rows.  (A plain contiguous split of the sorted list, as the survey
+    // words it, would give one GPU all the long clips.)  With one device the order is left as the caller gave it.
+    const size_t nd = std::min<size_t>(devices.size(), count);
+    std::vector<std::vector<uint32_t>> shard(std::max<size_t>(nd, 1));
+    if (nd <= 1) {
+      shard[0].resize(count);
+      for (uint32_t i = 0; i < count; ++i) shard[0][i] = i;
+    } else {
+      std::vector<uint32_t> order(count);
+      for (uint32_t i = 0; i < count; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+      for (uint32_t k = 0; k < count; ++k) {
+        const size_t round = k / nd, pos = k % nd;
+        shard[(round & 1) ? nd - 1 - pos : pos].push_back(order[k]);
       }
-      lanes_ready = true;
     }
-    // rows wide enough for the step budget of the longest clip (the engine's rule: ceil(seconds * tokens/s)) + BOS
-    size_t longest = 0;
-    for (uint64_t n : lens) longest = std::max<size_t>(longest, (size_t)n);
-    stride = (int32_t)ceilf((float)longest / 16000.0f * max_tokens_per_second) + 2;
-    tokens.assign((size_t)count * stride, 0);
-    std::vector<int64_t> tickets;
-    bool failed = false;
-    for (uint32_t lo = 0; lo < count; lo += chunk) {
-      const uint32_t n = std::min(chunk, count - lo);
-      const int64_t t = msh_submit_transcribe_tokens(engine, audio.data() + lo, lens.data() + lo, n, 0, max_tokens_per_second, -1,
-                                                     tokens.data() + (size_t)lo * stride, counts.data() + lo, stride);
-      if (t < 0) {
-        MSH_LOGF("submit failed: %s", error().c_str());
-        failed = true;
-        break;
-      }
-      tickets.push_back(t);
+    std::vector<int> rc(shard.size(), 0);
+    if (shard.size() == 1) {
+      rc[0] = run_shard(devices[0], shard[0], audio, lens, &ids);
+    } else {
+      std::vector<std::thread> workers;
+      for (size_t d = 0; d < shard.size(); ++d)
+        workers.emplace_back([&, d] {
+          try {
+            rc[d] = run_shard(devices[d], shard[d], audio, lens, &ids);
+          } catch (const std::exception& e) {
+            MSH_LOGF("device %d: %s", devices[d].device, e.what());
+            rc[d] = 1;
+          }
+        });
+      for (std::thread& t : workers) t.join();
     }
-    for (int64_t t : tickets)  // every queued sub-batch is waited for, also after a failure: they write into `tokens`
-      if (msh_wait(engine, t) != MSH_OK) {
-        MSH_LOGF("sub-batch failed: %s", error().c_str());
-        failed = true;
-      }
-    if (failed) return 1;
-    for (uint32_t i = 0; i < count; ++i)
-      (*out_texts)[i] = tokenizer->tokens_to_text(tokens.data() + (size_t)i * stride, (size_t)counts[i]);
+    for (int r : rc)
+      if (r != 0) return 1;
   }
-  if (log_ort_run) {
-    const int32_t n = msh_profile_count(engine);
-    for (int32_t i = 0; i < n; ++i) {
-      msh_profile_entry pe;
-      if (msh_profile_get(engine, i, &pe) == MSH_OK)
-        MSH_LOGF("kernel group %-24s %8.3f ms over %llu launches", pe.name, pe.ms, (unsigned long long)pe.launches);
-    }
-    msh_profile_enable(engine, 0);
-  }
+  for (uint32_t i = 0; i < count; ++i) (*out_texts)[i] = tokenizer->tokens_to_text(ids[i].data(), ids[i].size());
   return 0;
 }
 
@@ -279,7 +356,21 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
     const double by_steps = 504.0 / (double)opt_.max_tokens_per_second, by_frames = 8192.0 * 384.0 / kSampleRate;
     vad_hard_cap_ = (size_t)((by_steps < by_frames ? by_steps : by_frames) * kSampleRate);
   }
-  model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, opt_.device));
+  {
+    std::vector<int> ids = opt_.device_ids;
+    if (ids.empty()) {
+      int n = opt_.num_gpus;
+      if (n < 0) n = msh_device_count() - opt_.device;   // every visible GPU from `device` on
+      if (n < 1) n = 1;
+      for (int i = 0; i < n; ++i) ids.push_back(opt_.device + i);
+    }
+    const int visible = msh_device_count();
+    for (int d : ids)
+      if (d < 0 || d >= visible)
+        throw std::runtime_error("GPU " + std::to_string(d) + " requested (options device / num_gpus / devices) but only " +
+                                 std::to_string(visible) + " visible");
+    model_.reset(new MoonshineModel(opt_.log_ort_run, opt_.max_tokens_per_second, ids));
+  }
   model_->batch_clips = opt_.batch_clips;
   model_->batches_in_flight = opt_.batches_in_flight;
   model_->word_timestamps = opt_.word_timestamps;

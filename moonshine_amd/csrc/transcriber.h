@@ -27,7 +27,15 @@
 namespace msh_host {
 
 struct MoonshineModel {
-  msh_engine* engine = nullptr;
+  msh_engine* engine = nullptr;          // devices[0]
+  // utterance-batch data parallelism inside one process: one engine per GPU, every one holding
+  // its own copy of the weights; a batch call shards its clips over them, one host thread per device, no collective
+  struct DeviceShard {
+    msh_engine* engine = nullptr;
+    int device = 0;
+    bool lanes_ready = false;
+  };
+  std::vector<DeviceShard> devices;
   BinTokenizer* tokenizer = nullptr;
   std::mutex processing_mutex;
   float max_tokens_per_second = 6.5f;  // reference core/moonshine-model.h:49
@@ -36,13 +44,14 @@ struct MoonshineModel {
   // run on the GPU at once (include/moonshine_hip.h, msh_set_batches_in_flight); 1 = one sub-batch after the other
   int batch_clips = 256;
   int batches_in_flight = 2;
-  bool lanes_ready = false;
   // word timestamps (reference core/moonshine-model.cpp:600-645): with this on, transcribe_batch also keeps the device's
   // cross-attention and fills out_words[i] through align_words (times relative to the clip start)
   bool word_timestamps = false;
   std::string last_result;
 
-  MoonshineModel(bool log_ort_run, float max_tokens_per_second, int device);
+  // device_ids: the GPUs to use (an id may repeat: two engines on one GPU, which is how the sharding is tested on a
+  // single-GPU box)
+  MoonshineModel(bool log_ort_run, float max_tokens_per_second, const std::vector<int>& device_ids);
   ~MoonshineModel();
   // model_type: MOONSHINE_MODEL_ARCH_TINY / _BASE.  Both return 0 on success (reference convention).
   int load(const char* weights_path, const char* tokenizer_path, int32_t model_type);
@@ -55,6 +64,12 @@ struct MoonshineModel {
   int transcribe_batch(const std::vector<const float*>& audio, const std::vector<size_t>& n_samples,
                        std::vector<std::string>* out_texts, std::vector<std::vector<TranscriberWord>>* out_words = nullptr);
   std::string error() const;
+
+ private:
+  // clips `idx` (indices into audio / lens) on one device: sub-batches of batch_clips, batches_in_flight of them at once;
+  // ids[i] receives the token ids of clip i.  Returns 0 on success (the reference's status convention).
+  int run_shard(DeviceShard& d, const std::vector<uint32_t>& idx, const std::vector<const float*>& audio,
+                const std::vector<uint64_t>& lens, std::vector<std::vector<int32_t>>* ids);
 };
 
 struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields this build honours)
@@ -87,6 +102,8 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   bool log_ort_run = false;
   std::string save_input_wav_path;
   int device = 0;
+  int num_gpus = 1;                      // additive: GPUs device .. device + num_gpus - 1; -1 = every visible GPU
+  std::vector<int> device_ids;           // additive: explicit GPU list ("devices" option), overrides device / num_gpus
 };
 
 struct TranscriberLine {

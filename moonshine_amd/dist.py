@@ -34,33 +34,48 @@ def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def scatter_clips(clips: list[np.ndarray] | None, world: int, rank: int, device: torch.device) -> tuple[torch.Tensor, list[int]]:
-    """Rank 0 passes the full clip list, the others None.  Every rank returns (padded [n_local, max_len]
-    float32 tensor on ``device``, true lengths).  One scatter of lengths + one scatter of samples."""
+def shard_plan(lens: list[int], world: int) -> list[list[int]]:
+    """Which clips go to which rank -- the rule of the C++ host layer (moonshine_amd/csrc/transcriber.cpp,
+    MoonshineModel::transcribe_batch): sort by length, longest first (stable), deal the sorted list to the ranks in
+    snake order.  Every rank gets the same mix of lengths (equal audio within one clip) and its own list stays sorted, so
+    its sub-batches hold clips of similar length.  world == 1 keeps the caller's order."""
+    n = len(lens)
+    if world <= 1:
+        return [list(range(n))]
+    order = sorted(range(n), key=lambda i: -lens[i])   # stable: ties keep the caller's order
+    plan: list[list[int]] = [[] for _ in range(world)]
+    for k, i in enumerate(order):
+        rnd, pos = divmod(k, world)
+        plan[world - 1 - pos if rnd & 1 else pos].append(i)
+    return plan
+
+
+def scatter_clips(clips: list[np.ndarray] | None, world: int, rank: int, device: torch.device):
+    """Rank 0 passes the full clip list, the others None.  Every rank returns (padded [n_local, max_len] float32 tensor on
+    ``device``, true lengths, plan) where plan = shard_plan of the whole list (gather_tokens needs it to restore the
+    caller's order).  One broadcast of the plan, one scatter of lengths, one scatter of samples."""
     if world == 1:
         assert clips is not None
         lens = [int(c.shape[0]) for c in clips]
         buf = np.zeros((len(clips), max(lens)), np.float32)
         for i, c in enumerate(clips):
             buf[i, : lens[i]] = c
-        return torch.from_numpy(buf).to(device), lens
+        return torch.from_numpy(buf).to(device), lens, shard_plan(lens, 1)
     meta = [None]
     if rank == 0:
         lens_all = [int(c.shape[0]) for c in clips]
-        meta = [(len(clips), max(lens_all))]
+        meta = [(shard_plan(lens_all, world), max(lens_all))]
     dist.broadcast_object_list(meta, src=0)
-    n, max_len = meta[0]
-    counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
-    per = max(counts)  # equal-sized scatter chunks (padded with empty clips)
+    plan, max_len = meta[0]
+    per = max(len(p) for p in plan)  # equal-sized scatter chunks (padded with empty clips)
     lens_local = torch.zeros(per, dtype=torch.int64, device=device)
     audio_local = torch.zeros((per, max_len), dtype=torch.float32, device=device)
     if rank == 0:
         lens_chunks, audio_chunks = [], []
         for r in range(world):
-            lo, hi = shard_bounds(n, r, world)
             lt = torch.zeros(per, dtype=torch.int64)
             at = torch.zeros((per, max_len), dtype=torch.float32)
-            for j, i in enumerate(range(lo, hi)):
+            for j, i in enumerate(plan[r]):
                 lt[j] = lens_all[i]
                 at[j, : lens_all[i]] = torch.from_numpy(np.ascontiguousarray(clips[i], dtype=np.float32))
             lens_chunks.append(lt.to(device))
@@ -70,16 +85,15 @@ def scatter_clips(clips: list[np.ndarray] | None, world: int, rank: int, device:
     else:
         dist.scatter(lens_local, None, src=0)
         dist.scatter(audio_local, None, src=0)
-    k = counts[rank]
-    return audio_local[:k], [int(v) for v in lens_local[:k].tolist()]
+    k = len(plan[rank])
+    return audio_local[:k], [int(v) for v in lens_local[:k].tolist()], plan
 
 
-def gather_tokens(local: list[list[int]], n_total: int, world: int, rank: int, device: torch.device) -> list[list[int]]:
-    """All ranks receive the token lists of every clip, in global clip order."""
+def gather_tokens(local: list[list[int]], plan: list[list[int]], world: int, rank: int, device: torch.device) -> list[list[int]]:
+    """All ranks receive the token lists of every clip, in the caller's clip order (plan from scatter_clips)."""
     if world == 1:
         return local
-    counts = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
-    per = max(counts)
+    per = max(len(p) for p in plan)
     width = torch.tensor([max((len(t) for t in local), default=0)], dtype=torch.int64, device=device)
     dist.all_reduce(width, op=dist.ReduceOp.MAX)
     w = int(width.item())
@@ -92,11 +106,11 @@ def gather_tokens(local: list[list[int]], n_total: int, world: int, rank: int, d
     out = torch.empty((world * per, w + 1), dtype=torch.int32, device=device)  # concatenated along dim 0
     dist.all_gather_into_tensor(out, mine)
     out = out.view(world, per, w + 1).cpu().numpy()
-    res: list[list[int]] = []
+    res: list[list[int]] = [[] for _ in range(sum(len(p) for p in plan))]
     for r in range(world):
-        for i in range(counts[r]):
-            n = int(out[r, i, 0])
-            res.append(out[r, i, 1 : 1 + n].tolist())
+        for j, i in enumerate(plan[r]):
+            n = int(out[r, j, 0])
+            res[i] = out[r, j, 1 : 1 + n].tolist()
     return res
 
 

@@ -1,8 +1,10 @@
-"""Data-parallel plumbing on CPU: 2 ranks over gloo.  Rank 0 scatters a ragged clip list, every rank
-"transcribes" its shard with a deterministic stand-in (a pure function of the samples, so any
-mis-routing shows), ids are gathered, and every rank must reconstruct exactly what a single process
-produces.  The GPU engine itself is exercised by the -m gpu tests; this covers shard / scatter /
-gather / timing-reduction used by bench.py at N > 1."""
+"""Data-parallel plumbing on CPU: 2 ranks over gloo.  Rank 0 owns a RAGGED clip list (lengths from 0.06 s to 10 s, as
+real utterance batches are); the list is sharded by the rule of the C++ host layer (length-sorted, snake deal:
+moonshine_amd.dist.shard_plan == MoonshineModel::transcribe_batch), scattered, every rank "transcribes" its shard in
+engine-shaped sub-batches (sorted by length, padded to the sub-batch's longest clip -- a stand-in that is a pure function
+of each clip's own samples, so any mis-routing, padding leak or order mix-up shows), ids are gathered, and every rank must
+reconstruct exactly ids(1 process) in the caller's order.  The GPU engine itself is exercised by the -m gpu tests; this
+covers plan / scatter / gather / timing-reduction used by bench.py at N > 1."""
 import os
 import socket
 
@@ -18,9 +20,23 @@ def _fake_tokens(clip: np.ndarray) -> list[int]:
     return [1] + [int(abs(float(clip[(k * 131) % clip.shape[0]])) * 1e4) % 32768 for k in range(n)]
 
 
+def _fake_engine(audio: torch.Tensor, lens: list[int], sub_batch: int = 3) -> list[list[int]]:
+    """What the engine does with a shard: sub-batches in the given (length-sorted) order, each padded to its longest clip."""
+    out = []
+    for lo in range(0, len(lens), sub_batch):
+        part = lens[lo:lo + sub_batch]
+        width = max(part)
+        block = audio[lo:lo + len(part), :width].numpy()
+        for j, n in enumerate(part):
+            out.append(_fake_tokens(block[j, :n]))
+    return out
+
+
 def _clips(n):
     rng = np.random.default_rng(5)
-    return [rng.standard_normal(int(rng.integers(900, 5000))).astype(np.float32) for _ in range(n)]
+    lens = rng.integers(900, 160000, n)
+    lens[1] = lens[4]            # a tie: the stable sort keeps the caller's order
+    return [rng.standard_normal(int(k)).astype(np.float32) for k in lens]
 
 
 def _worker(rank, world, port, n_clips, q):
@@ -29,13 +45,13 @@ def _worker(rank, world, port, n_clips, q):
     r, w = msd.init_from_env("gloo")
     assert (r, w) == (rank, world)
     clips = _clips(n_clips) if rank == 0 else None
-    audio, lens = msd.scatter_clips(clips, world, rank, dev)
-    lo, hi = msd.shard_bounds(n_clips, rank, world)
-    assert audio.shape[0] == hi - lo == len(lens)
-    local = [_fake_tokens(audio[i, : lens[i]].numpy()) for i in range(len(lens))]
-    allt = msd.gather_tokens(local, n_clips, world, rank, dev)
+    audio, lens, plan = msd.scatter_clips(clips, world, rank, dev)
+    assert audio.shape[0] == len(plan[rank]) == len(lens)
+    assert lens == sorted(lens, reverse=True)        # a rank's shard arrives longest first
+    local = _fake_engine(audio, lens)
+    allt = msd.gather_tokens(local, plan, world, rank, dev)
     tmax = msd.max_over_ranks(1.0 + rank, world, dev)
-    q.put((rank, allt, tmax))
+    q.put((rank, allt, tmax, sum(lens)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -48,8 +64,8 @@ def _free_port():
     return p
 
 
-def test_two_rank_scatter_gather_equals_single_process():
-    n_clips, world = 7, 2  # odd count: uneven shards
+def test_two_rank_ids_equal_single_process():
+    n_clips, world = 11, 2  # odd count: uneven shards
     want = [_fake_tokens(c) for c in _clips(n_clips)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -61,9 +77,29 @@ def test_two_rank_scatter_gather_equals_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, allt, tmax in results:
-        assert allt == want, f"rank {rank} reconstructed a different transcript list"
+    for rank, allt, tmax, _ in results:
+        assert allt == want, f"rank {rank} reconstructed a different transcript list"     # ids(N) == ids(1)
         assert tmax == 2.0
+    audio = sorted(r[3] for r in results)
+    assert audio[1] - audio[0] <= 160000              # the shards hold the same amount of audio within one clip
+
+
+def test_shard_plan_properties():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 256, 2048, 2049):
+        lens = rng.integers(1000, 160000, n).tolist()
+        for world in (1, 2, 3, 8):
+            plan = msd.shard_plan(lens, world)
+            assert len(plan) == world and sorted(i for p in plan for i in p) == list(range(n))
+            sizes = [len(p) for p in plan]
+            assert max(sizes) - min(sizes) <= 1
+            if world > 1 and n:
+                for p in plan:
+                    assert [lens[i] for i in p] == sorted((lens[i] for i in p), reverse=True)
+                tot = [sum(lens[i] for i in p) for p in plan]
+                assert max(tot) - min(tot) <= max(lens)   # balanced within one clip
+    assert msd.shard_plan([5, 9, 7], 1) == [[0, 1, 2]]       # one rank: the caller's order
+    assert msd.shard_plan([5, 9, 7, 9], 2) == [[1, 0], [3, 2]]   # ties keep the caller's order; snake: 9a | 9b, 7 | 5
 
 
 def test_shard_bounds_cover_everything():

@@ -270,3 +270,26 @@ def test_default_vad_threshold_needs_silero_weights_at_load_and_works_with_them(
         text, _ = _expected_text(engine, vocab, audio[s:s + cnt])
         assert l.text_bytes == text
     t.close()
+
+
+def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir):
+    """Additive load options `devices` / `num_gpus` / `max_batch_size`: the batch call shards its
+    clips over one engine per listed GPU inside the C++ host layer (length-sorted snake deal, one host thread per device,
+    replicated weights, no collective) and must return ids(N devices) == ids(1 device), in the caller's order.  The box has
+    one GPU, so the device list names it twice -- two engines, two shards, the same code path as two GPUs."""
+    lens = [16000 + 3111 * ((5 * i + 3) % 17) for i in range(23)] + [900, 160000]
+    clips = [make_audio(500 + i, n) for i, n in enumerate(lens)]
+    want = [[l.text_bytes for l in t] for t in tiny.transcribe_batch_without_streaming(clips)]
+    for opts in ({"devices": "0,0"}, {"devices": "0, 0,0", "max_batch_size": "4", "batches_in_flight": "2"},
+                 {"devices": "0,0", "batch_clips": "5", "batches_in_flight": "1"}):
+        t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", **opts})
+        for _ in range(2):   # second call: warmed lanes on every shard
+            got = [[l.text_bytes for l in r] for r in t.transcribe_batch_without_streaming(clips)]
+            assert got == want, opts
+        assert [l.text_bytes for l in t.transcribe_without_streaming(clips[3])] == want[3]
+        t.close()
+    with pytest.raises(api.MoonshineError):      # more GPUs than the box has: the load fails and says so
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "num_gpus": "2"})
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "num_gpus": "-1"})   # "all visible" = 1 here
+    assert [[l.text_bytes for l in r] for r in t.transcribe_batch_without_streaming(clips[:5])] == want[:5]
+    t.close()
