@@ -101,6 +101,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_host_sanitize_utf8": (C.c_int64, [vp, u64, vp, u64]),
         "msh_host_resample": (C.c_int64, [vp, u64, f32, f32, vp, u64]),
         "msh_set_hw_queues": (i32, [i32]),
+        "msh_host_load_wav": (C.c_int64, [C.c_char_p, vp, u64, vp]),
+        "msh_host_save_wav": (i32, [C.c_char_p, vp, u64, i32]),
         "msh_host_silero_probabilities": (C.c_int64, [vp, u64, vp, u64, vp, u64, vp]),
         "msh_host_vad_segments": (C.c_int64, [vp, u64, f32, C.c_int32, C.c_int32, u64, u64, u64, vp, u64, C.c_int32, u64, vp, u64]),
     }

@@ -293,3 +293,44 @@ def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir):
     t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "num_gpus": "-1"})   # "all visible" = 1 here
     assert [[l.text_bytes for l in r] for r in t.transcribe_batch_without_streaming(clips[:5])] == want[:5]
     t.close()
+
+
+def test_config1_beckett_wav_through_the_c_api(tiny, tiny_dir, engine):
+    """BASELINE config 1: the reference's own fixture test-assets/beckett.wav (16 kHz mono PCM16, 9.963 s; committed as
+    tests/golden/beckett.wav) read by the library's WAV loader and transcribed through the public C API on the tiny
+    architecture.  With synthetic weights the text is not English (the reference's test expects "fail", which needs the
+    real checkpoint: tools/verify_real_checkpoint.py); what is checked is everything else on the path: 159,414 samples ->
+    159,232 after the 512-sample hops -> 413 encoder frames, a budget of 65 tokens, ids equal to
+    the engine's own call on the truncated segment and to the oracle wherever its margin is clear, determinism."""
+    import ctypes as C
+
+    from moonshine_amd.hip_api import load_library
+
+    lib = load_library()
+    path = os.path.join(os.path.dirname(__file__), "golden", "beckett.wav").encode()
+    rate = C.c_int32(0)
+    n = lib.msh_host_load_wav(path, None, 0, C.addressof(rate))
+    assert (n, rate.value) == (159414, 16000)
+    audio = np.zeros(n, np.float32)
+    assert lib.msh_host_load_wav(path, audio.ctypes.data, n, C.addressof(rate)) == n
+    assert 0.05 < float(np.abs(audio).max()) <= 1.0
+    lines = tiny.transcribe_without_streaming(audio)
+    assert len(lines) == 1 and lines[0].is_complete
+    seg = audio[:159232]
+    np.testing.assert_array_equal(lines[0].audio_data, seg)
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    want, toks = _expected_text(engine, vocab, seg)
+    assert lines[0].text_bytes == want
+    assert 2 <= len(toks) <= 66
+    cfg, w = ARCHS["tiny"], tiny_dir[1]
+    enc = ref.encoder_forward(w, cfg, seg)
+    assert enc.shape[0] == 413
+    o_toks, o_lg = ref.greedy_decode(w, cfg, enc, len(toks) - 1, ignore_eos=True, return_logits=True, teacher=toks)
+    checked = 0
+    for i in range(len(toks) - 1):
+        top2 = np.partition(o_lg[i], -2)[-2:]
+        if float(top2[1] - top2[0]) > 0.1:
+            assert toks[i + 1] == o_toks[i + 1], i
+            checked += 1
+    assert checked >= (len(toks) - 1) // 2
+    assert [l.text_bytes for l in tiny.transcribe_without_streaming(audio)] == [want]   # deterministic
