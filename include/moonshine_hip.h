@@ -269,6 +269,14 @@ MSH_EXPORT int32_t msh_stream_process_audio(msh_stream_engine* e, int32_t n, con
 MSH_EXPORT int32_t msh_stream_encode(msh_stream_engine* e, int32_t n, const int32_t* slots, const uint8_t* is_final,
                                      int32_t* new_frames_out);
 MSH_EXPORT int32_t msh_stream_decoder_reset(msh_stream_engine* e, int32_t n, const int32_t* slots);
+/* Word timestamps on the streaming architectures: the cross-attention probabilities of every decoder layer, head and
+ * position for `tokens` fed from an EMPTY self cache (the slot's decoder is reset first and holds these tokens afterwards)
+ * -- what the reference collects call by call from its decoder_kv_with_attention graph
+ * (core/moonshine-streaming-model.cpp:946-1066) and rearranges for align_words (core/transcriber.cpp:1028-1068).
+ * dims3 = {depth*heads, n_tokens, memory_len}; if `out` holds cap_floats >= their product it receives the fp32 block
+ * [depth*heads][n_tokens][memory_len].  Returns the element count or a negative msh error. */
+MSH_EXPORT int64_t msh_stream_cross_attention(msh_stream_engine* e, int32_t slot, const int32_t* tokens, int32_t n_tokens,
+                                              float* out, uint64_t cap_floats, int32_t* dims3);
 MSH_EXPORT int32_t msh_stream_decode_tokens(msh_stream_engine* e, int32_t n, const int32_t* slots,
                                             const int32_t* const* tokens, const int32_t* n_tokens,
                                             float* logits_out);

@@ -363,6 +363,50 @@ __global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16
   }
 }
 
+// Cross-attention PROBABILITIES of a decoder pass, for word timestamps on the streaming architectures (the
+// `cross_attentions.{l}` outputs of the reference's decoder_kv_with_attention graph,
+// core/moonshine-streaming-model.cpp:946-1066): plain two-pass softmax per (row, head) over the stream's memory frames,
+// written to out[row][layer][head][0..mem_len) with row stride L * heads * Ecap.  Only launched while a capture is on.
+__global__ __launch_bounds__(256) void cross_probs_kernel(const bf16_t* __restrict__ q, const int* __restrict__ row_slot,
+                                                          const SlotDev* __restrict__ slots, int D, int heads, int layer,
+                                                          int L, int Mcap, const bf16_t* __restrict__ crossKT, int Ecap,
+                                                          float* __restrict__ out) {
+  __shared__ float sq[128];
+  __shared__ float sp[CROSS_MMAX];
+  __shared__ float red[8];
+  const int row = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int dh = D / heads;
+  const float scale = rsqrtf((float)dh);
+  const int slot = row_slot[row];
+  const int nk = slots[slot].mem_len;
+  for (int d = tid; d < dh; d += 256) sq[d] = bf(q[(long)row * D + head * dh + d]) * scale;
+  __syncthreads();
+  const long base = (((long)slot * L + layer) * D + head * dh) * Mcap;
+  float mx = -INFINITY;
+  for (int j = tid; j < nk; j += 256) {
+    float a = 0.f;
+    for (int d = 0; d < dh; ++d) a += sq[d] * bf(crossKT[base + (long)d * Mcap + j]);
+    sp[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wmax(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int j = tid; j < nk; j += 256) {
+    const float e = __expf(sp[j] - mx);
+    sp[j] = e;
+    sum += e;
+  }
+  sum = wsum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  float* o = out + (((long)row * L + layer) * heads + head) * Ecap;
+  for (int j = tid; j < nk; j += 256) o[j] = sp[j] * inv;
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ pred) {
   __shared__ float bv[4];
@@ -652,6 +696,13 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
                          layer, L, Mcap, crossK, crossV, out);
   }
 #undef MSH_XATT
+}
+void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads, int layer,
+                        int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s) {
+  if (Mcap > CROSS_MMAX || D / heads > 128) throw std::runtime_error("stream_cross_probs: unsupported memory length or head_dim");
+  if (M <= 0) return;
+  hipLaunchKernelGGL(cross_probs_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+                     crossK, Ecap, out);
 }
 void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s) {
   if ((V & 3) != 0) throw std::runtime_error("stream_argmax: vocabulary must be a multiple of 4");

@@ -425,6 +425,17 @@ int32_t msh_stream_decode_tokens(msh_stream_engine* e, int32_t n, const int32_t*
     e->eng->decode_tokens(n, slots, tokens, n_tokens, logits_out);
   });
 }
+int64_t msh_stream_cross_attention(msh_stream_engine* e, int32_t slot, const int32_t* tokens, int32_t n_tokens, float* out,
+                                   uint64_t cap_floats, int32_t* dims3) {
+  int dims[3] = {0, 0, 0};
+  const int32_t rc = guarded(e, [&] {
+    if (tokens == nullptr && n_tokens > 0) throw std::invalid_argument("null tokens");
+    e->eng->cross_attention(slot, tokens, n_tokens, out, (size_t)cap_floats, dims);
+  });
+  if (rc != MSH_OK) return rc;
+  if (dims3 != nullptr) dims3[0] = dims[0], dims3[1] = dims[1], dims3[2] = dims[2];
+  return (int64_t)dims[0] * dims[1] * dims[2];
+}
 int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const int32_t* slots, const int32_t* const* drafts,
                                const int32_t* draft_lens, const int32_t* max_tokens, int32_t* tokens_out,
                                int32_t* counts_out, int32_t tokens_stride, int32_t* accepted_out) {

@@ -85,7 +85,7 @@ StreamingEngine::~StreamingEngine() {
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
-                    &steppos_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
+                    &steppos_, &probs_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -652,6 +652,8 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
       gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
     }
+    if (capture_probs_ != nullptr)  // word timestamps: this pass's cross-attention probabilities (cross_attention())
+      stream_cross_probs(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, capture_ecap_, capture_probs_, stream_);
     stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
     if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
       gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
@@ -704,6 +706,38 @@ void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* cons
   if (logits_out != nullptr)
     MSH_HIP(hipMemcpyAsync(logits_out, logits_.p, (size_t)M * V * sizeof(float), hipMemcpyDeviceToHost, stream_));
   MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+// Cross-attention of a token sequence fed from an empty self cache: [depth * heads][n][memory_len] fp32, the layout
+// align_words takes.  Replaces the `cross_attentions.{l}` outputs the reference collects call by call from its
+// decoder_kv_with_attention graph (core/moonshine-streaming-model.cpp:946-1066, core/transcriber.cpp:1028-1068).
+void StreamingEngine::cross_attention(int slot, const int32_t* tokens, int n, float* out, size_t cap, int dims[3]) {
+  if (!loaded_) throw std::runtime_error("weights not loaded");
+  check_slots(1, &slot);
+  MSH_HIP(hipSetDevice(device_));
+  const int L = cfg_.depth, Hh = cfg_.nheads, E = st(slot).mem_len;
+  dims[0] = L * Hh, dims[1] = n, dims[2] = E;
+  if (out == nullptr) return;
+  if (n <= 0 || E <= 0) throw std::invalid_argument("cross_attention: no tokens or empty memory");
+  if (cap < (size_t)L * Hh * n * E) throw std::invalid_argument("cross_attention: output buffer too small");
+  const int ecap = (E + 3) & ~3;
+  probs_.reserve((size_t)n * L * Hh * ecap * sizeof(float));
+  decoder_reset(1, &slot);
+  capture_probs_ = probs_.as<float>();
+  capture_ecap_ = ecap;
+  try {
+    decode_tokens(1, &slot, &tokens, &n, nullptr);
+  } catch (...) {
+    capture_probs_ = nullptr;
+    throw;
+  }
+  capture_probs_ = nullptr;
+  std::vector<float> tmp((size_t)n * L * Hh * ecap);
+  MSH_HIP(hipMemcpyAsync(tmp.data(), probs_.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+  for (int r = 0; r < n; ++r)          // device rows are [position][layer][head][ecap]
+    for (int lh = 0; lh < L * Hh; ++lh)
+      memcpy(out + ((size_t)lh * n + r) * E, tmp.data() + ((size_t)r * L * Hh + lh) * ecap, (size_t)E * sizeof(float));
 }
 
 void StreamingEngine::set_bias(int n_nodes, const int32_t* child_off, const int32_t* child_tok, const int32_t* child_node,

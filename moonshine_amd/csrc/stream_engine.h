@@ -60,6 +60,8 @@ class StreamingEngine {
   // streams concatenated, [sum(lens)][V]
   void decode_tokens(int n, const int* slots, const int32_t* const* tokens, const int* lens, float* logits_out);
   // decode_full for n streams at once.  max_tokens[i] < 0 = the reference rule from the memory length.
+  // word timestamps: resets the slot's decoder, feeds `tokens` and returns their cross-attention [depth*heads][n][memory_len]
+  void cross_attention(int slot, const int32_t* tokens, int n, float* out, size_t cap, int dims[3]);
   void decode_full(int n, const int* slots, const int32_t* const* drafts, const int* draft_lens, const int* max_tokens,
                    int32_t* tokens_out, int32_t* counts_out, int tokens_stride, int32_t* accepted_out);
 
@@ -103,6 +105,9 @@ class StreamingEngine {
     bf16_t *wqkv_f, *wq_c_f, *fc1_f;  // LayerNorm scale folded in (LN-fused small-batch GEMMs of the AR steps)
   };
 
+  float* capture_probs_ = nullptr;  // set while cross_attention() runs its pass
+  int capture_ecap_ = 0;
+  DevBuf probs_;
   int device_;
   hipStream_t stream_ = nullptr;
   bool loaded_ = false;

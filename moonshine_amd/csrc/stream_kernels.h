@@ -70,6 +70,9 @@ void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const in
                                   int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
                                   hipStream_t s);
 // cross-attention of every row over its stream's memory (keys [0, slots[slot].mem_len))
+// word timestamps: softmax probabilities of every (row, head) over the stream's memory frames -> out[row][layer][head][Ecap]
+void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads, int layer,
+                        int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s);
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
                             hipStream_t s);

@@ -258,6 +258,22 @@ int MoonshineStreamingModel::decoder_reset_batch(const std::vector<MoonshineStre
   return rc == MSH_OK ? 0 : fail(rc);
 }
 
+int MoonshineStreamingModel::cross_attention(MoonshineStreamingState* state, const std::vector<int>& tokens,
+                                             std::vector<float>* out, int dims[3]) {
+  std::lock_guard<std::mutex> lock(processing_mutex);
+  std::vector<int32_t> t(tokens.begin(), tokens.end());
+  int32_t d[3] = {0, 0, 0};
+  const int64_t need = msh_stream_cross_attention(engine, state->slot, t.data(), (int32_t)t.size(), nullptr, 0, d);
+  if (need < 0) return fail((int32_t)need);
+  out->assign((size_t)need, 0.f);
+  if (need > 0) {
+    const int64_t rc = msh_stream_cross_attention(engine, state->slot, t.data(), (int32_t)t.size(), out->data(), (uint64_t)need, d);
+    if (rc < 0) return fail((int32_t)rc);
+  }
+  dims[0] = d[0], dims[1] = d[1], dims[2] = d[2];
+  return 0;
+}
+
 int MoonshineStreamingModel::decode_full_batch(const std::vector<MoonshineStreamingState*>& states,
                                                const std::vector<std::vector<int>>& drafts,
                                                const std::vector<int>& max_tokens,

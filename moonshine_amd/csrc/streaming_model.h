@@ -65,6 +65,9 @@ struct MoonshineStreamingModel {
   int decode_full(MoonshineStreamingState* state, const int* speculative_tokens, int speculative_len,
                   int** tokens_out, int* tokens_len_out);                               // :174
   void decoder_reset(MoonshineStreamingState* state);                                   // :178
+  // word timestamps (reference :946-1066 + core/transcriber.cpp:1028-1068): cross-attention of `tokens` fed from an
+  // empty self cache as [depth*heads][tokens][memory_len]; dims = {depth*heads, tokens, memory_len}
+  int cross_attention(MoonshineStreamingState* state, const std::vector<int>& tokens, std::vector<float>* out, int dims[3]);
   std::string tokens_to_text(const std::vector<int64_t>& tokens);                       // :184
   // :189 -- byte-pair encoding (kTokenizerEncoding = kBpe, streaming-model.cpp:57); empty without a tokenizer
   std::vector<int32_t> text_to_tokens(const std::string& text);

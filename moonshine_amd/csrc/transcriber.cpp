@@ -417,8 +417,8 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
 // (the reference's holds frontend / encoder / adapter / cross_kv / decoder_kv .ort graphs next to the same
 // json and tokenizer, core/moonshine-streaming-model.cpp:233-300).
 void Transcriber::load_streaming_model() {
-  if (opt_.word_timestamps)  // the reference swaps in decoder_kv_with_attention.ort here (core/transcriber.cpp:327-345)
-    throw std::runtime_error("option 'word_timestamps' is only implemented for the non-streaming architectures in the MI355X build");
+  // (word_timestamps: the reference swaps in decoder_kv_with_attention.ort here, core/transcriber.cpp:327-345; this engine
+  //  computes the attention of the final token sequence on request, StreamingEngine::cross_attention)
   const int frames = (int)ceilf(opt_.max_stream_seconds * 50.0f);
   streaming_model_.reset(new MoonshineStreamingModel(opt_.device, opt_.max_streams, frames));
   if (opt_.model_source == TranscriberOptions::FILES) {
@@ -610,6 +610,20 @@ void Transcriber::transcribe_segments_with_streaming_model(std::vector<Streaming
     std::string text = m->tokens_to_text(tokens);
     if (opt_.log_output_text) MSH_LOGF("Streaming model transcribed text: '%s'", text.c_str());
     dec[i]->job->text = sanitize_utf8(text);
+    if (opt_.word_timestamps && tokens.size() >= 2) {
+      // reference core/transcriber.cpp:1028-1068: the cross-attention of every decoder call of the pass (inputs BOS,
+      // t1, ... = all tokens but the last), [layers*heads][steps][memory frames], seconds per frame = duration / frames
+      std::vector<int> inputs(tokens.begin(), tokens.end() - 1);
+      std::vector<float> att;
+      int dims[3] = {0, 0, 0};
+      if (m->cross_attention(s->sstate, inputs, &att, dims) != 0)
+        throw std::runtime_error("Streaming cross-attention failed: " + m->last_error);
+      if (dims[1] > 0 && dims[2] > 0 && m->tokenizer != nullptr) {
+        const float spf = ((float)dec[i]->job->segment->audio.size() / (float)kSampleRate) / (float)dims[2];
+        const std::vector<int32_t> ids(tokens.begin(), tokens.end());
+        dec[i]->job->words = align_words(att.data(), dims[0], dims[1], dims[2], ids, spf, *m->tokenizer);
+      }
+    }
   }
 }
 
@@ -723,8 +737,10 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
         idx.push_back(j);
       }
       transcribe_segments_with_streaming_model(round);
+      if (opt_.word_timestamps) words.resize(jobs.size());
       for (size_t k = 0; k < idx.size(); ++k) {
         texts[idx[k]] = round[k].text;
+        if (opt_.word_timestamps) words[idx[k]] = std::move(round[k].words);
         done[idx[k]] = 1;
       }
       remaining -= idx.size();
@@ -759,7 +775,8 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
           line.latency_ms = latency_ms;
           // words only for finished lines: an open segment is re-transcribed on the next update anyway (reference
           // core/transcriber.cpp:1103-1117); times become absolute by adding the segment start
-          if (job < words.size() && seg.is_complete) {
+          // (the streaming path attaches them on every update, like core/transcriber.cpp:1028-1068)
+          if (job < words.size() && (seg.is_complete || streaming)) {
             line.words = words[job];
             for (TranscriberWord& w : line.words) {
               w.start += seg.start_time;

@@ -187,6 +187,7 @@ class Transcriber {
     const VadSegment* segment;
     uint64_t line_id;
     std::string text;
+    std::vector<TranscriberWord> words;  // word_timestamps option: times relative to the segment start
   };
   // Transcriber::transcribe_segment_with_streaming_model (reference core/transcriber.cpp:1311-1487) for one
   // segment of each of several streams, as one GPU batch

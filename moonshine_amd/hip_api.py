@@ -92,6 +92,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_stream_encode": (i32, [vp, i32, vp, vp, vp]),
         "msh_stream_decoder_reset": (i32, [vp, i32, vp]),
         "msh_stream_decode_tokens": (i32, [vp, i32, vp, P(vp), vp, vp]),
+        "msh_stream_cross_attention": (C.c_int64, [vp, i32, vp, i32, vp, u64, vp]),
         "msh_stream_decode_full": (i32, [vp, i32, vp, P(vp), vp, vp, vp, vp, i32, vp]),
         "msh_stream_set_bias": (i32, [vp, i32, vp, vp, vp, vp, vp, i32]),
         "msh_stream_query": (i32, [vp, i32, i32]),
@@ -124,7 +125,7 @@ DECLARED_SYMBOLS = [
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_set_hw_queues", "msh_host_silero_probabilities", "msh_host_vad_segments", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
-    "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens",
+    "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens", "msh_stream_cross_attention",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_get_features",
 ]
@@ -405,6 +406,17 @@ class StreamEngine:
         for n in lens:
             out.append(logits[o:o + n])
             o += n
+        return out
+
+    def cross_attention(self, slot: int, tokens) -> np.ndarray:
+        """[depth*heads, len(tokens), memory_len] fp32 for `tokens` fed from an empty self cache (word timestamps)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        dims = (C.c_int32 * 3)()
+        n = int(self.lib.msh_stream_cross_attention(self.h, slot, t.ctypes.data, len(t), None, 0, dims))
+        if n < 0:
+            self._check(n)
+        out = np.zeros((dims[0], dims[1], dims[2]), np.float32)
+        self._check(int(min(0, self.lib.msh_stream_cross_attention(self.h, slot, t.ctypes.data, len(t), out.ctypes.data, out.size, dims))))
         return out
 
     def decode_full(self, slots, drafts=None, max_tokens=None):

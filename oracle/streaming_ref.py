@@ -160,9 +160,11 @@ def cross_kv(w, cfg: StreamingArchConfig, memory: np.ndarray):
     return np.stack(ks).astype(F32), np.stack(vs).astype(F32)
 
 
-def decoder_kv(w, cfg: StreamingArchConfig, tokens, k_self, v_self, k_cross, v_cross):
+def decoder_kv(w, cfg: StreamingArchConfig, tokens, k_self, v_self, k_cross, v_cross, cross_probs: list | None = None):
     """exp:207-256 (DecoderKV.forward): n tokens + caches -> logits [n, V], grown self caches.
-    k_self / v_self: [depth, H, S, dh] (S may be 0)."""
+    k_self / v_self: [depth, H, S, dh] (S may be 0).  ``cross_probs``: if a list, one [H, n, M] array of
+    cross-attention probabilities per layer is appended -- the ``cross_attentions.{l}`` outputs of the reference's
+    decoder_kv_with_attention graph (core/moonshine-streaming-model.cpp:946-1066)."""
     tokens = np.asarray(tokens, dtype=np.int64)
     n = tokens.shape[0]
     cached = k_self.shape[2]
@@ -193,6 +195,8 @@ def decoder_kv(w, cfg: StreamingArchConfig, tokens, k_self, v_self, k_cross, v_c
         x = layer_norm_nobias(h, w[p + "post_attention_layernorm.weight"])
         q = (x @ w[p + "encoder_attn.q_proj.weight"].T).reshape(n, H, dh).transpose(1, 0, 2)
         s = ((q @ k_cross[l].transpose(0, 2, 1)) * scale).astype(F32)
+        if cross_probs is not None:
+            cross_probs.append(softmax_f32(s))
         a = (softmax_f32(s) @ v_cross[l]).transpose(1, 0, 2).reshape(n, H * dh)
         h = h + a @ w[p + "encoder_attn.o_proj.weight"].T
         x = layer_norm_nobias(h, w[p + "final_layernorm.weight"])
@@ -279,6 +283,19 @@ def _run_decoder(w, cfg, st: StreamState, tokens) -> np.ndarray:
 def decode_tokens(w, cfg, st: StreamState, tokens) -> np.ndarray:
     """ref:1136-1185 (decode_step is the one-token case, ref:1089-1129)."""
     return _run_decoder(w, cfg, st, tokens)
+
+
+def cross_attention_for_tokens(w, cfg, st: StreamState, tokens) -> np.ndarray:
+    """The attention the word-timestamp path aligns (core/transcriber.cpp:1028-1068): probabilities of every layer, head
+    and decoder position for the token sequence fed from an empty self cache, as [depth * H, n, memory_len] -- the layout
+    align_words takes.  (The reference accumulates them call by call; fed the same tokens the result is the same.)"""
+    st.decoder_reset()
+    if not st.cross_kv_valid:
+        st.k_cross, st.v_cross = cross_kv(w, cfg, st.memory)
+        st.cross_kv_valid = True
+    probs: list = []
+    _, st.k_self, st.v_self = decoder_kv(w, cfg, tokens, st.k_self, st.v_self, st.k_cross, st.v_cross, probs)
+    return np.concatenate(probs, axis=0).astype(F32)   # [L][H, n, M] -> [L*H, n, M]
 
 
 def max_tokens_for_memory(cfg, memory_len: int) -> int:

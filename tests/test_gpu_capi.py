@@ -155,14 +155,8 @@ def test_reference_word_timestamp_test_flow_as_a_c_program(tiny_dir, tmp_path):
     assert r.stdout.startswith("words: ")
 
 
-def test_word_timestamps_off_by_default_and_refused_for_streaming_archs(tiny, tmp_path_factory):
+def test_word_timestamps_off_by_default(tiny):
     assert tiny.transcribe_without_streaming(make_audio(410, 32000))[0].words == []
-    from moonshine_amd.synth import STREAMING_ARCHS, write_streaming_model_dir
-
-    d = str(tmp_path_factory.mktemp("ws"))
-    write_streaming_model_dir(d, STREAMING_ARCHS["micro_streaming"], seed=5)
-    with pytest.raises(api.MoonshineError):
-        api.Transcriber(d, api.ARCH_TINY_STREAMING, {"word_timestamps": "true"})
 
 
 def test_other_sample_rate_goes_through_the_resampler(tiny, engine):

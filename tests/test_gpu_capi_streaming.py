@@ -247,3 +247,61 @@ def test_streaming_arch_context(model_dir, engine):
     finally:
         engine.set_bias(None)
     t.close()
+
+
+def test_streaming_arch_word_timestamps(model_dir, engine):
+    """Option word_timestamps on a streaming architecture (reference core/transcriber.cpp:1028-1068): every decoded line
+    carries words = the oracle's align_words applied to the engine's own cross-attention of the line's final tokens
+    (inputs BOS, t1, ... = all tokens but the last; seconds per frame = segment duration / memory frames), shifted by the
+    segment start; one-shot call, batch call and the stream API agree; without the option there are no words."""
+    from oracle import word_align_ref as wa
+
+    vocab = synthetic_vocab(CFG.vocab)
+    clips = [make_audio(700 + i, n) for i, n in enumerate([16000 * 3, 40000, 16000 * 4 + 640])]
+    t = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "word_timestamps": "true"})
+    plain = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
+    try:
+        single = [t.transcribe_without_streaming(c) for c in clips]
+        batch = t.transcribe_batch_without_streaming(clips)
+        for c, lines, blines in zip(clips, single, batch):
+            assert len(lines) == 1 and lines[0].is_complete
+            m = GlueMirror(engine)
+            seg = lines[0].audio_data
+            assert lines[0].text_bytes == m.update(seg, True)
+            toks = m.last
+            att = engine.cross_attention(m.slot, toks[:-1])
+            spf = float(np.float32(np.float32(len(seg)) / np.float32(16000.0)) / np.float32(att.shape[2]))
+            want = wa.align_words(att, toks, spf, vocab, host_ref.tokens_to_text)
+            got = lines[0].words
+            assert [w[0] for w in got] == [w["text"] for w in want]
+            np.testing.assert_allclose([w[1] for w in got], [w["start"] for w in want], rtol=0, atol=1e-6)
+            np.testing.assert_allclose([w[2] for w in got], [w["end"] for w in want], rtol=0, atol=1e-6)
+            assert got == blines[0].words
+            prev = -1.0
+            for _, start, end, conf in got:
+                assert end >= start >= prev and 0.0 <= conf <= 1.0 and end <= len(seg) / 16000 + 1e-3
+                prev = start
+            m.close()
+            assert plain.transcribe_without_streaming(c)[0].words == []
+            assert plain.transcribe_without_streaming(c)[0].text_bytes == lines[0].text_bytes   # the capture changes no text
+        assert any(len(l[0].words) > 0 for l in single)
+        # stream API: words on the open line too (the reference fills them on every update), final words == one-shot words
+        s = t.create_stream()
+        t.start_stream(s)
+        ci = int(np.argmax([len(l[0].words) for l in single]))   # the clip whose line has the most words
+        c = clips[ci]
+        open_words = 0
+        for k in range(0, len(c), 16000):
+            t.add_audio(s, c[k:k + 16000])
+            lines = t.transcribe_stream(s, api.FLAG_FORCE_UPDATE)
+            open_words += len(lines[0].words)
+        t.stop_stream(s)
+        final = t.transcribe_stream(s, api.FLAG_FORCE_UPDATE)
+        assert final[0].is_complete
+        if final[0].text_bytes == single[ci][0].text_bytes:     # same ids (no near-tie resolved differently on the way)
+            assert [w[0] for w in final[0].words] == [w[0] for w in single[ci][0].words]
+            assert open_words > 0
+        t.free_stream(s)
+    finally:
+        t.close()
+        plain.close()

@@ -438,3 +438,35 @@ def test_medium_dims_batch64_vs_oracle_and_golden(tmp_path):
         assert np.abs(got_lg - lg).max() < LOGIT_MAXABS
     assert checked >= 6
     eng.close()
+
+
+def test_stream_cross_attention_vs_oracle(tmp_path):
+    """msh_stream_cross_attention: the probabilities behind word timestamps on the streaming architectures -- the
+    `cross_attentions.{l}` outputs of the reference's decoder_kv_with_attention graph
+    (core/moonshine-streaming-model.cpp:946-1066) in the [layers*heads][tokens][memory frames] layout align_words takes
+    (core/transcriber.cpp:1028-1068) -- against the oracle fed the same tokens.  Softmax outputs in [0, 1], bf16 operands
+    upstream: max-abs <= 5e-3 (the offline tolerance)."""
+    eng, cfg, w = make_engine(tmp_path, "micro_streaming", 21)
+    audio = make_audio(5, 1280 * 40)
+    s = eng.open()
+    feed(eng, s, audio, 10)
+    st = oracle_state(w, cfg, audio, 10)
+    eng.decoder_reset([s])
+    (toks,), _ = eng.decode_full([s])
+    assert len(toks) >= 4
+    inputs = [cfg.bos] + toks[:-1]
+    att = eng.cross_attention(s, inputs)
+    want = sr.cross_attention_for_tokens(w, cfg, st, inputs)
+    assert att.shape == want.shape == (cfg.depth * cfg.heads, len(inputs), eng.memory_len(s))
+    np.testing.assert_allclose(att.sum(-1), 1.0, atol=1e-4)
+    assert float(np.abs(att - want).max()) <= 5e-3
+    # the capture pass leaves the decoder holding exactly these tokens, and a normal decode afterwards is unchanged
+    assert eng.cache_len(s) == len(inputs)
+    eng.decoder_reset([s])
+    (again,), _ = eng.decode_full([s])
+    assert again == toks
+    from moonshine_amd.hip_api import MshError
+    s2 = eng.open()
+    with pytest.raises(MshError):
+        eng.cross_attention(s2, [cfg.bos])          # empty memory
+    eng.close()
