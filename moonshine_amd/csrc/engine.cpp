@@ -120,7 +120,7 @@ Engine::~Engine() {
   }
   for (void* p : weight_allocs_) (void)hipFree(p);
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
-                    &Y_, &QKV_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
+                    &Y_, &QKV_, &VTe_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -531,7 +531,8 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= x2_.reserve((2 * R + 8) * 2 * D * sizeof(bf16_t));
   moved |= H_.reserve(R * D * sizeof(float));
   moved |= Y_.reserve(R * D * sizeof(bf16_t));
-  moved |= QKV_.reserve(R * 3 * D * sizeof(bf16_t));
+  moved |= QKV_.reserve(R * 2 * D * sizeof(bf16_t));                 // q | k rows of the current encoder layer
+  moved |= VTe_.reserve(((size_t)D * R + 64) * sizeof(bf16_t));          // its V^T [D][R]: keys contiguous
   moved |= AO_.reserve(R * D * sizeof(bf16_t));
   moved |= Z_.reserve(R * F * sizeof(bf16_t));
   moved |= ENC_.reserve(R * D * sizeof(bf16_t));
@@ -612,13 +613,19 @@ void Engine::run_encoder() {
       ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
       layernorm_bf16(H_.as<float>(), W.ln1, R, D, Y_.as<bf16_t>(), nullptr, s);
     }
-    {
-      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 3 * D, sT * D * 2 * 4);
-      gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 3 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
+    {  // q | k with RoPE, row-major [R][2D]
+      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 2 * D, sT * D * 2 * 3);
+      gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 2 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
+    }
+    {  // v TRANSPOSED, as one plain GEMM with the operands swapped: V^T [D][R] = Wv [D][D] x Y^T -- the weight is the
+       // "activation" (4 row tiles), the R stream rows are the output columns, so the keys of a clip are contiguous in
+       // every row of the result: what the attention kernel's P.V wants as its MFMA operand
+      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * D, sT * D * 2 * 2);
+      gemm_act(W.wqkv + (size_t)2 * D * D, D, Y_.as<bf16_t>(), nullptr, 0, D, (int)R, D, VTe_.as<bf16_t>(), nullptr, s);
     }
     {
       ProfScope p(this, "enc_attention", 4.0 * sT2 * D, sT * D * 2 * 4);
-      enc_attention(QKV_.as<bf16_t>(), AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
+      enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), (long)R, AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
     }
     {
       ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));

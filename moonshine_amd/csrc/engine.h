@@ -149,7 +149,7 @@ class Engine {
   std::vector<int32_t> cross_counts_;  // tokens per clip (incl. BOS) of the captured decode
 
   // workspace (grow-only)
-  DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, AO_, Z_,
+  DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, VTe_, AO_, Z_,
       ENC_, ENC32_, gn_part_, gn_stats_, gn_table_, KT_, VT_;
   int Smax_ = 0;
 

@@ -38,49 +38,136 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Reductions across the four 16-lane rows of a wave (lane ^ 16, lane ^ 32) with the gfx950 row-swap instructions: pure
+// VALU, no trip through the LDS crossbar (__shfl_xor lowers to ds_bpermute + a wait on lgkmcnt).
+// v_permlane16_swap(a, b): rows 1, 3 of a <-> rows 0, 2 of b;  v_permlane32_swap(a, b): upper half of a <-> lower half of b.
+__device__ __forceinline__ float rows_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const unsigned w = __float_as_uint(v);
+  auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned w = __float_as_uint(v);
+  auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // ------------------------------------------------------------------------------------------------
-// Encoder attention
+// Encoder attention: one workgroup per (clip, head) covers up to 64 * NW queries -- ALL queries of a 10 s clip with
+// NW = 7 (415 frames = 26 query tiles: waves 0-5 take four each, wave 6 two).
+//
+// Flash-style over 64-key LDS blocks: S^T = K Q^T and O^T = V^T P^T so that softmax statistics, P and O of a query live
+// in one lane (MFMA 16x16x32: S^T tile = 16 keys x 16 queries, lane = query li, keys kg*4 + r).  Compared with the
+// first version (128 queries per workgroup, four workgroups per (clip, head), V transposed on the way into LDS with
+// 2-byte stores):
+//   * every K / V block of a (clip, head) is staged ONCE and every LDS fragment read feeds up to four query tiles;
+//   * V arrives already transposed: the encoder's V projection is its own GEMM with the operands swapped
+//     (V^T [D][R] = Wv x Y^T: the R stream rows are its output columns), so a block's V^T tile is 52 rows of
+//     128 contiguous bytes -- one 16-byte load and one ds_write_b128 per thread instead of thirteen conflicting
+//     ds_write_b16 (PMC of the old kernel: 60 % of its LDS cycles were bank conflicts, 4.8x the algorithmic traffic).
+// fp32 online softmax in the exp2 domain, scale folded into the exponent's fma.
 // ------------------------------------------------------------------------------------------------
 constexpr int KB = 64;        // keys per LDS block
-constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: conflict-free ds_read_b64)
+constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: 16-byte aligned rows, conflict-free ds_read_b64)
+constexpr int EQT = 4;        // query tiles of 16 per wave
 
-// QT query tiles of 16 per wave: a workgroup covers 64 * QT queries of one (clip, head).  With QT = 2 every staged
-// K / V^T block and every LDS fragment read serves two MFMAs, and a 415-frame clip needs 4 passes over its keys
-// instead of 7.
-template <int DH, int QT>
-__global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __restrict__ qkv,
-                                                            bf16_t* __restrict__ out,
-                                                            const ClipMeta* __restrict__ clips, int D) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __restrict__ qk,
+                                                                const bf16_t* __restrict__ vt, long vt_ld,
+                                                                bf16_t* __restrict__ out,
+                                                                const ClipMeta* __restrict__ clips, int D) {
   static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
-  constexpr int PIECES = DH / 4;  // 8-byte pieces per K/V row
-  __shared__ __attribute__((aligned(16))) uint2 Ks[KB * 16];        // [key][8 x 16 B], chunk ^= (key>>1)&7
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * VT_LD];    // [d][key]
+  constexpr int PIECES = DH / 4;  // 8-byte pieces per K row
+  constexpr int NT = 64 * NW;
+  // two LDS buffers: block kb + 1 is fetched (into registers) while block kb is consumed and lands in the other buffer,
+  // so a workgroup that is alone on its CU (232 VGPRs) does not expose a memory round trip per key block
+  __shared__ __attribute__((aligned(16))) uint2 Ks2[2][KB * 16];        // [key][8 x 16 B], chunk ^= (key>>1)&7
+  __shared__ __attribute__((aligned(16))) bf16_t Vt2[2][64 * VT_LD];    // [d][key]
 
   const ClipMeta cm = clips[blockIdx.z];
-  const int q0 = blockIdx.x * 64 * QT;
+  const int q0 = blockIdx.x * 64 * NW;
   if (q0 >= cm.rows) return;
   const int h = blockIdx.y;
-  const int T = cm.T;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kg = lane >> 4;
-  const long ld = 3L * D;
-  const bf16_t* base = qkv + (long)cm.row_start * ld + h * DH;
+  const int T = cm.T, Tk = cm.Tk;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long ld = 2L * D;   // [row][q | k]
+  const bf16_t* base = qk + (long)cm.row_start * ld + h * DH;
+  const bf16_t* vbase = vt + (long)(h * DH) * vt_ld + cm.row_start;   // V^T [D][R]: row d, the clip's keys from row_start on
 
   // zero the head-dim padding once (never overwritten by the staging loop)
-  for (int p = tid; p < KB * 16; p += 256) {
-    const int key = p >> 4, piece = p & 15;
-    if (piece >= PIECES) Ks[(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = make_uint2(0u, 0u);
+  for (int b2 = 0; b2 < 2; ++b2) {
+    for (int p = tid; p < KB * 16; p += NT) {
+      const int key = p >> 4, piece = p & 15;
+      if (piece >= PIECES) Ks2[b2][(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = make_uint2(0u, 0u);
+    }
+    for (int p = tid; p < (64 - DH) * VT_LD; p += NT) Vt2[b2][DH * VT_LD + p] = 0;
   }
-  for (int p = tid; p < (64 - DH) * VT_LD; p += 256) Vt[DH * VT_LD + p] = 0;
-
-  // Q fragments (B operand of S^T = K Q^T): lane holds q row (li), d = s*32 + kg*8 .. +8
-  int qrow[QT];
-  bf16x8 qf[QT][2];
+  constexpr int KP = (KB * PIECES + NT - 1) / NT, VP = (DH * 8 + NT - 1) / NT;   // staged pieces per thread and block
+  uint2 kreg[KP];
+  uint4 vreg[VP];
+  auto fetch = [&](int kb) {   // K rows: 8-byte pieces (104 contiguous bytes per key); V^T rows: 16-byte chunks of 8 keys
 #pragma unroll
-  for (int qi = 0; qi < QT; ++qi) {
-    qrow[qi] = q0 + (wave * QT + qi) * 16 + li;
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + i * NT;
+      const int key = p / PIECES, piece = p - key * PIECES;
+      const int t = kb * KB + key;
+      kreg[i] = make_uint2(0u, 0u);
+      if (p < KB * PIECES && t < T) kreg[i] = *reinterpret_cast<const uint2*>(base + (long)t * ld + D + piece * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      const int p = tid + i * NT;
+      const int d = p >> 3, ch = p & 7;
+      const int key0 = kb * KB + ch * 8;
+      vreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < DH * 8 && key0 < T) {   // (row_start and key0 are multiples of 8: 16-byte aligned)
+        uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)d * vt_ld + key0);
+        if (key0 + 8 > T) {           // the clip's padding rows hold arbitrary values: exact zeros for keys >= T
+          const int nv = T - key0;    // 1..7 valid keys
+          unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (2 * e >= nv) w[e] = 0u;
+            else if (2 * e + 1 >= nv) w[e] &= 0xffffu;
+          }
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        vreg[i] = v;
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + i * NT;
+      const int key = p / PIECES, piece = p - key * PIECES;
+      if (p < KB * PIECES) Ks2[buf][(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      const int p = tid + i * NT;
+      if (p < DH * 8) *reinterpret_cast<uint4*>(&Vt2[buf][(p >> 3) * VT_LD + (p & 7) * 8]) = vreg[i];
+    }
+  };
+
+  // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
+  const int tq0 = q0 + wave * 64;
+  bool act[EQT];
+  int qrow[EQT];
+  bf16x8 qf[EQT][2];
+#pragma unroll
+  for (int qi = 0; qi < EQT; ++qi) {
+    act[qi] = tq0 + qi * 16 < T;   // wave-uniform
+    qrow[qi] = tq0 + qi * 16 + li;
     const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -94,10 +181,10 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
   }
 
   const float c = rsqrtf((float)DH) * kLog2e;  // scores are compared / exponentiated in the exp2 domain
-  float m_run[QT], l_run[QT];
-  f32x4 o[QT][4];
+  float m_run[EQT], l_run[EQT];
+  f32x4 o[EQT][4];
 #pragma unroll
-  for (int qi = 0; qi < QT; ++qi) {
+  for (int qi = 0; qi < EQT; ++qi) {
     m_run[qi] = -INFINITY;
     l_run[qi] = 0.f;
 #pragma unroll
@@ -105,32 +192,17 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
   }
 
   const int nkb = (T + KB - 1) / KB;
+  fetch(0);
   for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();  // previous block fully consumed (also orders the padding zero-fill)
-    for (int p = tid; p < KB * PIECES; p += 256) {
-      const int key = p / PIECES, piece = p - key * PIECES;
-      const int t = kb * KB + key;
-      // V is transposed on the way into LDS with 2-byte stores.  The piece-major lane mapping keeps the
-      // global reads coalesced (104 contiguous bytes per key) at the price of LDS write conflicts (a
-      // wave's 13 pieces of one key land on two banks); a key-major mapping removed the conflicts but
-      // measured 35 % slower overall (uncoalesced row reads), so this stays.
-      uint2 kv = make_uint2(0u, 0u), vv = make_uint2(0u, 0u);
-      if (t < T) {
-        const bf16_t* r = base + (long)t * ld + piece * 4;
-        kv = *reinterpret_cast<const uint2*>(r + D);
-        vv = *reinterpret_cast<const uint2*>(r + 2 * D);
-      }
-      Ks[(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = kv;
-      bf16_t* vd = Vt + (piece * 4) * VT_LD + key;
-      vd[0] = (bf16_t)(vv.x & 0xffffu);
-      vd[VT_LD] = (bf16_t)(vv.x >> 16);
-      vd[2 * VT_LD] = (bf16_t)(vv.y & 0xffffu);
-      vd[3 * VT_LD] = (bf16_t)(vv.y >> 16);
-    }
-    __syncthreads();
+    const int buf = kb & 1;
+    commit(buf);
+    __syncthreads();  // block kb is in LDS; every wave has finished block kb - 1 (it committed after computing it)
+    if (kb + 1 < nkb) fetch(kb + 1);   // in flight during the MFMAs below
+    const uint2* Ks = Ks2[buf];
+    const bf16_t* Vt = Vt2[buf];
 
     // S^T tiles: rows = keys, cols = queries.  st[qi][kt][r] = score(q = li of tile qi, key = kb*64 + kt*16 + kg*4 + r)
-    f32x4 st[QT][4];
+    f32x4 st[EQT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int key = kt * 16 + li;
@@ -138,7 +210,8 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
 #pragma unroll
       for (int s = 0; s < 2; ++s) kf[s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
 #pragma unroll
-      for (int qi = 0; qi < QT; ++qi) {
+      for (int qi = 0; qi < EQT; ++qi) {
+        if (!act[qi]) continue;
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -146,9 +219,10 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
         st[qi][kt] = a;
       }
     }
-    bf16x8 pf[QT][2];
+    bf16x8 pf[EQT][2];
 #pragma unroll
-    for (int qi = 0; qi < QT; ++qi) {
+    for (int qi = 0; qi < EQT; ++qi) {
+      if (!act[qi]) continue;
       // the softmax is VALU-bound (16 exp2 per lane per tile): keep the per-score work to max, one fma and the
       // exp2 -- the scale is folded into the fma (c > 0, so the max of the raw scores is the max), and keys past
       // the clip's length are masked only in the block that contains them
@@ -164,8 +238,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[qi][kt][r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      mloc = rows_max(mloc);
       const float m_new = fmaxf(m_run[qi], mloc * c);
       const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
       m_run[qi] = m_new;
@@ -192,7 +265,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
       }
     }
 
-    // O^T += V^T P^T: every V^T fragment read from LDS feeds the QT query tiles
+    // O^T += V^T P^T: every V^T fragment read from LDS feeds up to EQT query tiles
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -201,22 +274,21 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
         const bf16_t* vr = Vt + (dt * 16 + li) * VT_LD + ks * 32 + kg * 4;
         const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
         const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
-        uint4 vt = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
 #pragma unroll
-        for (int qi = 0; qi < QT; ++qi)
-          o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vt), pf[qi][ks], o[qi][dt], 0, 0, 0);
+        for (int qi = 0; qi < EQT; ++qi)
+          if (act[qi])
+            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[qi][ks], o[qi][dt], 0, 0, 0);
       }
     }
   }
 
 #pragma unroll
-  for (int qi = 0; qi < QT; ++qi) {
-    float l = l_run[qi];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+  for (int qi = 0; qi < EQT; ++qi) {
+    const float l = rows_sum(l_run[qi]);
     const float inv = 1.0f / l;
     if (qrow[qi] < cm.rows) {
-      const bool valid = qrow[qi] < T;
+      const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
       bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -600,22 +672,20 @@ void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta*
                      layers, layer, Smax, Tcap, out);
 }
 
-void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows, int D, int heads,
-                   hipStream_t s) {
+void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows,
+                   int D, int heads, hipStream_t s) {
   const int dh = D / heads;
-  static const int qt_env = [] {
-    const char* e = getenv("MSH_ENC_ATTN_QT");
-    return e ? atoi(e) : 2;
-  }();
-  // two query tiles per wave once a clip has more than one 64-query block (see enc_attention_kernel)
-  const int qt = (qt_env == 2 && max_rows > 64) ? 2 : 1;
-  dim3 grid((max_rows + 64 * qt - 1) / (64 * qt), heads, n_clips);
+  // 7 waves = 448 queries cover a 10 s clip (415 frames) in one workgroup; short clips take 4 waves (256 queries)
+  const bool wide = max_rows > 256;
+  const int per = wide ? 448 : 256;
+  dim3 grid((max_rows + per - 1) / per, heads, n_clips);
+  if (n_clips > 65535) throw std::runtime_error("enc_attention: more than 65535 clips in one batch");
 #define MSH_EATT(DHV)                                                                                          \
   case DHV:                                                                                                    \
-    if (qt == 2)                                                                                               \
-      hipLaunchKernelGGL((enc_attention_kernel<DHV, 2>), grid, dim3(256), 0, s, qkv, out, clips, D);           \
+    if (wide)                                                                                                  \
+      hipLaunchKernelGGL((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D);        \
     else                                                                                                       \
-      hipLaunchKernelGGL((enc_attention_kernel<DHV, 1>), grid, dim3(256), 0, s, qkv, out, clips, D);           \
+      hipLaunchKernelGGL((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D);        \
     break
   switch (dh) {
     MSH_EATT(52);

@@ -122,9 +122,10 @@ void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int
                           hipStream_t s);
 
 // ---------------- attention ----------------
-// encoder self-attention over the packed stream; qkv [R,3D] bf16 -> out [R,D] bf16
-void enc_attention(const bf16_t* qkv, bf16_t* out, const ClipMeta* clips, int n_clips, int max_T, int D, int heads,
-                   hipStream_t s);
+// encoder self-attention over the packed stream: qk [R,2D] bf16 (q | k, RoPE applied), vt = V^T [D][vt_ld] bf16 (row d,
+// stream rows contiguous; vt_ld >= R) -> out [R,D] bf16
+void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips,
+                   int max_rows, int D, int heads, hipStream_t s);
 // decode self-attention: q [M,D] f32, cache [M][H][Smax][dh] bf16, keys 0..*pos_ptr -> out [M16,D] bf16 in FM
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
                         int heads, int Smax, bf16_t* out, hipStream_t s);
