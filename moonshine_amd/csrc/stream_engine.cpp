@@ -78,6 +78,7 @@ StreamingEngine::StreamingEngine(int device, int max_slots, int max_memory_frame
 StreamingEngine::~StreamingEngine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (ar_graph_ != nullptr) (void)hipGraphExecDestroy(ar_graph_);
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
     for (void* p : allocs_) (void)hipFree(p);
@@ -839,6 +840,39 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   stream_argmax(logits_.as<float>(), M, V, pred_.as<int>(), stream_);
   stream_verify(jobs_d, J, pred_.as<int>(), draft_d, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd,
                 stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
+  // One autoregressive step = ~100 short dependent kernels whose every argument is a device pointer (positions, ids and
+  // stop flags live on the device): captured once per (row count, buffer addresses, trie) into a hipGraph and replayed -- an
+  // eager launch costs the host >= 3.5 us per kernel, a graph node ~1.6 us of GPU time.
+  auto ar_step = [&] {
+    decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
+    stream_bias_rows(bias_, nullptr, nullptr, jobs_d, slots_d_, result_, Scap_, J, logits_.as<float>(), V, stream_);
+    stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
+    stream_advance(jobs_d, J, pred_.as<int>(), slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd, stepH_.as<float>(),
+                   steppos_.as<int>(), n_active_d_, stream_);
+  };
+  static const bool use_graph = [] {
+    const char* e = getenv("MSH_NO_GRAPH");
+    return !(e != nullptr && e[0] == '1');
+  }();
+  if (use_graph && max_budget > 0) {
+    char key[512];
+    snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p, logits_.p,
+             pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p);
+    if (ar_graph_ == nullptr || ar_key_ != key) {
+      if (ar_graph_ != nullptr) {
+        MSH_HIP(hipGraphExecDestroy(ar_graph_));
+        ar_graph_ = nullptr;
+      }
+      hipGraph_t gr = nullptr;
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      MSH_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      ar_step();
+      MSH_HIP(hipStreamEndCapture(stream_, &gr));
+      MSH_HIP(hipGraphInstantiate(&ar_graph_, gr, nullptr, nullptr, 0));
+      MSH_HIP(hipGraphDestroy(gr));
+      ar_key_ = key;
+    }
+  }
   int32_t active = 1;
   for (int step = 0; step < max_budget; ++step) {
     if (step % 8 == 0) {
@@ -846,11 +880,8 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       MSH_HIP(hipStreamSynchronize(stream_));
       if (active <= 0) break;
     }
-    decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
-    stream_bias_rows(bias_, nullptr, nullptr, jobs_d, slots_d_, result_, Scap_, J, logits_.as<float>(), V, stream_);
-    stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
-    stream_advance(jobs_d, J, pred_.as<int>(), slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd, stepH_.as<float>(),
-                   steppos_.as<int>(), n_active_d_, stream_);
+    if (use_graph) MSH_HIP(hipGraphLaunch(ar_graph_, stream_));
+    else ar_step();
   }
   std::vector<SlotDev> sd(J);
   for (int j = 0; j < J; ++j)

@@ -105,6 +105,8 @@ class StreamingEngine {
     bf16_t *wqkv_f, *wq_c_f, *fc1_f;  // LayerNorm scale folded in (LN-fused small-batch GEMMs of the AR steps)
   };
 
+  hipGraphExec_t ar_graph_ = nullptr;  // one autoregressive decode step (decode_full), replayed
+  std::string ar_key_;
   float* capture_probs_ = nullptr;  // set while cross_attention() runs its pass
   int capture_ecap_ = 0;
   DevBuf probs_;

@@ -7,16 +7,16 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -2 gpurun_out/${TAG}_pytest.log
+timeout 1500 python -m pytest tests -m gpu -q --durations=6 > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json
 # kernel stats twice: steps strictly serial (the per-kernel durations the roofline figures are about), and the default
 # command with batches in flight (the same kernels stretched by the overlap)
-CMD="python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
+CMD="python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- $CMD > /tmp/prof_${TAG}.log 2>&1)
 f=$(find /tmp/prof_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_serial.csv && head -8 "$f" | cut -c1-160
-CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency"
+CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2_${TAG} -- $CMD2 > /tmp/prof2_${TAG}.log 2>&1)
 f=$(find /tmp/prof2_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_inflight.csv && head -4 "$f" | cut -c1-160
@@ -32,11 +32,44 @@ with open(sys.argv[1]) as src, gzip.open(sys.argv[2], "wt") as dst:
 PYT
 pass() { # name counters...
   local name=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /tmp/pmc_${TAG}_$name.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-streaming --no-pcie > /tmp/pmc_${TAG}_$name.log 2>&1)
   tail -1 /tmp/pmc_${TAG}_$name.log | cut -c1-160
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+[ -x tools/build/dec_gemm_timeline ] && tools/build/dec_gemm_timeline > gpurun_out/${TAG}_dec_gemm_timeline.txt 2>&1
+[ -x tools/build/launch_floor ] && tools/build/launch_floor > gpurun_out/${TAG}_launch_floor.txt 2>&1
+python - <<PY
+import csv, glob, collections, json, re
+# MFMA busy normalised to the chip: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) / (kernel duration in cycles x 1024 SIMDs);
+# the duration is GRBM_GUI_ACTIVE, which this stack reports summed over the 8 XCDs (a 0.27 ms kernel reads 5.3 M): / 8
+files = glob.glob("/tmp/pmc_${TAG}_mfma/**/*counter_collection.csv", recursive=True)
+if files:
+    agg = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(files[0])):
+        k = re.sub(r"msh::\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:90]
+        agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"])); cnt[k] += 1
+    rows = {}
+    for k, n in cnt.items():
+        gui = agg.get((k, "GRBM_GUI_ACTIVE"), 0.0) / 8.0
+        mf = agg.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0)
+        wave = max(agg.get((k, "SQ_WAVE_CYCLES"), 0.0), 1.0)
+        rows[k] = {"dispatches": n, "duration_cycles_per_dispatch": round(gui / n, 1),
+                   "mfma_busy_frac_of_chip": round(mf / (gui * 1024.0), 4) if gui > 0 else None,
+                   "valu_active_over_wave": round(agg.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) / wave, 3),
+                   "wait_any_over_wave": round(agg.get((k, "SQ_WAIT_ANY"), 0.0) / wave, 3)}
+    out = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, "
+                     "bench.py --in-flight 1 --steps 1 --warmup 0 (B=256, base).  mfma_busy_frac_of_chip = MFMA busy cycles / (kernel "
+                     "cycles x 1024 SIMDs): the fraction of the chip's matrix-pipe time the kernel uses (1.0 = every SIMD issuing MFMAs "
+                     "back to back).  GRBM_GUI_ACTIVE is summed over the 8 XCDs on this stack, hence / 8.",
+           "kernels": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["duration_cycles_per_dispatch"] * kv[1]["dispatches"])))}
+    json.dump(out, open("gpurun_out/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
+    for k, v in list(out["kernels"].items())[:14]:
+        print("%-86s n=%5d mfma_busy=%s valu=%.2f wait=%.2f" % (k[:86], v["dispatches"], v["mfma_busy_frac_of_chip"], v["valu_active_over_wave"], v["wait_any_over_wave"]))
+PY
 python - <<PY
 import csv, glob, collections, json, re
 GROUPS = {  # bench.py kernel group -> kernel-name pattern
