@@ -228,6 +228,12 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
   auto expect_shape = [&](const std::string& name, std::vector<int64_t> shape) {
     if (st.get(name).shape != shape) throw std::runtime_error("unexpected shape for " + name);
   };
+  // 1-D parameters (biases, norm scales): checked against the config like the matrices, so a file whose vectors are short
+  // can never make a kernel read past an allocation
+  auto vec = [&](const std::string& name, int64_t n) {
+    expect_shape(name, {n});
+    return st.to_f32(name);
+  };
 
   {  // conv stem
     std::vector<float> w = st.to_f32("model.encoder.conv1.weight"), r((size_t)D * 128, 0.f);
@@ -240,8 +246,8 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       // GroupNorm(1 group) between conv1 and conv2 is folded into conv2 (EpiGnBiasGeluBf16): its scale gamma goes into
       // the weights per input channel, its shift beta and the per-clip mean into two per-output-channel vectors.
       // S1 sums the bf16-ROUNDED folded weights, i.e. exactly what the MFMA multiplies.
-      const std::vector<float> gam = st.to_f32("model.encoder.groupnorm.weight"), bet = st.to_f32("model.encoder.groupnorm.bias");
-      const std::vector<float> b2 = st.to_f32("model.encoder.conv2.bias");
+      const std::vector<float> gam = vec("model.encoder.groupnorm.weight", D), bet = vec("model.encoder.groupnorm.bias", D);
+      const std::vector<float> b2 = vec("model.encoder.conv2.bias", 2 * D);
       r.assign((size_t)2 * D * 7 * D, 0.f);
       std::vector<float> s1((size_t)2 * D, 0.f), s2((size_t)2 * D, 0.f);
       for (int n = 0; n < 2 * D; ++n) {
@@ -268,8 +274,8 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       for (int ch = 0; ch < 2 * D; ++ch)
         for (int k = 0; k < 3; ++k) r[((size_t)n * 3 + k) * 2 * D + ch] = w[((size_t)n * 2 * D + ch) * 3 + k];
     upload_bf16(r, &conv3_w_);
-    upload(st.to_f32("model.encoder.conv3.bias"), &conv3_b_);
-    upload(st.to_f32("model.encoder.layer_norm.weight"), &enc_ln_);
+    upload(vec("model.encoder.conv3.bias", D), &conv3_b_);
+    upload(vec("model.encoder.layer_norm.weight", D), &enc_ln_);
   }
   auto fuse = [&](std::initializer_list<std::string> names) {
     std::vector<float> out;
@@ -291,17 +297,17 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     expect_shape(p + "mlp.fc2.weight", {D, F});
     upload_bf16(st.to_f32(p + "mlp.fc1.weight"), &L.fc1);
     upload_bf16(st.to_f32(p + "mlp.fc2.weight"), &L.fc2);
-    upload(st.to_f32(p + "mlp.fc1.bias"), &L.b1);
-    upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
-    upload(st.to_f32(p + "input_layernorm.weight"), &L.ln1);
-    upload(st.to_f32(p + "post_attention_layernorm.weight"), &L.ln2);
+    upload(vec(p + "mlp.fc1.bias", F), &L.b1);
+    upload(vec(p + "mlp.fc2.bias", D), &L.b2);
+    upload(vec(p + "input_layernorm.weight", D), &L.ln1);
+    upload(vec(p + "post_attention_layernorm.weight", D), &L.ln2);
   }
   {
     expect_shape("model.decoder.embed_tokens.weight", {V, D});
     std::vector<float> e = st.to_f32("model.decoder.embed_tokens.weight");
     upload(e, &embed_f32_);
     upload_bf16(e, &embed_bf16_);  // tied LM head (configuration_moonshine.py:103)
-    std::vector<float> g = st.to_f32("model.decoder.norm.weight");
+    std::vector<float> g = vec("model.decoder.norm.weight", D);
     upload(g, &dec_ln_);
     // copy of the head with the final LayerNorm scale folded in, for the LN-fused small-batch head GEMM
     for (int v = 0; v < V; ++v)
@@ -316,7 +322,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     // the decode GEMMs fuse LayerNorm into their A operand and expect its scale inside the weights:
     // LN(x) * W^T = ((x - mu) * rstd) * (W * diag(gamma))^T
     auto fold = [&](std::vector<float> w, const std::string& ln_name, int rows) {
-      const std::vector<float> gam = st.to_f32(ln_name);
+      const std::vector<float> gam = vec(ln_name, D);
       for (int r = 0; r < rows; ++r)
         for (int d = 0; d < D; ++d) w[(size_t)r * D + d] *= gam[d];
       return w;
@@ -337,7 +343,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     cross.insert(cross.end(), kv.begin(), kv.end());
     expect_shape(p + "mlp.fc1.weight", {2 * F, D});
     expect_shape(p + "mlp.fc2.weight", {D, F});
-    std::vector<float> w = st.to_f32(p + "mlp.fc1.weight"), b = st.to_f32(p + "mlp.fc1.bias");
+    std::vector<float> w = st.to_f32(p + "mlp.fc1.weight"), b = vec(p + "mlp.fc1.bias", 2 * F);
     std::vector<float> wi((size_t)2 * F * D), bi((size_t)2 * F);
     for (int j = 0; j < F; ++j) {  // first half = value, second half = gate (modeling_moonshine.py:92-96)
       memcpy(&wi[(size_t)(2 * j) * D], &w[(size_t)j * D], D * sizeof(float));
@@ -348,10 +354,10 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload_bf16_fm(fold(wi, p + "final_layernorm.weight", 2 * F), 2 * F, D, &L.fc1);
     upload(bi, &L.b1);
     upload_bf16_fm(st.to_f32(p + "mlp.fc2.weight"), D, F, &L.fc2);
-    upload(st.to_f32(p + "mlp.fc2.bias"), &L.b2);
-    upload(st.to_f32(p + "input_layernorm.weight"), &L.ln1);
-    upload(st.to_f32(p + "post_attention_layernorm.weight"), &L.ln2);
-    upload(st.to_f32(p + "final_layernorm.weight"), &L.ln3);
+    upload(vec(p + "mlp.fc2.bias", D), &L.b2);
+    upload(vec(p + "input_layernorm.weight", D), &L.ln1);
+    upload(vec(p + "post_attention_layernorm.weight", D), &L.ln2);
+    upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
 
@@ -471,6 +477,8 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 void Engine::plan_batch(const uint64_t* n_samples, uint32_t count, float mtps) {
   if (count == 0) throw std::invalid_argument("empty batch");
+  // the clip index is a grid y / z coordinate of the stem and attention launches (k_misc.hip, k_attn.hip)
+  if (count > 65535) throw std::invalid_argument("batch of " + std::to_string(count) + " clips: at most 65535 per call");
   clips_h_.assign(count, ClipMeta{});
   long row = 0, kv = 0;
   max_rows_ = 0;

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void dec_cross_probs_kernel(const float* __res
 
 void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta* clips, const int* pos_ptr, int M, int D,
                                int heads, int layers, int layer, int Smax, int Tcap, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(dec_cross_probs_kernel, dim3(M * heads), dim3(256), 0, s, q, KT, clips, pos_ptr, D, heads, D / heads,
+  MSH_LAUNCH(dec_cross_probs_kernel, dim3(M * heads), dim3(256), 0, s, q, KT, clips, pos_ptr, D, heads, D / heads,
                      layers, layer, Smax, Tcap, out);
 }
 
@@ -683,9 +683,9 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
 #define MSH_EATT(DHV)                                                                                          \
   case DHV:                                                                                                    \
     if (wide)                                                                                                  \
-      hipLaunchKernelGGL((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D);        \
+      MSH_LAUNCH((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D);        \
     else                                                                                                       \
-      hipLaunchKernelGGL((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D);        \
+      MSH_LAUNCH((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D);        \
     break
   switch (dh) {
     MSH_EATT(52);
@@ -701,9 +701,9 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
   const int dh = D / heads;
   dim3 grid((M * heads + 3) / 4);
   switch (dh) {
-    case 52: hipLaunchKernelGGL(dec_self_attention_kernel<52>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
-    case 36: hipLaunchKernelGGL(dec_self_attention_kernel<36>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
-    case 16: hipLaunchKernelGGL(dec_self_attention_kernel<16>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    case 52: MSH_LAUNCH(dec_self_attention_kernel<52>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    case 36: MSH_LAUNCH(dec_self_attention_kernel<36>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
+    case 16: MSH_LAUNCH(dec_self_attention_kernel<16>, grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out); break;
     default: throw std::runtime_error("dec_self_attention: unsupported head_dim " + std::to_string(dh));
   }
 }
@@ -713,9 +713,9 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
   const int dh = D / heads;
   dim3 grid(M * heads);
   switch (dh) {
-    case 52: hipLaunchKernelGGL((dec_cross_attention_kernel<52, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
-    case 36: hipLaunchKernelGGL((dec_cross_attention_kernel<36, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
-    case 16: hipLaunchKernelGGL((dec_cross_attention_kernel<16, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
+    case 16: MSH_LAUNCH((dec_cross_attention_kernel<16, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
     default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
   }
 }
@@ -726,9 +726,9 @@ void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t*
   if (D > 512 || (D & 7) != 0) throw std::runtime_error("dec_cross_attention_fused_q: unsupported width");
   dim3 grid(M * heads);
   switch (dh) {
-    case 52: hipLaunchKernelGGL((dec_cross_attention_kernel<52, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
-    case 36: hipLaunchKernelGGL((dec_cross_attention_kernel<36, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
-    case 16: hipLaunchKernelGGL((dec_cross_attention_kernel<16, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
+    case 16: MSH_LAUNCH((dec_cross_attention_kernel<16, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
     default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
   }
 }

@@ -357,7 +357,7 @@ void launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int
   constexpr int BM = 16 * NW * TM, BN = 16 * TN;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   const int nblocks = ntm * ntn;
-  hipLaunchKernelGGL((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
+  MSH_LAUNCH((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
                      W, M, N, K, ntn, nblocks, epi);
 }
 
@@ -529,7 +529,7 @@ void launch_astat_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, 
   const int ntm = (M + 127) / 128, ntn = (N + 16 * TN - 1) / (16 * TN);
   int nsplit = ntm >= 1024 ? 1 : (1024 + ntm - 1) / ntm;
   if (nsplit > ntn) nsplit = ntn;
-  hipLaunchKernelGGL((gemm_astat_kernel<KS, TN, NST, SWAP, Epi>), dim3(ntm * nsplit), dim3(256), 0, s, A, lda, W, M, N,
+  MSH_LAUNCH((gemm_astat_kernel<KS, TN, NST, SWAP, Epi>), dim3(ntm * nsplit), dim3(256), 0, s, A, lda, W, M, N,
                      ntn, nsplit, epi);
 }
 
@@ -550,7 +550,7 @@ void launch_tiled_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, 
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   const int nblocks = ntm * ntn;
-  hipLaunchKernelGGL((gemm_tiled_kernel<TM, TN, SWAP, Epi>), dim3(nblocks), dim3(256), 0, s, A, lda, W, M, N, K, ntn,
+  MSH_LAUNCH((gemm_tiled_kernel<TM, TN, SWAP, Epi>), dim3(nblocks), dim3(256), 0, s, A, lda, W, M, N, K, ntn,
                      nblocks, epi);
 }
 
@@ -682,7 +682,7 @@ void bench_launch(int abl, const bf16_t* A, long lda, const bf16_t* W, int M, in
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN, nb = ntm * ntn;
   EpiBf16 epi{C, N};
 #define MSH_BL(X)                                                                                                     \
-  hipLaunchKernelGGL((gemm_tiled_dma_kernel<NW, TM, 13, NSTAGE, true, EpiBf16, X>), dim3(nb), dim3(64 * NW), 0, s, A, \
+  MSH_LAUNCH((gemm_tiled_dma_kernel<NW, TM, 13, NSTAGE, true, EpiBf16, X>), dim3(nb), dim3(64 * NW), 0, s, A, \
                      lda, W, M, N, K, ntn, nb, epi)
   switch (abl) {
     case 0: MSH_BL(0); break;
@@ -717,11 +717,11 @@ static float gemm_lds_placement_probe(int M, int N, int K, long lda, int dyn_lds
   MSH_HIP(hipMalloc(&W, (long)N * K * 2));
   MSH_HIP(hipMalloc(&C, (long)M * N * 2));
   MSH_HIP(hipMalloc(&C2, (long)M * N * 2));
-  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
-  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+  MSH_LAUNCH(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
+  MSH_LAUNCH(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
   constexpr int BM = 128, BN = 208;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN, nb = ntm * ntn;
-  hipLaunchKernelGGL((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), 0, 0, A, lda, W, M, N, K,
+  MSH_LAUNCH((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), 0, 0, A, lda, W, M, N, K,
                      ntn, nb, EpiBf16{C, N});
   MSH_HIP(hipDeviceSynchronize());
   std::vector<uint16_t> ref((size_t)M * N), got((size_t)M * N);
@@ -729,7 +729,7 @@ static float gemm_lds_placement_probe(int M, int N, int K, long lda, int dyn_lds
   long bad = 0;
   for (int it = 0; it < iters; ++it) {
     MSH_HIP(hipMemset(C2, 0, (size_t)M * N * 2));
-    hipLaunchKernelGGL((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), dyn_lds, 0, A, lda, W, M,
+    MSH_LAUNCH((gemm_tiled_dma_kernel<4, 2, 13, 3, true, EpiBf16, 0>), dim3(nb), dim3(256), dyn_lds, 0, A, lda, W, M,
                        N, K, ntn, nb, EpiBf16{C2, N});
     MSH_HIP(hipDeviceSynchronize());
     MSH_HIP(hipMemcpy(got.data(), C2, got.size() * 2, hipMemcpyDeviceToHost));
@@ -749,8 +749,8 @@ float gemm_microbench(int M, int N, int K, long lda, int cfg, int abl, int iters
   MSH_HIP(hipMalloc(&A, a_elems * 2));
   MSH_HIP(hipMalloc(&W, (long)N * K * 2));
   MSH_HIP(hipMalloc(&C, (long)M * N * 2));
-  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
-  hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+  MSH_LAUNCH(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 1u);
+  MSH_LAUNCH(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
   MSH_HIP(hipDeviceSynchronize());
   auto run = [&] {
     switch (cfg) {

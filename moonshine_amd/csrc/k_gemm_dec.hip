@@ -272,7 +272,7 @@ template <int KS, int TN, bool LN, class Epi, int TM = 1>
 void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
                     hipStream_t s) {
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  hipLaunchKernelGGL((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W,
+  MSH_LAUNCH((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W,
                      M, N, n_tiles, epi);
 }
 static int dec_tm2_threshold() {
@@ -308,7 +308,7 @@ void launch_fm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hip
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
 #define MSH_FM_CASE(KK)                                                                                              \
   case KK:                                                                                                           \
-    hipLaunchKernelGGL((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
+    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
                        (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
     return;
   switch (K) {

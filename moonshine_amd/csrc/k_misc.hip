@@ -294,25 +294,25 @@ __global__ __launch_bounds__(256) void decode_advance_partials_kernel(const floa
 
 void pack_audio(const float* const* clip_ptrs, const ClipMeta* clips, int n_clips, bf16_t* out, long /*out_elems*/,
                 hipStream_t s) {
-  hipLaunchKernelGGL(pack_audio_kernel, dim3(32, n_clips), dim3(256), 0, s, clip_ptrs, clips, out);
+  MSH_LAUNCH(pack_audio_kernel, dim3(32, n_clips), dim3(256), 0, s, clip_ptrs, clips, out);
 }
 
 void build_row_meta(const ClipMeta* clips, int n_clips, int* row_pos, int* row_clip, hipStream_t s) {
-  hipLaunchKernelGGL(build_row_meta_kernel, dim3(2, n_clips), dim3(256), 0, s, clips, row_pos, row_clip);
+  MSH_LAUNCH(build_row_meta_kernel, dim3(2, n_clips), dim3(256), 0, s, clips, row_pos, row_clip);
 }
 
 void groupnorm_stats(const bf16_t* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
                      hipStream_t s) {
   if ((D & 7) != 0) throw std::runtime_error("groupnorm_stats: width must be a multiple of 8");
-  hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(GN_CHUNKS, n_clips), dim3(256), 0, s, x1, clips, D,
+  MSH_LAUNCH(groupnorm_partial_kernel, dim3(GN_CHUNKS, n_clips), dim3(256), 0, s, x1, clips, D,
                      reinterpret_cast<float2*>(partials));
-  hipLaunchKernelGGL(groupnorm_final_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, s,
+  MSH_LAUNCH(groupnorm_final_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, s,
                      reinterpret_cast<const float2*>(partials), clips, n_clips, D, stats);
 }
 
 void gn_fold_table(const float2* stats, const float* s1, const float* b2, int n_clips, int N, float* table,
                    hipStream_t s) {
-  hipLaunchKernelGGL(gn_fold_table_kernel, dim3(n_clips), dim3(256), 0, s, stats, s1, b2, N, table);
+  MSH_LAUNCH(gn_fold_table_kernel, dim3(n_clips), dim3(256), 0, s, stats, s1, b2, N, table);
 }
 
 void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t* y, float* y_f32, hipStream_t s) {
@@ -320,9 +320,9 @@ void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t*
   dim3 grid((rows + 3) / 4);
   if ((D & 3) != 0 || nch > 4) throw std::runtime_error("layernorm: unsupported width");
   switch (nch) {
-    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
-    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
-    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
+    case 1: MSH_LAUNCH(layernorm_kernel<1>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
+    case 2: MSH_LAUNCH(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
+    default: MSH_LAUNCH(layernorm_kernel<4>, grid, dim3(256), 0, s, x, gamma, rows, D, y, y_f32); break;
   }
 }
 
@@ -331,24 +331,24 @@ void dec_final_layernorm(const float* H, const float* gamma, int M, int D, bf16_
   dim3 grid((M + 3) / 4);
   if ((D & 31) != 0 || nch > 4) throw std::runtime_error("dec_final_layernorm: unsupported width");
   switch (nch) {
-    case 1: hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
-    default: hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
+    case 1: MSH_LAUNCH((layernorm_kernel<1, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
+    case 2: MSH_LAUNCH((layernorm_kernel<2, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
+    default: MSH_LAUNCH((layernorm_kernel<4, true>), grid, dim3(256), 0, s, H, gamma, M, D, y, (float*)nullptr); break;
   }
 }
 
 void decode_begin(int M, DecodeState st, int bos, const float* embed_f32, int D, float* H, hipStream_t s) {
-  hipLaunchKernelGGL(decode_begin_kernel, dim3(M), dim3(128), 0, s, M, st, bos, embed_f32, D, H);
+  MSH_LAUNCH(decode_begin_kernel, dim3(M), dim3(128), 0, s, M, st, bos, embed_f32, D, H);
 }
 
 void decode_advance(const float* logits, int M, int V, const ClipMeta* clips, DecodeState st, const float* embed_f32,
                     int D, float* H, hipStream_t s) {
-  hipLaunchKernelGGL(decode_advance_kernel, dim3(M), dim3(1024), 0, s, logits, V, clips, st, embed_f32, D, H);
+  MSH_LAUNCH(decode_advance_kernel, dim3(M), dim3(1024), 0, s, logits, V, clips, st, embed_f32, D, H);
 }
 
 void decode_advance_partials(const float* pval, const int* pidx, int ntn, int M, const ClipMeta* clips, DecodeState st,
                              const float* embed_f32, int D, float* H, hipStream_t s) {
-  hipLaunchKernelGGL(decode_advance_partials_kernel, dim3(M), dim3(256), 0, s, pval, pidx, ntn, clips, st, embed_f32, D,
+  MSH_LAUNCH(decode_advance_partials_kernel, dim3(M), dim3(256), 0, s, pval, pidx, ntn, clips, st, embed_f32, D,
                      H);
 }
 

@@ -620,11 +620,11 @@ __global__ void bump_cache_kernel(const DecJob* __restrict__ jobs, int n, SlotDe
 void stream_frames(const float* audio, const FrameJob* jobs, int n_jobs, int max_frames, float k, bf16_t* frames,
                    hipStream_t s) {
   if (n_jobs <= 0 || max_frames <= 0) return;
-  hipLaunchKernelGGL(frames_kernel, dim3((max_frames + 3) / 4, n_jobs), dim3(256), 0, s, audio, jobs, k, frames);
+  MSH_LAUNCH(frames_kernel, dim3((max_frames + 3) / 4, n_jobs), dim3(256), 0, s, audio, jobs, k, frames);
 }
 void copy_segments(const StreamSeg* segs, int n, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(copy_segments_kernel, dim3(n, 4), dim3(256), 0, s, segs);
+  MSH_LAUNCH(copy_segments_kernel, dim3(n, 4), dim3(256), 0, s, segs);
 }
 void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_hi, int R, int D, int heads, int past,
                           int future, bf16_t* out, hipStream_t s) {
@@ -632,23 +632,23 @@ void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_h
   if (past + future + 1 > 64 || dh > 128 || (dh & 3) != 0)
     throw std::runtime_error("stream_enc_attention: window wider than 64 keys or unsupported head_dim");
   if (R <= 0) return;
-  hipLaunchKernelGGL(enc_window_attention_kernel, dim3((R * heads + 3) / 4), dim3(256), 0, s, qkv, row_lo, row_hi, R,
+  MSH_LAUNCH(enc_window_attention_kernel, dim3((R * heads + 3) / 4), dim3(256), 0, s, qkv, row_lo, row_hi, R,
                      D, heads, past, future, out);
 }
 void stream_adapter_in(const float* y32, const int* rows, const int* pos, int n, int D, const float* pos_emb,
                        bf16_t* out16, float* out32, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(adapter_in_kernel, dim3(n), dim3(256), 0, s, y32, rows, pos, D, pos_emb, out16, out32);
+  MSH_LAUNCH(adapter_in_kernel, dim3(n), dim3(256), 0, s, y32, rows, pos, D, pos_emb, out16, out32);
 }
 void stream_scatter_cross(const bf16_t* tmp, const int* slot, const int* idx, int n, int L, int D, int Mcap,
                           bf16_t* crossK, bf16_t* crossV, hipStream_t s) {
   if (n <= 0) return;
   if ((D & 7) != 0) throw std::runtime_error("stream_scatter_cross: width must be a multiple of 8");
-  hipLaunchKernelGGL(scatter_cross_kernel, dim3(n, L), dim3(128), 0, s, tmp, slot, idx, L, D, Mcap, crossK, crossV);
+  MSH_LAUNCH(scatter_cross_kernel, dim3(n, L), dim3(128), 0, s, tmp, slot, idx, L, D, Mcap, crossK, crossV);
 }
 void stream_embed(const int* tokens, int M, const float* embed, int D, float* H, hipStream_t s) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(128), 0, s, tokens, embed, D, H);
+  MSH_LAUNCH(embed_kernel, dim3(M), dim3(128), 0, s, tokens, embed, D, H);
 }
 void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* row_pos, int M, int D, int heads, int layer,
                            int L, int Scap, bf16_t* cacheK, bf16_t* cacheV, bf16_t* out, hipStream_t s) {
@@ -656,9 +656,9 @@ void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* ro
   if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
     throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
   if (M <= 0) return;
-  hipLaunchKernelGGL(self_append_kernel, dim3(M), dim3(128), 0, s, qkv, row_slot, row_pos, D, layer, L, Scap, cacheK,
+  MSH_LAUNCH(self_append_kernel, dim3(M), dim3(128), 0, s, qkv, row_slot, row_pos, D, layer, L, Scap, cacheK,
                      cacheV);
-  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, 3 * D, row_slot, row_pos, M,
+  MSH_LAUNCH(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, 3 * D, row_slot, row_pos, M,
                      D, heads, layer, L, Scap, cacheK, cacheV, out);
 }
 void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
@@ -668,7 +668,7 @@ void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const in
   if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
     throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
   if (M <= 0) return;
-  hipLaunchKernelGGL(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, q, D, row_slot, row_pos, M, D,
+  MSH_LAUNCH(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, q, D, row_slot, row_pos, M, D,
                      heads, layer, L, Scap, cacheK, cacheV, out);
 }
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
@@ -680,7 +680,7 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
   if (M <= 0) return;
 #define MSH_XATT(DHV)                                                                                                  \
   case DHV:                                                                                                            \
-    hipLaunchKernelGGL(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
+    MSH_LAUNCH(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
                        layer, L, Mcap, crossK, crossV, out);                                                          \
     break
   switch (dh) {
@@ -692,7 +692,7 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
     MSH_XATT(64);
     MSH_XATT(80);
     default:
-      hipLaunchKernelGGL(cross_attention_generic_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,
+      MSH_LAUNCH(cross_attention_generic_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,
                          layer, L, Mcap, crossK, crossV, out);
   }
 #undef MSH_XATT
@@ -701,40 +701,40 @@ void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slo
                         int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s) {
   if (Mcap > CROSS_MMAX || D / heads > 128) throw std::runtime_error("stream_cross_probs: unsupported memory length or head_dim");
   if (M <= 0) return;
-  hipLaunchKernelGGL(cross_probs_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+  MSH_LAUNCH(cross_probs_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
                      crossK, Ecap, out);
 }
 void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s) {
   if ((V & 3) != 0) throw std::runtime_error("stream_argmax: vocabulary must be a multiple of 4");
   if (M <= 0) return;
-  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, pred);
+  MSH_LAUNCH(argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, pred);
 }
 void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* draft, SlotDev* slots, int* result,
                    int result_stride, int eos, const float* embed, int D, float* H, int* step_pos, int* n_active,
                    hipStream_t s) {
   if (n_jobs <= 0) return;
-  hipLaunchKernelGGL(verify_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, draft, slots, result, result_stride, eos,
+  MSH_LAUNCH(verify_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, draft, slots, result, result_stride, eos,
                      embed, D, H, step_pos, n_active);
 }
 void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
                     int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s) {
   if (n_jobs <= 0) return;
-  hipLaunchKernelGGL(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
+  MSH_LAUNCH(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
                      D, H, step_pos, n_active);
 }
 void stream_bias_rows(BiasTrie trie, const int2* prefix, const int* tokens, const DecJob* jobs, const SlotDev* slots,
                       const int* result, int result_stride, int rows, float* logits, int V, hipStream_t s) {
   if (rows <= 0 || trie.n_nodes <= 0) return;
-  hipLaunchKernelGGL(bias_rows_kernel, dim3(rows), dim3(64), 0, s, trie, prefix, tokens, jobs, slots, result,
+  MSH_LAUNCH(bias_rows_kernel, dim3(rows), dim3(64), 0, s, trie, prefix, tokens, jobs, slots, result,
                      result_stride, logits, V);
 }
 void stream_slot_update(const int4* upd, int n, SlotDev* slots, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(slot_update_kernel, dim3((n + 63) / 64), dim3(64), 0, s, upd, n, slots);
+  MSH_LAUNCH(slot_update_kernel, dim3((n + 63) / 64), dim3(64), 0, s, upd, n, slots);
 }
 void stream_bump_cache(const DecJob* jobs, int n_jobs, SlotDev* slots, hipStream_t s) {
   if (n_jobs <= 0) return;
-  hipLaunchKernelGGL(bump_cache_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs, n_jobs, slots);
+  MSH_LAUNCH(bump_cache_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs, n_jobs, slots);
 }
 
 }  // namespace msh

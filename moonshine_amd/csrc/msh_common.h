@@ -28,6 +28,16 @@ struct HipError : std::runtime_error {
     }                                                                                        \
   } while (0)
 
+// Every kernel launch goes through this: a launch the runtime refuses (grid above the limits, too much LDS for the
+// kernel, a template instance that was never compiled) is reported HERE, by name and line, instead of surfacing later as a
+// sticky error at an unrelated synchronise -- or as garbage ids.  hipGetLastError is legal during stream capture and
+// costs a thread-local read; launches in the steady state are graph replays, which do not pass through here at all.
+#define MSH_LAUNCH(...)                 \
+  do {                                  \
+    hipLaunchKernelGGL(__VA_ARGS__);    \
+    MSH_HIP(hipGetLastError());         \
+  } while (0)
+
 // Blocking copies / zero-fills that stay OFF the legacy (null) stream: hipMemcpy / hipMemset / hipDeviceSynchronize
 // touch it, and the legacy stream may not be used while ANOTHER host thread captures a decode-step graph on its own
 // stream ("operation would make the legacy stream depend on a capturing blocking stream") -- which is exactly what

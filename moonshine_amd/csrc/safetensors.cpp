@@ -233,7 +233,15 @@ void SafeTensors::parse(const uint8_t* data, size_t size) {
       t.nbytes = (size_t)(off1 - off0);
       size_t esz = t.dtype == "F32" ? 4 : (t.dtype == "F16" || t.dtype == "BF16") ? 2 : 0;
       if (esz == 0) throw std::runtime_error("safetensors: unsupported dtype " + t.dtype + " for " + key);
-      if ((size_t)t.numel() * esz != t.nbytes) throw std::runtime_error("safetensors: size mismatch for " + key);
+      // model files are caller-supplied bytes: no negative extents, no product that wraps around
+      uint64_t numel = 1;
+      for (int64_t d : t.shape) {
+        if (d < 0) throw std::runtime_error("safetensors: negative dimension in " + key);
+        if (d != 0 && numel > (uint64_t)1 << 40) throw std::runtime_error("safetensors: shape of " + key + " is too large");
+        numel *= (uint64_t)d;
+      }
+      if (numel > ((uint64_t)1 << 40) || numel * esz != (uint64_t)t.nbytes)
+        throw std::runtime_error("safetensors: size mismatch for " + key);
       tensors[key] = t;
     }
     if (r.peek(',')) {
@@ -248,9 +256,12 @@ void SafeTensors::parse(const uint8_t* data, size_t size) {
 void SafeTensors::load_file(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("cannot open " + path);
-  fseek(f, 0, SEEK_END);
-  long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
+  long n = -1;
+  if (fseek(f, 0, SEEK_END) == 0) n = ftell(f);
+  if (n < 0 || fseek(f, 0, SEEK_SET) != 0) {
+    fclose(f);
+    throw std::runtime_error("cannot determine the size of " + path);
+  }
   owned.resize((size_t)n);
   size_t got = fread(owned.data(), 1, (size_t)n, f);
   fclose(f);

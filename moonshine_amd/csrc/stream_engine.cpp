@@ -188,6 +188,10 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
   auto shape_is = [&](const std::string& name, std::vector<int64_t> shape) {
     if (st.get(name).shape != shape) throw std::runtime_error("unexpected shape for " + name);
   };
+  auto vec = [&](const std::string& name, int64_t n) {  // 1-D parameters are checked like the matrices
+    shape_is(name, {n});
+    return st.to_f32(name);
+  };
   while (st.has("model.encoder.layers." + std::to_string(c.enc_layers) + ".mlp.fc1.weight")) ++c.enc_layers;
   int dec_layers = 0;
   while (st.has("model.decoder.layers." + std::to_string(dec_layers) + ".mlp.fc1.weight")) ++dec_layers;
@@ -237,8 +241,8 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
       for (int ch = 0; ch < 2 * De; ++ch)
         for (int k = 0; k < 5; ++k) r[((size_t)n * 5 + k) * 2 * De + ch] = w[((size_t)n * 2 * De + ch) * 5 + k];
     upload_bf16(r, &conv2_w_);
-    upload(st.to_f32("model.encoder.embedder.conv1.bias"), &conv1_b_);
-    upload(st.to_f32("model.encoder.embedder.conv2.bias"), &conv2_b_);
+    upload(vec("model.encoder.embedder.conv1.bias", 2 * De), &conv1_b_);
+    upload(vec("model.encoder.embedder.conv2.bias", De), &conv2_b_);
   }
   auto cat = [&](std::initializer_list<std::string> names, int rows, int cols) {
     std::vector<float> out;
@@ -250,7 +254,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     return out;
   };
   auto gamma1 = [&](const std::string& name) {
-    std::vector<float> g = st.to_f32(name);
+    std::vector<float> g = vec(name, De);
     for (float& x : g) x += 1.0f;  // unit_offset LayerNorm, modeling_moonshine_streaming.py:127-130
     return g;
   };
@@ -263,8 +267,8 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     upload_bf16(cat({p + "self_attn.o_proj.weight"}, De, De), &E.wo);
     upload_bf16(cat({p + "mlp.fc1.weight"}, Fe, De), &E.fc1);
     upload_bf16(cat({p + "mlp.fc2.weight"}, De, Fe), &E.fc2);
-    upload(st.to_f32(p + "mlp.fc1.bias"), &E.b1);
-    upload(st.to_f32(p + "mlp.fc2.bias"), &E.b2);
+    upload(vec(p + "mlp.fc1.bias", Fe), &E.b1);
+    upload(vec(p + "mlp.fc2.bias", De), &E.b2);
     upload(gamma1(p + "input_layernorm.gamma"), &E.ln1);
     upload(gamma1(p + "post_attention_layernorm.gamma"), &E.ln2);
   }
@@ -283,7 +287,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     // untied head when the checkpoint has one (lora/export.py:198-203), else the embedding
     std::vector<float> head = st.has("proj_out.weight") ? cat({"proj_out.weight"}, V, Dd) : e;
     upload_bf16(head, &head_w_);
-    const std::vector<float> gn = st.to_f32("model.decoder.norm.weight");
+    const std::vector<float> gn = vec("model.decoder.norm.weight", Dd);
     upload(gn, &dec_ln_);
     for (int v = 0; v < V; ++v)
       for (int d = 0; d < Dd; ++d) head[(size_t)v * Dd + d] *= gn[d];
@@ -296,7 +300,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     DecW& W = dec_[l];
     // LN(x) * W^T = ((x - mu) * rstd) * (W * diag(gamma))^T: folded copies for the LN-fused small-batch kernels
     auto fold = [&](std::vector<float> wmat, const std::string& ln_name, int rows) {
-      const std::vector<float> gam = st.to_f32(ln_name);
+      const std::vector<float> gam = vec(ln_name, Dd);
       for (int r = 0; r < rows; ++r)
         for (int d = 0; d < Dd; ++d) wmat[(size_t)r * Dd + d] *= gam[d];
       return wmat;
@@ -314,7 +318,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     std::vector<float> kv = cat({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"}, Dd, Dd);
     cross.insert(cross.end(), kv.begin(), kv.end());
     shape_is(p + "mlp.fc1.weight", {2 * Fd, Dd});
-    std::vector<float> f1 = st.to_f32(p + "mlp.fc1.weight"), b1 = st.to_f32(p + "mlp.fc1.bias");
+    std::vector<float> f1 = st.to_f32(p + "mlp.fc1.weight"), b1 = vec(p + "mlp.fc1.bias", 2 * Fd);
     std::vector<float> f1i((size_t)2 * Fd * Dd), b1i((size_t)2 * Fd);
     for (int j = 0; j < Fd; ++j) {  // chunk(2): first half value, second half gate (modeling_moonshine_streaming.py:459-461)
       memcpy(&f1i[(size_t)(2 * j) * Dd], &f1[(size_t)j * Dd], Dd * sizeof(float));
@@ -326,10 +330,10 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     upload_bf16(fold(f1i, p + "final_layernorm.weight", 2 * Fd), &W.fc1_f);
     upload(b1i, &W.b1);
     upload_bf16(cat({p + "mlp.fc2.weight"}, Dd, Fd), &W.fc2);
-    upload(st.to_f32(p + "mlp.fc2.bias"), &W.b2);
-    upload(st.to_f32(p + "input_layernorm.weight"), &W.ln1);
-    upload(st.to_f32(p + "post_attention_layernorm.weight"), &W.ln2);
-    upload(st.to_f32(p + "final_layernorm.weight"), &W.ln3);
+    upload(vec(p + "mlp.fc2.bias", Dd), &W.b2);
+    upload(vec(p + "input_layernorm.weight", Dd), &W.ln1);
+    upload(vec(p + "post_attention_layernorm.weight", Dd), &W.ln2);
+    upload(vec(p + "final_layernorm.weight", Dd), &W.ln3);
   }
   upload_bf16(cross, &cross_w_);
   {  // RoPE tables: inv_freq over dim = int(head_dim * factor); ceil(dim / 2) rotated pairs
