@@ -80,21 +80,29 @@ constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: 16-byte aligned 
 constexpr int EQT = 4;        // query tiles of 16 per wave
 
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(64 * NW, 2) void enc_attention_kernel(const bf16_t* __restrict__ qk,
                                                                 const bf16_t* __restrict__ vt, long vt_ld,
                                                                 bf16_t* __restrict__ out,
-                                                                const ClipMeta* __restrict__ clips, int D) {
+                                                                const ClipMeta* __restrict__ clips, int D,
+                                                                int tiles_per_wg) {
   static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
   constexpr int PIECES = DH / 4;  // 8-byte pieces per K row
   constexpr int NT = 64 * NW;
+  // head_dim is padded to a multiple of 16 rows of V^T for the MFMA: when there is a spare row, it holds ones, and the
+  // softmax denominator comes out of the P.V MFMA as "dimension DH" of O (the same bf16 P that forms the numerator)
+  // instead of 16 VALU adds per query tile and key block
+  constexpr bool ONES_ROW = (DH % 16) != 0;
+  constexpr float kTau = 8.0f;
   // two LDS buffers: block kb + 1 is fetched (into registers) while block kb is consumed and lands in the other buffer,
   // so a workgroup that is alone on its CU (232 VGPRs) does not expose a memory round trip per key block
   __shared__ __attribute__((aligned(16))) uint2 Ks2[2][KB * 16];        // [key][8 x 16 B], chunk ^= (key>>1)&7
   __shared__ __attribute__((aligned(16))) bf16_t Vt2[2][64 * VT_LD];    // [d][key]
 
   const ClipMeta cm = clips[blockIdx.z];
-  const int q0 = blockIdx.x * 64 * NW;
-  if (q0 >= cm.rows) return;
+  // this workgroup's run of 16-query tiles; its waves take them round-robin (tile0 + wave, + NW, ...), so the last,
+  // partly filled round is spread over the waves instead of leaving one wave with half the work of the others
+  const int tile0 = blockIdx.x * tiles_per_wg;
+  if (tile0 * 16 >= cm.rows) return;
   const int h = blockIdx.y;
   const int T = cm.T, Tk = cm.Tk;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __
       const int key = p >> 4, piece = p & 15;
       if (piece >= PIECES) Ks2[b2][(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = make_uint2(0u, 0u);
     }
-    for (int p = tid; p < (64 - DH) * VT_LD; p += NT) Vt2[b2][DH * VT_LD + p] = 0;
+    for (int p = tid; p < (64 - DH) * VT_LD; p += NT) Vt2[b2][DH * VT_LD + p] = (ONES_ROW && p < VT_LD) ? 0x3f80 : 0;
   }
   constexpr int KP = (KB * PIECES + NT - 1) / NT, VP = (DH * 8 + NT - 1) / NT;   // staged pieces per thread and block
   uint2 kreg[KP];
@@ -160,14 +168,14 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __
   };
 
   // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
-  const int tq0 = q0 + wave * 64;
   bool act[EQT];
   int qrow[EQT];
   bf16x8 qf[EQT][2];
 #pragma unroll
   for (int qi = 0; qi < EQT; ++qi) {
-    act[qi] = tq0 + qi * 16 < T;   // wave-uniform
-    qrow[qi] = tq0 + qi * 16 + li;
+    const int tile = qi * NW + wave;   // within the workgroup's run
+    act[qi] = tile < tiles_per_wg && (tile0 + tile) * 16 < T;   // wave-uniform
+    qrow[qi] = (tile0 + tile) * 16 + li;
     const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -201,28 +209,29 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __
     const uint2* Ks = Ks2[buf];
     const bf16_t* Vt = Vt2[buf];
 
-    // S^T tiles: rows = keys, cols = queries.  st[qi][kt][r] = score(q = li of tile qi, key = kb*64 + kt*16 + kg*4 + r)
-    f32x4 st[EQT][4];
+    // S^T tiles: rows = keys, cols = queries.  st[kt][r] = score(q = li of tile qi, key = kb*64 + kt*16 + kg*4 + r).
+    // The block's K fragments are read once (32 registers) and one query tile at a time goes through scores -> softmax ->
+    // P fragments, so only 16 score registers are live instead of 16 per tile.
+    uint4 kf[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int key = kt * 16 + li;
-      uint4 kf[2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) kf[s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
-#pragma unroll
-      for (int qi = 0; qi < EQT; ++qi) {
-        if (!act[qi]) continue;
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[s]), qf[qi][s], a, 0, 0, 0);
-        st[qi][kt] = a;
-      }
+      for (int s = 0; s < 2; ++s) kf[kt][s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
     }
     bf16x8 pf[EQT][2];
 #pragma unroll
     for (int qi = 0; qi < EQT; ++qi) {
       if (!act[qi]) continue;
+      f32x4 st[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[kt][s]), qf[qi][s], a, 0, 0, 0);
+        st[kt] = a;
+      }
       // the softmax is VALU-bound (16 exp2 per lane per tile): keep the per-score work to max, one fma and the
       // exp2 -- the scale is folded into the fma (c > 0, so the max of the raw scores is the max), and keys past
       // the clip's length are masked only in the block that contains them
@@ -231,36 +240,43 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kb * KB + kt * 16 + kg * 4 + r >= T) st[qi][kt][r] = -INFINITY;
+            if (kb * KB + kt * 16 + kg * 4 + r >= T) st[kt][r] = -INFINITY;
       }
       float mloc = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[qi][kt][r]);
-      mloc = rows_max(mloc);
-      const float m_new = fmaxf(m_run[qi], mloc * c);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-      m_run[qi] = m_new;
+        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[kt][r]);
+      const float cand = rows_max(mloc) * c;
+      // The reference point of the exponent moves only when some query of the tile found a score more than kTau above
+      // it (wave-uniform test): the accumulators are rescaled a few times per clip instead of once per block.  Numerator
+      // and denominator use the same reference, so the quotient is unchanged; p <= 2^kTau keeps bf16 / fp32 in range.
+      if (__any(cand > m_run[qi] + kTau)) {
+        const float m_new = fmaxf(m_run[qi], cand);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+        m_run[qi] = m_new;
+        if constexpr (!ONES_ROW) l_run[qi] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+      }
+      const float m_ref = m_run[qi];
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[qi][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][kt][r], c, -m_new));
-          psum += st[qi][kt][r];
+          st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c, -m_ref));
+          if constexpr (!ONES_ROW) psum += st[kt][r];
         }
-      l_run[qi] = l_run[qi] * alpha + psum;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+      if constexpr (!ONES_ROW) l_run[qi] += psum;
       // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         uint4 pt;
-        pt.x = pack_bf16x2(st[qi][2 * ks][0], st[qi][2 * ks][1]);
-        pt.y = pack_bf16x2(st[qi][2 * ks][2], st[qi][2 * ks][3]);
-        pt.z = pack_bf16x2(st[qi][2 * ks + 1][0], st[qi][2 * ks + 1][1]);
-        pt.w = pack_bf16x2(st[qi][2 * ks + 1][2], st[qi][2 * ks + 1][3]);
+        pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
+        pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
+        pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+        pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
         pf[qi][ks] = *reinterpret_cast<bf16x8*>(&pt);
       }
     }
@@ -285,9 +301,14 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const bf16_t* __
 
 #pragma unroll
   for (int qi = 0; qi < EQT; ++qi) {
-    const float l = rows_sum(l_run[qi]);
+    float l;
+    if constexpr (ONES_ROW) {   // row DH of O^T: tile DH / 16, lane group (DH % 16) / 4, register 0
+      l = __shfl(o[qi][DH / 16][0], ((DH % 16) / 4) * 16 + li);
+    } else {
+      l = rows_sum(l_run[qi]);
+    }
     const float inv = 1.0f / l;
-    if (qrow[qi] < cm.rows) {
+    if (qi * NW + wave < tiles_per_wg && qrow[qi] < cm.rows) {
       const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
       bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
 #pragma unroll
@@ -675,17 +696,26 @@ void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta*
 void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows,
                    int D, int heads, hipStream_t s) {
   const int dh = D / heads;
-  // 7 waves = 448 queries cover a 10 s clip (415 frames) in one workgroup; short clips take 4 waves (256 queries)
-  const bool wide = max_rows > 256;
-  const int per = wide ? 448 : 256;
-  dim3 grid((max_rows + per - 1) / per, heads, n_clips);
+  // 16-query tiles, four per wave at most.  Long clips (a 10 s clip is 415 frames = 26 tiles): two workgroups of 4 waves
+  // per (clip, head), 13 tiles each -- two of them share a CU (232 VGPRs), so one's barriers and prologue are covered by
+  // the other; MSH_ENC_ATT_WIDE=1 selects the earlier shape, one workgroup of 7 waves (28 tile slots) alone on its CU.
+  static const bool wide_wg = [] {
+    const char* e = getenv("MSH_ENC_ATT_WIDE");
+    return e != nullptr && e[0] == '1';
+  }();
+  const int ntiles = (max_rows + 15) / 16;
+  const bool wide = wide_wg && ntiles > 16 && ntiles <= 28;
+  const int slots = wide ? 28 : 16;
+  const int gx = (ntiles + slots - 1) / slots;
+  const int tiles_per_wg = (ntiles + gx - 1) / gx;
+  dim3 grid(gx, heads, n_clips);
   if (n_clips > 65535) throw std::runtime_error("enc_attention: more than 65535 clips in one batch");
-#define MSH_EATT(DHV)                                                                                          \
-  case DHV:                                                                                                    \
-    if (wide)                                                                                                  \
-      MSH_LAUNCH((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D);        \
-    else                                                                                                       \
-      MSH_LAUNCH((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D);        \
+#define MSH_EATT(DHV)                                                                                                       \
+  case DHV:                                                                                                                 \
+    if (wide)                                                                                                               \
+      MSH_LAUNCH((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
+    else                                                                                                                    \
+      MSH_LAUNCH((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
     break
   switch (dh) {
     MSH_EATT(52);
