@@ -4,7 +4,11 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace msh_host {
 
@@ -223,6 +227,39 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out) {
   if (n < 0) return false;
   out->resize((size_t)n);
   return std::fread(out->data(), 1, (size_t)n, file.f) == (size_t)n;
+}
+
+void parallel_for(size_t n, const std::function<void(size_t)>& fn, unsigned max_threads) {
+  unsigned nt = max_threads ? max_threads : std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > n) nt = (unsigned)n;
+  if (nt <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  std::exception_ptr err;
+  std::mutex err_mutex;
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n || failed.load()) return;
+      try {
+        fn(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(err_mutex);
+        if (!err) err = std::current_exception();
+        failed.store(true);
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve(nt - 1);
+  for (unsigned t = 0; t + 1 < nt; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  if (err) std::rethrow_exception(err);
 }
 
 }  // namespace msh_host

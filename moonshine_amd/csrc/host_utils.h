@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -39,5 +40,9 @@ bool save_wav(const std::string& path, const float* samples, size_t count, int32
 std::string join_path(const std::string& dir, const std::string& name);
 bool file_exists(const std::string& path);
 bool read_file(const std::string& path, std::vector<uint8_t>* out);
+
+// fn(i) for i in [0, n) on up to max_threads host threads (0 = one per hardware thread); items are handed out one at a
+// time, the first exception is re-thrown on the caller's thread after every worker has stopped
+void parallel_for(size_t n, const std::function<void(size_t)>& fn, unsigned max_threads = 0);
 
 }  // namespace msh_host

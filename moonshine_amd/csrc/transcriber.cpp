@@ -827,13 +827,18 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   std::vector<std::vector<VadSegment>> segs(count);
   for (uint64_t i = 0; i < count; ++i) {
     batch_streams_.emplace_back(new_stream(-1));
-    TranscriberStream* s = batch_streams_.back().get();
+    streams.push_back(batch_streams_.back().get());
+  }
+  // Segmentation is per clip (its own detector state, shared read-only weights) and runs on the host: one clip per host
+  // thread.  With Silero on, a 10 s clip costs ~25 ms of one core -- serially that is seconds for a batch the GPU
+  // transcribes in tens of milliseconds (the reference walks the clips one after the other, transcriber.cpp:997).
+  parallel_for((size_t)count, [&](size_t i) {
+    TranscriberStream* s = streams[i];
     s->vad->start();
     s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
     s->vad->stop();
     segs[i] = s->vad->segments();
-    streams.push_back(s);
-  }
+  }, opt_.host_threads > 0 ? (unsigned)opt_.host_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency())));
   std::vector<transcript_t*> outs(count, nullptr);
   // A streaming architecture keeps one device slot per line being decoded (max_streams of them): larger batches run in
   // waves of that size, and a wave's slots are handed back before the next one starts.  The transcripts stay.

@@ -266,6 +266,43 @@ def test_default_vad_threshold_needs_silero_weights_at_load_and_works_with_them(
     t.close()
 
 
+def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_path):
+    """With Silero on, the batch call segments its clips on host threads (one detector per clip, shared weights; additive
+    option `host_threads`): every clip is segmented as in a single-clip call, and the transcripts do not depend on the
+    thread count."""
+    import shutil
+    import time
+
+    from moonshine_amd.synth import save_safetensors
+    from oracle import silero_ref as sr
+
+    d = str(tmp_path / "with_vad")
+    shutil.copytree(tiny_dir[0], d)
+    save_safetensors(os.path.join(d, "silero_vad.safetensors"), sr.make_weights(2))
+    clips = []
+    for i in range(24):
+        n = int((4.0 + 0.37 * i) * 16000)
+        env = (np.sin(np.arange(n) / 16000 * 2 * np.pi * (0.5 + 0.05 * i)) > 0).astype(np.float32)
+        clips.append((make_audio(900 + i, n) * (0.05 + 3.0 * env)).astype(np.float32))
+    one = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "1"})
+    spans = [[(l.start_time, l.duration) for l in one.transcribe_without_streaming(c)] for c in clips]
+    assert sum(len(w) for w in spans) > len(clips)          # the detector does split these clips
+    t0 = time.perf_counter()
+    want = [[(l.text_bytes, l.start_time, l.duration) for l in r] for r in one.transcribe_batch_without_streaming(clips)]
+    t1 = time.perf_counter() - t0
+    one.close()
+    # segmentation is a function of the clip alone (the text of a near-tie token may depend on the batch it was decoded in)
+    assert [[(a, b) for _, a, b in r] for r in want] == spans
+    many = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "16"})
+    many.transcribe_batch_without_streaming(clips[:2])    # warm
+    t0 = time.perf_counter()
+    got = [[(l.text_bytes, l.start_time, l.duration) for l in r] for r in many.transcribe_batch_without_streaming(clips)]
+    t16 = time.perf_counter() - t0
+    many.close()
+    assert got == want                                      # same batch, any thread count: identical transcripts
+    print(f"batch of {len(clips)} clips with Silero: {t1 * 1e3:.0f} ms on 1 host thread, {t16 * 1e3:.0f} ms on 16")
+
+
 def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir):
     """Additive load options `devices` / `num_gpus` / `max_batch_size`: the batch call shards its
     clips over one engine per listed GPU inside the C++ host layer (length-sorted snake deal, one host thread per device,
