@@ -17,6 +17,7 @@ Extra objects in the line:
   serial_steps  the same steps strictly one after the other (one batch of 256 on the GPU at a time).
   pcie_inclusive  the same steps with the clips handed over in pinned host memory.
   typical_40_steps  the same batch with 40 forced decode steps.
+  c_api_batch   2048 of the same clips through moonshine_transcribe_batch_without_streaming (the drop-in entry point).
   streaming_config5  BASELINE config 5 (64 streams of the medium streaming architecture), a short run.
   decode_step_us  cost of every decode kernel group inside a replayed hipGraph chain.
 """
@@ -58,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-streaming", action="store_true", help="skip the short config-5 (streaming) run inside the default bench")
+    ap.add_argument("--no-c-api", action="store_true", help="skip the run through moonshine_transcribe_batch_without_streaming")
     ap.add_argument("--no-typical", action="store_true", help="skip the 40-forced-steps (typical English) run")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (clips in pinned host memory) run")
     ap.add_argument("--cpu-clips", type=int, default=6)
@@ -340,6 +342,38 @@ def main():
         typical = {"value": round(B * CLIP_SECONDS * k / dtt, 1), "unit": "audio-seconds/sec", "ms_per_step": round(dtt / k * 1e3, 3),
                    "steps": k, "decode_steps": 40}
 
+    # ---- the same clips through the drop-in boundary: moonshine_transcribe_batch_without_streaming (include/moonshine-c-api.h)
+    # on pageable host buffers, vad_threshold = 0 (all audio is speech: one line per clip), EOS honoured (random weights
+    # almost never emit it, so nearly every clip runs its 65-token budget), detokenise + transcript assembly included.
+    # What a caller of the reference's C API gets from this library; never `value`. ----
+    c_api = None
+    if world == 1 and not args.no_c_api:
+        import ctypes as C
+
+        from moonshine_amd import api as mapi
+        from moonshine_amd.synth import write_model_dir
+
+        with tempfile.TemporaryDirectory() as md:
+            write_model_dir(md, cfg, seed=0, weights=w)
+            tr = mapi.Transcriber(md, mapi.ARCH_BASE if args.arch == "base" else mapi.ARCH_TINY,
+                                  {"vad_threshold": "0", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank)})
+        reps = 8   # 2048 clips: BASELINE config 4's clip count, here on one GPU (8 sub-batches over the lanes)
+        n = reps * B
+        arrs = [host[i % B] for i in range(n)]
+        cptrs = (C.POINTER(C.c_float) * n)(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
+        clens = (C.c_uint64 * n)(*[a.shape[0] for a in arrs])
+        outs = (C.POINTER(mapi.TranscriptC) * n)()
+        call = lambda: mapi.lib().moonshine_transcribe_batch_without_streaming(tr.handle, cptrs, clens, n, 16000, 0, outs)
+        assert call() == 0          # lanes allocate and capture their graphs
+        tc = time.perf_counter()
+        assert call() == 0
+        dtc = time.perf_counter() - tc
+        lines = sum(int(outs[i].contents.line_count) for i in range(n))
+        c_api = {"value": round(n * CLIP_SECONDS / dtc, 1), "unit": "audio-seconds/sec", "clips": n, "ms_per_call": round(dtc * 1e3, 1),
+                 "lines": lines, "entry_point": "moonshine_transcribe_batch_without_streaming", "host_buffers": "pageable",
+                 "options": {"vad_threshold": 0, "batch_clips": B, "batches_in_flight": F}}
+        tr.close()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -502,6 +536,7 @@ def main():
         "serial_steps": serial,
         "pcie_inclusive": pcie,
         "typical_40_steps": typical,
+        "c_api_batch": c_api,
         "streaming_config5": streaming,
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
             "kernel": dominant["kernel"], "ms_per_launch": dominant["ms_per_launch"],

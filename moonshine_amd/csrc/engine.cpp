@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include "host_utils.h"
+
 #include <mutex>
 
 #include <math.h>
@@ -122,6 +124,7 @@ Engine::~Engine() {
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
                     &Y_, &QKV_, &VTe_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
   for (DevBuf* b : bufs) b->release();
+  if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -560,12 +563,41 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
     size_t total = 0;
     for (uint32_t i = 0; i < count; ++i) total += (n_samples[i] + 3) & ~size_t(3);
     pcm_stage_.reserve(total * sizeof(float));
+    std::vector<size_t> offs(count);
     size_t off = 0;
     for (uint32_t i = 0; i < count; ++i) {
-      float* dst = pcm_stage_.as<float>() + off;
-      MSH_HIP(hipMemcpyAsync(dst, pcm[i], n_samples[i] * sizeof(float), hipMemcpyHostToDevice, stream_));
-      ptrs[i] = dst;
+      offs[i] = off;
+      ptrs[i] = pcm_stage_.as<float>() + off;
       off += (n_samples[i] + 3) & ~size_t(3);
+    }
+    // A large batch in PAGEABLE host memory (what a caller of the C API hands over): hipMemcpyAsync would stage every clip
+    // through the runtime's bounce buffers on this one thread (~10 GB/s, synchronous).  Gather the clips into this
+    // engine's pinned buffer on a few host threads instead and move them with ONE asynchronous DMA.  Pinned or
+    // registered caller memory, and small batches, are copied directly as before.
+    bool pageable = false;
+    if (total * sizeof(float) >= ((size_t)8 << 20)) {
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, pcm[0]) != hipSuccess) {
+        (void)hipGetLastError();  // "not a registered pointer" is an answer here, not an error to keep
+        pageable = true;
+      } else {
+        pageable = at.type == hipMemoryTypeUnregistered;
+      }
+    }
+    if (pageable) {
+      if (pcm_pinned_cap_ < total * sizeof(float)) {
+        if (pcm_pinned_) MSH_HIP(hipHostFree(pcm_pinned_));
+        pcm_pinned_ = nullptr;
+        pcm_pinned_cap_ = 0;
+        MSH_HIP(hipHostMalloc(&pcm_pinned_, total * sizeof(float), hipHostMallocDefault));
+        pcm_pinned_cap_ = total * sizeof(float);
+      }
+      float* pin = static_cast<float*>(pcm_pinned_);
+      msh_host::parallel_for(count, [&](size_t i) { memcpy(pin + offs[i], pcm[i], n_samples[i] * sizeof(float)); }, 8);
+      MSH_HIP(hipMemcpyAsync(pcm_stage_.p, pin, total * sizeof(float), hipMemcpyHostToDevice, stream_));
+    } else {
+      for (uint32_t i = 0; i < count; ++i)
+        MSH_HIP(hipMemcpyAsync(pcm_stage_.as<float>() + offs[i], pcm[i], n_samples[i] * sizeof(float), hipMemcpyHostToDevice, stream_));
     }
   }
   MSH_HIP(hipMemcpyAsync(clips_d_.p, clips_h_.data(), count * sizeof(ClipMeta), hipMemcpyHostToDevice, stream_));

@@ -149,6 +149,8 @@ class Engine {
   std::vector<int32_t> cross_counts_;  // tokens per clip (incl. BOS) of the captured decode
 
   // workspace (grow-only)
+  void* pcm_pinned_ = nullptr;  // host staging for clips handed over in pageable memory (see encode())
+  size_t pcm_pinned_cap_ = 0;
   DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, VTe_, AO_, Z_,
       ENC_, ENC32_, gn_part_, gn_stats_, gn_table_, KT_, VT_;
   int Smax_ = 0;

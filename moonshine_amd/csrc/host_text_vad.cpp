@@ -187,7 +187,6 @@ void VoiceActivityDetector::start() {
   active_ = true;
   processed_ = 0;
   segments_.clear();
-  cur_.clear();
   remainder_.clear();
   look_buf_.assign(look_behind_, 0.f);
   prev_voice_ = false;
@@ -201,7 +200,6 @@ void VoiceActivityDetector::stop() {
   active_ = false;
   if (prev_voice_ && !segments_.empty()) {  // close the open segment as it stands (the sub-hop tail is dropped)
     VadSegment& s = segments_.back();
-    s.audio = cur_;
     s.end_time = (float)processed_ / kSampleRate;
     s.is_complete = true;
     s.just_updated = true;
@@ -211,20 +209,32 @@ void VoiceActivityDetector::stop() {
 void VoiceActivityDetector::process_audio(const float* audio, size_t count, int32_t sample_rate) {
   if (!active_) return;
   for (VadSegment& s : segments_) s.just_updated = false;
-  std::vector<float> in(audio, audio + count);
-  std::vector<float> buf = remainder_;
-  if (sample_rate == kSampleRate) {
-    buf.insert(buf.end(), in.begin(), in.end());
-  } else {
-    std::vector<float> r = resample(in, (float)sample_rate, (float)kSampleRate);
-    buf.insert(buf.end(), r.begin(), r.end());
+  std::vector<float> resampled;
+  const float* src = audio;
+  size_t n = count;
+  if (sample_rate != kSampleRate) {
+    resampled = resample(std::vector<float>(audio, audio + count), (float)sample_rate, (float)kSampleRate);
+    src = resampled.data();
+    n = resampled.size();
   }
+  // whole hops only; the sub-hop tail waits in remainder_ for the next call.  Hops are read in place (no staging copy).
   size_t off = 0;
-  while (buf.size() - off >= (size_t)hop_) {
-    process_hop(buf.data() + off);
+  if (!remainder_.empty()) {
+    const size_t take = std::min((size_t)hop_ - remainder_.size(), n);
+    remainder_.insert(remainder_.end(), src, src + take);
+    off = take;
+    if (remainder_.size() < (size_t)hop_) return;
+    call_remaining_ = n - off;
+    process_hop(remainder_.data());
+    remainder_.clear();
+  }
+  while (n - off >= (size_t)hop_) {
+    call_remaining_ = n - off - hop_;
+    process_hop(src + off);
     off += hop_;
   }
-  remainder_.assign(buf.begin() + off, buf.end());
+  call_remaining_ = 0;
+  remainder_.assign(src + off, src + n);
 }
 
 void VoiceActivityDetector::clear_completed_audio() {
@@ -252,34 +262,36 @@ void VoiceActivityDetector::process_hop(const float* hop) {
     p = sum / (float)prob_window_.size();
   }
   const size_t fade = (max_segment_ * 2) / 3;
-  if (max_segment_ && cur_.size() > fade) p = p * ((float)(cur_.size() - fade) / (float)fade);
+  const size_t cur = open_size();
+  if (max_segment_ && cur > fade) p = p * ((float)(cur - fade) / (float)fade);
   bool voice = p > threshold_;
   bool cut = false;
-  if (voice && prev_voice_ && hard_cap_ && cur_.size() + 2 * (size_t)hop_ > hard_cap_) voice = false, cut = true;  // engine capacity
+  if (voice && prev_voice_ && hard_cap_ && cur + 2 * (size_t)hop_ > hard_cap_) voice = false, cut = true;  // engine capacity
   const float now = (float)processed_ / kSampleRate;
   if (voice && !prev_voice_) {
     const size_t lb = forced_cut_ ? std::min((size_t)hop_, look_buf_.size()) : std::min(look_behind_, processed_);
     forced_cut_ = false;
-    cur_.assign(look_buf_.end() - lb, look_buf_.end());
     VadSegment s;
-    s.audio = cur_;
-    s.start_time = now - (float)cur_.size() / kSampleRate;
+    // one allocation for what this call can still add (bounded by the caps), instead of regrowing hop by hop
+    size_t want = lb + call_remaining_;
+    if (max_segment_) want = std::min(want, max_segment_ + (size_t)hop_);
+    if (hard_cap_) want = std::min(want, hard_cap_);
+    s.audio.reserve(std::max(want, lb));
+    s.audio.assign(look_buf_.end() - lb, look_buf_.end());
+    s.start_time = now - (float)s.audio.size() / kSampleRate;
     s.end_time = now;
     s.just_updated = true;
     segments_.push_back(std::move(s));
   } else if (!voice && prev_voice_) {
-    cur_.insert(cur_.end(), hop, hop + hop_);
     VadSegment& s = segments_.back();
-    s.audio = cur_;
+    s.audio.insert(s.audio.end(), hop, hop + hop_);
     s.end_time = now;
     s.is_complete = true;
     s.just_updated = true;
-    cur_.clear();  // (the reference's resize() of the look-behind buffer here is a no-op: it keeps its contents)
-    forced_cut_ = cut;
+    forced_cut_ = cut;   // (the reference's resize() of the look-behind buffer here is a no-op: it keeps its contents)
   } else if (voice && prev_voice_) {
-    cur_.insert(cur_.end(), hop, hop + hop_);
     VadSegment& s = segments_.back();
-    s.audio = cur_;
+    s.audio.insert(s.audio.end(), hop, hop + hop_);
     s.end_time = now;
     s.is_complete = false;
     s.just_updated = true;

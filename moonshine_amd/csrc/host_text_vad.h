@@ -73,6 +73,7 @@ class VoiceActivityDetector {
   bool is_active() const { return active_; }
   void process_audio(const float* audio, size_t count, int32_t sample_rate);
   const std::vector<VadSegment>& segments() const { return segments_; }
+  std::vector<VadSegment> take_segments() { return std::move(segments_); }  // after stop(): hands the audio over, no copy
   void clear_completed_audio();
 
  private:
@@ -85,7 +86,11 @@ class VoiceActivityDetector {
   size_t prob_index_ = 0;
   bool active_ = false, prev_voice_ = false, forced_cut_ = false;
   size_t processed_ = 0;
-  std::vector<float> look_buf_, cur_, remainder_;
+  // the open segment's samples live in segments_.back().audio only (the reference re-copies its growing buffer into the
+  // segment on every hop -- quadratic in the segment length: ~100 MB of memcpy for one 10 s clip)
+  size_t open_size() const { return prev_voice_ && !segments_.empty() ? segments_.back().audio.size() : 0; }
+  std::vector<float> look_buf_, remainder_;
+  size_t call_remaining_ = 0;  // samples of the current process_audio call not yet consumed (a reserve() hint)
   std::vector<VadSegment> segments_;
 };
 

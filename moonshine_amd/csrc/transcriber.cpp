@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <iterator>
 #include <random>
 #include <stdexcept>
 #include <thread>
@@ -268,7 +269,7 @@ void TranscriptOutput::add_or_update(TranscriberLine& line) {
     line.is_new = true;
     line.has_text_changed = line.has_text;
   }
-  lines[line.id] = line;
+  lines[line.id] = std::move(line);
 }
 
 void TranscriptOutput::rebuild() {
@@ -687,7 +688,7 @@ void Transcriber::save_input(TranscriberStream* s, const float* audio, uint64_t 
 // The per-segment loop of reference core/transcriber.cpp:989-1148, with every model call of the pass
 // gathered into one GPU batch.
 void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& streams,
-                                       const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs) {
+                                       std::vector<std::vector<VadSegment>>& segments, transcript_t** outs) {
   struct Job {
     size_t stream, segment;
   };
@@ -752,12 +753,15 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
     if (model_->transcribe_batch(ptrs, lens, &texts, opt_.word_timestamps ? &words : nullptr) != 0)
       throw std::runtime_error("Failed to transcribe: " + model_->error());
     latency_ms = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("MSH_HOST_TIMING") != nullptr)
+      MSH_LOGF("update: model transcribe_batch of %zu segments in %.1f ms", jobs.size(),
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   size_t job = 0;
   for (size_t si = 0; si < streams.size(); ++si) {
     TranscriberStream* s = streams[si];
     for (size_t gi = 0; gi < segments[si].size(); ++gi) {
-      const VadSegment& seg = segments[si][gi];
+      VadSegment& seg = segments[si][gi];
       if (!seg.just_updated) continue;
       std::lock_guard<std::mutex> lock(s->out.mutex);
       TranscriberLine line;
@@ -786,7 +790,7 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
           ++job;
         }
       }
-      if (opt_.return_audio_data) line.audio = seg.audio;
+      if (opt_.return_audio_data) line.audio = std::move(seg.audio);
       s->out.add_or_update(line);
     }
     if (!s->vad->is_active()) s->out.mark_all_complete();
@@ -812,7 +816,7 @@ void Transcriber::transcribe_without_streaming(const float* audio, uint64_t n, i
     }
     s->vad->process_audio(audio, (size_t)n, sample_rate);
     s->vad->stop();
-    segs[0] = s->vad->segments();
+    segs[0] = s->vad->take_segments();
   }
   transcript_t* one = nullptr;
   update_from_segments({s}, segs, &one);
@@ -822,13 +826,21 @@ void Transcriber::transcribe_without_streaming(const float* audio, uint64_t n, i
 void Transcriber::transcribe_batch_without_streaming(const float* const* audio, const uint64_t* n, uint64_t count,
                                                      int32_t sample_rate, uint32_t /*flags*/, transcript_t** out) {
   std::lock_guard<std::mutex> lock(batch_mutex_);
+  static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;   // phase times of the host layer, to the log
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  auto t_phase = now();
   batch_streams_.clear();
+  if (timing) MSH_LOGF("batch call: previous results freed in %.1f ms", ms_since(t_phase));
+  t_phase = now();
   std::vector<TranscriberStream*> streams;
   std::vector<std::vector<VadSegment>> segs(count);
   for (uint64_t i = 0; i < count; ++i) {
     batch_streams_.emplace_back(new_stream(-1));
     streams.push_back(batch_streams_.back().get());
   }
+  if (timing) MSH_LOGF("batch call: %llu streams created in %.1f ms", (unsigned long long)count, ms_since(t_phase));
+  t_phase = now();
   // Segmentation is per clip (its own detector state, shared read-only weights) and runs on the host: one clip per host
   // thread.  With Silero on, a 10 s clip costs ~25 ms of one core -- serially that is seconds for a batch the GPU
   // transcribes in tens of milliseconds (the reference walks the clips one after the other, transcriber.cpp:997).
@@ -837,8 +849,10 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     s->vad->start();
     s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
     s->vad->stop();
-    segs[i] = s->vad->segments();
+    segs[i] = s->vad->take_segments();
   }, opt_.host_threads > 0 ? (unsigned)opt_.host_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency())));
+  if (timing) MSH_LOGF("batch call: segmentation in %.1f ms", ms_since(t_phase));
+  t_phase = now();
   std::vector<transcript_t*> outs(count, nullptr);
   // A streaming architecture keeps one device slot per line being decoded (max_streams of them): larger batches run in
   // waves of that size, and a wave's slots are handed back before the next one starts.  The transcripts stay.
@@ -846,7 +860,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   for (uint64_t w0 = 0; w0 < count; w0 += wave) {
     const uint64_t w1 = std::min(count, w0 + wave);
     std::vector<TranscriberStream*> sub(streams.begin() + w0, streams.begin() + w1);
-    std::vector<std::vector<VadSegment>> sub_segs(segs.begin() + w0, segs.begin() + w1);
+    std::vector<std::vector<VadSegment>> sub_segs(std::make_move_iterator(segs.begin() + w0), std::make_move_iterator(segs.begin() + w1));
     update_from_segments(sub, sub_segs, outs.data() + w0);
     if (streaming_model_)
       for (TranscriberStream* s : sub)
@@ -855,6 +869,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
           s->sstate = nullptr;
         }
   }
+  if (timing) MSH_LOGF("batch call: transcription + transcript assembly in %.1f ms", ms_since(t_phase));
   if (out != nullptr)
     for (uint64_t i = 0; i < count; ++i) out[i] = outs[i];
 }

@@ -179,9 +179,10 @@ class Transcriber {
   TranscriberStream* new_stream(int32_t id);
   void load_streaming_model();
   std::shared_ptr<TranscriberStream> find_stream(int32_t id);  // the caller's copy keeps the stream alive against free_stream
-  // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs
-  void update_from_segments(const std::vector<TranscriberStream*>& streams,
-                            const std::vector<std::vector<VadSegment>>& segments, transcript_t** outs);
+  // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs.  `segments` is the
+  // caller's snapshot and is consumed: the audio of a segment moves into its transcript line (no copy per line)
+  void update_from_segments(const std::vector<TranscriberStream*>& streams, std::vector<std::vector<VadSegment>>& segments,
+                            transcript_t** outs);
   void save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush);
   struct StreamingJob {
     TranscriberStream* stream;
