@@ -3,7 +3,7 @@
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3
-B="python bench.py --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --steps 12 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api --steps 12 --warmup 2"
 for w in 0 1; do
   echo "== MSH_ENC_ATT_WIDE=$w"
   MSH_ENC_ATT_WIDE=$w timeout 300 $B 2>/dev/null | python -c "

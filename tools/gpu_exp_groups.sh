@@ -3,7 +3,7 @@
 # decode kernels; plus the GPU suite on the current build.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-latency --no-streaming --no-pcie --steps 12 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api --steps 12 --warmup 2"
 for g in 1 2 3 4; do
   echo "== MSH_DEC_GROUPS=$g in-flight 4"
   MSH_DEC_GROUPS=$g timeout 300 $B 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], 'serial', d.get('serial_steps'))"

@@ -12,11 +12,11 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json
 # kernel stats twice: steps strictly serial (the per-kernel durations the roofline figures are about), and the default
 # command with batches in flight (the same kernels stretched by the overlap)
-CMD="python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie"
+CMD="python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- $CMD > /tmp/prof_${TAG}.log 2>&1)
 f=$(find /tmp/prof_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_serial.csv && head -8 "$f" | cut -c1-160
-CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie"
+CMD2="python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2_${TAG} -- $CMD2 > /tmp/prof2_${TAG}.log 2>&1)
 f=$(find /tmp/prof2_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_b256_inflight.csv && head -4 "$f" | cut -c1-160
@@ -32,7 +32,7 @@ with open(sys.argv[1]) as src, gzip.open(sys.argv[2], "wt") as dst:
 PYT
 pass() { # name counters...
   local name=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-streaming --no-pcie > /tmp/pmc_${TAG}_$name.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api > /tmp/pmc_${TAG}_$name.log 2>&1)
   tail -1 /tmp/pmc_${TAG}_$name.log | cut -c1-160
 }
 pass fetch FETCH_SIZE

@@ -5,7 +5,7 @@ set -u
 TAG=$1; PAT=$2; shift 2
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie"
+CMD="python $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api"
 (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmck_${TAG} -o p -- $CMD > /tmp/pmck_${TAG}.log 2>&1)
 python - "$PAT" <<PY
 import csv, glob, collections, re, sys
