@@ -113,6 +113,12 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
     n_upd = CLIP_SAMPLES // upd
     stats = {"accepted": 0, "draft": 0, "tokens": 0, "decode_ms": 0.0, "encode_ms": 0.0, "frontend_ms": 0.0}
 
+    trace = os.environ.get("MSH_BENCH_TRACE") is not None
+
+    def mark(msg):
+        if trace:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
     def step():
         for s in slots:
             eng.reset(s)
@@ -123,12 +129,15 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
             final = u == n_upd - 1
             t0 = time.perf_counter()
             cc = (n - processed) // 1280
+            mark(f"update {u}: frontend")
             if cc:
                 eng.process_audio(slots, [a[processed:processed + cc * 1280] for a in audio])
                 processed += cc * 1280
             t1 = time.perf_counter()
+            mark(f"update {u}: encode")
             eng.encode(slots, [final] * S)
             t2 = time.perf_counter()
+            mark(f"update {u}: decode")
             eng.decoder_reset(slots)
             if u == 0:
                 budget = min(int(math.ceil(n / 16000.0 * 6.5)), 256)

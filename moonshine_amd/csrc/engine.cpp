@@ -34,6 +34,21 @@ UtilStreams& util_streams() {
 }
 }  // namespace
 
+void trace_launch(const char* kernel, const char* file, int line, hipStream_t s) {
+  static const bool on = [] {
+    const char* e = getenv("MSH_TRACE_LAUNCH");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (!on) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  const char* base = strrchr(file, '/');
+  fprintf(stderr, "[msh launch] %.100s (%s:%d)%s\n", kernel, base ? base + 1 : file, line,
+          cs == hipStreamCaptureStatusNone ? "" : " [captured]");
+  fflush(stderr);
+  if (cs == hipStreamCaptureStatusNone) MSH_HIP(hipStreamSynchronize(s));
+}
+
 std::mutex& device_structure_mutex() {
   static std::mutex* m = new std::mutex();
   return *m;

@@ -608,7 +608,11 @@ __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restr
   auto col = epi.col_ctx(n0 + kg * 4);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    stg[li * ROWP + j * 4 + kg] = epi.pack4(ctx, col, n0 + j * 16 + kg * 4, acc[j]);
+    // a column group beyond N (ragged last tile, e.g. N = 3072 on 208-wide tiles) is dropped by the stores below, but
+    // pack4 READS per-column inputs (bias, folded GroupNorm table): it gets the last valid group's address instead of one
+    // up to 188 bytes past the end of a 1-D parameter -- a GPU memory fault when that parameter ends on a mapping boundary
+    const int n = n0 + j * 16 + kg * 4;
+    stg[li * ROWP + j * 4 + kg] = epi.pack4(ctx, col, n < N ? n : N - 4, acc[j]);
     epi.col_next16(col);
   }
   __builtin_amdgcn_wave_barrier();

@@ -32,10 +32,14 @@ struct HipError : std::runtime_error {
 // kernel, a template instance that was never compiled) is reported HERE, by name and line, instead of surfacing later as a
 // sticky error at an unrelated synchronise -- or as garbage ids.  hipGetLastError is legal during stream capture and
 // costs a thread-local read; launches in the steady state are graph replays, which do not pass through here at all.
-#define MSH_LAUNCH(...)                 \
-  do {                                  \
-    hipLaunchKernelGGL(__VA_ARGS__);    \
-    MSH_HIP(hipGetLastError());         \
+// MSH_TRACE_LAUNCH=1 (diagnostic): every eager launch prints its kernel to stderr and waits for it, so that a GPU memory
+// fault is attributed to the kernel that caused it (launches inside a stream capture are only printed).
+void trace_launch(const char* kernel, const char* file, int line, hipStream_t s);
+#define MSH_LAUNCH(kernel, grid, block, lds, stream, ...)                     \
+  do {                                                                        \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    MSH_HIP(hipGetLastError());                                               \
+    ::msh::trace_launch(#kernel, __FILE__, __LINE__, stream);                 \
   } while (0)
 
 // Blocking copies / zero-fills that stay OFF the legacy (null) stream: hipMemcpy / hipMemset / hipDeviceSynchronize
