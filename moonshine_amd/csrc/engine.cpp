@@ -756,15 +756,21 @@ double Engine::profile_cross_attention_ms(int rounds) {
   MSH_HIP(hipSetDevice(device_));
   if (!encoded_ || groups_.empty() || groups_[0]->M != (int)n_clips_)
     throw std::runtime_error("profile_cross_attention: encode and decode a batch first");
-  if (rounds <= 0) rounds = 1;
+  // rounds < 0 (probe): every launch reads layer 0's K / V again -- one layer of a 256-clip batch is 177 MB, inside the
+  // 256 MB memory-side cache, so this is the kernel's rate when its operands do NOT come from HBM
+  const bool same_layer = rounds < 0;
+  if (rounds < 0) rounds = -rounds;
+  if (rounds == 0) rounds = 1;
   DecodeGroup& g = *groups_[0];
   const int D = cfg_.hidden, L = cfg_.dec_layers;
   MSH_HIP(hipStreamSynchronize(g.stream));
   hipEvent_t a = get_event(), b = get_event();
   auto sweep = [&] {
-    for (int l = 0; l < L; ++l)
-      dec_cross_attention(g.dq.as<float>(), KT_.as<bf16_t>() + (size_t)l * D * kv_keys_, VT_.as<bf16_t>() + (size_t)l * D * kv_keys_,
+    for (int l = 0; l < L; ++l) {
+      const int ll = same_layer ? 0 : l;
+      dec_cross_attention(g.dq.as<float>(), KT_.as<bf16_t>() + (size_t)ll * D * kv_keys_, VT_.as<bf16_t>() + (size_t)ll * D * kv_keys_,
                           clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
+    }
   };
   sweep();  // warm
   MSH_HIP(hipEventRecord(a, stream_));
