@@ -157,6 +157,9 @@ MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
  * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]) to host memory; returns the buffer's
  * size in bytes, -1 on error.  No reference counterpart (ORT owns these tensors there). */
 MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
+/* Developer hook: self-test of the library's device allocator (odd sizes, pageable copies, interior slices); 0 = ok.
+ * Meant for MSH_GUARD_ALLOC=1 (tools/gpu_guard.sh), where every buffer ends on an unmapped page. */
+MSH_EXPORT int32_t msh_test_device_alloc(void);
 /* Developer hook: ms per launch of one tiled-GEMM configuration on synthetic operands (tools/gemm_microbench.py). */
 MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
                                           int32_t iters);

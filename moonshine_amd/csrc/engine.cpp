@@ -3,6 +3,7 @@
 #include "host_utils.h"
 
 #include <mutex>
+#include <unordered_map>
 
 #include <math.h>
 #include <string.h>
@@ -34,12 +35,18 @@ UtilStreams& util_streams() {
 }
 }  // namespace
 
-void trace_launch(const char* kernel, const char* file, int line, hipStream_t s) {
-  static const bool on = [] {
+int trace_launch_level() {
+  static const int level = [] {
     const char* e = getenv("MSH_TRACE_LAUNCH");
-    return e != nullptr && e[0] == '1';
+    return e != nullptr ? atoi(e) : 0;
   }();
-  if (!on) return;
+  return level;
+}
+void trace_launch_begin(const char* kernel, dim3 grid, dim3 block) {
+  fprintf(stderr, "[msh args] %.60s <<<(%u,%u,%u),(%u)>>>", kernel, grid.x, grid.y, grid.z, block.x);
+}
+void trace_launch(const char* kernel, const char* file, int line, hipStream_t s) {
+  if (trace_launch_level() < 1) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cs);
   const char* base = strrchr(file, '/');
@@ -47,6 +54,95 @@ void trace_launch(const char* kernel, const char* file, int line, hipStream_t s)
           cs == hipStreamCaptureStatusNone ? "" : " [captured]");
   fflush(stderr);
   if (cs == hipStreamCaptureStatusNone) MSH_HIP(hipStreamSynchronize(s));
+}
+
+// ---- device allocation (msh_common.h) ----
+namespace {
+struct GuardBlock {
+  hipMemGenericAllocationHandle_t handle;
+  void* va;
+  size_t va_size, map_size;
+};
+std::unordered_map<void*, GuardBlock>& guard_blocks() {
+  static auto* m = new std::unordered_map<void*, GuardBlock>();
+  return *m;
+}
+}  // namespace
+bool guard_alloc_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MSH_GUARD_ALLOC");
+    return e != nullptr && (e[0] == '1' || e[0] == '2');   // 2: also log every allocation
+  }();
+  return on;
+}
+void* device_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  void* p = nullptr;
+  if (!guard_alloc_enabled()) {
+    MSH_HIP(hipMalloc(&p, bytes));
+    return p;
+  }
+  int dev = 0;
+  MSH_HIP(hipGetDevice(&dev));
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  MSH_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  if (gran == 0) gran = (size_t)2 << 20;
+  GuardBlock b{};
+  b.map_size = (bytes + gran - 1) / gran * gran;
+  b.va_size = b.map_size + gran;   // the granule after the mapping stays unmapped
+  MSH_HIP(hipMemAddressReserve(&b.va, b.va_size, gran, nullptr, 0));
+  MSH_HIP(hipMemCreate(&b.handle, b.map_size, &prop, 0));
+  MSH_HIP(hipMemMap(b.va, b.map_size, 0, b.handle, 0));
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  MSH_HIP(hipMemSetAccess(b.va, b.map_size, &acc, 1));
+  // the buffer keeps hipMalloc's 256-byte alignment by default (MSH_GUARD_ALIGN=16 tightens the net to 16 bytes, but then
+  // the bases are less aligned than anything the product ever sees)
+  static const size_t align = [] {
+    const char* e = getenv("MSH_GUARD_ALIGN");
+    const long v = e ? atol(e) : 256;
+    return (size_t)(v >= 16 && (v & (v - 1)) == 0 ? v : 256);
+  }();
+  const size_t tail = (bytes + align - 1) & ~(align - 1);
+  // the bytes in front of the buffer (same mapping) read as zeros, like fresh hipMalloc memory -- or, with MSH_GUARD_POISON=1,
+  // as 0xFF bytes (bf16 / fp32 NaN, int -1): a kernel whose RESULT depends on what lies before its buffer then shows it
+  static const int fill = [] {
+    const char* e = getenv("MSH_GUARD_POISON");
+    return e != nullptr && e[0] == '1' ? 0xFF : 0;
+  }();
+  MSH_HIP(hipMemset(b.va, fill, b.map_size));
+  MSH_HIP(hipDeviceSynchronize());
+  p = static_cast<char*>(b.va) + (b.map_size - tail);
+  guard_blocks()[p] = b;
+  static const bool log = [] {
+    const char* e = getenv("MSH_GUARD_ALLOC");
+    return e != nullptr && e[0] == '1' && e[1] == '\0' ? false : true;
+  }();
+  if (log) fprintf(stderr, "[msh alloc] %p .. %p (%zu bytes)\n", p, (void*)(static_cast<char*>(p) + bytes), bytes);
+  return p;
+}
+void device_free(void* p) {
+  if (p == nullptr) return;
+  if (!guard_alloc_enabled()) {
+    (void)hipFree(p);
+    return;
+  }
+  auto it = guard_blocks().find(p);
+  if (it == guard_blocks().end()) return;
+  const GuardBlock b = it->second;
+  guard_blocks().erase(it);
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(b.va, b.map_size);
+  (void)hipMemRelease(b.handle);
+  // The address range is NOT handed back: on this stack a range that is reserved and mapped again straight away can still
+  // be served from stale translations / cache lines of its previous mapping (seen as index arrays full of the old
+  // buffer's activations).  A diagnostic run leaks address space instead -- and a use-after-free keeps pointing at
+  // unmapped addresses for the rest of the process.
 }
 
 std::mutex& device_structure_mutex() {
@@ -74,21 +170,21 @@ void zero_blocking(void* p, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 bool DevBuf::reserve(size_t bytes) {
   if (bytes <= cap && p != nullptr) return false;
-  size_t want = bytes + bytes / 8 + 256;  // a little slack so ragged batches do not thrash
-  void* np = nullptr;
+  // a little slack so ragged batches do not thrash (none under the guard allocator: it would hide over-reads)
+  size_t want = guard_alloc_enabled() ? bytes : bytes + bytes / 8 + 256;
   std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-  MSH_HIP(hipMalloc(&np, want));
+  void* np = device_alloc(want);
   // The zero-fill must be complete before the first kernel or copy on an engine stream writes the new buffer (a plain
   // hipMemset is asynchronous null-stream work those streams do not wait for: seen as rare garbage logits).
   zero_blocking(np, want);
-  if (p) MSH_HIP(hipFree(p));
+  if (p) device_free(p);
   p = np;
   cap = want;
   return true;
 }
 void DevBuf::release() {
   std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-  if (p) (void)hipFree(p);
+  if (p) device_free(p);
   p = nullptr;
   cap = 0;
 }
@@ -108,7 +204,7 @@ Engine::Engine(int device) : device_(device) {
     // engines (lanes) created one after the other get consecutive queues only if each touches its stream right away
     {
       std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-      MSH_HIP(hipMalloc(&stream_probe_, 256));
+      stream_probe_ = device_alloc(256);
     }
     MSH_HIP(hipMemsetAsync(stream_probe_, 0, 256, stream_));
     MSH_HIP(hipStreamSynchronize(stream_));
@@ -126,8 +222,8 @@ Engine::~Engine() {
   if (enc_done_) (void)hipEventDestroy(enc_done_);
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    if (stream_probe_) (void)hipFree(stream_probe_);
-    for (void* p : weight_allocs_) (void)hipFree(p);
+    if (stream_probe_) device_free(stream_probe_);
+    for (void* p : weight_allocs_) device_free(p);
     weight_allocs_.clear();
   }
   for (hipEvent_t ev : event_pool_) (void)hipEventDestroy(ev);
@@ -135,7 +231,6 @@ Engine::~Engine() {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
-  for (void* p : weight_allocs_) (void)hipFree(p);
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
                     &Y_, &QKV_, &VTe_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
   for (DevBuf* b : bufs) b->release();
@@ -152,7 +247,7 @@ void Engine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    MSH_HIP(hipMalloc(&p, src.size() * sizeof(float)));
+    p = device_alloc(src.size() * sizeof(float));
   }
   weight_allocs_.push_back(p);
   copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -165,7 +260,7 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+    p = device_alloc(tmp.size() * sizeof(bf16_t));
   }
   weight_allocs_.push_back(p);
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
@@ -184,7 +279,7 @@ void Engine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+    p = device_alloc(tmp.size() * sizeof(bf16_t));
   }
   weight_allocs_.push_back(p);
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);

@@ -4,10 +4,13 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace msh {
 
@@ -34,9 +37,38 @@ struct HipError : std::runtime_error {
 // costs a thread-local read; launches in the steady state are graph replays, which do not pass through here at all.
 // MSH_TRACE_LAUNCH=1 (diagnostic): every eager launch prints its kernel to stderr and waits for it, so that a GPU memory
 // fault is attributed to the kernel that caused it (launches inside a stream capture are only printed).
+// MSH_TRACE_LAUNCH=2 also prints grid, block and every pointer / integer argument BEFORE the launch (with
+// MSH_GUARD_ALLOC=2, which logs every allocation, an out-of-bounds access can be worked out from the log alone).
 void trace_launch(const char* kernel, const char* file, int line, hipStream_t s);
+int trace_launch_level();
+void trace_launch_begin(const char* kernel, dim3 grid, dim3 block);
+template <class T>
+inline void trace_launch_arg(const T& v) {
+  if constexpr (std::is_pointer<T>::value) fprintf(stderr, " %p", (const void*)v);
+  else if constexpr (std::is_integral<T>::value) fprintf(stderr, " %lld", (long long)v);
+  else if constexpr (std::is_floating_point<T>::value) fprintf(stderr, " %g", (double)v);
+  else {   // a struct of arguments (epilogue functors): its 8-byte words
+    fprintf(stderr, " {");
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&v);
+    for (size_t i = 0; i + 8 <= sizeof(T) && i < 96; i += 8) {
+      unsigned long long w;
+      memcpy(&w, b + i, 8);
+      fprintf(stderr, "%s0x%llx", i ? " " : "", w);
+    }
+    fprintf(stderr, "}");
+  }
+}
+template <class... A>
+inline void trace_launch_args(const char* kernel, dim3 grid, dim3 block, const A&... a) {
+  if (trace_launch_level() < 2) return;
+  trace_launch_begin(kernel, grid, block);
+  (trace_launch_arg(a), ...);
+  fprintf(stderr, "\n");
+  fflush(stderr);
+}
 #define MSH_LAUNCH(kernel, grid, block, lds, stream, ...)                     \
   do {                                                                        \
+    ::msh::trace_launch_args(#kernel, grid, block, __VA_ARGS__);              \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
     MSH_HIP(hipGetLastError());                                               \
     ::msh::trace_launch(#kernel, __FILE__, __LINE__, stream);                 \
@@ -55,6 +87,13 @@ void trace_launch(const char* kernel, const char* file, int line, hipStream_t s)
 // hipStreamBeginCapture and hipStreamEndCapture is where a (rare) crash of the multi-lane tests pointed.  Both sides
 // take this mutex; it is only ever contended while engines warm up.
 std::mutex& device_structure_mutex();
+// Every device allocation of the library (call with device_structure_mutex held).  Normally hipMalloc / hipFree.  With
+// MSH_GUARD_ALLOC=1 (diagnostic) each buffer gets its own virtual-memory mapping whose END is the end of the mapped range,
+// followed by an unmapped granule: a kernel that reads or writes 16 bytes or more past the end of ANY buffer takes a GPU
+// memory fault there and then (tools/gpu_debug_fault.sh names the kernel) instead of silently reading a neighbour.
+void* device_alloc(size_t bytes);
+void device_free(void* p);
+bool guard_alloc_enabled();
 void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 void zero_blocking(void* p, size_t bytes);
 

@@ -81,7 +81,7 @@ StreamingEngine::~StreamingEngine() {
   if (ar_graph_ != nullptr) (void)hipGraphExecDestroy(ar_graph_);
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    for (void* p : allocs_) (void)hipFree(p);
+    for (void* p : allocs_) device_free(p);
   }
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
@@ -100,7 +100,7 @@ void StreamingEngine::upload(const std::vector<float>& src, float** dst) {
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    MSH_HIP(hipMalloc(&p, std::max<size_t>(src.size(), 4) * sizeof(float)));
+    p = device_alloc(std::max<size_t>(src.size(), 4) * sizeof(float));
   }
   allocs_.push_back(p);
   copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -112,7 +112,7 @@ void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    MSH_HIP(hipMalloc(&p, tmp.size() * sizeof(bf16_t)));
+    p = device_alloc(tmp.size() * sizeof(bf16_t));
   }
   allocs_.push_back(p);
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
@@ -357,7 +357,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     void* p = nullptr;
     {
       std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-      MSH_HIP(hipMalloc(&p, bytes));
+      p = device_alloc(bytes);
     }
     allocs_.push_back(p);
     zero_blocking(p, bytes);  // complete before anything on the engine stream touches the slab (see DevBuf::reserve)
