@@ -10,6 +10,8 @@ export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --durations=6 > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json
+# the launch line the driver uses for N > 1, here with one rank: rendezvous, RCCL init, scatter / gather / max-over-ranks on hardware
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api > gpurun_out/${TAG}_bench_torchrun1.json 2> gpurun_out/${TAG}_bench_torchrun1.err; echo "torchrun rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_torchrun1.json
 # kernel stats twice: steps strictly serial (the per-kernel durations the roofline figures are about), and the default
 # command with batches in flight (the same kernels stretched by the overlap)
 CMD="python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api"
