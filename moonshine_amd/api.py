@@ -18,6 +18,7 @@ MOONSHINE_HEADER_VERSION = 30000
 ARCH_TINY, ARCH_BASE = 0, 1
 ARCH_TINY_STREAMING, ARCH_BASE_STREAMING, ARCH_SMALL_STREAMING, ARCH_MEDIUM_STREAMING = 2, 3, 4, 5
 FLAG_FORCE_UPDATE = 1
+MOONSHINE_ERROR_NONE, MOONSHINE_ERROR_UNKNOWN, MOONSHINE_ERROR_INVALID_HANDLE, MOONSHINE_ERROR_INVALID_ARGUMENT = 0, -1, -2, -3
 
 
 class TranscriptWordC(C.Structure):
