@@ -314,6 +314,156 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
   }
 }
 
+// The same attention for RUNS of rows that belong to one stream (the wide verify pass: BOS + draft of a stream are up to
+// 66 consecutive rows over ONE memory).  A workgroup takes up to RB consecutive rows of a stream and streams the K^T / V^T
+// chunk once for all of them -- the per-row kernel above re-read a stream's 1.3 MB of K / V for every row (5.4 GB per layer
+// at 64 streams x 66 rows: 396 us per launch, half of the wide pass).  Per row the arithmetic, its order and therefore the
+// result are those of cross_attention_kernel.
+struct RowRun {
+  int row0, n;   // rows [row0, row0 + n) of the pass, all of one stream, 1 <= n <= RB
+};
+template <int DH, int RB>
+__global__ __launch_bounds__(256, 2) void cross_attention_runs_kernel(const bf16_t* __restrict__ q,
+                                                                      const int* __restrict__ row_slot,
+                                                                      const RowRun* __restrict__ runs,
+                                                                      const SlotDev* __restrict__ slots, int D, int heads,
+                                                                      int layer, int L, int Mcap,
+                                                                      const bf16_t* __restrict__ crossKT,
+                                                                      const bf16_t* __restrict__ crossVT,
+                                                                      bf16_t* __restrict__ out) {
+  constexpr int DQ = DH / 4;
+  __shared__ float sp[RB][4][512];
+  __shared__ float red[4][DQ][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const RowRun run = runs[blockIdx.x];
+  const int h = blockIdx.y;
+  const int slot = row_slot[run.row0];
+  const int nk = slots[slot].mem_len;
+  const long base = (((long)slot * L + layer) * D + h * DH + wave * DQ) * Mcap;
+  // buffer descriptors over this wave's dh/4 rows (row d at SCALAR offset d * Mcap * 2, the lane's keys at one shared 32-bit
+  // vector offset): no per-row 64-bit addresses in registers; a read past the last row returns 0.  Lanes whose keys lie
+  // beyond mem_len read stale (finite) cache contents; their scores are masked and their probabilities are exactly 0.
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(crossKT + base), 0, DQ * Mcap * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(crossVT + base), 0, DQ * Mcap * 2, 0x00020000);
+  const float c = rsqrtf((float)DH) * 1.4426950408889634f;
+  // the queries of the run sit in LDS (every lane of a wave uses the same value: broadcast reads), not in 80 registers
+  __shared__ __attribute__((aligned(16))) float sq[4][DQ][RB];   // rows fastest: one 16-byte read per head-dim row
+  float opart[RB][DQ], m_run[RB], l_part[RB];
+  if (lane < RB * DQ) {
+    const int r = lane / DQ, d = lane - r * DQ;
+    const int row = run.row0 + (r < run.n ? r : run.n - 1);   // a short run repeats its last row; the copy is not stored
+    sq[wave][d][r] = bf(q[(long)row * D + h * DH + wave * DQ + d]);
+  }
+  if constexpr (RB * DQ > 64) {
+    const int i = lane + 64;
+    if (i < RB * DQ) {
+      const int r = i / DQ, d = i - r * DQ;
+      const int row = run.row0 + (r < run.n ? r : run.n - 1);
+      sq[wave][d][r] = bf(q[(long)row * D + h * DH + wave * DQ + d]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) opart[r][d] = 0.f;
+    m_run[r] = -INFINITY;
+    l_part[r] = 0.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int k0 = 0; k0 < nk; k0 += 512) {
+    const int key = k0 + lane * 8;
+    su32x4 kv[DQ];
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Mcap * 2, 0);
+    float sc[RB][8];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc[r][e] = 0.f;
+    // d outside, rows inside: one row of K is unpacked once and used by every row of the run (per row the sum still runs
+    // over d in ascending order, as in the single-row kernel)
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) {
+      const su32x4 u = kv[d];
+      const float k0f = s_lo(u.x), k1f = s_hi(u.x), k2f = s_lo(u.y), k3f = s_hi(u.y), k4f = s_lo(u.z), k5f = s_hi(u.z),
+                  k6f = s_lo(u.w), k7f = s_hi(u.w);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float qv = sq[wave][d][r];
+        sc[r][0] += qv * k0f; sc[r][1] += qv * k1f; sc[r][2] += qv * k2f; sc[r][3] += qv * k3f;
+        sc[r][4] += qv * k4f; sc[r][5] += qv * k5f; sc[r][6] += qv * k6f; sc[r][7] += qv * k7f;
+      }
+      if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four query reads ahead at most, not all dh/4 of them
+    }
+    // the V rows are requested only now, when the K registers are dead: the scores are pinned in registers first (the
+    // empty asm makes them "used" here), so neither the optimiser nor the scheduler can float the V loads above the FMAs
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(sc[r][e]));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Mcap * 2, 0);
+    if (k0 > 0) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      *reinterpret_cast<float4*>(&sp[r][wave][lane * 8]) = make_float4(sc[r][0], sc[r][1], sc[r][2], sc[r][3]);
+      *reinterpret_cast<float4*>(&sp[r][wave][lane * 8 + 4]) = make_float4(sc[r][4], sc[r][5], sc[r][6], sc[r][7]);
+    }
+    __syncthreads();
+    float alpha[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane * 8 + e;
+        const float t = (sp[r][0][i] + sp[r][1][i]) + (sp[r][2][i] + sp[r][3][i]);
+        sc[r][e] = (key + e < nk) ? t * c : -INFINITY;
+        mloc = fmaxf(mloc, sc[r][e]);
+      }
+      mloc = wmax(mloc);
+      const float m_new = fmaxf(m_run[r], mloc);
+      alpha[r] = exp2f(m_run[r] - m_new);
+      m_run[r] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[r][e] = exp2f(sc[r][e] - m_new);
+        psum += sc[r][e];
+      }
+      l_part[r] = l_part[r] * alpha[r] + psum;
+      __builtin_amdgcn_sched_barrier(0);   // one row's 32 LDS reads at a time (hoisting all rows' reads spilled 200 registers)
+    }
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) {
+      const su32x4 u = kv[d];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float part = sc[r][0] * s_lo(u.x) + sc[r][1] * s_hi(u.x) + sc[r][2] * s_lo(u.y) + sc[r][3] * s_hi(u.y) +
+                           sc[r][4] * s_lo(u.z) + sc[r][5] * s_hi(u.z) + sc[r][6] * s_lo(u.w) + sc[r][7] * s_hi(u.w);
+        opart[r][d] = opart[r][d] * alpha[r] + part;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const float l = wsum(l_part[r]);
+    __builtin_amdgcn_wave_barrier();   // the previous row's reads of this wave's slab are done
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) red[wave][d][lane] = opart[r][d];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < DQ && r < run.n) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
+      out[(long)(run.row0 + r) * D + h * DH + wave * DQ + lane] = f32_to_bf16(acc / l);
+    }
+  }
+}
+
 // Any other head_dim (multiple of 4, <= 128): plain two-pass kernel over the same transposed layouts.
 __global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16_t* __restrict__ q,
                                                                       const int* __restrict__ row_slot,
@@ -696,6 +846,33 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
                          layer, L, Mcap, crossK, crossV, out);
   }
 #undef MSH_XATT
+}
+void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int2* runs, int n_runs, const SlotDev* slots, int D,
+                                 int heads, int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
+                                 hipStream_t s) {
+  if (n_runs <= 0) return;
+  static_assert(sizeof(RowRun) == sizeof(int2), "RowRun is passed as int2");
+  const RowRun* rr = reinterpret_cast<const RowRun*>(runs);
+#define MSH_XRUN(DHV)                                                                                                   \
+  case DHV:                                                                                                             \
+    MSH_LAUNCH((cross_attention_runs_kernel<DHV, kCrossRunRows>), dim3(n_runs, heads), dim3(256), 0, s, q, row_slot, rr, \
+               slots, D, heads, layer, L, Mcap, crossK, crossV, out);                                                   \
+    break
+  switch (D / heads) {
+    MSH_XRUN(16);
+    MSH_XRUN(24);
+    MSH_XRUN(36);
+    MSH_XRUN(40);
+    MSH_XRUN(52);
+    MSH_XRUN(64);
+    MSH_XRUN(80);
+    default: throw std::runtime_error("stream_cross_attention_runs: unsupported head_dim");
+  }
+#undef MSH_XRUN
+}
+bool stream_cross_attention_runs_supported(int D, int heads, int Mcap) {
+  const int dh = D / heads;
+  return (dh == 16 || dh == 24 || dh == 36 || dh == 40 || dh == 52 || dh == 64 || dh == 80) && Mcap <= CROSS_MMAX && (Mcap & 7) == 0;
 }
 void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads, int layer,
                         int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s) {

@@ -86,7 +86,7 @@ StreamingEngine::~StreamingEngine() {
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
-                    &steppos_, &probs_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
+                    &steppos_, &probs_, &runs_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -626,7 +626,29 @@ void StreamingEngine::decoder_reset(int n, const int* slots) {
 
 // One pass of the decoder (lora/export.py:207-256) over M rows whose embeddings sit in H; row r belongs to
 // stream row_slot[r] at position row_pos[r].
-void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_pos, float* logits) {
+const int2* StreamingEngine::stage_runs(const std::vector<int>& rs, int* n_runs) {
+  *n_runs = 0;
+  static const bool off = [] {   // A/B switch: MSH_NO_CROSS_RUNS=1 keeps the one-row-per-workgroup kernel for every pass
+    const char* e = getenv("MSH_NO_CROSS_RUNS");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (off || !stream_cross_attention_runs_supported(cfg_.decoder_dim, cfg_.nheads, Mcap_)) return nullptr;
+  std::vector<int2> runs;
+  bool any_long = false;
+  for (size_t r = 0; r < rs.size();) {
+    size_t e = r + 1;
+    while (e < rs.size() && rs[e] == rs[r] && e - r < (size_t)kCrossRunRows) ++e;
+    runs.push_back(make_int2((int)r, (int)(e - r)));
+    any_long |= e - r > 1;
+    r = e;
+  }
+  if (!any_long) return nullptr;
+  *n_runs = (int)runs.size();
+  return stage(runs_, runs);
+}
+
+void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_pos, float* logits, const int2* runs_d,
+                                   int n_runs) {
   const int Dd = cfg_.decoder_dim, L = cfg_.depth, Fd = cfg_.dec_ffn, V = cfg_.vocab_size;
   Y_.reserve((size_t)M * Dd * 2);
   QKV_.reserve((size_t)M * 3 * Dd * 2);
@@ -659,7 +681,10 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     }
     if (capture_probs_ != nullptr)  // word timestamps: this pass's cross-attention probabilities (cross_attention())
       stream_cross_probs(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, capture_ecap_, capture_probs_, stream_);
-    stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+    if (runs_d != nullptr)
+      stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+    else
+      stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
     if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
       gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
     if (!(small && small_ln_gemm_swiglu(H, W.fc1_f, W.b1, M, 2 * Fd, Dd, Z, stream_))) {
@@ -705,8 +730,10 @@ void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* cons
   const int* rp_d = stage(rowpos_, rpos);
   const int* tok_d = stage(tokens_, tok);
   const DecJob* jobs_d = stage(decjobs_, jobs);
+  int n_runs = 0;
+  const int2* runs_d = stage_runs(rs, &n_runs);
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
-  decoder_pass(M, rs_d, rp_d, logits_.as<float>());
+  decoder_pass(M, rs_d, rp_d, logits_.as<float>(), runs_d, n_runs);
   stream_bump_cache(jobs_d, (int)jobs.size(), slots_d_, stream_);
   if (logits_out != nullptr)
     MSH_HIP(hipMemcpyAsync(logits_out, logits_.p, (size_t)M * V * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -837,7 +864,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
   const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
-  decoder_pass(M, rs_d, rp_d, logits_.as<float>());
+  int n_runs = 0;
+  const int2* runs_d = stage_runs(rs, &n_runs);
+  decoder_pass(M, rs_d, rp_d, logits_.as<float>(), runs_d, n_runs);
   // the biaser's bonuses go in before every token choice, the verify pass included (streaming-model.cpp:1241-1246,
   // 1304-1315); row t of a stream is conditioned on draft[0..t)
   stream_bias_rows(bias_, prefix_d, draft_d, nullptr, nullptr, nullptr, 0, M, logits_.as<float>(), V, stream_);

@@ -76,6 +76,13 @@ void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slo
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
                             hipStream_t s);
+// The same for runs of consecutive rows of one stream (runs[i] = {first row, rows <= kCrossRunRows}): a run's rows share one
+// pass over the stream's K / V.  Results equal stream_cross_attention's bit for bit.
+constexpr int kCrossRunRows = 4;
+void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int2* runs, int n_runs, const SlotDev* slots, int D,
+                                 int heads, int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
+                                 hipStream_t s);
+bool stream_cross_attention_runs_supported(int D, int heads, int Mcap);
 // first-max argmax of every logits row (moonshine-streaming-model.cpp:1222-1232)
 void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s);
 // speculative verify (moonshine-streaming-model.cpp:1304-1366): longest agreeing draft prefix, rollback of the

@@ -470,3 +470,45 @@ def test_stream_cross_attention_vs_oracle(tmp_path):
     with pytest.raises(MshError):
         eng.cross_attention(s2, [cfg.bos])          # empty memory
     eng.close()
+
+
+def test_cross_attention_runs_kernel_is_bit_identical_to_the_per_row_kernel(tmp_path):
+    """The wide pass shares one sweep over a stream's K / V between up to four consecutive rows
+    (cross_attention_runs_kernel); per row the arithmetic and its order are the single-row kernel's, so the logits of a
+    teacher-forced pass must be EQUAL with the kernel on (default) and off (MSH_NO_CROSS_RUNS=1, read once per process:
+    two child processes).  Ragged runs: 7 and 13 tokens (one full run + a rest of 3 / three runs + a rest of 1)."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ".")
+from tests.test_gpu_streaming import make_engine, feed
+from moonshine_amd.synth import make_audio
+import pathlib, tempfile
+out = sys.argv[1]
+with tempfile.TemporaryDirectory() as d:
+    eng, cfg, w = make_engine(pathlib.Path(d), "tiny_streaming", 5, max_slots=3)
+    slots = [eng.open() for _ in range(3)]
+    for i, s in enumerate(slots):
+        feed(eng, s, make_audio(70 + i, 1280 * (20 + 6 * i)), 5)
+    toks = [[cfg.bos] + [(37 * (i + 1) * (t + 3)) % cfg.vocab for t in range(n - 1)] for i, n in enumerate([7, 13, 1])]
+    eng.decoder_reset(slots)
+    lg = eng.decode_tokens(slots, toks)
+    np.savez(out, *[np.asarray(x) for x in lg])
+    eng.close()
+'''
+    outs = []
+    for flag in ("0", "1"):
+        o = str(tmp_path / f"logits_{flag}.npz")
+        env = dict(os.environ, MSH_NO_CROSS_RUNS=flag)
+        r = subprocess.run([sys.executable, "-c", code, o], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(o))
+    assert len(outs[0].files) == 3
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
