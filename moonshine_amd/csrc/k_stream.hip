@@ -638,6 +638,71 @@ __global__ void verify_kernel(const DecJob* __restrict__ jobs, const int* __rest
   }
 }
 
+// The same step when the LM head ran as the tiled GEMM with the per-tile argmax epilogue (gemm_argmax_partials): the row's
+// token is the first maximum over its ntn (max, lowest index) pairs -- tiles are in ascending column order, ties keep the
+// lowest index, a row without any value above -inf (all NaN) yields token 0 like argmax_kernel.  No logits, no argmax launch.
+__global__ __launch_bounds__(128) void advance_partials_kernel(const DecJob* __restrict__ jobs,
+                                                               const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                               int ntn, SlotDev* __restrict__ slots, int* __restrict__ result,
+                                                               int result_stride, int eos, const float* __restrict__ embed,
+                                                               int D, float* __restrict__ H, int* __restrict__ step_pos,
+                                                               int* __restrict__ n_active) {
+  __shared__ int s_cur, s_fin;
+  __shared__ float bv[2];
+  __shared__ int bi[2];
+  const DecJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < ntn; i += 128) {
+    const float v = pval[(long)blockIdx.x * ntn + i];
+    const int ix = pidx[(long)blockIdx.x * ntn + i];
+    if (v > best || (v == best && ix < besti)) {
+      best = v;
+      besti = ix;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    bv[tid >> 6] = best;
+    bi[tid >> 6] = besti;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (bv[1] > best || (bv[1] == best && bi[1] < besti)) besti = bi[1];
+    const int token = besti == 0x7fffffff ? 0 : besti;
+    SlotDev sd = slots[job.slot];
+    s_fin = 1;
+    if (!sd.finished) {
+      sd.cache_len += 1;  // the token just fed is now cached
+      sd.current = token;
+      if (sd.current == eos || sd.count >= sd.max_tokens) {
+        sd.finished = 1;
+        atomicSub(n_active, 1);
+      } else {
+        result[(long)job.slot * result_stride + sd.count++] = sd.current;
+        step_pos[blockIdx.x] = sd.cache_len;
+        s_fin = 0;
+      }
+      slots[job.slot] = sd;
+      s_cur = sd.current;
+    }
+  }
+  __syncthreads();
+  if (!s_fin) {
+    const float* e = embed + (long)s_cur * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+  }
+}
+
 __global__ void advance_kernel(const DecJob* __restrict__ jobs, const int* __restrict__ pred,
                                SlotDev* __restrict__ slots, int* __restrict__ result, int result_stride, int eos,
                                const float* __restrict__ embed, int D, float* __restrict__ H,
@@ -898,6 +963,13 @@ void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* sl
   if (n_jobs <= 0) return;
   MSH_LAUNCH(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
                      D, H, step_pos, n_active);
+}
+void stream_advance_partials(const DecJob* jobs, int n_jobs, const float* pval, const int* pidx, int ntn, SlotDev* slots,
+                             int* result, int result_stride, int eos, const float* embed, int D, float* H, int* step_pos,
+                             int* n_active, hipStream_t s) {
+  if (n_jobs <= 0) return;
+  MSH_LAUNCH(advance_partials_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pval, pidx, ntn, slots, result, result_stride, eos,
+             embed, D, H, step_pos, n_active);
 }
 void stream_bias_rows(BiasTrie trie, const int2* prefix, const int* tokens, const DecJob* jobs, const SlotDev* slots,
                       const int* result, int result_stride, int rows, float* logits, int V, hipStream_t s) {

@@ -86,7 +86,7 @@ StreamingEngine::~StreamingEngine() {
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
-                    &steppos_, &probs_, &runs_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
+                    &steppos_, &probs_, &runs_, &pval_, &pidx_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -648,7 +648,7 @@ const int2* StreamingEngine::stage_runs(const std::vector<int>& rs, int* n_runs)
 }
 
 void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_pos, float* logits, const int2* runs_d,
-                                   int n_runs) {
+                                   int n_runs, float* pval, int* pidx) {
   const int Dd = cfg_.decoder_dim, L = cfg_.depth, Fd = cfg_.dec_ffn, V = cfg_.vocab_size;
   Y_.reserve((size_t)M * Dd * 2);
   QKV_.reserve((size_t)M * 3 * Dd * 2);
@@ -696,6 +696,10 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
   }
   // (an LN-fused head would redo the LayerNorm in each of its V / 64 column tiles: measured 46 vs 28 + 5 us)
   layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
+  if (pval != nullptr) {   // nobody reads the logits of this pass: only each column tile's maximum leaves the GEMM
+    gemm_argmax_partials(Y, Dd, head_w_, M, V, Dd, pval, pidx, stream_);
+    return;
+  }
   if (!(small && small_gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_)))
     gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_);
 }
@@ -876,7 +880,26 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   // One autoregressive step = ~100 short dependent kernels whose every argument is a device pointer (positions, ids and
   // stop flags live on the device): captured once per (row count, buffer addresses, trie) into a hipGraph and replayed -- an
   // eager launch costs the host >= 3.5 us per kernel, a graph node ~1.6 us of GPU time.
+  // Without a bias trie nobody needs the logits of an AR step: from 32 streams on, the LM head runs as the tiled GEMM with the
+  // per-tile argmax epilogue (W read once instead of once per 16-row tile: 40 -> 14 us at 64 streams) and the advance kernel
+  // picks the token from the tile maxima; no logits, no argmax launch.  Same first-max rule.
+  static const bool no_fused_head = [] {
+    const char* e = getenv("MSH_NO_FUSED_ARGMAX");
+    return e != nullptr && e[0] == '1';
+  }();
+  const bool fused_head = !no_fused_head && bias_.n_nodes == 0 && J >= 32 && (Dd & 31) == 0;
+  const int ntn = gemm_argmax_tiles(V);
+  if (fused_head) {
+    pval_.reserve((size_t)J * ntn * sizeof(float));
+    pidx_.reserve((size_t)J * ntn * sizeof(int));
+  }
   auto ar_step = [&] {
+    if (fused_head) {
+      decoder_pass(J, jslot_d, steppos_.as<int>(), nullptr, nullptr, 0, pval_.as<float>(), pidx_.as<int>());
+      stream_advance_partials(jobs_d, J, pval_.as<float>(), pidx_.as<int>(), ntn, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_,
+                              Dd, stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
+      return;
+    }
     decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
     stream_bias_rows(bias_, nullptr, nullptr, jobs_d, slots_d_, result_, Scap_, J, logits_.as<float>(), V, stream_);
     stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
@@ -889,8 +912,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   }();
   if (use_graph && max_budget > 0) {
     char key[512];
-    snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p, logits_.p,
-             pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p);
+    snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
+             logits_.p, pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p,
+             (int)fused_head, pval_.p, pidx_.p);
     if (ar_graph_ == nullptr || ar_key_ != key) {
       if (ar_graph_ != nullptr) {
         MSH_HIP(hipGraphExecDestroy(ar_graph_));

@@ -93,8 +93,10 @@ class StreamingEngine {
   template <class T>
   T* stage(DevBuf& buf, const std::vector<T>& host);  // async H2D of a small descriptor array
   // runs_d (optional): the pass's rows as runs of consecutive rows of one stream, for the shared-K/V cross-attention
+  // pval / pidx (optional, then logits may be null): the LM head as the tiled GEMM whose epilogue keeps only each 128-column
+  // tile's (max, lowest index) per row -- [M][gemm_argmax_tiles(V)] -- instead of M x V logits
   void decoder_pass(int M, const int* row_slot_d, const int* row_pos_d, float* logits, const int2* runs_d = nullptr,
-                    int n_runs = 0);
+                    int n_runs = 0, float* pval = nullptr, int* pidx = nullptr);
   // rows of `rs` (slot per row) -> runs of <= kCrossRunRows consecutive rows with the same slot, staged on the device;
   // nullptr when the pass has no run longer than one row (the auto-regressive steps) or the kernel does not cover the shape
   const int2* stage_runs(const std::vector<int>& rs, int* n_runs);
@@ -145,7 +147,7 @@ class StreamingEngine {
   DevBuf audio_, frames_, hidden_, c1out_, feat_pk_, segs_, jobs_, H_, Y_, Y32_, QKV_, AO_, Z_, Q_, rowlo_, rowhi_,
       newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_,
       logits_, pred_, draft_, decjobs_, stepH_, steppos_;
-  DevBuf runs_;
+  DevBuf runs_, pval_, pidx_;
   DevBuf bias_off_, bias_tok_, bias_node_, bias_depth_, bias_bonus_, bias_prefix_;
   BiasTrie bias_{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 };

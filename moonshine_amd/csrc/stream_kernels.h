@@ -93,6 +93,10 @@ void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* d
 // one auto-regressive step of decode_full's loop (moonshine-streaming-model.cpp:1271-1288)
 void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
                     int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s);
+// the same step from the per-tile (max, lowest index) pairs of gemm_argmax_partials (kernels.h): pval / pidx [n_jobs][ntn]
+void stream_advance_partials(const DecJob* jobs, int n_jobs, const float* pval, const int* pidx, int ntn, SlotDev* slots,
+                             int* result, int result_stride, int eos, const float* embed, int D, float* H, int* step_pos,
+                             int* n_active, hipStream_t s);
 // Contextual biasing (reference core/context-biaser.cpp:88-149): flat trie over token ids, children sorted by token.
 struct BiasTrie {
   const int* child_off;    // [n_nodes + 1]
