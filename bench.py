@@ -71,6 +71,26 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus() -> int:
+    """CPUs this process may use: affinity mask, cut down to the cgroup quota (v2 cpu.max, v1 cfs_quota / cfs_period)."""
+    import math
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def main_streaming(args):
     import torch
 
@@ -382,6 +402,27 @@ def main():
                  "lines": lines, "entry_point": "moonshine_transcribe_batch_without_streaming", "host_buffers": "pageable",
                  "options": {"vad_threshold": 0, "batch_clips": B, "batches_in_flight": F}}
         tr.close()
+        # ---- the same call with the reference's DEFAULT options: vad_threshold 0.5, every 32 ms hop of every clip through the
+        # Silero network on the host (synthetic Silero weights: what counts here is the cost, not where the cuts fall) ----
+        try:
+            from moonshine_amd.synth import make_silero_weights
+
+            with tempfile.TemporaryDirectory() as md:
+                write_model_dir(md, cfg, seed=0, weights=w)
+                save_safetensors(os.path.join(md, "silero_vad.safetensors"), make_silero_weights(2))
+                trv = mapi.Transcriber(md, mapi.ARCH_BASE if args.arch == "base" else mapi.ARCH_TINY,
+                                       {"vad_threshold": "0.5", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank)})
+            callv = lambda: mapi.lib().moonshine_transcribe_batch_without_streaming(trv.handle, cptrs, clens, n, 16000, 0, outs)
+            assert callv() == 0
+            tv = time.perf_counter()
+            assert callv() == 0
+            dtv = time.perf_counter() - tv
+            c_api["default_vad"] = {"value": round(n * CLIP_SECONDS / dtv, 1), "unit": "audio-seconds/sec", "ms_per_call": round(dtv * 1e3, 1),
+                                    "lines": sum(int(outs[i].contents.line_count) for i in range(n)),
+                                    "options": {"vad_threshold": 0.5, "vad": "Silero on the host, one clip per host thread"}}
+            trv.close()
+        except Exception as e:  # the headline does not depend on this sub-run
+            print(f"default-VAD sub-run failed: {e}", file=sys.stderr)
 
     if rank != 0:
         if dist is not None:
@@ -474,12 +515,13 @@ def main():
 
         cands = []
         cores = os.cpu_count() or 1
+        usable = effective_cpus()   # affinity mask cut down to the cgroup CPU quota (a 256-core host may grant 16)
         try:
-            threads = min(cores, 64)
-            nb, per = 48, 16   # three batches of 16: ~15 s of wall time on a 64-thread host
+            threads = min(usable, 64)
+            nb, per = 96, 16   # six batches of 16: ~10 s of wall time (~150 CPU-seconds) on the 16 CPUs the benchmark box grants
             toks_hf, dt = hf_baseline.run(cfg, w, host[:nb], args.decode_steps, per, threads)
             cands.append({"value": round(nb * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": threads,
-                          "host_cores_visible": cores, "kind": "port",
+                          "host_cores_visible": cores, "host_cpus_usable": usable, "kind": "port",
                           "sample": f"{nb} clips x 10 s in batches of {per}, {args.decode_steps} forced decode steps, HuggingFace "
                                     f"MoonshineForConditionalGeneration fp32 eager (torch {threads} threads), {dt:.1f} s of wall time; "
                                     "stand-in for the reference's CPU-ORT int8 path, which cannot be built here",
@@ -500,7 +542,7 @@ def main():
         except Exception:
             blas_threads = cores
         cands.append({"value": round(n_clips * CLIP_SECONDS / dt, 2), "unit": "audio-seconds/sec", "cores": blas_threads,
-                      "host_cores_visible": cores, "kind": "port",
+                      "host_cores_visible": cores, "host_cpus_usable": usable, "kind": "port",
                       "sample": f"{n_clips} clips x 10 s, {args.decode_steps} forced decode steps, batch 1, numpy fp32 oracle "
                                 f"(multi-threaded BLAS), {dt:.1f} s of CPU time"})
         cands.sort(key=lambda c: -c["value"])

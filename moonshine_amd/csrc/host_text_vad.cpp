@@ -228,9 +228,16 @@ void VoiceActivityDetector::process_audio(const float* audio, size_t count, int3
     process_hop(remainder_.data());
     remainder_.clear();
   }
-  while (n - off >= (size_t)hop_) {
+  // Silero probabilities of all the whole hops of this call in one go (the network's state-independent part runs for
+  // eight hops at a time, silero_vad.h predict_many; per hop the value is the one predict() would return)
+  const size_t whole = (n - off) / (size_t)hop_;
+  if (silero_ && whole > 0) {
+    hop_probs_.resize(whole);
+    silero_->predict_many(src + off, whole, hop_probs_.data());
+  }
+  for (size_t i = 0; i < whole; ++i) {
     call_remaining_ = n - off - hop_;
-    process_hop(src + off);
+    process_hop(src + off, silero_ ? &hop_probs_[i] : nullptr);
     off += hop_;
   }
   call_remaining_ = 0;
@@ -242,7 +249,7 @@ void VoiceActivityDetector::clear_completed_audio() {
     if (s.is_complete) std::vector<float>().swap(s.audio);
 }
 
-void VoiceActivityDetector::process_hop(const float* hop) {
+void VoiceActivityDetector::process_hop(const float* hop, const float* silero_prob) {
   processed_ += hop_;
   // slide the look-behind window
   if ((size_t)hop_ >= look_buf_.size()) {
@@ -255,7 +262,7 @@ void VoiceActivityDetector::process_hop(const float* hop) {
   // starts at zero, reference :139-151).  Either is scaled by the max-length fade once the segment passes 2/3 of the cap.
   float p = 1.0f;
   if (silero_) {
-    prob_window_[prob_index_] = silero_->predict(hop);
+    prob_window_[prob_index_] = silero_prob != nullptr ? *silero_prob : silero_->predict(hop);
     prob_index_ = (prob_index_ + 1) % prob_window_.size();
     float sum = 0.0f;  // std::accumulate(..., 0.0f) in the reference: fp32, in ring order
     for (float v : prob_window_) sum += v;

@@ -77,7 +77,7 @@ class VoiceActivityDetector {
   void clear_completed_audio();
 
  private:
-  void process_hop(const float* hop);
+  void process_hop(const float* hop, const float* silero_prob = nullptr);   // silero_prob: precomputed for this hop
   float threshold_;
   int32_t hop_;
   size_t look_behind_, max_segment_, hard_cap_;
@@ -89,7 +89,7 @@ class VoiceActivityDetector {
   // the open segment's samples live in segments_.back().audio only (the reference re-copies its growing buffer into the
   // segment on every hop -- quadratic in the segment length: ~100 MB of memcpy for one 10 s clip)
   size_t open_size() const { return prev_voice_ && !segments_.empty() ? segments_.back().audio.size() : 0; }
-  std::vector<float> look_buf_, remainder_;
+  std::vector<float> look_buf_, remainder_, hop_probs_;
   size_t call_remaining_ = 0;  // samples of the current process_audio call not yet consumed (a reserve() hint)
   std::vector<VadSegment> segments_;
 };

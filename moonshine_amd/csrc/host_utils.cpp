@@ -1,5 +1,10 @@
 #include "host_utils.h"
 
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include <string.h>
 #include <sys/stat.h>
 
@@ -229,8 +234,37 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out) {
   return std::fread(out->data(), 1, (size_t)n, file.f) == (size_t)n;
 }
 
+unsigned effective_cpus() {
+  static const unsigned cached = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    auto read_file = [](const char* path, char* buf, size_t cap) -> bool {
+      FILE* f = fopen(path, "r");
+      if (f == nullptr) return false;
+      const size_t got = fread(buf, 1, cap - 1, f);
+      fclose(f);
+      buf[got] = 0;
+      return got > 0;
+    };
+    char buf[128];
+    double quota = -1.0, period = -1.0;
+    if (read_file("/sys/fs/cgroup/cpu.max", buf, sizeof(buf))) {           // cgroup v2: "<quota|max> <period>"
+      if (strncmp(buf, "max", 3) != 0) sscanf(buf, "%lf %lf", &quota, &period);
+    } else if (read_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", buf, sizeof(buf))) {   // cgroup v1
+      quota = atof(buf);
+      if (read_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us", buf, sizeof(buf))) period = atof(buf);
+    }
+    if (quota > 0.0 && period > 0.0) {
+      const unsigned q = (unsigned)ceil(quota / period);
+      if (q >= 1 && q < n) n = q;
+    }
+    return n;
+  }();
+  return cached;
+}
+
 void parallel_for(size_t n, const std::function<void(size_t)>& fn, unsigned max_threads) {
-  unsigned nt = max_threads ? max_threads : std::thread::hardware_concurrency();
+  unsigned nt = max_threads ? max_threads : effective_cpus();
   if (nt == 0) nt = 1;
   if (nt > n) nt = (unsigned)n;
   if (nt <= 1) {

@@ -44,5 +44,10 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out);
 // fn(i) for i in [0, n) on up to max_threads host threads (0 = one per hardware thread); items are handed out one at a
 // time, the first exception is re-thrown on the caller's thread after every worker has stopped
 void parallel_for(size_t n, const std::function<void(size_t)>& fn, unsigned max_threads = 0);
+// CPUs this process may actually use: the affinity mask, cut down to the cgroup CPU quota when there is one (cgroup v2
+// cpu.max or v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A container with 256 visible cores and a 16-CPU quota gets 16:
+// more threads than that only buy throttling (measured on the benchmark box: the host VAD peaks at 2x the quota and
+// loses half its rate at 8x).
+unsigned effective_cpus();
 
 }  // namespace msh_host

@@ -7,6 +7,7 @@
 #include <iterator>
 #include <random>
 #include <stdexcept>
+#include <future>
 #include <thread>
 #include <algorithm>
 
@@ -842,23 +843,22 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   if (timing) MSH_LOGF("batch call: %llu streams created in %.1f ms", (unsigned long long)count, ms_since(t_phase));
   t_phase = now();
   // Segmentation is per clip (its own detector state, shared read-only weights) and runs on the host: one clip per host
-  // thread.  With Silero on, a 10 s clip costs ~25 ms of one core -- serially that is seconds for a batch the GPU
+  // thread.  With Silero on, a 10 s clip costs ~15 ms of one core -- serially that is seconds for a batch the GPU
   // transcribes in tens of milliseconds (the reference walks the clips one after the other, transcriber.cpp:997).
-  parallel_for((size_t)count, [&](size_t i) {
-    TranscriberStream* s = streams[i];
-    s->vad->start();
-    s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
-    s->vad->stop();
-    segs[i] = s->vad->take_segments();
-  }, opt_.host_threads > 0 ? (unsigned)opt_.host_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency())));
-  if (timing) MSH_LOGF("batch call: segmentation in %.1f ms", ms_since(t_phase));
-  t_phase = now();
+  const unsigned vad_threads = opt_.host_threads > 0 ? (unsigned)opt_.host_threads
+                                                     : std::min(128u, 2u * effective_cpus());   // 2x: the lanes' threads mostly wait
+  auto segment = [&](uint64_t c0, uint64_t c1) {
+    parallel_for((size_t)(c1 - c0), [&](size_t k) {
+      const size_t i = (size_t)c0 + k;
+      TranscriberStream* s = streams[i];
+      s->vad->start();
+      s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
+      s->vad->stop();
+      segs[i] = s->vad->take_segments();
+    }, vad_threads);
+  };
   std::vector<transcript_t*> outs(count, nullptr);
-  // A streaming architecture keeps one device slot per line being decoded (max_streams of them): larger batches run in
-  // waves of that size, and a wave's slots are handed back before the next one starts.  The transcripts stay.
-  const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) : std::max<uint64_t>(count, 1);
-  for (uint64_t w0 = 0; w0 < count; w0 += wave) {
-    const uint64_t w1 = std::min(count, w0 + wave);
+  auto transcribe = [&](uint64_t w0, uint64_t w1) {
     std::vector<TranscriberStream*> sub(streams.begin() + w0, streams.begin() + w1);
     std::vector<std::vector<VadSegment>> sub_segs(std::make_move_iterator(segs.begin() + w0), std::make_move_iterator(segs.begin() + w1));
     update_from_segments(sub, sub_segs, outs.data() + w0);
@@ -868,8 +868,44 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
           s->sowner->free_state(s->sstate);
           s->sstate = nullptr;
         }
+  };
+  // Waves.  A streaming architecture keeps one device slot per line being decoded (max_streams of them): larger batches run
+  // in waves of that size, and a wave's slots are handed back before the next one starts (the transcripts stay).  An offline
+  // model with Silero on is VAD-bound on the host (the network runs for every 32 ms hop of every clip): clips go in waves of
+  // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
+  // is a copy and everything is one wave.
+  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
+  const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams)
+                        : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * 2
+                                         : std::max<uint64_t>(count, 1);
+  double seg_ms = 0.0;
+  if (!pipelined) {
+    segment(0, count);
+    seg_ms = ms_since(t_phase);
+    if (timing) MSH_LOGF("batch call: segmentation in %.1f ms", seg_ms);
+    t_phase = now();
+    for (uint64_t w0 = 0; w0 < count; w0 += wave) transcribe(w0, std::min(count, w0 + wave));
+    if (timing) MSH_LOGF("batch call: transcription + transcript assembly in %.1f ms", ms_since(t_phase));
+  } else {
+    std::future<void> pending;   // the previous wave on the GPU
+    try {
+      for (uint64_t w0 = 0; w0 < count; w0 += wave) {
+        const uint64_t w1 = std::min(count, w0 + wave);
+        const auto ts = now();
+        segment(w0, w1);
+        seg_ms += ms_since(ts);
+        if (pending.valid()) pending.get();
+        pending = std::async(std::launch::async, [&transcribe, w0, w1] { transcribe(w0, w1); });
+      }
+      if (pending.valid()) pending.get();
+    } catch (...) {
+      if (pending.valid()) pending.wait();   // never leave the worker running on this frame's state
+      throw;
+    }
+    if (timing)
+      MSH_LOGF("batch call: %.1f ms, of which segmentation %.1f ms on %u threads with the previous wave's transcription beside it",
+               ms_since(t_phase), seg_ms, vad_threads);
   }
-  if (timing) MSH_LOGF("batch call: transcription + transcript assembly in %.1f ms", ms_since(t_phase));
   if (out != nullptr)
     for (uint64_t i = 0; i < count; ++i) out[i] = outs[i];
 }

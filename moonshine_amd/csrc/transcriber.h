@@ -93,7 +93,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   int32_t context_max_terms = 0;         // 0 = ContextExtractor::kDefaultMaxTerms
   float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
-  int host_threads = 0;                  // additive: host threads for the per-clip VAD of batch calls (0 = hardware threads, <= 64)
+  int host_threads = 0;                  // additive: host threads for the per-clip VAD of batch calls (0 = twice the CPUs the process may use -- affinity and cgroup quota --, <= 128)
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool word_timestamps = false;          // reference core/transcriber.h (word_timestamps): offline architectures here
   int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call

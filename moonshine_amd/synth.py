@@ -411,3 +411,40 @@ def write_synthetic_tokenizer(path: str, vocab: int) -> list[bytes]:
     with open(path, "wb") as f:
         f.write(encode_tokenizer_bin(toks))
     return toks
+
+
+# ---------------------------------------------------------------------------
+# Silero VAD (the `silero_vad.safetensors` the C++ host layer reads, csrc/silero_vad.cpp): synthetic weights with the
+# published model's parameter names, for benchmarks and tests that need `vad_threshold > 0` without the real file.
+# ---------------------------------------------------------------------------
+SILERO_STATE = 128
+SILERO_CONV = [(129, 128, 1), (128, 64, 2), (64, 64, 2), (64, 128, 1)]  # (in, out, stride), kernel 3, padding 1
+
+
+def silero_stft_basis() -> np.ndarray:
+    """[258, 1, 256]: hann-windowed DFT rows, real then imaginary (the published model's forward_basis_buffer)."""
+    n = 256
+    k = np.arange(129)[:, None]
+    t = np.arange(n)[None, :]
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)  # periodic hann
+    re = np.cos(2 * np.pi * k * t / n) * win
+    im = -np.sin(2 * np.pi * k * t / n) * win
+    return np.concatenate([re, im])[:, None, :].astype(np.float32)
+
+
+def make_silero_weights(seed: int = 0) -> dict[str, np.ndarray]:
+    """Fan-in scaled random weights so that gates / logits are O(1)."""
+    f32 = np.float32
+    rng = np.random.default_rng(seed)
+    w = {"stft.forward_basis_buffer": silero_stft_basis()}
+    for i, (cin, cout, _) in enumerate(SILERO_CONV):
+        w[f"encoder.{i}.reparam_conv.weight"] = (rng.standard_normal((cout, cin, 3)) * (1.6 / np.sqrt(cin * 3))).astype(f32)
+        w[f"encoder.{i}.reparam_conv.bias"] = (rng.standard_normal(cout) * 0.1).astype(f32)
+    for n in ("weight_ih", "weight_hh"):
+        w[f"decoder.rnn.{n}"] = (rng.standard_normal((4 * SILERO_STATE, SILERO_STATE)) * (1.5 / np.sqrt(SILERO_STATE))).astype(f32)
+    for n in ("bias_ih", "bias_hh"):
+        w[f"decoder.rnn.{n}"] = (rng.standard_normal(4 * SILERO_STATE) * 0.1).astype(f32)
+    w["decoder.decoder.2.weight"] = (rng.standard_normal((1, SILERO_STATE, 1)) * 0.8).astype(f32)
+    w["decoder.decoder.2.bias"] = np.asarray([0.1], f32)
+    return w
+
