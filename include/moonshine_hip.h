@@ -170,11 +170,14 @@ MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64
  *                           Returns the text length (excluding the terminating NUL), or a negative status;
  *                           at most out_cap-1 bytes are written.
  * msh_host_sanitize_utf8  : invalid UTF-8 bytes -> '?' (reference core/transcriber.cpp:1489-1543); same return rule.
+ * msh_host_effective_cpus : CPUs the process may use (affinity mask cut down to the cgroup CPU quota): what the host
+ *                           layer sizes its default thread counts with (option host_threads = 0)
  * msh_host_resample       : box-filter down / linear up (reference core/resampler.cpp:5-86); returns the output
  *                           sample count (call with out == NULL to size the buffer). */
 MSH_EXPORT int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_t tokenizer_size, const int32_t* ids,
                                            uint64_t n_ids, char* out, uint64_t out_cap);
 MSH_EXPORT int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap);
+MSH_EXPORT int32_t msh_host_effective_cpus(void);
 MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out,
                                      uint64_t out_cap);
 /* msh_host_text_to_tokens : BinTokenizer::text_to_tokens (reference core/bin-tokenizer/bin-tokenizer.cpp:277-402);

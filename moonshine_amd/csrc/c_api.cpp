@@ -472,6 +472,8 @@ int64_t msh_host_silero_probabilities(const uint8_t* weights, uint64_t weights_s
   }
 }
 
+int32_t msh_host_effective_cpus(void) { return (int32_t)msh_host::effective_cpus(); }
+
 int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window, int32_t hop,
                               uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap, const float* audio,
                               uint64_t n_samples, int32_t sample_rate, uint64_t chunk, int64_t* bounds, uint64_t max_segments) {

@@ -407,3 +407,27 @@ def test_reference_python_binding_binds_every_symbol_unedited():
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp", env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "bound libmoonshine.so" in r.stdout
+
+
+def test_effective_cpus_follows_affinity_and_cgroup_quota():
+    """Default host thread counts come from msh_host_effective_cpus: the affinity mask, cut down to the cgroup CPU quota
+    (a container that sees 256 cores but is granted 16 CPUs must not start 128 VAD threads: measured, that halves the rate)."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    lib = api.lib()
+    lib.msh_host_effective_cpus.restype = __import__("ctypes").c_int32
+    assert lib.msh_host_effective_cpus() == max(1, n)
