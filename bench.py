@@ -403,7 +403,7 @@ def main():
                  "options": {"vad_threshold": 0, "batch_clips": B, "batches_in_flight": F}}
         tr.close()
         # ---- the same call with the reference's DEFAULT options: vad_threshold 0.5, every 32 ms hop of every clip through the
-        # Silero network on the host (synthetic Silero weights: what counts here is the cost, not where the cuts fall) ----
+        # Silero network (synthetic Silero weights: what counts here is the cost, not where the cuts fall) ----
         try:
             from moonshine_amd.synth import make_silero_weights
 
@@ -419,7 +419,9 @@ def main():
             dtv = time.perf_counter() - tv
             c_api["default_vad"] = {"value": round(n * CLIP_SECONDS / dtv, 1), "unit": "audio-seconds/sec", "ms_per_call": round(dtv * 1e3, 1),
                                     "lines": sum(int(outs[i].contents.line_count) for i in range(n)),
-                                    "options": {"vad_threshold": 0.5, "vad": "Silero on the host, one clip per host thread"}}
+                                    "options": {"vad_threshold": 0.5, "vad_device": 1,
+                                                "vad": "Silero network on the GPU for the whole batch (k_silero.hip), the detectors' "
+                                                       "state machines on host threads"}}
             trv.close()
         except Exception as e:  # the headline does not depend on this sub-run
             print(f"default-VAD sub-run failed: {e}", file=sys.stderr)

@@ -210,6 +210,18 @@ MSH_EXPORT int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t t
                                         int32_t heads_total, int32_t n_steps, int32_t frames, const int32_t* tokens,
                                         uint64_t n_tokens, float seconds_per_frame, char* text_out, uint64_t text_cap,
                                         float* times_out, uint64_t max_words);
+/* Silero VAD on the device for batch calls (no reference counterpart: the reference runs the published ONNX model one hop
+ * at a time on the host).  msh_silero_probabilities takes 16 kHz clips in HOST memory and writes, concatenated, the
+ * probability of every whole 512-sample hop of every clip (clip i at offset sum_{j<i} n[j] / 512), each clip from a fresh
+ * state -- what msh_host_silero_probabilities returns clip by clip, up to fp32 summation order.  Returns the number of
+ * probabilities, or a negative msh error (cap too small: MSH_ERR_INVALID_ARGUMENT). */
+typedef struct msh_silero msh_silero;
+MSH_EXPORT int32_t msh_silero_create(int32_t device, const uint8_t* weights, uint64_t weights_size, msh_silero** out);
+MSH_EXPORT void msh_silero_destroy(msh_silero* s);
+MSH_EXPORT int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count,
+                                            float* probs_out, uint64_t cap);
+MSH_EXPORT const char* msh_silero_last_error(msh_silero* s);
+
 /* Voice activity detection (reference core/silero-vad.cpp:78-173, core/voice-activity-detector.cpp:125-199), as the
  * Transcriber's streams run it -- host code, no GPU:
  * msh_host_silero_probabilities : Silero VAD over whole 512-sample hops of 16 kHz audio from a fresh state; weights = a

@@ -81,6 +81,7 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "device") o->device = parse_int32(v);
     else if (k == "use_speculative_decoding") o->use_speculative_decoding = parse_bool(v);
     else if (k == "max_streams") o->max_streams = parse_int32(v);                  // additive (streaming archs)
+    else if (k == "vad_device") o->vad_device = parse_int32(v);                    // additive: Silero on the GPU for batch calls
     else if (k == "host_threads") o->host_threads = parse_int32(v);                // additive: VAD threads of batch calls
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
     else if (k == "batch_clips" || k == "max_batch_size") o->batch_clips = parse_int32(v);  // additive (batch calls; SURVEY 8b names it max_batch_size)

@@ -206,8 +206,12 @@ void VoiceActivityDetector::stop() {
   }
 }
 
-void VoiceActivityDetector::process_audio(const float* audio, size_t count, int32_t sample_rate) {
+void VoiceActivityDetector::process_audio(const float* audio, size_t count, int32_t sample_rate, const float* silero_probs,
+                                          size_t n_probs) {
   if (!active_) return;
+  if (silero_probs != nullptr &&
+      (!silero_ || sample_rate != kSampleRate || !remainder_.empty() || n_probs != count / (size_t)hop_))
+    throw std::runtime_error("precomputed VAD probabilities need 16 kHz audio on a hop boundary and one value per whole hop");
   for (VadSegment& s : segments_) s.just_updated = false;
   std::vector<float> resampled;
   const float* src = audio;
@@ -232,8 +236,12 @@ void VoiceActivityDetector::process_audio(const float* audio, size_t count, int3
   // eight hops at a time, silero_vad.h predict_many; per hop the value is the one predict() would return)
   const size_t whole = (n - off) / (size_t)hop_;
   if (silero_ && whole > 0) {
-    hop_probs_.resize(whole);
-    silero_->predict_many(src + off, whole, hop_probs_.data());
+    if (silero_probs != nullptr) {
+      hop_probs_.assign(silero_probs, silero_probs + whole);
+    } else {
+      hop_probs_.resize(whole);
+      silero_->predict_many(src + off, whole, hop_probs_.data());
+    }
   }
   for (size_t i = 0; i < whole; ++i) {
     call_remaining_ = n - off - hop_;

@@ -71,7 +71,11 @@ class VoiceActivityDetector {
   void start();
   void stop();
   bool is_active() const { return active_; }
-  void process_audio(const float* audio, size_t count, int32_t sample_rate);
+  // silero_probs (optional): the Silero probability of every whole hop of THIS call, computed elsewhere (the device network
+  // of batch calls, silero_device.h); only for 16 kHz audio handed over on a hop boundary (nothing waiting from an earlier
+  // call), n_probs = count / hop.  The detector's own network state is then not advanced.
+  void process_audio(const float* audio, size_t count, int32_t sample_rate, const float* silero_probs = nullptr,
+                     size_t n_probs = 0);
   const std::vector<VadSegment>& segments() const { return segments_; }
   std::vector<VadSegment> take_segments() { return std::move(segments_); }  // after stop(): hands the audio over, no copy
   void clear_completed_audio();

@@ -13,6 +13,7 @@
 #include "engine.h"
 #include "host_utils.h"
 #include "pipeline.h"
+#include "silero_device.h"
 #include "stream_engine.h"
 
 struct msh_engine {
@@ -297,6 +298,63 @@ float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int
     return -1.0f;
   }
 }
+
+// ---- Silero VAD on the device ----
+struct msh_silero {
+  msh::SileroDevice* dev = nullptr;
+  std::string last_error;
+};
+
+int32_t msh_silero_create(int32_t device, const uint8_t* weights, uint64_t weights_size, msh_silero** out) {
+  if (out == nullptr || weights == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  try {
+    msh_host::SileroWeights w;
+    w.load_memory(weights, (size_t)weights_size);
+    std::unique_ptr<msh_silero> h(new msh_silero());
+    h->dev = new msh::SileroDevice(device, w);
+    *out = h.release();
+    return MSH_OK;
+  } catch (const msh::HipError& ex) {
+    fprintf(stderr, "msh_silero_create: %s\n", ex.what());
+    return MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "msh_silero_create: %s\n", ex.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+void msh_silero_destroy(msh_silero* s) {
+  if (s == nullptr) return;
+  delete s->dev;
+  delete s;
+}
+int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count, float* probs_out,
+                                 uint64_t cap) {
+  if (s == nullptr || s->dev == nullptr || (count > 0 && (pcm == nullptr || n_samples == nullptr))) return MSH_ERR_INVALID_ARGUMENT;
+  try {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < count; ++i) total += n_samples[i] / 512;
+    if (total > cap || (total > 0 && probs_out == nullptr)) {
+      s->last_error = "probs_out too small";
+      return MSH_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<std::vector<float>> probs;
+    s->dev->probabilities(pcm, n_samples, (size_t)count, &probs);
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+      if (!probs[i].empty()) memcpy(probs_out + off, probs[i].data(), probs[i].size() * sizeof(float));
+      off += probs[i].size();
+    }
+    return (int64_t)off;
+  } catch (const msh::HipError& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+const char* msh_silero_last_error(msh_silero* s) { return s != nullptr ? s->last_error.c_str() : ""; }
 
 // Self-test of the device allocator (meant for MSH_GUARD_ALLOC=1): odd-sized buffers, pageable H2D / D2H through the
 // utility stream, zero-fill, D2D.  Returns 0 when every byte came back, a negative step number otherwise.

@@ -519,6 +519,7 @@ Transcriber::~Transcriber() {
   streams_.clear();
   batch_streams_.clear();
   batch_stream_.reset();
+  if (silero_device_ != nullptr) msh_silero_destroy(silero_device_);
 }
 
 // reference core/transcriber.cpp:1311-1487, batched over streams: feed only the new whole 1280-sample chunks of
@@ -637,13 +638,30 @@ void Transcriber::load_vad_model() {
   static const char* kName = "silero_vad.safetensors";
   std::shared_ptr<SileroWeights> w(new SileroWeights());
   auto mem = opt_.memory_files.find(kName);
+  auto from_file = [&](const std::string& path) {   // the bytes are kept: the device network is built from them on demand
+    FILE* f = fopen(path.c_str(), "rb");
+    if (f == nullptr) throw std::runtime_error("cannot open the Silero VAD weights " + path);
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (size <= 0) {
+      fclose(f);
+      throw std::runtime_error("the Silero VAD weights file " + path + " is empty");
+    }
+    silero_blob_.resize((size_t)size);
+    const size_t got = fread(silero_blob_.data(), 1, (size_t)size, f);
+    fclose(f);
+    if (got != (size_t)size) throw std::runtime_error("short read of the Silero VAD weights " + path);
+    w->load_memory(silero_blob_.data(), silero_blob_.size());
+  };
   if (!opt_.vad_model_path.empty()) {
-    w->load_file(opt_.vad_model_path);
+    from_file(opt_.vad_model_path);
   } else if (mem != opt_.memory_files.end() && mem->second.first != nullptr) {
-    w->load_memory(mem->second.first, mem->second.second);
+    silero_blob_.assign(mem->second.first, mem->second.first + mem->second.second);
+    w->load_memory(silero_blob_.data(), silero_blob_.size());
   } else if (opt_.model_source == TranscriberOptions::FILES && !opt_.model_path.empty() &&
              file_exists(join_path(opt_.model_path, kName))) {
-    w->load_file(join_path(opt_.model_path, kName));
+    from_file(join_path(opt_.model_path, kName));
   } else {
     throw std::runtime_error(
         "vad_threshold=" + std::to_string(opt_.vad_threshold) + " (the default is 0.5) needs the Silero VAD weights: pass the "
@@ -847,12 +865,35 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // transcribes in tens of milliseconds (the reference walks the clips one after the other, transcriber.cpp:997).
   const unsigned vad_threads = opt_.host_threads > 0 ? (unsigned)opt_.host_threads
                                                      : std::min(128u, 2u * effective_cpus());   // 2x: the lanes' threads mostly wait
+  // With Silero on and 16 kHz input the network runs on the GPU for the whole wave (silero_device.h: tens of milliseconds
+  // for 2048 clips against ~1 s of host threads); the detectors' state machines then only consume the probabilities.
+  const bool device_vad = opt_.vad_threshold > 0.0f && opt_.vad_device != 0 && sample_rate == kSampleRate && !silero_blob_.empty() &&
+                          !silero_device_failed_;
+  if (device_vad && silero_device_ == nullptr) {
+    if (msh_silero_create(opt_.device, silero_blob_.data(), silero_blob_.size(), &silero_device_) != MSH_OK) {
+      silero_device_failed_ = true;   // (logged by the library) -- the host network takes over
+      silero_device_ = nullptr;
+    }
+  }
   auto segment = [&](uint64_t c0, uint64_t c1) {
+    std::vector<float> probs;
+    std::vector<size_t> poff;
+    if (silero_device_ != nullptr) {
+      poff.resize((size_t)(c1 - c0) + 1, 0);
+      for (uint64_t i = c0; i < c1; ++i) poff[i - c0 + 1] = poff[i - c0] + (size_t)(n[i] / (uint64_t)opt_.vad_hop_size);
+      probs.resize(std::max<size_t>(poff.back(), 1));
+      const int64_t got = msh_silero_probabilities(silero_device_, audio + c0, n + c0, c1 - c0, probs.data(), poff.back());
+      if (got != (int64_t)poff.back())
+        throw std::runtime_error(std::string("device VAD failed: ") + msh_silero_last_error(silero_device_));
+    }
     parallel_for((size_t)(c1 - c0), [&](size_t k) {
       const size_t i = (size_t)c0 + k;
       TranscriberStream* s = streams[i];
       s->vad->start();
-      s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
+      if (silero_device_ != nullptr)
+        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate, probs.data() + poff[k], poff[k + 1] - poff[k]);
+      else
+        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
       s->vad->stop();
       segs[i] = s->vad->take_segments();
     }, vad_threads);
@@ -874,7 +915,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // model with Silero on is VAD-bound on the host (the network runs for every 32 ms hop of every clip): clips go in waves of
   // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
   // is a copy and everything is one wave.
-  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
+  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f && silero_device_ == nullptr;
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams)
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * 2
                                          : std::max<uint64_t>(count, 1);

@@ -93,6 +93,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   int32_t context_max_terms = 0;         // 0 = ContextExtractor::kDefaultMaxTerms
   float keyterm_boost = ContextBiaser::kDefaultBoost;
   int max_streams = 64;                  // additive: device slots for concurrent streaming lines
+  int vad_device = 1;                    // additive: 1 = batch calls run the Silero network on the GPU (16 kHz input), 0 = host only
   int host_threads = 0;                  // additive: host threads for the per-clip VAD of batch calls (0 = twice the CPUs the process may use -- affinity and cgroup quota --, <= 128)
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool word_timestamps = false;          // reference core/transcriber.h (word_timestamps): offline architectures here
@@ -198,6 +199,9 @@ class Transcriber {
   void load_vad_model();
   TranscriberOptions opt_;
   std::shared_ptr<const SileroWeights> silero_;  // shared by every stream's detector (each keeps its own state)
+  std::vector<uint8_t> silero_blob_;             // the weights file as read: what the device network is created from
+  msh_silero* silero_device_ = nullptr;          // batch calls: the network on the GPU (option vad_device, default on)
+  bool silero_device_failed_ = false;
   size_t vad_hard_cap_ = 0;                      // longest segment (samples) the engine behind this transcriber takes
   std::unique_ptr<MoonshineModel> model_;
   std::unique_ptr<MoonshineStreamingModel> streaming_model_;

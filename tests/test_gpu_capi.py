@@ -284,7 +284,7 @@ def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_pat
         n = int((4.0 + 0.37 * i) * 16000)
         env = (np.sin(np.arange(n) / 16000 * 2 * np.pi * (0.5 + 0.05 * i)) > 0).astype(np.float32)
         clips.append((make_audio(900 + i, n) * (0.05 + 3.0 * env)).astype(np.float32))
-    one = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "1"})
+    one = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "1", "vad_device": "0"})
     spans = [[(l.start_time, l.duration) for l in one.transcribe_without_streaming(c)] for c in clips]
     assert sum(len(w) for w in spans) > len(clips)          # the detector does split these clips
     t0 = time.perf_counter()
@@ -293,14 +293,24 @@ def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_pat
     one.close()
     # segmentation is a function of the clip alone (the text of a near-tie token may depend on the batch it was decoded in)
     assert [[(a, b) for _, a, b in r] for r in want] == spans
-    many = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "16"})
+    many = api.Transcriber(d, api.ARCH_TINY, {"host_threads": "16", "vad_device": "0"})
     many.transcribe_batch_without_streaming(clips[:2])    # warm
     t0 = time.perf_counter()
     got = [[(l.text_bytes, l.start_time, l.duration) for l in r] for r in many.transcribe_batch_without_streaming(clips)]
     t16 = time.perf_counter() - t0
     many.close()
     assert got == want                                      # same batch, any thread count: identical transcripts
-    print(f"batch of {len(clips)} clips with Silero: {t1 * 1e3:.0f} ms on 1 host thread, {t16 * 1e3:.0f} ms on 16")
+    # default options: the network runs on the GPU for the whole batch (silero_device.h), the detectors consume its
+    # probabilities: same cuts, same transcripts
+    dev = api.Transcriber(d, api.ARCH_TINY, {})
+    dev.transcribe_batch_without_streaming(clips[:2])     # warm
+    t0 = time.perf_counter()
+    got_dev = [[(l.text_bytes, l.start_time, l.duration) for l in r] for r in dev.transcribe_batch_without_streaming(clips)]
+    tdev = time.perf_counter() - t0
+    dev.close()
+    assert got_dev == want
+    print(f"batch of {len(clips)} clips with Silero: {t1 * 1e3:.0f} ms on 1 host thread, {t16 * 1e3:.0f} ms on 16, "
+          f"{tdev * 1e3:.0f} ms with the network on the GPU")
 
 
 def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir):
