@@ -878,19 +878,25 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   auto segment = [&](uint64_t c0, uint64_t c1) {
     std::vector<float> probs;
     std::vector<size_t> poff;
+    bool have_probs = false;
     if (silero_device_ != nullptr) {
       poff.resize((size_t)(c1 - c0) + 1, 0);
       for (uint64_t i = c0; i < c1; ++i) poff[i - c0 + 1] = poff[i - c0] + (size_t)(n[i] / (uint64_t)opt_.vad_hop_size);
       probs.resize(std::max<size_t>(poff.back(), 1));
       const int64_t got = msh_silero_probabilities(silero_device_, audio + c0, n + c0, c1 - c0, probs.data(), poff.back());
-      if (got != (int64_t)poff.back())
-        throw std::runtime_error(std::string("device VAD failed: ") + msh_silero_last_error(silero_device_));
+      have_probs = got == (int64_t)poff.back();
+      if (!have_probs) {   // e.g. out of device memory: the host network does this wave and every later one
+        MSH_LOGF("device VAD failed (%s): falling back to the host network", msh_silero_last_error(silero_device_));
+        msh_silero_destroy(silero_device_);
+        silero_device_ = nullptr;
+        silero_device_failed_ = true;
+      }
     }
     parallel_for((size_t)(c1 - c0), [&](size_t k) {
       const size_t i = (size_t)c0 + k;
       TranscriberStream* s = streams[i];
       s->vad->start();
-      if (silero_device_ != nullptr)
+      if (have_probs)
         s->vad->process_audio(audio[i], (size_t)n[i], sample_rate, probs.data() + poff[k], poff[k + 1] - poff[k]);
       else
         s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
