@@ -236,6 +236,12 @@ MSH_EXPORT int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weight
                                          int32_t hop, uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap,
                                          const float* audio, uint64_t n_samples, int32_t sample_rate, uint64_t chunk,
                                          int64_t* bounds, uint64_t max_segments);
+/* the same detector fed with precomputed Silero probabilities (one per whole hop of a 16 kHz clip): the host half of the
+ * device-VAD path of batch calls (msh_silero_probabilities computes them on the GPU) */
+MSH_EXPORT int64_t msh_host_vad_segments_from_probs(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window,
+                                                    int32_t hop, uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap,
+                                                    const float* audio, uint64_t n_samples, const float* probs, uint64_t n_probs,
+                                                    int64_t* bounds, uint64_t max_segments);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

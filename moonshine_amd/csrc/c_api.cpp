@@ -504,6 +504,33 @@ int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, flo
   }
 }
 
+// The same detector fed with PRECOMPUTED Silero probabilities (one per whole hop of the 16 kHz clip, given in one
+// process_audio call): the host half of the device-VAD path of batch calls.
+int64_t msh_host_vad_segments_from_probs(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window, int32_t hop,
+                                         uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap, const float* audio,
+                                         uint64_t n_samples, const float* probs, uint64_t n_probs, int64_t* bounds,
+                                         uint64_t max_segments) {
+  try {
+    if (weights == nullptr || probs == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+    std::shared_ptr<SileroWeights> w(new SileroWeights());
+    w->load_memory(weights, (size_t)weights_size);
+    VoiceActivityDetector vad(threshold, window, hop, (size_t)look_behind, (size_t)max_segment, w, (size_t)hard_cap);
+    vad.start();
+    vad.process_audio(audio, (size_t)n_samples, kSampleRate, probs, (size_t)n_probs);
+    vad.stop();
+    const std::vector<VadSegment>& segs = vad.segments();
+    for (size_t i = 0; i < segs.size() && i < max_segments; ++i) {
+      bounds[3 * i] = (int64_t)llroundf(segs[i].start_time * kSampleRate);
+      bounds[3 * i + 1] = (int64_t)segs[i].audio.size();
+      bounds[3 * i + 2] = segs[i].is_complete ? 1 : 0;
+    }
+    return (int64_t)segs.size();
+  } catch (const std::exception& e) {
+    MSH_LOGF("vad_segments_from_probs failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
 int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap) {
   if (text == nullptr && n > 0) return MSH_ERR_INVALID_ARGUMENT;
   return copy_out(sanitize_utf8(std::string(text ? text : "", (size_t)n)), out, out_cap);
