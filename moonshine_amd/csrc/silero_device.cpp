@@ -16,8 +16,24 @@ constexpr long kMaxHopsPerChunk = 200000;   // ~1.6 GB of workspace per chunk (f
 }  // namespace
 
 SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : device_(device) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) throw HipError("no HIP device available for the device VAD");
+  if (device < 0 || device >= n_dev) throw HipError("invalid device index " + std::to_string(device));
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  try {
+    upload_weights(w);
+  } catch (...) {   // a constructor that throws runs no destructor: hand back what was taken so far
+    {
+      std::lock_guard<std::mutex> lock(device_structure_mutex());
+      for (void* p : weights_) device_free(p);
+    }
+    (void)hipStreamDestroy(stream_);
+    throw;
+  }
+}
+
+void SileroDevice::upload_weights(const msh_host::SileroWeights& w) {
   auto upload = [&](const std::vector<float>& src) {
     void* p = nullptr;
     {

@@ -28,6 +28,7 @@ class SileroDevice {
   void probabilities(const float* const* pcm, const uint64_t* n, size_t count, std::vector<std::vector<float>>* probs);
 
  private:
+  void upload_weights(const msh_host::SileroWeights& w);
   void run_chunk(const float* const* pcm, const uint64_t* n, size_t c0, size_t c1, std::vector<std::vector<float>>* probs);
   int device_;
   hipStream_t stream_ = nullptr;
