@@ -100,7 +100,7 @@ def main_streaming(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rank, world = msd.init_from_env("nccl", dev)
-    dist = torch.distributed if world > 1 else None
+    dist = torch.distributed if msd.use_collectives(world) else None   # MSH_DIST_FORCE_GROUP=1: RCCL at one rank too
     line = run_streaming(args, args.steps, args.warmup, local_rank, rank, world, dev, dist)
     if rank == 0:
         print(json.dumps(line))
@@ -251,7 +251,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rank, world = msd.init_from_env("nccl", dev)  # "nccl" is RCCL on ROCm
-    dist = torch.distributed if world > 1 else None
+    dist = torch.distributed if msd.use_collectives(world) else None   # MSH_DIST_FORCE_GROUP=1: RCCL at one rank too
 
     cfg = ARCHS[args.arch]
     eng = Engine(local_rank)

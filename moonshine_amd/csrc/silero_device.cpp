@@ -12,7 +12,11 @@ namespace msh {
 namespace {
 constexpr int kHop = msh_host::SileroVad::kHop, kContext = msh_host::SileroVad::kContext;
 const int kConvIn[4] = {129, 128, 64, 64}, kConvOut[4] = {128, 64, 64, 128}, kConvStride[4] = {1, 2, 2, 1};
-constexpr long kMaxHopsPerChunk = 200000;   // ~1.6 GB of workspace per chunk (frames + |STFT| + im2col columns)
+// Workspace per hop: frames 4096 B + |STFT| 4128 + im2col columns 6400 + activations 2064 + 2048 + gate inputs 2048 + audio
+// ~2.3 KB = ~23 KB (plus DevBuf's 12.5 % growth slack), so 64 Ki hops = ~1.5 GB per chunk, 209 clips of 10 s.  (200000
+// hops, the first value, was 4.6 GB per chunk on top of the engines' workspaces: the out-of-memory fallback to the host
+// network would have come far earlier than intended.)
+constexpr long kMaxHopsPerChunk = 65536;
 }  // namespace
 
 SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : device_(device) {

@@ -780,6 +780,12 @@ void StreamingEngine::set_bias(int n_nodes, const int32_t* child_off, const int3
                                const int32_t* depth, const float* depth_bonus, int n_depth_bonus) {
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamSynchronize(stream_));
+  // the captured AR step holds the trie's device pointers: a new trie (its buffers may move when they grow) needs a new graph
+  if (ar_graph_ != nullptr) {
+    (void)hipGraphExecDestroy(ar_graph_);
+    ar_graph_ = nullptr;
+  }
+  ar_key_.clear();
   bias_ = BiasTrie{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (n_nodes <= 0) return;
   if (child_off == nullptr || depth == nullptr || depth_bonus == nullptr) throw std::invalid_argument("null trie array");
@@ -923,10 +929,22 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       hipGraph_t gr = nullptr;
       std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
       MSH_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      ar_step();
+      try {
+        ar_step();
+      } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
+        (void)hipStreamEndCapture(stream_, &gr);
+        if (gr != nullptr) (void)hipGraphDestroy(gr);
+        ar_key_.clear();
+        throw;
+      }
       MSH_HIP(hipStreamEndCapture(stream_, &gr));
-      MSH_HIP(hipGraphInstantiate(&ar_graph_, gr, nullptr, nullptr, 0));
-      MSH_HIP(hipGraphDestroy(gr));
+      const hipError_t inst = hipGraphInstantiate(&ar_graph_, gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      if (inst != hipSuccess) {
+        ar_graph_ = nullptr;
+        ar_key_.clear();
+        MSH_HIP(inst);
+      }
       ar_key_ = key;
     }
   }

@@ -662,6 +662,10 @@ void Transcriber::load_vad_model() {
   } else if (opt_.model_source == TranscriberOptions::FILES && !opt_.model_path.empty() &&
              file_exists(join_path(opt_.model_path, kName))) {
     from_file(join_path(opt_.model_path, kName));
+  } else if (opt_.model_source == TranscriberOptions::NONE) {
+    // no model at all (the reference loads such a transcriber with its embedded VAD): the load succeeds, and the first
+    // stream that would need the network says what is missing (new_stream)
+    return;
   } else {
     throw std::runtime_error(
         "vad_threshold=" + std::to_string(opt_.vad_threshold) + " (the default is 0.5) needs the Silero VAD weights: pass the "
@@ -674,6 +678,9 @@ void Transcriber::load_vad_model() {
 TranscriberStream* Transcriber::new_stream(int32_t id) {
   const int32_t window = (int32_t)ceilf((opt_.vad_window_duration * kSampleRate) / opt_.vad_hop_size);
   const size_t max_seg = (size_t)roundf(opt_.vad_max_segment_duration * kSampleRate);
+  if (opt_.vad_threshold > 0.0f && !silero_)
+    throw std::runtime_error("vad_threshold=" + std::to_string(opt_.vad_threshold) + " needs the Silero VAD weights (option "
+                             "vad_model_path=<silero_vad.safetensors>); vad_threshold=0 treats all audio as speech");
   TranscriberStream* s = new TranscriberStream();
   s->vad.reset(new VoiceActivityDetector(opt_.vad_threshold, window, opt_.vad_hop_size, opt_.vad_look_behind_sample_count,
                                          max_seg, silero_, vad_hard_cap_));
@@ -875,11 +882,14 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
       silero_device_ = nullptr;
     }
   }
+  // THIS call's decision: a device VAD left over from an earlier 16 kHz call must not see the un-resampled audio of a
+  // call at another rate (process_audio would refuse the probabilities and the whole batch would fail)
+  bool use_device_vad = device_vad && silero_device_ != nullptr;
   auto segment = [&](uint64_t c0, uint64_t c1) {
     std::vector<float> probs;
     std::vector<size_t> poff;
     bool have_probs = false;
-    if (silero_device_ != nullptr) {
+    if (use_device_vad) {
       poff.resize((size_t)(c1 - c0) + 1, 0);
       for (uint64_t i = c0; i < c1; ++i) poff[i - c0 + 1] = poff[i - c0] + (size_t)(n[i] / (uint64_t)opt_.vad_hop_size);
       probs.resize(std::max<size_t>(poff.back(), 1));
@@ -890,6 +900,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
         msh_silero_destroy(silero_device_);
         silero_device_ = nullptr;
         silero_device_failed_ = true;
+        use_device_vad = false;
       }
     }
     parallel_for((size_t)(c1 - c0), [&](size_t k) {
@@ -921,7 +932,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // model with Silero on is VAD-bound on the host (the network runs for every 32 ms hop of every clip): clips go in waves of
   // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
   // is a copy and everything is one wave.
-  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f && silero_device_ == nullptr;
+  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f && !use_device_vad;
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams)
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * 2
                                          : std::max<uint64_t>(count, 1);

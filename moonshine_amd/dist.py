@@ -14,12 +14,26 @@ import torch
 import torch.distributed as dist
 
 
+def force_group() -> bool:
+    """MSH_DIST_FORCE_GROUP=1: create the process group and take the collective path even at world == 1 -- the way to run
+    the RCCL init / scatter / all-gather / all-reduce code on a box with ONE GPU (tests/test_gpu_dist.py,
+    `MSH_DIST_FORCE_GROUP=1 python bench.py`).  Without it a one-rank run touches no collective at all."""
+    return os.environ.get("MSH_DIST_FORCE_GROUP", "") == "1"
+
+
+def use_collectives(world: int) -> bool:
+    return world > 1 or (force_group() and dist.is_initialized())
+
+
 def init_from_env(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
-    """(rank, world) from the torchrun environment; world == 1 needs no process group."""
+    """(rank, world) from the torchrun environment; world == 1 needs no process group (unless MSH_DIST_FORCE_GROUP=1)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         kw = {}
         if device is not None and device.type == "cuda":
             kw["device_id"] = device
@@ -54,7 +68,7 @@ def scatter_clips(clips: list[np.ndarray] | None, world: int, rank: int, device:
     """Rank 0 passes the full clip list, the others None.  Every rank returns (padded [n_local, max_len] float32 tensor on
     ``device``, true lengths, plan) where plan = shard_plan of the whole list (gather_tokens needs it to restore the
     caller's order).  One broadcast of the plan, one scatter of lengths, one scatter of samples."""
-    if world == 1:
+    if not use_collectives(world):
         assert clips is not None
         lens = [int(c.shape[0]) for c in clips]
         buf = np.zeros((len(clips), max(lens)), np.float32)
@@ -91,7 +105,7 @@ def scatter_clips(clips: list[np.ndarray] | None, world: int, rank: int, device:
 
 def gather_tokens(local: list[list[int]], plan: list[list[int]], world: int, rank: int, device: torch.device) -> list[list[int]]:
     """All ranks receive the token lists of every clip, in the caller's clip order (plan from scatter_clips)."""
-    if world == 1:
+    if not use_collectives(world):
         return local
     per = max(len(p) for p in plan)
     width = torch.tensor([max((len(t) for t in local), default=0)], dtype=torch.int64, device=device)
@@ -115,7 +129,7 @@ def gather_tokens(local: list[list[int]], plan: list[list[int]], world: int, ran
 
 
 def max_over_ranks(value: float, world: int, device: torch.device) -> float:
-    if world == 1:
+    if not use_collectives(world):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

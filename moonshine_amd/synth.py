@@ -128,6 +128,22 @@ def make_weights(cfg: ArchConfig, seed: int = 0) -> dict[str, np.ndarray]:
     return out
 
 
+SHARP_EMBED_GAIN = 4.0
+
+
+def sharp_weights(cfg: ArchConfig, seed: int = 0, gain: float = SHARP_EMBED_GAIN) -> dict[str, np.ndarray]:
+    """``make_weights`` with the tied embedding (input lookup AND LM head) multiplied by ``gain``: the "sharpened" synthetic
+    checkpoint of tests/test_gpu_long_parity.py and bench.py's ``cpu_baseline`` id comparison.  With fan-in-scaled random
+    weights the logits are ~N(0, 1) over 32768 entries, so ~20 % of the decode positions have a top-1 margin below the 0.1
+    id tolerance and a free-running 65-step comparison almost always meets one (a trained checkpoint is far more peaked).
+    The gain puts the token's own embedding in charge of the residual stream: >= 95 % of the positions clear 0.1 and
+    free-running ids become comparable clip by clip.  The sequences it produces are repetitive (the price of peaked
+    logits without training); the generic-data parity cases keep the plain weights."""
+    w = dict(make_weights(cfg, seed))
+    w["model.decoder.embed_tokens.weight"] = np.ascontiguousarray(w["model.decoder.embed_tokens.weight"] * np.float32(gain))
+    return w
+
+
 # ---------------------------------------------------------------------------
 # Streaming architectures (reference core/moonshine-streaming-model.{h,cpp}; float definition
 # transformers/models/moonshine_streaming/modeling_moonshine_streaming.py)

@@ -56,6 +56,36 @@ def _worker(rank, world, port, n_clips, q):
     torch.distributed.destroy_process_group()
 
 
+def _one_rank_worker(port, n_clips, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSH_DIST_FORCE_GROUP="1")
+    dev = torch.device("cpu")
+    r, w = msd.init_from_env("gloo")
+    assert (r, w) == (0, 1) and torch.distributed.is_initialized() and msd.use_collectives(w)
+    clips = _clips(n_clips)
+    audio, lens, plan = msd.scatter_clips(clips, w, r, dev)        # the collective path, not the early return
+    assert plan == [list(range(n_clips))] and lens == [len(c) for c in clips]   # one rank: the caller's order
+    allt = msd.gather_tokens(_fake_engine(audio, lens), plan, w, r, dev)
+    q.put((allt, msd.max_over_ranks(3.5, w, dev)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_group_at_one_rank_takes_the_collective_path():
+    """MSH_DIST_FORCE_GROUP=1 (moonshine_amd.dist.force_group): a one-rank run creates the group and goes through
+    broadcast / scatter / all-reduce / all-gather instead of returning early -- what tests/test_gpu_dist.py runs over
+    RCCL on the one-GPU box; here over gloo."""
+    assert not msd.use_collectives(1)                                 # default: no group, no collective at world == 1
+    n_clips = 7
+    want = [_fake_tokens(c) for c in _clips(n_clips)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), n_clips, q))
+    p.start()
+    allt, tmax = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and allt == want and tmax == 3.5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -309,6 +309,23 @@ def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_pat
     tdev = time.perf_counter() - t0
     dev.close()
     assert got_dev == want
+    # a batch call at ANOTHER sample rate on the same handle, after the 16 kHz calls created the device network: it must
+    # take the host path (resample + host network) for that call instead of feeding un-resampled audio to the GPU network
+    # and failing (transcriber.cpp `use_device_vad`); and 16 kHz calls afterwards still use the device
+    def up24(c):
+        m = int(len(c) * 1.5)
+        return np.interp(np.arange(m) / 1.5, np.arange(len(c)), c).astype(np.float32)
+    clips24 = [up24(c) for c in clips[:6]]
+    dev = api.Transcriber(d, api.ARCH_TINY, {})
+    dev.transcribe_batch_without_streaming(clips[:2])
+    got24 = [[(l.start_time, l.duration) for l in r] for r in dev.transcribe_batch_without_streaming(clips24, sample_rate=24000)]
+    host24 = api.Transcriber(d, api.ARCH_TINY, {"vad_device": "0"})
+    want24 = [[(l.start_time, l.duration) for l in r] for r in host24.transcribe_batch_without_streaming(clips24, sample_rate=24000)]
+    host24.close()
+    assert got24 == want24 and sum(len(r) for r in got24) >= len(clips24)
+    again16 = [[(l.text_bytes, l.start_time, l.duration) for l in r] for r in dev.transcribe_batch_without_streaming(clips)]
+    dev.close()
+    assert again16 == want
     print(f"batch of {len(clips)} clips with Silero: {t1 * 1e3:.0f} ms on 1 host thread, {t16 * 1e3:.0f} ms on 16, "
           f"{tdev * 1e3:.0f} ms with the network on the GPU")
 

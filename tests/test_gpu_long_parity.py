@@ -1,0 +1,244 @@
+"""GPU parity on the configurations round 2 left un-oracled ("what's weak" 1-3): every comparison here is
+HIP path vs the ORACLE (oracle/moonshine_ref.py, oracle/silero_ref.py), never engine vs engine.
+
+  * clips longer than 10 s -- 30 s, the reference fixture's 44.4 s and the engine's capacity cut (77.5 s = 504 decode
+    steps), tiny and base dims, ragged batches of 8: the encoder attention beyond 7 key blocks, the RoPE table beyond
+    position 415, chunks 2..7 of the decode cross-attention's 512-key online softmax (k_attn.hip) and -- with more than
+    71 decode steps -- the second and later 72-key blocks of the decode self-attention all run under comparison;
+  * the reference's long fixture test-assets/two_cities_16k.wav (committed as tests/golden/two_cities_16k.wav) through
+    the public C API, next to beckett.wav (tests/test_gpu_capi.py);
+  * a "sharpened" synthetic base checkpoint on which free-running greedy ids can be compared clip by clip (with the
+    plain synthetic weights one near-tie in 65 steps cascades: 33 of 96 clips agreed in BENCH_r02).
+
+Stated tolerances (bf16 operands, fp32 accumulate): encoder rel-RMS <= 1e-2 and max-abs <= 6e-2, logits
+max-abs <= 5e-2, greedy ids identical wherever the oracle's top-1 margin exceeds 0.1 (teacher-forced: no cascade).
+Reference semantics: core/moonshine-model.cpp:347-517."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import moonshine_ref as ref
+from oracle.host_ref import max_decode_len
+from oracle.weights import ARCHS, make_audio, make_weights, save_safetensors
+
+pytestmark = pytest.mark.gpu
+
+ENC_RELRMS = 1e-2
+ENC_MAXABS = 6e-2
+LOGIT_MAXABS = 5e-2
+# A clip of ONE encoder frame (895 samples, the shortest the stem accepts): its cross-attention is a softmax over a single
+# key, so the bf16 rounding of that one V row enters the residual stream un-averaged in all layers -- measured logits RMS error
+# 0.0116 against 0.0067 for every other length from 50 to 3227 frames (profiles/r3b_long_parity_diag.log), max-abs 0.0503.
+# Its ids are checked like everyone's; its logits are held to 8e-2.
+LOGIT_MAXABS_1FRAME = 8e-2
+MARGIN = 0.1
+CAPACITY_SAMPLES = 1_240_000    # 77.5 s: ceil(77.5 * 6.5) = 504 steps, the engine's decode capacity (moonshine_hip.h)
+TWO_CITIES_SAMPLES = 709_986    # the reference fixture's length (44.39 s): the same frame count as that file
+
+
+def _engine(tmp_path_factory, arch, seed=0, weights=None):
+    from moonshine_amd.hip_api import Engine
+
+    cfg = ARCHS[arch]
+    w = weights if weights is not None else make_weights(cfg, seed)
+    d = tmp_path_factory.mktemp(f"wl_{arch}_{seed}")
+    path = os.path.join(d, "model.safetensors")
+    save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
+    e = Engine(0)
+    e.load_weights_file(path)
+    os.remove(path)
+    return e, w, cfg
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    return _engine(tmp_path_factory, "tiny", 5)
+
+
+@pytest.fixture(scope="module")
+def base(tmp_path_factory):
+    return _engine(tmp_path_factory, "base", 0)
+
+
+def _enc_check(got, want):
+    assert got.shape == want.shape
+    err = got - want
+    relrms = float(np.sqrt((err**2).mean()) / np.sqrt((want**2).mean()))
+    maxabs = float(np.abs(err).max())
+    assert relrms <= ENC_RELRMS, (relrms, maxabs)
+    assert maxabs <= ENC_MAXABS, (relrms, maxabs)
+    return relrms, maxabs
+
+
+def _ids_and_logits_vs_oracle(e, w, cfg, clips, picked, steps, logit_steps):
+    """Free-running forced decode of the whole batch on the graph-replayed path; then for the `picked` clips the oracle is
+    teacher-forced with the GPU's ids (no cascade): ids must agree wherever the oracle margin is clear, the logits of a
+    second, teacher-forced pass (materialised logits) must be within LOGIT_MAXABS for the first and the LAST logit_steps
+    steps (the late steps are the ones that sit in the 2nd+ self-attention block)."""
+    e.set_keep_encoder_output(True)
+    e.encode(clips)
+    encs = {b: e.encoder_output(b) for b in picked}
+    toks, _ = e.decode(forced_steps=steps)
+    assert all(len(t) == steps + 1 and t[0] == cfg.bos for t in toks)
+    teacher = np.asarray(toks, np.int32)
+    e.encode(clips)
+    toks2, logits = e.decode(forced_steps=steps, teacher=teacher, want_logits=steps)
+    assert toks2 == toks                     # materialised-logits path == graph path, all clips
+    checked = flips = 0
+    worst_logit = worst_enc = worst_1frame = 0.0
+    for b in picked:
+        enc = ref.encoder_forward(w, cfg, clips[b])
+        assert enc.shape[0] == ref.conv_out_lengths(len(clips[b]))[2]
+        one_frame = enc.shape[0] == 1
+        worst_enc = max(worst_enc, _enc_check(encs[b], enc)[0])
+        o_toks, o_logits = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, return_logits=True, teacher=toks[b])
+        for i in range(steps):
+            top2 = np.partition(o_logits[i], -2)[-2:]
+            if float(top2[1] - top2[0]) > MARGIN:
+                assert toks[b][i + 1] == o_toks[i + 1], (b, i, float(top2[1] - top2[0]))
+                checked += 1
+            elif toks[b][i + 1] != o_toks[i + 1]:
+                flips += 1
+            if i < logit_steps or i >= steps - logit_steps:
+                d = float(np.abs(logits[i, b] - o_logits[i]).max())
+                if one_frame:
+                    worst_1frame = max(worst_1frame, d)
+                else:
+                    worst_logit = max(worst_logit, d)
+    assert worst_logit <= LOGIT_MAXABS, worst_logit
+    assert worst_1frame <= LOGIT_MAXABS_1FRAME, worst_1frame
+    assert checked >= len(picked) * steps // 2, (checked, flips)
+    return checked, flips, worst_logit, worst_enc
+
+
+def test_tiny_long_ragged_batch_vs_oracle(tiny):
+    """tiny dims, ragged batch of 8 with 30 s, 44.4 s and the 77.5 s capacity cut (T = 1249 / 1848 / 3228 frames: up to 7
+    cross-attention chunks of 512 keys, 51 encoder key blocks), 100 forced steps (two 72-key self-attention blocks)."""
+    e, w, cfg = tiny
+    lens = [480_000, CAPACITY_SAMPLES, 160_000, TWO_CITIES_SAMPLES, 48_000, 895, 1_000_003, 333_333]
+    clips = [make_audio(700 + i, n) for i, n in enumerate(lens)]
+    checked, flips, wl, we = _ids_and_logits_vs_oracle(e, w, cfg, clips, picked=[0, 1, 3, 5], steps=100, logit_steps=10)
+    print(f"tiny long ragged: {checked} ids checked vs oracle, {flips} near-tie flips, logits max-abs {wl:.3e}, encoder rel-RMS {we:.2e}")
+
+
+def test_base_long_ragged_batch_vs_oracle(base):
+    """base dims (the benchmarked architecture), ragged batch of 8 up to the capacity cut, 100 forced steps."""
+    e, w, cfg = base
+    lens = [480_000, 160_000, TWO_CITIES_SAMPLES, 900_000, 52_000, CAPACITY_SAMPLES, 250_000, 20_000]
+    clips = [make_audio(800 + i, n) for i, n in enumerate(lens)]
+    checked, flips, wl, we = _ids_and_logits_vs_oracle(e, w, cfg, clips, picked=[0, 2, 5], steps=100, logit_steps=10)
+    print(f"base long ragged: {checked} ids checked vs oracle, {flips} near-tie flips, logits max-abs {wl:.3e}, encoder rel-RMS {we:.2e}")
+
+
+def test_tiny_capacity_clip_full_budget_vs_oracle(tiny):
+    """The longest call the engine accepts: a 77.5 s clip decoded for its whole budget of 504 steps (7 self-attention
+    blocks of 72 keys, RoPE positions up to 503 in the decoder and 3227 in the encoder), in a batch with a 30 s clip that
+    stops at ITS budget (195); reference stopping rule (core/moonshine-model.cpp:347-349) with EOS ignored via the forced
+    mode for the id comparison, and the budget rule checked on the free run."""
+    e, w, cfg = tiny
+    clips = [make_audio(900, CAPACITY_SAMPLES), make_audio(901, 480_000)]
+    e.encode(clips)
+    assert e.max_decode_steps() == 504 == max_decode_len(CAPACITY_SAMPLES)
+    free, _ = e.decode()                                       # reference semantics: EOS or per-clip budget
+    assert len(free[0]) <= 505 and len(free[1]) <= max_decode_len(480_000) + 1
+    for t, n in zip(free, [CAPACITY_SAMPLES, 480_000]):
+        assert t[-1] == cfg.eos or len(t) == max_decode_len(n) + 1
+    e.encode(clips)
+    toks, _ = e.decode(forced_steps=504)
+    assert all(len(t) == 505 for t in toks)
+    for t_free, t_forced in zip(free, toks):                   # the free run is a prefix of the forced run
+        assert t_free == t_forced[: len(t_free)]
+    checked = 0
+    for b in (0, 1):
+        enc = ref.encoder_forward(w, cfg, clips[b])
+        o_toks, o_logits = ref.greedy_decode(w, cfg, enc, 504, ignore_eos=True, return_logits=True, teacher=toks[b])
+        for i in range(504):
+            top2 = np.partition(o_logits[i], -2)[-2:]
+            if float(top2[1] - top2[0]) > MARGIN:
+                assert toks[b][i + 1] == o_toks[i + 1], (b, i)
+                checked += 1
+    assert checked >= 504
+    print(f"capacity clip: {checked} of 1008 ids checked against the oracle over 504 steps")
+
+
+def test_two_cities_wav_through_the_c_api(tmp_path_factory):
+    """BASELINE config 1's long fixture: the reference's test-assets/two_cities_16k.wav (16 kHz mono PCM16, 44.39 s; its
+    bindings' tests expect "best of times" / "worst of times" with the real checkpoint, TranscriberTest.java:124-125 --
+    tools/verify_real_checkpoint.py) through the library's WAV loader and the public C API on the tiny architecture with
+    vad_threshold = 0 (one segment, 512-sample hop truncation) -- the ids behind the line's text against the ORACLE."""
+    import ctypes as C
+
+    from moonshine_amd import api
+    from moonshine_amd.hip_api import Engine, load_library
+    from moonshine_amd.synth import synthetic_vocab, write_model_dir
+    from oracle import host_ref
+
+    lib = load_library()
+    path = os.path.join(os.path.dirname(__file__), "golden", "two_cities_16k.wav").encode()
+    rate = C.c_int32(0)
+    n = lib.msh_host_load_wav(path, None, 0, C.addressof(rate))
+    assert (n, rate.value) == (TWO_CITIES_SAMPLES, 16000)
+    audio = np.zeros(n, np.float32)
+    assert lib.msh_host_load_wav(path, audio.ctypes.data, n, C.addressof(rate)) == n
+    d = str(tmp_path_factory.mktemp("tiny_model_tc"))
+    cfg = ARCHS["tiny"]
+    w = write_model_dir(d, cfg, seed=3)
+    t = api.Transcriber(d, api.ARCH_TINY, {"vad_threshold": "0"})
+    try:
+        lines = t.transcribe_without_streaming(audio)
+        again = t.transcribe_without_streaming(audio)
+    finally:
+        t.close()
+    assert len(lines) == 1 and lines[0].is_complete
+    seg = audio[: (n // 512) * 512]
+    np.testing.assert_array_equal(lines[0].audio_data, seg)
+    assert [l.text_bytes for l in again] == [lines[0].text_bytes]
+    e = Engine(0)
+    e.load_weights_file(os.path.join(d, "model.safetensors"), 0)
+    toks = e.transcribe_tokens([seg])[0]
+    budget = max_decode_len(len(seg))
+    assert budget == 289 and 2 <= len(toks) <= budget + 1
+    vocab = synthetic_vocab(cfg.vocab)
+    assert lines[0].text_bytes == host_ref.sanitize_text(host_ref.tokens_to_text(vocab, toks))
+    enc = ref.encoder_forward(w, cfg, seg)
+    o_toks, o_lg = ref.greedy_decode(w, cfg, enc, len(toks) - 1, ignore_eos=True, return_logits=True, teacher=toks)
+    checked = 0
+    for i in range(len(toks) - 1):
+        top2 = np.partition(o_lg[i], -2)[-2:]
+        if float(top2[1] - top2[0]) > MARGIN:
+            assert toks[i + 1] == o_toks[i + 1], i
+            checked += 1
+    assert checked >= (len(toks) - 1) // 2
+    print(f"two_cities_16k.wav: {len(toks) - 1} steps, {checked} ids checked against the oracle")
+
+
+def test_sharpened_checkpoint_free_running_ids(tmp_path_factory):
+    """Free-running greedy ids, clip by clip, against the oracle's own free-running loop (no teacher forcing): with the
+    plain synthetic weights ~20 % of the positions have a top-1 margin below the 0.1 tolerance and one of them in 65 steps
+    cascades.  `sharp_weights` (moonshine_amd/synth.py) raises the margins (tied embedding x 4: >= 95 % of the positions
+    clear 0.1); on it the GPU's 65 forced steps must equal the oracle's on >= 90 % of 32 base clips of 10 s, and every
+    difference must start at a position whose oracle margin is within the tolerance."""
+    from moonshine_amd.synth import sharp_weights
+
+    cfg = ARCHS["base"]
+    w = sharp_weights(cfg, 0)
+    e, w, cfg = _engine(tmp_path_factory, "base", 0, w)
+    n, steps = 32, 65
+    clips = [make_audio(1234 + i, 160_000) for i in range(n)]
+    got = e.transcribe_tokens(clips, forced_steps=steps)
+    equal = clear = total = 0
+    for b in range(n):
+        enc = ref.encoder_forward(w, cfg, clips[b])
+        o_toks, o_lg = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, return_logits=True)
+        margins = [float(np.diff(np.partition(l, -2)[-2:])[0]) for l in o_lg]
+        total += steps
+        clear += sum(m > MARGIN for m in margins)
+        if got[b] == o_toks:
+            equal += 1
+        else:
+            k = next(i for i in range(steps) if got[b][i + 1] != o_toks[i + 1])
+            assert margins[k] <= MARGIN, (b, k, margins[k])      # a flip may only start at a near-tie
+    print(f"sharpened checkpoint: {equal} of {n} clips with ids equal to the oracle's free run; {clear / total:.3f} of the positions clear {MARGIN}")
+    assert clear / total >= 0.95
+    assert equal >= (9 * n + 9) // 10, equal

@@ -1,6 +1,8 @@
-"""Silero VAD on the device (msh_silero_*, k_silero.hip) against the host implementation (msh_host_silero_probabilities,
-itself pinned on the numpy oracle and an independent torch restatement in tests/test_silero_vad.py): the probability of
-every hop of every clip, each clip from a fresh state, ragged lengths incl. clips shorter than one hop."""
+"""Silero VAD on the device (msh_silero_*, k_silero.hip) against the ORACLE (oracle/silero_ref.py::SileroRef, the numpy
+restatement of the network behind reference core/silero-vad.cpp:78-173, itself pinned on an independent torch build in
+tests/test_silero_vad.py) and, as a second assert, against the library's host implementation
+(msh_host_silero_probabilities): the probability of every hop of every clip, each clip from a fresh state, ragged
+lengths incl. clips shorter than one hop."""
 import ctypes as C
 import os
 
@@ -9,6 +11,7 @@ import pytest
 
 from moonshine_amd.hip_api import load_library
 from moonshine_amd.synth import make_audio, make_silero_weights, save_safetensors
+from oracle.silero_ref import SileroRef
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # the bound the host code is held to against the oracle
@@ -62,21 +65,31 @@ def _host_probs(lib, blob, clip):
     return out[:k]
 
 
-def test_device_probabilities_match_the_host_network(blob):
+def _oracle_probs(clip):
+    """SileroRef hop by hop from a fresh state (what SileroVad::predict returns, reference core/silero-vad.cpp:78-173)."""
+    net = SileroRef(make_silero_weights(2))
+    return np.asarray([net.predict(clip[i * 512:(i + 1) * 512]) for i in range(clip.shape[0] // 512)], np.float32)
+
+
+def test_device_probabilities_match_the_oracle_and_the_host_network(blob):
     lib = _lib()
     h = C.c_void_p()
     assert lib.msh_silero_create(0, blob, len(blob), C.byref(h)) == 0
     lens = [160000, 512, 300, 0, 1023, 16000 * 3 + 77, 52000, 160000, 8192]
     clips = [np.ascontiguousarray(make_audio(400 + i, max(n, 1))[:n], dtype=np.float32) for i, n in enumerate(lens)]
     dev = _device_probs(lib, h, clips)
-    worst = 0.0
+    worst = worst_host = 0.0
     for c, d in zip(clips, dev):
-        want = _host_probs(lib, blob, c)
+        want = _oracle_probs(c)                      # HIP path vs the oracle: the parity claim
         assert d.shape == want.shape
+        host = _host_probs(lib, blob, c)             # and vs the product's host code (streams use that one)
+        assert d.shape == host.shape
         if len(want):
             assert np.isfinite(d).all()
             worst = max(worst, float(np.abs(d - want).max()))
+            worst_host = max(worst_host, float(np.abs(d - host).max()))
     assert worst < TOL, worst
+    assert worst_host < TOL, worst_host
     # the probabilities move (a constant output would pass a lazy tolerance on a saturated network)
     assert float(np.std(dev[0])) > 1e-3
     # a second call reuses the workspace: same result

@@ -111,6 +111,18 @@ def _load_skip(options=None):
     return api.Transcriber("", api.ARCH_BASE, opts)
 
 
+def test_default_options_without_a_model_load_and_say_what_is_missing():
+    """A drop-in caller with the reference's default options (vad_threshold 0.5) and no model (skip_transcription) loads
+    -- the reference embeds its VAD, this build reads silero_vad.safetensors -- and the first call that needs the
+    network fails with an error code instead of the load (keep the NONE-source path loadable)."""
+    t = api.Transcriber("", api.ARCH_BASE, {"skip_transcription": "true"})
+    with pytest.raises(api.MoonshineError):
+        t.transcribe_without_streaming(np.zeros(16000, np.float32))
+    with pytest.raises(api.MoonshineError):
+        t.create_stream()
+    t.close()
+
+
 @pytest.mark.parametrize("n", [160000, 159414, 511, 512, 16000 * 31 + 7, 600])
 def test_vad_threshold0_segments_match_reference_rules(n):
     """Hop truncation / look-behind / never-split behaviour through the public API
