@@ -164,6 +164,10 @@ MSH_EXPORT int32_t msh_test_device_alloc(void);
 MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
                                           int32_t iters);
 
+/* Developer hook: ms per launch of the fused encoder MLP kernel (LayerNorm + fc1 + GELU + fc2 + residual, k_mlp.hip) on R
+ * rows of uniform random data (tools/mlp_microbench.py); abl = 0, or an ablation of k_mlp.hip (garbage results). */
+MSH_EXPORT float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_t iters, int32_t abl);
+
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

@@ -414,6 +414,20 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "mlp.fc2.bias", D), &L.b2);
     upload(vec(p + "input_layernorm.weight", D), &L.ln1);
     upload(vec(p + "post_attention_layernorm.weight", D), &L.ln2);
+    if (mlp_fused_supported(D, F)) {   // the same block once more, packed for the fused kernel (k_mlp.hip)
+      const std::vector<float> w1 = st.to_f32(p + "mlp.fc1.weight"), w2 = st.to_f32(p + "mlp.fc2.weight");
+      const std::vector<float> g = vec(p + "post_attention_layernorm.weight", D), b1 = vec(p + "mlp.fc1.bias", F);
+      std::vector<bf16_t> packed(mlp_packed_elems(D, F));
+      pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data());
+      void* dp = nullptr;
+      {
+        std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+        dp = device_alloc(packed.size() * sizeof(bf16_t));
+      }
+      weight_allocs_.push_back(dp);
+      copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+      L.mlp = reinterpret_cast<bf16_t*>(dp);
+    }
   }
   {
     expect_shape("model.decoder.embed_tokens.weight", {V, D});
@@ -733,6 +747,11 @@ void Engine::run_encoder() {
     sN += c.n_samples;
   }
   RopeParams rp{rope_cos_, rope_sin_, cfg_.rot_pairs(), cfg_.head_dim(), D};
+  // MSH_ENC_MLP=0: the MLP block as LayerNorm + two tiled GEMMs (A/B switch; the fused kernel is the default)
+  static const bool fused_mlp = [] {
+    const char* e = getenv("MSH_ENC_MLP");
+    return !(e != nullptr && e[0] == '0');
+  }();
 
   {
     ProfScope p(this, "pack_audio", 0, sN * 4 + 384.0 * R * 2);
@@ -780,6 +799,12 @@ void Engine::run_encoder() {
     {
       ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));
       gemm_resid_f32(AO_.as<bf16_t>(), D, W.wo, nullptr, R, D, D, H_.as<float>(), s);
+    }
+    if (fused_mlp && W.mlp != nullptr) {
+      // LayerNorm + fc1 + GELU + fc2 + residual in one kernel: the [R][F] intermediate never exists (k_mlp.hip)
+      ProfScope p(this, "enc_mlp_fused", 4.0 * sT * D * F, sT * D * 8);
+      mlp_fused(H_.as<float>(), W.mlp, W.b2, R, D, F, s);
+      continue;
     }
     {
       ProfScope p(this, "enc_layernorm", 0, sT * D * 6);

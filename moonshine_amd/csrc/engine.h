@@ -39,6 +39,7 @@ struct DevBuf {
 struct EncLayerW {
   float *ln1, *ln2, *b1, *b2;
   bf16_t *wqkv, *wo, *fc1, *fc2;
+  bf16_t* mlp = nullptr;   // fc1 (LayerNorm scale folded in) + b1 + fc2 packed for the fused MLP kernel (k_mlp.hip), or null
 };
 struct DecLayerW {
   float *ln1, *ln2, *ln3, *b1, *b2;

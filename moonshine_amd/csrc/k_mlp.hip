@@ -1,0 +1,407 @@
+// Encoder MLP block as ONE kernel for gfx950:   H += fc2( gelu( fc1( LayerNorm(H) ) + b1 ) ) + b2
+// (modeling_moonshine.py:69-85 MoonshineEncoderMLP inside the pre-LN layer wiring :382-411; the ORT encoder graph the
+// reference runs at core/moonshine-model.cpp:270-274).
+//
+// Why fused.  As two GEMMs the block writes the [R][F] intermediate (354 MB per layer at 256 x 10 s) and reads it back,
+// and each GEMM pays its pipeline fill, accumulator drain and store tail every 13 k-slices (K = 416): fc1 ran at 0.17 and
+// fc2 at 0.19 of the MFMA peak.  Here a workgroup owns a PANEL of 128 rows for the whole block:
+//   * 4 waves x 32 rows, one wave per SIMD, v_mfma_f32_32x32x16_bf16 (a W fragment read from LDS feeds 32 rows: half the
+//     LDS traffic per flop of the 16-row shape);
+//   * LayerNorm of the wave's rows is computed in registers straight from the fp32 residual stream and stays there as
+//     the 32 x D bf16 B-operand of fc1 for the whole kernel (gamma is folded into W1 at load);
+//   * the hidden dimension F is walked in chunks of 32: fc1 gives Z^T[32 n][32 m] in the accumulator layout, bias rides
+//     in as the accumulator's initial value, GELU runs on the accumulator registers, and the packed bf16 result IS the
+//     B-operand of fc2 for that chunk -- the k-order of W2 inside each 32-chunk is permuted at load to the order the
+//     accumulator layout hands the values over in, so the intermediate never touches LDS or HBM;
+//   * fc2 accumulates all D output columns of the wave's rows in registers (D/32 tiles x 16 = 208 VGPRs at D = 416)
+//     over the whole F: ONE epilogue per panel (bias + residual add into H) instead of one per GEMM tile;
+//   * the only operand that moves is W: W1 and W2 are packed at load into the exact fragment order, chunk by chunk, so a
+//     stage of the LDS ring is (D/8 + 1) contiguous KiB fetched by global_load_lds_dwordx4 (whole 128-B lines, no
+//     per-row 64-B segments), three stages (159 KiB) deep, one workgroup barrier per chunk; 123 flop per ingested byte.
+// fc2 of chunk j-1 and GELU of chunk j are independent and sit in one basic block: matrix and vector pipes overlap.
+#include <stdlib.h>
+
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "gemm_common.h"
+
+namespace msh {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int D>
+struct MlpGeom {
+  static constexpr int KS = D / 16;         // fc1 k-steps = W1 fragments per chunk
+  static constexpr int CT = D / 32;         // output column tiles of fc2
+  static constexpr int WP = KS + 2 * CT;    // weight fragments (1 KiB each) per stage
+  static constexpr int PIECES = WP + 1;     // + the bias piece (first 32 floats = b1 of the chunk)
+  static constexpr int NST = (160 / PIECES) >= 4 ? 4 : 3;   // ring stages that fit the CU's 160 KiB
+  static constexpr int PMAX = (PIECES + 3) / 4;             // pieces per wave per stage
+  static_assert(D % 32 == 0 && KS == 2 * CT, "hidden size must be a multiple of 32");
+  static_assert(NST * PIECES <= 160, "ring does not fit the LDS");
+};
+
+__device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N).  Every index derived from I is a constant in
+// the FRONT END (if constexpr, fixed register-array slots) -- with `#pragma unroll` and a runtime-looking index the kernel
+// below came out with its accumulators in scratch (1408 bytes per lane) whenever the GELU placement was not trivial.
+template <class Body, int... I>
+__device__ __forceinline__ void static_for_impl(Body&& body, std::integer_sequence<int, I...>) {
+  (body(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Body>
+__device__ __forceinline__ void static_for(Body&& body) {
+  static_for_impl(static_cast<Body&&>(body), std::make_integer_sequence<int, N>{});
+}
+
+// gelu(x) = x * Phi(x) with Phi(x) ~ sigmoid(x * (a0 + a1 x^2 + a2 x^4)), x^2 clamped at 81 (beyond |x| = 9 the result is
+// x or 0 to 1e-18): minimax fit against the erf form, max abs error 2.8e-5 over the whole line (tools/fit_gelu.py) -- a
+// tenth of the bf16 rounding of the result -- in 9 instructions (2 transcendental) where the erf formula of gemm_common.h
+// takes 19: this kernel runs one wave per SIMD, and GELU shares that wave's issue slots with the MFMAs it overlaps.
+__device__ __forceinline__ float gelu_sig(float x) {
+  constexpr float kL2e = -1.4426950408889634f;   // sigmoid(t) = 1 / (1 + 2^(-t log2 e))
+  constexpr float c0 = 1.5949708004086212f * kL2e, c1 = 0.07405211422714464f * kL2e, c2 = -0.000709652592810915f * kL2e;
+  const float s = fminf(x * x, 81.0f);
+  float p = fmaf(s, c2, c1);
+  p = fmaf(p, s, c0);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// rows [128 * blockIdx.x, +128) of H [R][D] fp32, in place.  Wp: (NC + 1) stages x PIECES KiB, see pack_mlp_weights.
+// ABL (microbenchmark ablations, 0 in the product; results are garbage unless noted): bit 0 = no DMA / no vmcnt waits after
+// the prologue (compute side alone), bit 1 = no GELU arithmetic, bit 2 = fc1 on ONE accumulator (a chain of D/16 dependent
+// MFMAs; correct results), bit 3 = ring of 4 fragment registers instead of 6 (correct), bit 4 = a stage's DMAs issued
+// together behind the barrier instead of spread over the stage's MFMAs (correct), bit 5 = no stages at all (LayerNorm
+// prologue + residual epilogue only), bit 6 = no fragment reads (MFMAs on whatever the ring registers hold), bit 7 = no
+// workgroup barrier.
+template <int D, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H, const bf16_t* __restrict__ Wp,
+                                                           const float* __restrict__ b2, int R, int NC) {
+  using G = MlpGeom<D>;
+  constexpr int KS = G::KS, CT = G::CT, WP = G::WP, PIECES = G::PIECES, NST = G::NST, PMAX = G::PMAX;
+  __shared__ __attribute__((aligned(16))) uint4 lds[NST * PIECES * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, mrow = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int my_pieces = (PIECES - wave + 3) / 4;   // wave-uniform: pieces wave, wave + 4, ...; PMAX or PMAX - 1
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
+  const int nstages = NC + 1;
+
+  // piece q of this wave for stage `st` into ring buffer `buf` (a stage past the end re-fetches the last one into a
+  // buffer nobody reads any more: the issue / wait pattern is the same for every stage)
+  const bf16_t* wsrc = Wp + (long)wave * 512 + lane * 8;
+  auto stage_src = [&](int st) { return wsrc + (long)(st < nstages ? st : nstages - 1) * (PIECES * 512); };
+  auto stage_dst = [&](int buf) { return lds_base + (unsigned)(buf * PIECES + wave) * 1024u; };
+  auto issue_piece = [&](const bf16_t* src, unsigned dst, int q) {
+    if (q < PMAX - 1 || my_pieces == PMAX) dma16(src + (long)q * 2048, dst + (unsigned)q * 4096u);
+  };
+  auto wait_landed = [&] {   // this wave's pieces of the oldest stage in flight; NST - 2 younger stages stay in flight
+    if (my_pieces == PMAX) wait_vmcnt<(NST - 2) * PMAX>();
+    else wait_vmcnt<(NST - 2) * (PMAX - 1)>();
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    const bf16_t* src = stage_src(s);
+    const unsigned dst = stage_dst(s);
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) issue_piece(src, dst, q);
+  }
+
+  // ---- LayerNorm of this lane's row straight from the residual stream, kept as the fc1 B-operand ----
+  // lane (mrow, hh) holds columns s*16 + hh*8 + 0..7 of row m0 + mrow for every k-step s: half a row
+  const int row = blockIdx.x * 128 + wave * 32 + mrow;
+  const float* hp = H + (long)(row < R ? row : R - 1) * D + hh * 8;
+  bf16x8 yf[KS];
+  {
+    float4 xa[KS], xb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      xa[s] = *reinterpret_cast<const float4*>(hp + s * 16);
+      xb[s] = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) sum += (xa[s].x + xa[s].y) + (xa[s].z + xa[s].w) + (xb[s].x + xb[s].y) + (xb[s].z + xb[s].w);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float d0 = xa[s].x - mean, d1 = xa[s].y - mean, d2 = xa[s].z - mean, d3 = xa[s].w - mean;
+      const float d4 = xb[s].x - mean, d5 = xb[s].y - mean, d6 = xb[s].z - mean, d7 = xb[s].w - mean;
+      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
+    }
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4 p;
+      p.x = pack_bf16x2((xa[s].x - mean) * rstd, (xa[s].y - mean) * rstd);
+      p.y = pack_bf16x2((xa[s].z - mean) * rstd, (xa[s].w - mean) * rstd);
+      p.z = pack_bf16x2((xb[s].x - mean) * rstd, (xb[s].y - mean) * rstd);
+      p.w = pack_bf16x2((xb[s].z - mean) * rstd, (xb[s].w - mean) * rstd);
+      yf[s] = as_frag(p);
+    }
+  }
+
+  f32x16 oacc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  bf16x8 zb0, zb1;   // gelu(fc1) of the previous chunk: the two 16-deep k-steps of fc2's B operand
+  {
+    uint4 zero = make_uint4(0, 0, 0, 0);
+    zb0 = as_frag(zero);
+    zb1 = as_frag(zero);
+  }
+
+  // One stage = fc1 of chunk j (W1 pieces 0..KS-1 + the bias piece) then fc2 of chunk j-1 (W2 pieces KS..WP-1, k-step
+  // major: every accumulator is touched once per half).  What runs beside the 2 KS MFMAs, all from this one wave:
+  //   * the fragments, read from LDS in consumption order through a ring of PF register sets (PF reads ahead, counted
+  //     lgkmcnt) with the piece offset in the instruction's immediate;
+  //   * GELU of chunk j (vector pipe), spread over the fc2 MFMAs of chunk j-1 (matrix pipe), which do not depend on it;
+  //   * the DMAs of the stage NST-1 ahead, one every few MFMAs (issued together behind the barrier they cost this wave
+  //     ~14 x 60-180 cycles in which its matrix pipe had nothing queued);
+  //   * fc1 alternates between two accumulators (bias rides in one of them): no MFMA waits for its predecessor.
+  // The instruction order is pinned (compile-time loop, sched_barrier after every step): left to itself hipcc issued
+  // every ds_read right before its MFMA behind an lgkmcnt(0) -- one LDS latency per MFMA with one wave per SIMD.
+  constexpr int PF = (ABL & 8) ? 4 : 6;
+  constexpr bool ONE_ACC = (ABL & 4) != 0;
+  auto stage = [&](int j, int buf, auto do1, auto do2) {
+    constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
+    constexpr int F0 = DO1 ? 0 : KS, NF = (DO1 ? KS : 0) + (DO2 ? KS : 0);
+    // GELU values [16 (i - G0) / GN, 16 (i + 1 - G0) / GN) (rounded up) are computed behind fc2 step i
+    constexpr int G0 = KS > 2 ? 1 : 0, GN = KS - G0 - (KS > 3 ? 1 : 0);
+    // DMA piece q of this wave goes behind step 1 + q * DS (everything at step 0 with ABL bit 4)
+    constexpr int DS = (ABL & 16) ? 0 : ((NF - 2) / PMAX > 0 ? (NF - 2) / PMAX : 1);
+    if constexpr ((ABL & 1) == 0) wait_landed();
+    if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage j have landed; stage j-1 has been read by everyone
+    const bf16_t* nsrc = stage_src(j + NST - 1);
+    const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);
+    const uint4* st = lds + buf * (PIECES * 64) + lane;
+    uint4 fr[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fr[p] = st[(F0 + p) * 64];
+    if constexpr ((ABL & 64) != 0) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) asm volatile("" : "+v"(fr[p].x), "+v"(fr[p].y), "+v"(fr[p].z), "+v"(fr[p].w));
+    }
+    f32x16 za, zc;   // fc1 accumulators: even / odd k-steps
+    if constexpr (DO1) {
+      const float4* bp = reinterpret_cast<const float4*>(lds + buf * (PIECES * 64) + WP * 64) + hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // accumulator row of register 4q + e is n = 8q + 4hh + e
+        const float4 b = bp[2 * q];
+        za[4 * q] = b.x;
+        za[4 * q + 1] = b.y;
+        za[4 * q + 2] = b.z;
+        za[4 * q + 3] = b.w;
+      }
+      if constexpr (!ONE_ACC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zc[r] = 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float gv[16];
+    uint32_t zn[8];
+    static_for<NF>([&](auto fc) {
+      constexpr int f = decltype(fc)::value, piece = F0 + f;
+      if constexpr (piece < KS) {
+        if constexpr (ONE_ACC || (piece & 1) == 0)
+          za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), yf[piece], za, 0, 0, 0);
+        else
+          zc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), yf[piece], zc, 0, 0, 0);
+      } else {
+        constexpr int i = piece - KS, u = i / CT, t = i % CT;
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), u ? zb1 : zb0, oacc[t], 0, 0, 0);
+        if constexpr (DO1) {
+          // (the empty asm pins each value HERE: the IR-level passes otherwise sink the whole GELU below the last MFMA,
+          // where nothing overlaps it -- sched_barrier only binds the machine scheduler)
+          constexpr int r0 = i < G0 ? 0 : (16 * (i - G0) + GN - 1) / GN, r1x = i + 1 < G0 ? 0 : (16 * (i + 1 - G0) + GN - 1) / GN;
+          constexpr int r1 = r1x > 16 ? 16 : r1x;
+          static_for<(r1 > r0 ? r1 - r0 : 0)>([&](auto rc) {
+            constexpr int r = r0 + decltype(rc)::value;
+            const float x = ONE_ACC ? za[r] : za[r] + zc[r];
+            gv[r] = (ABL & 2) ? x : gelu_sig(x);
+            if constexpr ((r & 1) != 0) {
+              zn[r >> 1] = pack_bf16x2(gv[r - 1], gv[r]);
+              asm volatile("" : "+v"(zn[r >> 1]));
+            } else {
+              asm volatile("" : "+v"(gv[r]));
+            }
+          });
+        }
+      }
+      if constexpr ((ABL & 1) == 0) {
+        static_for<PMAX>([&](auto qc) {
+          constexpr int q = decltype(qc)::value, at = (1 + q * DS) < NF ? (1 + q * DS) : NF - 1;
+          if constexpr (at == f) issue_piece(nsrc, ndst, q);
+        });
+      }
+      if constexpr (f + PF < NF && (ABL & 64) == 0) fr[f % PF] = st[(F0 + f + PF) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (DO1 && !DO2) {   // first stage: nothing to overlap with
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float x0 = ONE_ACC ? za[r] : za[r] + zc[r], x1 = ONE_ACC ? za[r + 1] : za[r + 1] + zc[r + 1];
+        zn[r >> 1] = pack_bf16x2(gelu_sig(x0), gelu_sig(x1));
+      }
+    }
+    if constexpr (DO1) {
+      const uint4 p0 = make_uint4(zn[0], zn[1], zn[2], zn[3]), p1 = make_uint4(zn[4], zn[5], zn[6], zn[7]);
+      zb0 = as_frag(p0);
+      zb1 = as_frag(p1);
+    }
+  };
+  if constexpr ((ABL & 32) == 0) {
+    int buf = 0;
+    stage(0, buf, std::true_type{}, std::false_type{});
+    for (int j = 1; j < NC; ++j) {
+      buf = buf + 1 == NST ? 0 : buf + 1;
+      stage(j, buf, std::true_type{}, std::true_type{});
+    }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    stage(NC, buf, std::false_type{}, std::true_type{});
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(yf[s]));
+  }
+  wait_vmcnt<0>();   // the trailing re-fetches land in buffers nobody reads; they must not outlive the workgroup's LDS
+
+  // ---- epilogue: H[row][c] += out + b2, accumulator rows are output columns c = 32t + 8q + 4hh + e ----
+  if (row < R) {
+    float* op = H + (long)row * D + hh * 4;
+    const float* bp = b2 + hh * 4;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = t * 32 + q * 8;
+        float4 h = *reinterpret_cast<const float4*>(op + c);
+        const float4 b = *reinterpret_cast<const float4*>(bp + c);
+        h.x += oacc[t][4 * q] + b.x;
+        h.y += oacc[t][4 * q + 1] + b.y;
+        h.z += oacc[t][4 * q + 2] + b.z;
+        h.w += oacc[t][4 * q + 3] + b.w;
+        *reinterpret_cast<float4*>(op + c) = h;
+      }
+  }
+}
+
+template <int D, int ABL = 0>
+void launch_mlp(float* H, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s) {
+  MSH_LAUNCH((mlp_fused_kernel<D, ABL>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32);
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int D, int F) { return (D == 416 || D == 288 || D == 64) && F % 32 == 0 && F >= 32; }
+
+size_t mlp_packed_elems(int D, int F) { return (size_t)(F / 32 + 1) * (D / 8 + 1) * 512; }
+
+// Host-side packing (once, at load).  w1 [F][D] (gamma is folded in here), b1 [F], w2 [D][F] -> (F/32 + 1) stages of
+// (D/8 + 1) KiB: stage j = { W1 fragments of hidden rows 32j..32j+31 (k-step s: lane l holds row 32j + (l & 31), columns
+// 16s + 8(l >> 5) + 0..7) | W2 fragments of chunk j-1 (tile t, k-step u: lane l holds output row 32t + (l & 31), hidden
+// columns 32(j-1) + 8(2u + (e >> 2)) + 4(l >> 5) + (e & 3) for e = 0..7 -- the order the 32x32 accumulator layout hands
+// gelu(fc1) over in) | 32 floats of b1 }.  Stage 0 has no W2 part and stage F/32 no W1 part (zeros).
+void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out) {
+  const int KS = D / 16, CT = D / 32, WP = KS + 2 * CT, PIECES = WP + 1, NC = F / 32;
+  const bf16_t zero = f32_to_bf16(0.f);
+  for (int j = 0; j <= NC; ++j) {
+    bf16_t* stage = out + (size_t)j * PIECES * 512;
+    for (int s = 0; s < KS; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 8; ++e) {
+          const int n = 32 * j + (l & 31), k = 16 * s + 8 * (l >> 5) + e;
+          stage[((size_t)s * 64 + l) * 8 + e] = j < NC ? f32_to_bf16(w1[(size_t)n * D + k] * gamma[k]) : zero;
+        }
+    for (int t = 0; t < CT; ++t)
+      for (int u = 0; u < 2; ++u)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 8; ++e) {
+            const int c = 32 * t + (l & 31), n = 32 * (j - 1) + 8 * (2 * u + (e >> 2)) + 4 * (l >> 5) + (e & 3);
+            stage[((size_t)(KS + u * CT + t) * 64 + l) * 8 + e] = j >= 1 ? f32_to_bf16(w2[(size_t)c * F + n]) : zero;
+          }
+    float* bias = reinterpret_cast<float*>(stage + (size_t)WP * 512);
+    for (int i = 0; i < 256; ++i) bias[i] = (i < 32 && j < NC) ? b1[32 * j + i] : 0.f;
+  }
+}
+
+void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s) {
+  if (R <= 0) return;
+  switch (D) {
+    case 416: return launch_mlp<416>(H, Wp, b2, R, F, s);
+    case 288: return launch_mlp<288>(H, Wp, b2, R, F, s);
+    case 64: return launch_mlp<64>(H, Wp, b2, R, F, s);
+    default: throw std::runtime_error("mlp_fused: unsupported hidden size");
+  }
+}
+
+// Microbenchmark (tools/mlp_microbench.py): ms per launch on uniform random [-1, 1) data, R rows.
+float mlp_microbench(int R, int D, int F, int iters, int abl) {
+  if (!mlp_fused_supported(D, F)) throw std::runtime_error("mlp_microbench: unsupported shape");
+  std::vector<float> w1((size_t)F * D), w2((size_t)D * F), g(D, 1.f), b1(F), b2(D), h((size_t)R * D);
+  unsigned x = 12345u;
+  auto rnd = [&] {
+    x = x * 1664525u + 1013904223u;
+    return (float)((x >> 8) & 0xffff) / 32768.0f - 1.0f;
+  };
+  for (auto& v : w1) v = rnd() * 0.05f;
+  for (auto& v : w2) v = rnd() * 0.025f;
+  for (auto& v : b1) v = rnd() * 0.1f;
+  for (auto& v : b2) v = rnd() * 0.1f;
+  for (auto& v : h) v = rnd();
+  std::vector<bf16_t> packed(mlp_packed_elems(D, F));
+  pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data());
+  float *H = nullptr, *B2 = nullptr;
+  bf16_t* Wp = nullptr;
+  MSH_HIP(hipMalloc(&H, h.size() * 4));
+  MSH_HIP(hipMalloc(&B2, b2.size() * 4));
+  MSH_HIP(hipMalloc(&Wp, packed.size() * 2));
+  MSH_HIP(hipMemcpy(H, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(B2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(Wp, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  auto run = [&] {
+    if (abl == 0) return mlp_fused(H, Wp, B2, R, D, F, 0);
+    if (D != 416) throw std::runtime_error("mlp_microbench: ablations are compiled for D = 416");
+    switch (abl) {
+      case 1: return launch_mlp<416, 1>(H, Wp, B2, R, F, 0);
+      case 2: return launch_mlp<416, 2>(H, Wp, B2, R, F, 0);
+      case 3: return launch_mlp<416, 3>(H, Wp, B2, R, F, 0);
+      case 4: return launch_mlp<416, 4>(H, Wp, B2, R, F, 0);
+      case 8: return launch_mlp<416, 8>(H, Wp, B2, R, F, 0);
+      case 16: return launch_mlp<416, 16>(H, Wp, B2, R, F, 0);
+      case 32: return launch_mlp<416, 32>(H, Wp, B2, R, F, 0);
+      case 67: return launch_mlp<416, 67>(H, Wp, B2, R, F, 0);
+      case 195: return launch_mlp<416, 195>(H, Wp, B2, R, F, 0);
+      default: throw std::runtime_error("mlp_microbench: bad ablation");
+    }
+  };
+  run();
+  MSH_HIP(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  MSH_HIP(hipEventCreate(&e0));
+  MSH_HIP(hipEventCreate(&e1));
+  MSH_HIP(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) run();   // (H stays bounded: every pass normalises its input)
+  MSH_HIP(hipEventRecord(e1, 0));
+  MSH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MSH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(H);
+  (void)hipFree(B2);
+  (void)hipFree(Wp);
+  return ms / iters;
+}
+
+}  // namespace msh

@@ -121,6 +121,14 @@ int gemm_argmax_tiles(int N);
 void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* pval, int* pidx,
                           hipStream_t s);
 
+// ---------------- encoder MLP block as one kernel (k_mlp.hip) ----------------
+// H[R][D] fp32 += fc2(gelu(fc1(LayerNorm(H)) + b1)) + b2, in place; Wp from pack_mlp_weights (LayerNorm scale folded in).
+bool mlp_fused_supported(int D, int F);
+size_t mlp_packed_elems(int D, int F);
+void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out);
+void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s);
+float mlp_microbench(int R, int D, int F, int iters, int abl);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream: qk [R,2D] bf16 (q | k, RoPE applied), vt = V^T [D][vt_ld] bf16 (row d,
 // stream rows contiguous; vt_ld >= R) -> out [R,D] bf16

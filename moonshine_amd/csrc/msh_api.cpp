@@ -299,6 +299,15 @@ float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int
   }
 }
 
+float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_t iters, int32_t abl) {
+  try {
+    return msh::mlp_microbench(R, D, F, iters, abl);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "mlp_microbench: %s\n", ex.what());
+    return -1.0f;
+  }
+}
+
 // ---- Silero VAD on the device ----
 struct msh_silero {
   msh::SileroDevice* dev = nullptr;
