@@ -168,6 +168,11 @@ MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64
  * rows of uniform random data (tools/mlp_microbench.py); abl = 0, or an ablation of k_mlp.hip (garbage results). */
 MSH_EXPORT float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_t iters, int32_t abl);
 
+/* Test hook: the fused encoder MLP kernel alone -- h [R][D] (host, in place) += fc2(gelu(fc1(LayerNorm(h) * gamma) + b1)) + b2
+ * with w1 [F][D], w2 [D][F] fp32 (rounded to bf16 inside, as at load).  D in {64, 288, 416}, F % 32 == 0. */
+MSH_EXPORT int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
+                                    const float* b1, const float* w2, const float* b2);
+
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

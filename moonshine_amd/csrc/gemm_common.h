@@ -79,8 +79,8 @@ struct EpiGnBiasGeluBf16 {
   __device__ uint2 pack4(const RowCtx& r, const ColCtx&, int n, f32x4 v) const {
     const float4 t = *reinterpret_cast<const float4*>(r.trow + n);
     uint2 o;
-    o.x = pack_bf16x2(gelu_erf(v[0] * r.rstd + t.x), gelu_erf(v[1] * r.rstd + t.y));
-    o.y = pack_bf16x2(gelu_erf(v[2] * r.rstd + t.z), gelu_erf(v[3] * r.rstd + t.w));
+    o.x = pack_bf16x2(gelu_sig(v[0] * r.rstd + t.x), gelu_sig(v[1] * r.rstd + t.y));
+    o.y = pack_bf16x2(gelu_sig(v[2] * r.rstd + t.z), gelu_sig(v[3] * r.rstd + t.w));
     return o;
   }
   __device__ void n4(int m, int n, f32x4 v) const {
@@ -101,8 +101,8 @@ struct EpiBiasGeluBf16 {
   __device__ uint2 pack4(const RowCtx&, const ColCtx&, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     uint2 o;
-    o.x = pack_bf16x2(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y));
-    o.y = pack_bf16x2(gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    o.x = pack_bf16x2(gelu_sig(v[0] + b.x), gelu_sig(v[1] + b.y));
+    o.y = pack_bf16x2(gelu_sig(v[2] + b.z), gelu_sig(v[3] + b.w));
     return o;
   }
   __device__ void n4(int m, int n, f32x4 v) const {
@@ -116,7 +116,7 @@ struct EpiBiasGeluF32 {
   const float* bias;
   __device__ void n4(int m, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
-    float4 o = make_float4(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    float4 o = make_float4(gelu_sig(v[0] + b.x), gelu_sig(v[1] + b.y), gelu_sig(v[2] + b.z), gelu_sig(v[3] + b.w));
     *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
   }
 };
@@ -548,7 +548,7 @@ struct EpiAct {
       for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
     } else if (act == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+      for (int i = 0; i < 4; ++i) v[i] = gelu_sig(v[i]);
     }
     if (out16 != nullptr) {
       uint2 o;

@@ -38,13 +38,25 @@ struct MlpGeom {
   static constexpr int CT = D / 32;         // output column tiles of fc2
   static constexpr int WP = KS + 2 * CT;    // weight fragments (1 KiB each) per stage
   static constexpr int PIECES = WP + 1;     // + the bias piece (first 32 floats = b1 of the chunk)
-  static constexpr int NST = (160 / PIECES) >= 4 ? 4 : 3;   // ring stages that fit the CU's 160 KiB
+  static constexpr int NST = 3;             // ring stages: being read, published, being filled (159 KiB at D = 416)
   static constexpr int PMAX = (PIECES + 3) / 4;             // pieces per wave per stage
   static_assert(D % 32 == 0 && KS == 2 * CT, "hidden size must be a multiple of 32");
   static_assert(NST * PIECES <= 160, "ring does not fit the LDS");
 };
 
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) { return *reinterpret_cast<const bf16x8*>(&v); }
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N).  Every index derived from I is a constant in
+// the FRONT END (if constexpr, fixed register-array slots) -- with `#pragma unroll` and a runtime-looking index the kernel
+// below came out with its accumulators in scratch (1408 bytes per lane) whenever the GELU placement was not trivial.
+template <class Body, int... I>
+__device__ __forceinline__ void static_for_impl(Body&& body, std::integer_sequence<int, I...>) {
+  (body(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Body>
+__device__ __forceinline__ void static_for(Body&& body) {
+  static_for_impl(static_cast<Body&&>(body), std::make_integer_sequence<int, N>{});
+}
 
 // compile-time loop: body(std::integral_constant<int, I>) for I in [0, N).  Every index derived from I is a constant in
 // the FRONT END (if constexpr, fixed register-array slots) -- with `#pragma unroll` and a runtime-looking index the kernel
@@ -74,11 +86,10 @@ __device__ __forceinline__ float gelu_sig(float x) {
 
 // rows [128 * blockIdx.x, +128) of H [R][D] fp32, in place.  Wp: (NC + 1) stages x PIECES KiB, see pack_mlp_weights.
 // ABL (microbenchmark ablations, 0 in the product; results are garbage unless noted): bit 0 = no DMA / no vmcnt waits after
-// the prologue (compute side alone), bit 1 = no GELU arithmetic, bit 2 = fc1 on ONE accumulator (a chain of D/16 dependent
-// MFMAs; correct results), bit 3 = ring of 4 fragment registers instead of 6 (correct), bit 4 = a stage's DMAs issued
-// together behind the barrier instead of spread over the stage's MFMAs (correct), bit 5 = no stages at all (LayerNorm
-// prologue + residual epilogue only), bit 6 = no fragment reads (MFMAs on whatever the ring registers hold), bit 7 = no
-// workgroup barrier.
+// the prologue (compute side alone), bit 1 = no GELU arithmetic, bit 2 = fc1 alternating between TWO accumulators instead
+// of one chain (correct), bit 3 = ring of 2 fragment registers instead of 4 (correct), bit 4 = a stage's DMAs issued
+// together behind the barrier instead of spread over the MFMAs that follow it (correct), bit 5 = no stages at all
+// (LayerNorm prologue + residual epilogue only), bit 6 = no fragment reads, bit 7 = no workgroup barrier.
 template <int D, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H, const bf16_t* __restrict__ Wp,
                                                            const float* __restrict__ b2, int R, int NC) {
@@ -100,12 +111,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
   auto issue_piece = [&](const bf16_t* src, unsigned dst, int q) {
     if (q < PMAX - 1 || my_pieces == PMAX) dma16(src + (long)q * 2048, dst + (unsigned)q * 4096u);
   };
-  auto wait_landed = [&] {   // this wave's pieces of the oldest stage in flight; NST - 2 younger stages stay in flight
-    if (my_pieces == PMAX) wait_vmcnt<(NST - 2) * PMAX>();
-    else wait_vmcnt<(NST - 2) * (PMAX - 1)>();
-  };
 #pragma unroll
-  for (int s = 0; s < NST - 1; ++s) {
+  for (int s = 0; s < 2; ++s) {   // stages 0 and 1 up front
     const bf16_t* src = stage_src(s);
     const unsigned dst = stage_dst(s);
 #pragma unroll
@@ -117,43 +124,58 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
   const int row = blockIdx.x * 128 + wave * 32 + mrow;
   const float* hp = H + (long)(row < R ? row : R - 1) * D + hh * 8;
   bf16x8 yf[KS];
+  f32x16 oacc[CT];   // fc2 accumulators, started from the residual itself (below): H leaves HBM ONCE
   {
-    float4 xa[KS], xb[KS];
+    // Pass 1: the row's moments, nothing kept (half a row is 208 fp32 values per lane: keeping them next to the bf16
+    // operand and the accumulators they turn into does not fit the register file).  Shifted sums per lane half, merged
+    // with the partner lane's (Chan): no cancellation whatever the row's mean.
+    const float k0 = hp[0];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      xa[s] = *reinterpret_cast<const float4*>(hp + s * 16);
-      xb[s] = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+      const float4 a = *reinterpret_cast<const float4*>(hp + s * 16), b = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+      const float d0 = a.x - k0, d1 = a.y - k0, d2 = a.z - k0, d3 = a.w - k0, d4 = b.x - k0, d5 = b.y - k0, d6 = b.z - k0, d7 = b.w - k0;
+      s1 += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) sum += (xa[s].x + xa[s].y) + (xa[s].z + xa[s].w) + (xb[s].x + xb[s].y) + (xb[s].z + xb[s].w);
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.0f / D);
-    float sq = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float d0 = xa[s].x - mean, d1 = xa[s].y - mean, d2 = xa[s].z - mean, d3 = xa[s].w - mean;
-      const float d4 = xb[s].x - mean, d5 = xb[s].y - mean, d6 = xb[s].z - mean, d7 = xb[s].w - mean;
-      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
-    }
-    sq += __shfl_xor(sq, 32, 64);
-    const float rstd = rsqrtf(sq * (1.0f / D) + 1e-5f);
+    constexpr float kHalf = D / 2;
+    const float mean_l = k0 + s1 * (1.0f / kHalf), m2_l = s2 - s1 * s1 * (1.0f / kHalf);
+    const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2_l, 32, 64);
+    const float mean = 0.5f * (mean_l + mean_o), dm = mean_l - mean_o;
+    const float var = (m2_l + m2_o + dm * dm * (0.5f * kHalf)) * (1.0f / D);
+    const float rstd = rsqrtf(var + 1e-5f);
+    // Pass 2 (the panel is in L2 now): normalise into the fc1 operand, and hand the raw values to the fc2 accumulators --
+    // the residual add without a second HBM read of H.  This lane pair holds columns 16s + 8hh + 0..7; the accumulator
+    // layout wants lane hh to hold columns 8g + 4hh + 0..3 of every group of 8: lane 0 keeps its first four of each eight
+    // and takes lane 1's first four, lane 1 keeps its last four and takes lane 0's -- one v_permlane32_swap per register
+    // pair (lanes l and l + 32 are the two halves of a row).
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+      const float4 xa = *reinterpret_cast<const float4*>(hp + s * 16), xb = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
       uint4 p;
-      p.x = pack_bf16x2((xa[s].x - mean) * rstd, (xa[s].y - mean) * rstd);
-      p.y = pack_bf16x2((xa[s].z - mean) * rstd, (xa[s].w - mean) * rstd);
-      p.z = pack_bf16x2((xb[s].x - mean) * rstd, (xb[s].y - mean) * rstd);
-      p.w = pack_bf16x2((xb[s].z - mean) * rstd, (xb[s].w - mean) * rstd);
+      p.x = pack_bf16x2((xa.x - mean) * rstd, (xa.y - mean) * rstd);
+      p.y = pack_bf16x2((xa.z - mean) * rstd, (xa.w - mean) * rstd);
+      p.z = pack_bf16x2((xb.x - mean) * rstd, (xb.y - mean) * rstd);
+      p.w = pack_bf16x2((xb.z - mean) * rstd, (xb.w - mean) * rstd);
       yf[s] = as_frag(p);
+      float a[4] = {xa.x, xa.y, xa.z, xa.w}, b[4] = {xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // lanes 32-63 of the first operand <-> lanes 0-31 of the second: a[32..63] <-> b[0..31].  Inline asm on purpose:
+        // __builtin_amdgcn_permlane32_swap on bit-cast floats came back with BOTH result elements in the first operand's
+        // register (hipcc 7.2; columns 8..15 of every 16 were copies of 0..7).  s_nop 1 = the two wait states a VALU write
+        // of an operand needs before the swap reads it (nothing inside an asm statement is padded by the compiler).
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
+      }
+      // columns 16s + 4hh + e (q even) and 16s + 8 + 4hh + e (q odd) of tile s / 2
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oacc[s >> 1][4 * (2 * (s & 1)) + e] = a[e];
+        oacc[s >> 1][4 * (2 * (s & 1) + 1) + e] = b[e];
+      }
     }
   }
 
-  f32x16 oacc[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
   bf16x8 zb0, zb1;   // gelu(fc1) of the previous chunk: the two 16-deep k-steps of fc2's B operand
   {
     uint4 zero = make_uint4(0, 0, 0, 0);
@@ -164,63 +186,63 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
   // One stage = fc1 of chunk j (W1 pieces 0..KS-1 + the bias piece) then fc2 of chunk j-1 (W2 pieces KS..WP-1, k-step
   // major: every accumulator is touched once per half).  What runs beside the 2 KS MFMAs, all from this one wave:
   //   * the fragments, read from LDS in consumption order through a ring of PF register sets (PF reads ahead, counted
-  //     lgkmcnt) with the piece offset in the instruction's immediate;
+  //     lgkmcnt, piece offset in the instruction's immediate) -- ACROSS stage boundaries: the ring never drains;
   //   * GELU of chunk j (vector pipe), spread over the fc2 MFMAs of chunk j-1 (matrix pipe), which do not depend on it;
-  //   * the DMAs of the stage NST-1 ahead, one every few MFMAs (issued together behind the barrier they cost this wave
-  //     ~14 x 60-180 cycles in which its matrix pipe had nothing queued);
-  //   * fc1 alternates between two accumulators (bias rides in one of them): no MFMA waits for its predecessor.
+  //   * ONE workgroup barrier, in the MIDDLE of the stage: it publishes stage j+1 (every wave has waited for its own
+  //     pieces, issued half a stage earlier) and retires stage j-1, whose buffer the DMAs of stage j+2 then refill, one
+  //     every other MFMA of the second half.  At the stage boundary itself there is no synchronisation at all (a barrier
+  //     there cost ~450 cycles per stage: the matrix pipe ran dry while the first fragments of the new stage were read).
   // The instruction order is pinned (compile-time loop, sched_barrier after every step): left to itself hipcc issued
   // every ds_read right before its MFMA behind an lgkmcnt(0) -- one LDS latency per MFMA with one wave per SIMD.
-  constexpr int PF = (ABL & 8) ? 4 : 6;
-  constexpr bool ONE_ACC = (ABL & 4) != 0;
-  auto stage = [&](int j, int buf, auto do1, auto do2) {
-    constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
-    constexpr int F0 = DO1 ? 0 : KS, NF = (DO1 ? KS : 0) + (DO2 ? KS : 0);
+  constexpr int PF = (ABL & 8) ? 2 : 4;
+  constexpr bool TWO_ACC = (ABL & 4) != 0;
+  uint4 fr[PF];
+  f32x16 za, zc;   // fc1 accumulator(s); za arrives at a stage holding the chunk's bias
+  auto load_bias = [&](int buf) {
+    const float4* bp = reinterpret_cast<const float4*>(lds + buf * (PIECES * 64) + WP * 64) + hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // accumulator row of register 4q + e is n = 8q + 4hh + e
+      const float4 b = bp[2 * q];
+      za[4 * q] = b.x;
+      za[4 * q + 1] = b.y;
+      za[4 * q + 2] = b.z;
+      za[4 * q + 3] = b.w;
+    }
+  };
+  // kind: 0 = first stage (fc1 only), 1 = steady, 2 = last stage (fc2 only); next_f0 = first piece the NEXT stage reads
+  auto stage = [&](int j, int buf, auto kind_c, int next_f0) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr bool DO1 = KIND != 2, DO2 = KIND != 0, LAST = KIND == 2;
+    constexpr int F0 = DO1 ? 0 : KS, NF = (DO1 ? KS : 0) + (DO2 ? KS : 0), MID = NF / 2;
+    // slot of step f in the fragment ring: the ring runs on across stages, the first stage is KS steps long, every other
+    // one 2 KS (a multiple of PF), the last one KS again
+    constexpr int RO = KIND == 0 ? 0 : KS % PF;
+    static_assert((2 * KS) % PF == 0, "a steady stage must leave the ring's phase unchanged");
     // GELU values [16 (i - G0) / GN, 16 (i + 1 - G0) / GN) (rounded up) are computed behind fc2 step i
     constexpr int G0 = KS > 2 ? 1 : 0, GN = KS - G0 - (KS > 3 ? 1 : 0);
-    // DMA piece q of this wave goes behind step 1 + q * DS (everything at step 0 with ABL bit 4)
-    constexpr int DS = (ABL & 16) ? 0 : ((NF - 2) / PMAX > 0 ? (NF - 2) / PMAX : 1);
-    if constexpr ((ABL & 1) == 0) wait_landed();
-    if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage j have landed; stage j-1 has been read by everyone
-    const bf16_t* nsrc = stage_src(j + NST - 1);
-    const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);
+    // DMA piece q of this wave goes behind step MID + 1 + q * DS (all behind MID with ABL bit 4)
+    constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / PMAX > 0 ? (NF - MID - 2) / PMAX : 1);
+    const int nbuf = buf + 1 == NST ? 0 : buf + 1;           // stage j + 1
+    const bf16_t* nsrc = stage_src(j + 2);
+    const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);   // stage j + 2 goes where stage j - 1 was
     const uint4* st = lds + buf * (PIECES * 64) + lane;
-    uint4 fr[PF];
+    const uint4* stn = lds + nbuf * (PIECES * 64) + next_f0 * 64 + lane;
+    if constexpr (DO1 && TWO_ACC) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p) fr[p] = st[(F0 + p) * 64];
-    if constexpr ((ABL & 64) != 0) {
-#pragma unroll
-      for (int p = 0; p < PF; ++p) asm volatile("" : "+v"(fr[p].x), "+v"(fr[p].y), "+v"(fr[p].z), "+v"(fr[p].w));
+      for (int r = 0; r < 16; ++r) zc[r] = 0.f;
     }
-    f32x16 za, zc;   // fc1 accumulators: even / odd k-steps
-    if constexpr (DO1) {
-      const float4* bp = reinterpret_cast<const float4*>(lds + buf * (PIECES * 64) + WP * 64) + hh;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {   // accumulator row of register 4q + e is n = 8q + 4hh + e
-        const float4 b = bp[2 * q];
-        za[4 * q] = b.x;
-        za[4 * q + 1] = b.y;
-        za[4 * q + 2] = b.z;
-        za[4 * q + 3] = b.w;
-      }
-      if constexpr (!ONE_ACC) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zc[r] = 0.f;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
     float gv[16];
     uint32_t zn[8];
     static_for<NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value, piece = F0 + f;
       if constexpr (piece < KS) {
-        if constexpr (ONE_ACC || (piece & 1) == 0)
-          za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), yf[piece], za, 0, 0, 0);
+        if constexpr (!TWO_ACC || (piece & 1) == 0)
+          za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), yf[piece], za, 0, 0, 0);
         else
-          zc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), yf[piece], zc, 0, 0, 0);
+          zc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), yf[piece], zc, 0, 0, 0);
       } else {
         constexpr int i = piece - KS, u = i / CT, t = i % CT;
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), u ? zb1 : zb0, oacc[t], 0, 0, 0);
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), u ? zb1 : zb0, oacc[t], 0, 0, 0);
         if constexpr (DO1) {
           // (the empty asm pins each value HERE: the IR-level passes otherwise sink the whole GELU below the last MFMA,
           // where nothing overlaps it -- sched_barrier only binds the machine scheduler)
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
           constexpr int r1 = r1x > 16 ? 16 : r1x;
           static_for<(r1 > r0 ? r1 - r0 : 0)>([&](auto rc) {
             constexpr int r = r0 + decltype(rc)::value;
-            const float x = ONE_ACC ? za[r] : za[r] + zc[r];
+            const float x = TWO_ACC ? za[r] + zc[r] : za[r];
             gv[r] = (ABL & 2) ? x : gelu_sig(x);
             if constexpr ((r & 1) != 0) {
               zn[r >> 1] = pack_bf16x2(gv[r - 1], gv[r]);
@@ -239,19 +261,26 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
           });
         }
       }
-      if constexpr ((ABL & 1) == 0) {
+      if constexpr (f == MID) {
+        if constexpr ((ABL & 1) == 0) wait_vmcnt<0>();            // this wave's pieces of stage j + 1 (nothing younger is in flight)
+        if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();   // stage j + 1 complete for everyone; stage j - 1 read by everyone
+      }
+      if constexpr ((ABL & 1) == 0 && f > MID) {
         static_for<PMAX>([&](auto qc) {
-          constexpr int q = decltype(qc)::value, at = (1 + q * DS) < NF ? (1 + q * DS) : NF - 1;
+          constexpr int q = decltype(qc)::value, at = (MID + 1 + q * DS) < NF ? (MID + 1 + q * DS) : NF - 1;
           if constexpr (at == f) issue_piece(nsrc, ndst, q);
         });
       }
-      if constexpr (f + PF < NF && (ABL & 64) == 0) fr[f % PF] = st[(F0 + f + PF) * 64];
+      if constexpr ((ABL & 64) == 0) {
+        if constexpr (f + PF < NF) fr[(RO + f) % PF] = st[(F0 + f + PF) * 64];
+        else if constexpr (!LAST) fr[(RO + f) % PF] = stn[(f + PF - NF) * 64];   // the next stage's first fragments (published at MID)
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (DO1 && !DO2) {   // first stage: nothing to overlap with
+    if constexpr (KIND == 0) {   // first stage: nothing to overlap with
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float x0 = ONE_ACC ? za[r] : za[r] + zc[r], x1 = ONE_ACC ? za[r + 1] : za[r + 1] + zc[r + 1];
+        const float x0 = TWO_ACC ? za[r] + zc[r] : za[r], x1 = TWO_ACC ? za[r + 1] + zc[r + 1] : za[r + 1];
         zn[r >> 1] = pack_bf16x2(gelu_sig(x0), gelu_sig(x1));
       }
     }
@@ -260,23 +289,33 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
       zb0 = as_frag(p0);
       zb1 = as_frag(p1);
     }
+    if constexpr (!LAST) load_bias(nbuf);   // next chunk's bias into the fc1 accumulator (only read when the next stage has an fc1)
   };
   if constexpr ((ABL & 32) == 0) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // stages 0 and 1 are in the ring
+    {
+      const uint4* st = lds + lane;
+#pragma unroll
+      for (int p = 0; p < PF; ++p) fr[p] = st[p * 64];
+      load_bias(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     int buf = 0;
-    stage(0, buf, std::true_type{}, std::false_type{});
+    stage(0, buf, std::integral_constant<int, 0>{}, NC > 1 ? 0 : KS);
     for (int j = 1; j < NC; ++j) {
       buf = buf + 1 == NST ? 0 : buf + 1;
-      stage(j, buf, std::true_type{}, std::true_type{});
+      stage(j, buf, std::integral_constant<int, 1>{}, j + 1 < NC ? 0 : KS);
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
-    stage(NC, buf, std::false_type{}, std::true_type{});
+    stage(NC, buf, std::integral_constant<int, 2>{}, 0);
+    wait_vmcnt<0>();   // the trailing re-fetches land in buffers nobody reads; they must not outlive the workgroup's LDS
   } else {
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(yf[s]));
   }
-  wait_vmcnt<0>();   // the trailing re-fetches land in buffers nobody reads; they must not outlive the workgroup's LDS
 
-  // ---- epilogue: H[row][c] += out + b2, accumulator rows are output columns c = 32t + 8q + 4hh + e ----
+  // ---- epilogue: H[row][c] = acc + b2, accumulator rows are output columns c = 32t + 8q + 4hh + e ----
   if (row < R) {
     float* op = H + (long)row * D + hh * 4;
     const float* bp = b2 + hh * 4;
@@ -285,13 +324,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = t * 32 + q * 8;
-        float4 h = *reinterpret_cast<const float4*>(op + c);
         const float4 b = *reinterpret_cast<const float4*>(bp + c);
-        h.x += oacc[t][4 * q] + b.x;
-        h.y += oacc[t][4 * q + 1] + b.y;
-        h.z += oacc[t][4 * q + 2] + b.z;
-        h.w += oacc[t][4 * q + 3] + b.w;
-        *reinterpret_cast<float4*>(op + c) = h;
+        *reinterpret_cast<float4*>(op + c) = make_float4(oacc[t][4 * q] + b.x, oacc[t][4 * q + 1] + b.y, oacc[t][4 * q + 2] + b.z, oacc[t][4 * q + 3] + b.w);
       }
   }
 }
@@ -343,6 +377,28 @@ void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F,
     case 64: return launch_mlp<64>(H, Wp, b2, R, F, s);
     default: throw std::runtime_error("mlp_fused: unsupported hidden size");
   }
+}
+
+// Test hook (tests/test_gpu_mlp.py): packs the weights and runs the kernel once on h [R][D] (host, in / out).
+void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
+                    const float* b2) {
+  if (!mlp_fused_supported(D, F)) throw std::runtime_error("mlp_fused: unsupported shape");
+  std::vector<bf16_t> packed(mlp_packed_elems(D, F));
+  pack_mlp_weights(w1, gamma, b1, w2, D, F, packed.data());
+  float *H = nullptr, *B2 = nullptr;
+  bf16_t* Wp = nullptr;
+  MSH_HIP(hipMalloc(&H, (size_t)R * D * 4));
+  MSH_HIP(hipMalloc(&B2, (size_t)D * 4));
+  MSH_HIP(hipMalloc(&Wp, packed.size() * 2));
+  MSH_HIP(hipMemcpy(H, h, (size_t)R * D * 4, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(B2, b2, (size_t)D * 4, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(Wp, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  mlp_fused(H, Wp, B2, R, D, F, 0);
+  MSH_HIP(hipDeviceSynchronize());
+  MSH_HIP(hipMemcpy(h, H, (size_t)R * D * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(H);
+  (void)hipFree(B2);
+  (void)hipFree(Wp);
 }
 
 // Microbenchmark (tools/mlp_microbench.py): ms per launch on uniform random [-1, 1) data, R rows.

@@ -128,6 +128,8 @@ size_t mlp_packed_elems(int D, int F);
 void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out);
 void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s);
 float mlp_microbench(int R, int D, int F, int iters, int abl);
+void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
+                    const float* b2);
 
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream: qk [R,2D] bf16 (q | k, RoPE applied), vt = V^T [D][vt_ld] bf16 (row d,
