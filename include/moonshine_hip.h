@@ -101,6 +101,13 @@ MSH_EXPORT int32_t msh_clip_frames(const msh_engine* e, uint32_t clip); /* encod
 MSH_EXPORT int32_t msh_set_keep_encoder_output(msh_engine* e, int32_t keep);
 MSH_EXPORT int32_t msh_get_encoder_output(msh_engine* e, uint32_t clip, float* out);
 
+/* Storage of the cross-attention K / V the decoder streams every step (the `past_key_values.{l}.encoder.{key,value}` tensors
+ * of the reference's decoder graph, core/moonshine-model.cpp:354-368, fp32 there): 0 = bf16 (default; the parity
+ * tolerances of tests/ are stated for it), 1 = fp8 e4m3 with one scale per head-dim row fixed at load -- half the bytes of
+ * the HBM-bound kernel that dominates a decode step; scores, softmax and accumulation stay fp32.  Applies from the next
+ * msh_encode; call it before msh_set_batches_in_flight.  Not combinable with the cross-attention capture. */
+MSH_EXPORT int32_t msh_set_kv_dtype(msh_engine* e, int32_t dtype);
+
 /* Per-kernel-group timing with HIP events on the engine's stream (the role of the reference's
  * log_ort_run option, core/ort-utils/ort-utils.cpp:256-288).  While enabled the decode step runs
  * eagerly instead of from its hipGraph. */

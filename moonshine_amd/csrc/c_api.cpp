@@ -84,6 +84,13 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
     else if (k == "vad_device") o->vad_device = parse_int32(v);                    // additive: Silero on the GPU for batch calls
     else if (k == "host_threads") o->host_threads = parse_int32(v);                // additive: VAD threads of batch calls
     else if (k == "max_stream_seconds") o->max_stream_seconds = parse_float(v);     // additive (streaming archs)
+    else if (k == "kv_dtype") {   // additive: cross K / V on the device as bf16 (default) or fp8 e4m3
+      std::string t = v;
+      for (char& ch : t) ch = (char)tolower((unsigned char)ch);
+      if (t == "bf16") o->kv_dtype = 0;
+      else if (t == "fp8" || t == "fp8_e4m3" || t == "e4m3") o->kv_dtype = 1;
+      else throw std::runtime_error("kv_dtype must be bf16 or fp8, got '" + v + "'");
+    }
     else if (k == "batch_clips" || k == "max_batch_size") o->batch_clips = parse_int32(v);  // additive (batch calls; SURVEY 8b names it max_batch_size)
     else if (k == "num_gpus") o->num_gpus = parse_int32(v);                         // additive: shard batch calls over GPUs device .. device+n-1 (-1 = all)
     else if (k == "devices") {                                                      // additive: explicit GPU list, e.g. "0,1,2,3"

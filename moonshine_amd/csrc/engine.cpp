@@ -306,6 +306,8 @@ void Engine::share_weights_from(const Engine& o) {
   dec_ = o.dec_;
   embed_bf16_ = o.embed_bf16_, embed_head_folded_ = o.embed_head_folded_, cross_kv_w_ = o.cross_kv_w_;
   embed_f32_ = o.embed_f32_, dec_ln_ = o.dec_ln_;
+  kv_qscale_ = o.kv_qscale_, kv_dq_ = o.kv_dq_;
+  kv_fp8_ = o.kv_fp8_;
   rope_cos_ = o.rope_cos_, rope_sin_ = o.rope_sin_;
   rope_max_pos_ = o.rope_max_pos_;
   loaded_ = true;  // weight_allocs_ stays empty: the owner frees
@@ -487,6 +489,30 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
+  {
+    // Scales of the optional fp8 (e4m3) cross K / V (set_kv_dtype): column n of the cross-KV GEMM is w_n . enc with
+    // enc = LayerNorm(x) * gamma, so |value| <= |w_n|_2 * sqrt(D) * max|gamma| whatever the audio (Cauchy-Schwarz on a
+    // normalised row).  qscale maps that bound to 448, e4m3's largest value: nothing can overflow, typical values
+    // (~ bound / sqrt(D)) land around 20, three binades of normal range below them.  dq = 1 / qscale is what the decode
+    // kernel applies to the query (K) and to the output (V).
+    const std::vector<float> genc = vec("model.encoder.layer_norm.weight", D);
+    float gmax = 0.f;
+    for (float g : genc) gmax = std::max(gmax, fabsf(g));
+    const size_t N = (size_t)c.dec_layers * 2 * D;
+    std::vector<float> qs(N), dq(N);
+    for (size_t n = 0; n < N; ++n) {
+      double ss = 0.0;
+      for (int k = 0; k < D; ++k) {
+        const double w = (double)bf16_to_f32(f32_to_bf16(cross[n * D + k]));
+        ss += w * w;
+      }
+      const float bound = (float)(sqrt(ss) * sqrt((double)D)) * gmax;
+      qs[n] = bound > 0.f ? 448.0f / bound : 1.0f;
+      dq[n] = 1.0f / qs[n];
+    }
+    upload(qs, &kv_qscale_);
+    upload(dq, &kv_dq_);
+  }
 
   // RoPE tables in fp32, computed the way the float definition does (modeling_moonshine.py:132-154):
   // inv_freq = 1 / theta^(2j/dim), angle = pos * inv_freq, then cos / sin.
@@ -675,8 +701,8 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= gn_part_.reserve((size_t)count * 64 * sizeof(float2));
   moved |= gn_stats_.reserve(count * sizeof(float2));
   moved |= gn_table_.reserve((size_t)count * 2 * D * sizeof(float));
-  moved |= KT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
-  moved |= VT_.reserve((size_t)L * D * kv_keys_ * sizeof(bf16_t));
+  moved |= KT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
+  moved |= VT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
   if (moved) ++ws_gen_;
 
   // clip pointers: stage host PCM into one device buffer, or use the caller's device pointers
@@ -827,8 +853,12 @@ void Engine::run_encoder() {
   }
   {  // cross-attention K/V of all decoder layers in one GEMM, written as K^T / V^T for the decode stream
     ProfScope p(this, "cross_kv_gemm", 2.0 * sT * D * 2 * D * L, sT * D * 2 + sT * D * 2.0 * L * 2);
-    gemm_cross_kv(ENC_.as<bf16_t>(), D, cross_kv_w_, R, L * 2 * D, D, row_clip_.as<int>(), clips, D,
-                  (long)D * kv_keys_, KT_.as<bf16_t>(), VT_.as<bf16_t>(), s);
+    if (kv_fp8_)
+      gemm_cross_kv_fp8(ENC_.as<bf16_t>(), D, cross_kv_w_, R, L * 2 * D, D, row_clip_.as<int>(), clips, D, (long)D * kv_keys_,
+                        kv_qscale_, KT_.as<uint8_t>(), VT_.as<uint8_t>(), s);
+    else
+      gemm_cross_kv(ENC_.as<bf16_t>(), D, cross_kv_w_, R, L * 2 * D, D, row_clip_.as<int>(), clips, D,
+                    (long)D * kv_keys_, KT_.as<bf16_t>(), VT_.as<bf16_t>(), s);
   }
 }
 
@@ -890,8 +920,8 @@ double Engine::profile_cross_attention_ms(int rounds) {
   auto sweep = [&] {
     for (int l = 0; l < L; ++l) {
       const int ll = same_layer ? 0 : l;
-      dec_cross_attention(g.dq.as<float>(), KT_.as<bf16_t>() + (size_t)ll * D * kv_keys_, VT_.as<bf16_t>() + (size_t)ll * D * kv_keys_,
-                          clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
+      dec_cross_attention(g.dq.as<float>(), kv_layer(KT_, ll), kv_layer(VT_, ll), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads,
+                          g.dao.as<bf16_t>(), stream_, kdq(ll), vdq(ll));
     }
   };
   sweep();  // warm
@@ -973,13 +1003,13 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       const char* e = getenv("MSH_NO_FUSED_CROSSQ");
       return !(e != nullptr && e[0] == '1');
     }();
-    const bf16_t* KTl = KT_.as<bf16_t>() + (size_t)l * D * kv_keys_;
-    const bf16_t* VTl = VT_.as<bf16_t>() + (size_t)l * D * kv_keys_;
+    const bf16_t* KTl = kv_layer(KT_, l);
+    const bf16_t* VTl = kv_layer(VT_, l);
     if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
       if (on(4)) {
-        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * 2 + w_dd + M * D * 4.0);
-        dec_cross_attention_fused_q(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, dao, s);
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
+        dec_cross_attention_fused_q(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, dao, s, kdq(l), vdq(l));
       }
     } else {
       if (on(3)) {
@@ -990,8 +1020,8 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         dec_cross_attention_probs(dq, KTl, clips, pos, M, D, Hh, cfg_.dec_layers, l, cross_smax_, cross_tcap_,
                                   cross_probs_.as<float>() + (size_t)g.first * cfg_.dec_layers * Hh * cross_smax_ * cross_tcap_, s);
       if (on(4)) {
-        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * 2);
-        dec_cross_attention(dq, KTl, VTl, clips, M, D, Hh, dao, s);
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D, sT * D * 2.0 * kv_bytes());
+        dec_cross_attention(dq, KTl, VTl, clips, M, D, Hh, dao, s, kdq(l), vdq(l));
       }
     }
     if (on(5)) {
@@ -1209,24 +1239,35 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(ws_gen_) + ":" +
                               std::to_string(g.gen) + ":" + std::to_string(Smax_) + ":" + std::to_string(stride) + ":" +
                               std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
-                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax);
+                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" + std::to_string(kv_fp8_);
       if (g.graph == nullptr || g.key != key) {
         if (g.graph) {
           MSH_HIP(hipGraphExecDestroy(g.graph));
           g.graph = nullptr;
         }
+        g.key.clear();
         hipGraph_t gr = nullptr;
         std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
         MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        decode_step_enqueue(g);
-        if (g.fused_argmax)
-          decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
-                                  g.dH.as<float>(), g.stream);
-        else
-          decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+        try {
+          decode_step_enqueue(g);
+          if (g.fused_argmax)
+            decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
+                                    g.dH.as<float>(), g.stream);
+          else
+            decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+        } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
+          (void)hipStreamEndCapture(g.stream, &gr);
+          if (gr != nullptr) (void)hipGraphDestroy(gr);
+          throw;
+        }
         MSH_HIP(hipStreamEndCapture(g.stream, &gr));
-        MSH_HIP(hipGraphInstantiate(&g.graph, gr, nullptr, nullptr, 0));
-        MSH_HIP(hipGraphDestroy(gr));
+        const hipError_t inst = hipGraphInstantiate(&g.graph, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (inst != hipSuccess) {
+          g.graph = nullptr;
+          MSH_HIP(inst);
+        }
         g.key = key;
       }
     }

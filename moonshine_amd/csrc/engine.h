@@ -86,7 +86,20 @@ class Engine {
   // decode, one extra kernel per layer and step).  get_cross_attention copies clip `clip`'s [layers*heads][steps][T]
   // fp32 block (steps = tokens generated, T = encoder frames) to `out` if it holds `cap` >= that many floats, and
   // returns the three dimensions.
-  void set_capture_cross_attention(bool on) { capture_cross_ = on; }
+  void set_capture_cross_attention(bool on) {
+    if (on && kv_fp8_) throw std::invalid_argument("cross-attention capture (word timestamps) needs kv_dtype = bf16");
+    capture_cross_ = on;
+  }
+  // cross K^T / V^T storage: bf16 (default) or e4m3 bytes with per-column scales fixed at load; applies to the next encode.
+  // Lanes (batches in flight) take the setting when they are created.
+  void set_kv_fp8(bool on) {
+    if (on && capture_cross_) throw std::invalid_argument("kv_dtype = fp8 cannot be combined with the cross-attention capture");
+    if (on != kv_fp8_) {
+      kv_fp8_ = on;
+      encoded_ = false;
+    }
+  }
+  bool kv_fp8() const { return kv_fp8_; }
   void get_cross_attention(uint32_t clip, float* out, size_t cap, int dims[3]);
 
   // per-kernel-group timing with HIP events on the engine stream
@@ -145,6 +158,14 @@ class Engine {
   int max_rows_ = 0, max_steps_ = 0;
   bool encoded_ = false, keep_enc_f32_ = false;
   bool capture_cross_ = false;
+  bool kv_fp8_ = false;
+  float *kv_qscale_ = nullptr, *kv_dq_ = nullptr;   // [L * 2D]: e4m3 scale of every cross-KV column and its inverse
+  size_t kv_bytes() const { return kv_fp8_ ? 1 : 2; }
+  const bf16_t* kv_layer(const DevBuf& b, int l) const {
+    return reinterpret_cast<const bf16_t*>(static_cast<const char*>(b.p) + (size_t)l * cfg_.hidden * kv_keys_ * kv_bytes());
+  }
+  const float* kdq(int l) const { return kv_fp8_ ? kv_dq_ + (size_t)l * 2 * cfg_.hidden : nullptr; }
+  const float* vdq(int l) const { return kv_fp8_ ? kv_dq_ + (size_t)l * 2 * cfg_.hidden + cfg_.hidden : nullptr; }
   DevBuf cross_probs_;                // [clips][layers][heads][Smax][Tcap] fp32 (capture_cross_)
   int cross_tcap_ = 0, cross_smax_ = 0;
   std::vector<int32_t> cross_counts_;  // tokens per clip (incl. BOS) of the captured decode

@@ -25,6 +25,20 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// gelu(x) = x * Phi(x) with Phi(x) ~ sigmoid(x * (a0 + a1 x^2 + a2 x^4)), x^2 clamped at 81 (beyond |x| = 9 the result is
+// x or 0 to 1e-18): minimax fit against the erf form, max abs error 2.8e-5 over the whole line (tools/fit_gelu.py) -- a
+// tenth of the bf16 rounding of the result -- in 9 instructions (2 transcendental) where the erf formula of gemm_common.h
+// takes 19.  In the fused MLP kernel (one wave per SIMD) GELU shares the wave's issue slots with the MFMAs it overlaps; in
+// the tiled GEMMs' epilogues it is plain VALU time behind the main loop.
+__device__ __forceinline__ float gelu_sig(float x) {
+  constexpr float kL2e = -1.4426950408889634f;   // sigmoid(t) = 1 / (1 + 2^(-t log2 e))
+  constexpr float c0 = 1.5949708004086212f * kL2e, c1 = 0.07405211422714464f * kL2e, c2 = -0.000709652592810915f * kL2e;
+  const float s = fminf(x * x, 81.0f);
+  float p = fmaf(s, c2, c1);
+  p = fmaf(p, s, c0);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 // tanh(x) = 1 - 2 / (1 + e^{2x}); saturates cleanly (e^{2x} -> inf gives 1, -> 0 gives -1)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -370,6 +384,73 @@ struct EpiCrossKV {
     *reinterpret_cast<uint4*>((which ? VT : KT) + layer * layer_stride + k.off + (long)c * k.Tk) = v;
   }
 };
+// The same tensor as e4m3 bytes (engine option kv_dtype = fp8): value * qscale[n], qscale fixed per output column at load
+// from a bound on |value| (Engine::load_weights), so nothing data-dependent has to be known before the store.  The decode
+// kernel multiplies the query (K) and the output (V) by 1 / qscale.  Layout as above with one byte per key.
+struct EpiCrossKVFp8 {
+  uint8_t* KT;
+  uint8_t* VT;
+  const int* row_clip;
+  const ClipMeta* clips;
+  int D;
+  long layer_stride;     // bytes per layer = D * sum(Tk)
+  const float* qscale;   // [N]
+  static __device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d) {
+    // v_cvt_pk_fp8_f32 does not saturate: keep the (already bounded) values inside e4m3's +-448
+    a = fminf(fmaxf(a, -448.f), 448.f);
+    b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f);
+    d = fminf(fmaxf(d, -448.f), 448.f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
+  }
+  __device__ void m4(int m, int n, f32x4 v) const {
+    const int b = row_clip[m];
+    const ClipMeta cm = clips[b];
+    const int t = m - cm.row_start;
+    if (t >= cm.Tk) return;
+    const int layer = n / (2 * D);
+    const int r = n - layer * 2 * D;
+    const int which = r / D;
+    const int c = r - which * D;
+    const float qs = qscale[n];
+    uint8_t* base = (which ? VT : KT) + layer * layer_stride + (long)cm.kv_start * D + (long)c * cm.Tk + t;
+    *reinterpret_cast<uint32_t*>(base) = pack4(t < cm.T ? v[0] * qs : 0.f, t + 1 < cm.T ? v[1] * qs : 0.f,
+                                               t + 2 < cm.T ? v[2] * qs : 0.f, t + 3 < cm.T ? v[3] * qs : 0.f);
+  }
+  static constexpr bool kPairedKeysFp8 = true;
+  struct KeyRow {
+    int t, T, Tk;
+    long off;  // kv_start * D + t
+  };
+  __device__ KeyRow key_row(int m) const {
+    const ClipMeta cm = clips[row_clip[m]];
+    KeyRow k;
+    k.t = m - cm.row_start;
+    k.T = cm.T;
+    k.Tk = cm.Tk;
+    k.off = (long)cm.kv_start * D + k.t;
+    return k;
+  }
+  __device__ uint32_t pack_keys4(const KeyRow& k, f32x4 v, float qs) const {
+    return pack4(k.t < k.T ? v[0] * qs : 0.f, k.t + 1 < k.T ? v[1] * qs : 0.f, k.t + 2 < k.T ? v[2] * qs : 0.f,
+                 k.t + 3 < k.T ? v[3] * qs : 0.f);
+  }
+  __device__ void store_keys8(const KeyRow& k, int n, uint2 v) const {  // k = first of 8 consecutive keys of one clip
+    if (k.t >= k.Tk) return;
+    const int layer = n / (2 * D);
+    const int r = n - layer * 2 * D;
+    const int which = r / D;
+    const int c = r - which * D;
+    *reinterpret_cast<uint2*>((which ? VT : KT) + layer * layer_stride + k.off + (long)c * k.Tk) = v;
+  }
+};
+template <class E, class = void>
+struct is_paired_keys_fp8 : std::false_type {};
+template <class E>
+struct is_paired_keys_fp8<E, std::void_t<decltype(E::kPairedKeysFp8)>> : std::true_type {};
+
 template <class E, class = void>
 struct is_paired_keys : std::false_type {};
 template <class E>

@@ -20,6 +20,8 @@ namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // cache-policy bits of the buffer-load aux operand: 2 = nt (non-temporal).  The cross K^T/V^T stream
 // (1.4 GB per decode step at batch 256) is read exactly once per step; marking it streaming keeps it from
 // evicting the 77 MB of decoder weights that every step re-reads (MI355X_MICROARCH.md, row nt-weights).
@@ -27,6 +29,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MSH_CROSS_KV_AUX 2
 #endif
 constexpr int kStreamAux = MSH_CROSS_KV_AUX;
+#ifndef MSH_FP8_ATT_OCC
+#define MSH_FP8_ATT_OCC 2   // minimum workgroups per CU the fp8 variant is compiled for: it lands at 114 VGPRs = 4 per CU by itself;
+                          // forcing 5 (96 VGPRs, 13 spilled) measured 26.5 us per launch against 19.2
+#endif
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -491,16 +497,23 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
 // few dozen shuffles that sit under the latency of the first K loads, instead of a separate 7 us GEMM launch.
 // Only for small batches: every (clip, head) workgroup re-reads its 43 KB slice of Wq, which at batch 256 adds
 // 88 MB of L2 traffic per layer next to the 177 MB K/V stream and costs more (31 -> 48 us) than the GEMM saved.
-template <int DH, bool FUSEQ>
-__global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float* __restrict__ q,
+// FP8: K^T / V^T are e4m3 bytes (engine option kv_dtype = fp8: half the bytes of the kernel that bounds a decode step),
+// written by the cross-KV GEMM as value * qscale[column] with a per-column scale fixed at load (gemm_common.h
+// EpiCrossKVFp8).  Same lane / key mapping with 8-byte loads; the K scale is folded into the query (kdq[d] = 1 / qscale of
+// K row d), the V scale into the output (vdq).  Scores, softmax and accumulation stay fp32.
+template <int DH, bool FUSEQ, bool FP8 = false>
+__global__ __launch_bounds__(256, FP8 ? MSH_FP8_ATT_OCC : 2) void dec_cross_attention_kernel(const float* __restrict__ q,
                                                                   const bf16_t* __restrict__ Wq,
                                                                   const bf16_t* __restrict__ KT,
                                                                   const bf16_t* __restrict__ VT,
                                                                   const ClipMeta* __restrict__ clips, int D,
-                                                                  int heads, bf16_t* __restrict__ out) {
+                                                                  int heads, bf16_t* __restrict__ out,
+                                                                  const float* __restrict__ kdq = nullptr,
+                                                                  const float* __restrict__ vdq = nullptr) {
   constexpr int DQ = DH / 4;
+  constexpr int EB = FP8 ? 1 : 2;   // bytes per stored key
   __shared__ float sp[4][512];
-  __shared__ float red[4][DQ][65];
+  __shared__ float red[4][DQ][65];   // (a butterfly reduction of the tail instead of this slab measured 1 us SLOWER at bf16)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const ClipMeta cm = clips[b];
@@ -509,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
   const long off = (long)cm.kv_start * D + (long)(h * DH + wave * DQ) * Tk;
   // buffer descriptors over this wave's dh/4 rows: row d sits at scalar offset d*Tk*2, the lane's keys at
   // one shared 32-bit vector offset -> no per-row 64-bit addresses in VGPRs; reads past the last row return 0
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(KT + off), 0, DQ * Tk * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VT + off), 0, DQ * Tk * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)KT + off * EB), 0, DQ * Tk * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)VT + off * EB), 0, DQ * Tk * EB, 0x00020000);
   const float c = rsqrtf((float)DH) * kLog2e;
 
   float qd[DQ];
@@ -563,6 +576,10 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
 #pragma unroll
     for (int d = 0; d < DQ; ++d) qd[d] = qp[d];
   }
+  if constexpr (FP8) {
+#pragma unroll
+    for (int d = 0; d < DQ; ++d) qd[d] *= kdq[h * DH + wave * DQ + d];
+  }
   float opart[DQ];
 #pragma unroll
   for (int d = 0; d < DQ; ++d) opart[d] = 0.f;
@@ -572,13 +589,35 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
   for (int k0 = 0; k0 < Tk; k0 += 512) {
     const int key = k0 + lane * 8;
     const bool in = key < Tk;
-    u32x4 kr[DQ], vr[DQ];
-#pragma unroll
-    for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Tk * 2, kStreamAux);
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    {
+    u32x4 vr[DQ];     // bf16: 8 keys in 4 dwords; fp8: 8 keys in .x / .y
+    if constexpr (FP8) {
+      // K and V rows are requested together: at one byte per key both fit the register file (2 x 26 VGPRs), and the
+      // workgroup sits through ONE memory latency per chunk instead of two
+      u32x2 kr[DQ];
+#pragma unroll
+      for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b64(rk, key, d * Tk, kStreamAux);
+#pragma unroll
+      for (int d = 0; d < DQ; ++d) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rv, key, d * Tk, kStreamAux);
+        vr[d] = u32x4{t.x, t.y, 0u, 0u};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 0; d < DQ; ++d) {
+        const f32x2 k01 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].x, false), k23 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].x, true);
+        const f32x2 k45 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].y, false), k67 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].y, true);
+        s[0] += qd[d] * k01[0]; s[1] += qd[d] * k01[1];
+        s[2] += qd[d] * k23[0]; s[3] += qd[d] * k23[1];
+        s[4] += qd[d] * k45[0]; s[5] += qd[d] * k45[1];
+        s[6] += qd[d] * k67[0]; s[7] += qd[d] * k67[1];
+      }
+    } else {
+      u32x4 kr[DQ];
+#pragma unroll
+      for (int d = 0; d < DQ; ++d) kr[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Tk * 2, kStreamAux);
 #pragma unroll
       for (int d = 0; d < DQ; ++d) {
         const u32x4 u = kr[d];
@@ -587,11 +626,11 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
         s[4] += qd[d] * bf_lo(u.z); s[5] += qd[d] * bf_hi(u.z);
         s[6] += qd[d] * bf_lo(u.w); s[7] += qd[d] * bf_hi(u.w);
       }
-    }
-    // the V rows are requested only now (K registers are dead): they fly during the score exchange
-    __builtin_amdgcn_sched_barrier(0);
+      // the V rows are requested only now (K registers are dead): they fly during the score exchange
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) vr[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Tk * 2, kStreamAux);
+      for (int d = 0; d < DQ; ++d) vr[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Tk * 2, kStreamAux);
+    }
     if (k0 > 0) __syncthreads();  // previous chunk's partial scores fully consumed
     *reinterpret_cast<float4*>(&sp[wave][lane * 8]) = make_float4(s[0], s[1], s[2], s[3]);
     *reinterpret_cast<float4*>(&sp[wave][lane * 8 + 4]) = make_float4(s[4], s[5], s[6], s[7]);
@@ -619,8 +658,15 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
 #pragma unroll
       for (int d = 0; d < DQ; ++d) {
         const u32x4 u = vr[d];
-        const float part = s[0] * bf_lo(u.x) + s[1] * bf_hi(u.x) + s[2] * bf_lo(u.y) + s[3] * bf_hi(u.y) +
-                           s[4] * bf_lo(u.z) + s[5] * bf_hi(u.z) + s[6] * bf_lo(u.w) + s[7] * bf_hi(u.w);
+        float part;
+        if constexpr (FP8) {
+          const f32x2 v01 = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, false), v23 = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, true);
+          const f32x2 v45 = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, false), v67 = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, true);
+          part = s[0] * v01[0] + s[1] * v01[1] + s[2] * v23[0] + s[3] * v23[1] + s[4] * v45[0] + s[5] * v45[1] + s[6] * v67[0] + s[7] * v67[1];
+        } else {
+          part = s[0] * bf_lo(u.x) + s[1] * bf_hi(u.x) + s[2] * bf_lo(u.y) + s[3] * bf_hi(u.y) +
+                 s[4] * bf_lo(u.z) + s[5] * bf_hi(u.z) + s[6] * bf_lo(u.w) + s[7] * bf_hi(u.w);
+        }
         opart[d] = opart[d] * alpha + part;
       }
     }
@@ -633,6 +679,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_attention_kernel(const float
     float acc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
+    if constexpr (FP8) acc *= vdq[h * DH + wave * DQ + lane];
     out[fm16(b, h * DH + wave * DQ + lane, D >> 5)] = f32_to_bf16(acc / l);   // FM: the o-proj GEMM's A operand
   }
 }
@@ -739,9 +786,18 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
 }
 
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
-                         int heads, bf16_t* out, hipStream_t s) {
+                         int heads, bf16_t* out, hipStream_t s, const float* kdq, const float* vdq) {
   const int dh = D / heads;
   dim3 grid(M * heads);
+  if (kdq != nullptr) {   // fp8 K^T / V^T
+    switch (dh) {
+      case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, false, true>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, false, true>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      case 16: MSH_LAUNCH((dec_cross_attention_kernel<16, false, true>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
+    }
+    return;
+  }
   switch (dh) {
     case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
     case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, false>), grid, dim3(256), 0, s, q, nullptr, KT, VT, clips, D, heads, out); break;
@@ -751,10 +807,20 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
 }
 
 void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t* KT, const bf16_t* VT,
-                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s) {
+                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s, const float* kdq,
+                                 const float* vdq) {
   const int dh = D / heads;
   if (D > 512 || (D & 7) != 0) throw std::runtime_error("dec_cross_attention_fused_q: unsupported width");
   dim3 grid(M * heads);
+  if (kdq != nullptr) {   // fp8 K^T / V^T
+    switch (dh) {
+      case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, true, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, true, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      case 16: MSH_LAUNCH((dec_cross_attention_kernel<16, true, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out, kdq, vdq); break;
+      default: throw std::runtime_error("dec_cross_attention: unsupported head_dim");
+    }
+    return;
+  }
   switch (dh) {
     case 52: MSH_LAUNCH((dec_cross_attention_kernel<52, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;
     case 36: MSH_LAUNCH((dec_cross_attention_kernel<36, true>), grid, dim3(256), 0, s, H, Wq, KT, VT, clips, D, heads, out); break;

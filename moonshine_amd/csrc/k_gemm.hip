@@ -503,6 +503,31 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
           }
         }
       }
+    } else if constexpr (!SWAP && is_paired_keys_fp8<Epi>::value) {
+      // the same key pairing with one byte per key: a lane stores 8 consecutive keys as 8 bytes
+      const int mr = m0 + kg * 4;
+      if (m0 + 31 < M) {
+        const auto klo = epi.key_row(mr), khi = epi.key_row(mr + 16);
+        const auto kst = epi.key_row((kg & 1) ? m0 + 16 + (kg - 1) * 4 : mr);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 16 + li;
+          const float qs = epi.qscale[n < N ? n : N - 1];
+          const uint32_t lo = epi.pack_keys4(klo, acc[0][j], qs), hi = epi.pack_keys4(khi, acc[1][j], qs);
+          const uint32_t recv = __shfl_xor((kg & 1) ? lo : hi, 16, 64);
+          if (n < N) epi.store_keys8(kst, n, (kg & 1) ? make_uint2(recv, hi) : make_uint2(lo, recv));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 16 + li;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 16 + kg * 4;
+            if (m < M && n < N) epi.m4(m, n, acc[i][j]);
+          }
+        }
+      }
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -615,6 +640,12 @@ void gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bia
 void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
                    const ClipMeta* clips, int D, long layer_stride, bf16_t* KT, bf16_t* VT, hipStream_t s) {
   launch_tiled<false>(A, lda, W, M, N, K, EpiCrossKV{KT, VT, row_clip, clips, D, layer_stride}, s);
+}
+
+void gemm_cross_kv_fp8(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
+                       const ClipMeta* clips, int D, long layer_stride, const float* qscale, uint8_t* KT, uint8_t* VT,
+                       hipStream_t s) {
+  launch_tiled<false>(A, lda, W, M, N, K, EpiCrossKVFp8{KT, VT, row_clip, clips, D, layer_stride, qscale}, s);
 }
 
 void gemm_act(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int act, int M, int N, int K,

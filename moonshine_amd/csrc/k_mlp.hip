@@ -58,32 +58,6 @@ __device__ __forceinline__ void static_for(Body&& body) {
   static_for_impl(static_cast<Body&&>(body), std::make_integer_sequence<int, N>{});
 }
 
-// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N).  Every index derived from I is a constant in
-// the FRONT END (if constexpr, fixed register-array slots) -- with `#pragma unroll` and a runtime-looking index the kernel
-// below came out with its accumulators in scratch (1408 bytes per lane) whenever the GELU placement was not trivial.
-template <class Body, int... I>
-__device__ __forceinline__ void static_for_impl(Body&& body, std::integer_sequence<int, I...>) {
-  (body(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class Body>
-__device__ __forceinline__ void static_for(Body&& body) {
-  static_for_impl(static_cast<Body&&>(body), std::make_integer_sequence<int, N>{});
-}
-
-// gelu(x) = x * Phi(x) with Phi(x) ~ sigmoid(x * (a0 + a1 x^2 + a2 x^4)), x^2 clamped at 81 (beyond |x| = 9 the result is
-// x or 0 to 1e-18): minimax fit against the erf form, max abs error 2.8e-5 over the whole line (tools/fit_gelu.py) -- a
-// tenth of the bf16 rounding of the result -- in 9 instructions (2 transcendental) where the erf formula of gemm_common.h
-// takes 19: this kernel runs one wave per SIMD, and GELU shares that wave's issue slots with the MFMAs it overlaps.
-__device__ __forceinline__ float gelu_sig(float x) {
-  constexpr float kL2e = -1.4426950408889634f;   // sigmoid(t) = 1 / (1 + 2^(-t log2 e))
-  constexpr float c0 = 1.5949708004086212f * kL2e, c1 = 0.07405211422714464f * kL2e, c2 = -0.000709652592810915f * kL2e;
-  const float s = fminf(x * x, 81.0f);
-  float p = fmaf(s, c2, c1);
-  p = fmaf(p, s, c0);
-  const float e = __builtin_amdgcn_exp2f(x * p);
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 // rows [128 * blockIdx.x, +128) of H [R][D] fp32, in place.  Wp: (NC + 1) stages x PIECES KiB, see pack_mlp_weights.
 // ABL (microbenchmark ablations, 0 in the product; results are garbage unless noted): bit 0 = no DMA / no vmcnt waits after
 // the prologue (compute side alone), bit 1 = no GELU arithmetic, bit 2 = fc1 alternating between TWO accumulators instead

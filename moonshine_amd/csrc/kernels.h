@@ -61,6 +61,11 @@ void gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bia
 void gemm_cross_kv(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
                    const ClipMeta* clips, int D, long layer_stride, bf16_t* KT, bf16_t* VT, hipStream_t s);
 
+// the same as e4m3 bytes: value * qscale[n] (per output column, fixed at load); layer_stride in bytes
+void gemm_cross_kv_fp8(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_clip,
+                       const ClipMeta* clips, int D, long layer_stride, const float* qscale, uint8_t* KT, uint8_t* VT,
+                       hipStream_t s);
+
 // ---------------- decode GEMMs (M = batch rows; k_gemm_dec.hip) ----------------
 // "LN" variants take the fp32 residual stream H and fuse LayerNorm (no bias, eps 1e-5) into the A-fragment
 // build; the LayerNorm scale gamma must already be folded into W (W' = W * diag(gamma), done at load).
@@ -140,8 +145,9 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
                         int heads, int Smax, bf16_t* out, hipStream_t s);
 // decode cross-attention: q [M,D] f32, K^T/V^T of one layer -> out [M16,D] bf16 in FM
+// kdq / vdq non-null: K^T / V^T are e4m3 bytes and kdq[c] / vdq[c] = 1 / qscale of K / V column c of this layer
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
-                         int heads, bf16_t* out, hipStream_t s);
+                         int heads, bf16_t* out, hipStream_t s, const float* kdq = nullptr, const float* vdq = nullptr);
 
 // same with the query projection fused in: H = fp32 residual stream (FM), Wq = cross-q weight [D,D] ROW-MAJOR with the
 // LayerNorm scale folded in (replaces dec_gemm_ln_f32 + dec_cross_attention)
@@ -150,7 +156,8 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
 void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta* clips, const int* pos_ptr, int M, int D,
                                int heads, int layers, int layer, int Smax, int Tcap, float* out, hipStream_t s);
 void dec_cross_attention_fused_q(const float* H, const bf16_t* Wq, const bf16_t* KT, const bf16_t* VT,
-                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s);
+                                 const ClipMeta* clips, int M, int D, int heads, bf16_t* out, hipStream_t s,
+                                 const float* kdq = nullptr, const float* vdq = nullptr);
 
 // ---------------- elementwise / reductions ----------------
 // pack fp32 clips into the bf16 conv1 input stream (clip b at 384*row_start samples)

@@ -193,6 +193,14 @@ int32_t msh_set_keep_encoder_output(msh_engine* e, int32_t keep) {
   return guarded(e, [&] { e->eng->set_keep_encoder_f32(keep != 0); });
 }
 
+int32_t msh_set_kv_dtype(msh_engine* e, int32_t dtype) {
+  return guarded(e, [&] {
+    if (dtype != 0 && dtype != 1) throw std::invalid_argument("kv dtype: 0 = bf16, 1 = fp8 (e4m3)");
+    if (e->pipe) throw std::invalid_argument("msh_set_kv_dtype: set it before msh_set_batches_in_flight (lanes take it at creation)");
+    e->eng->set_kv_fp8(dtype == 1);
+  });
+}
+
 int32_t msh_get_encoder_output(msh_engine* e, uint32_t clip, float* out) {
   return guarded(e, [&] {
     if (out == nullptr || clip >= e->eng->batch_count()) throw std::invalid_argument("bad clip index / null output");

@@ -97,6 +97,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   int host_threads = 0;                  // additive: host threads for the per-clip VAD of batch calls (0 = twice the CPUs the process may use -- affinity and cgroup quota --, <= 128)
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool word_timestamps = false;          // reference core/transcriber.h (word_timestamps): offline architectures here
+  int kv_dtype = 0;                      // additive: storage of the decoder's cross K / V on the device: 0 = bf16, 1 = fp8 e4m3 (msh_set_kv_dtype)
   int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call
   int batches_in_flight = 2;             // additive: sub-batches on the GPU at once (1 = strictly one after the other)
   bool return_audio_data = true;

@@ -66,6 +66,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_clip_frames": (i32, [vp, u32]),
         "msh_set_keep_encoder_output": (i32, [vp, i32]),
         "msh_get_encoder_output": (i32, [vp, u32, vp]),
+        "msh_set_kv_dtype": (i32, [vp, i32]),
         "msh_profile_enable": (i32, [vp, i32]),
         "msh_profile_reset": (i32, [vp]),
         "msh_profile_count": (i32, [vp]),
@@ -119,7 +120,7 @@ def load_library(path: str | None = None) -> C.CDLL:
 DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
-    "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output",
+    "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output", "msh_set_kv_dtype",
     "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_profile_decode_chain", "msh_debug_read",
     "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
@@ -198,6 +199,10 @@ class Engine:
 
     def set_keep_encoder_output(self, keep: bool = True):
         self._check(self.lib.msh_set_keep_encoder_output(self.h, 1 if keep else 0))
+
+    def set_kv_dtype(self, dtype: str = "bf16"):
+        """Cross K / V storage: "bf16" (default) or "fp8" (e4m3, per-row scales fixed at load); before set_batches_in_flight."""
+        self._check(self.lib.msh_set_kv_dtype(self.h, {"bf16": 0, "fp8": 1}[dtype]))
 
     def encoder_output(self, clip: int) -> np.ndarray:
         T = self._check(self.lib.msh_clip_frames(self.h, clip))
