@@ -331,6 +331,13 @@ MSH_EXPORT int32_t msh_stream_decode_full(msh_stream_engine* e, int32_t n, const
 MSH_EXPORT int32_t msh_stream_set_bias(msh_stream_engine* e, int32_t n_nodes, const int32_t* child_off,
                                        const int32_t* child_tok, const int32_t* child_node, const int32_t* depth,
                                        const float* depth_bonus, int32_t n_depth_bonus);
+/* Per-kernel-group timing of the streaming engine, as msh_profile_* above (groups: stream_frontend, senc_* window encoder,
+ * stream_adapter_cross_kv, sver_* wide verify pass, sdec_* auto-regressive steps).  While enabled the AR steps run eagerly
+ * instead of from their hipGraph. */
+MSH_EXPORT int32_t msh_stream_profile_enable(msh_stream_engine* e, int32_t on);
+MSH_EXPORT int32_t msh_stream_profile_reset(msh_stream_engine* e);
+MSH_EXPORT int32_t msh_stream_profile_count(msh_stream_engine* e);
+MSH_EXPORT int32_t msh_stream_profile_get(msh_stream_engine* e, int32_t index, msh_profile_entry* out);
 /* state queries: 0 memory_len, 1 feature_count, 2 cache_len, 3 frames_emitted, 4 max_tokens for the memory */
 MSH_EXPORT int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what);
 MSH_EXPORT int32_t msh_stream_get_memory(msh_stream_engine* e, int32_t slot, float* out);   /* [memory_len][Dd] */

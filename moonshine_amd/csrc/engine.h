@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "profiler.h"
 #include "safetensors.h"
 
 namespace msh {
@@ -45,14 +46,6 @@ struct DecLayerW {
   float *ln1, *ln2, *ln3, *b1, *b2;
   bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;  // MFMA-fragment-major (kernels.h fm16)
   bf16_t* wq_c_rm;                              // cross-q again, row-major (fused-q attention kernel, small batches)
-};
-
-struct ProfEntry {
-  std::string name;
-  double ms = 0;
-  uint64_t launches = 0;
-  double flops = 0;  // algorithmic flops over all launches
-  double bytes = 0;  // algorithmic HBM bytes over all launches
 };
 
 class Engine {

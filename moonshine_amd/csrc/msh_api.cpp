@@ -27,6 +27,7 @@ struct msh_engine {
 struct msh_stream_engine {
   msh::StreamingEngine* eng = nullptr;
   std::string last_error;
+  std::vector<msh::ProfEntry> prof_cache;
 };
 
 namespace {
@@ -575,6 +576,31 @@ int32_t msh_stream_set_bias(msh_stream_engine* e, int32_t n_nodes, const int32_t
                             const int32_t* child_node, const int32_t* depth, const float* depth_bonus,
                             int32_t n_depth_bonus) {
   return guarded(e, [&] { e->eng->set_bias(n_nodes, child_off, child_tok, child_node, depth, depth_bonus, n_depth_bonus); });
+}
+int32_t msh_stream_profile_enable(msh_stream_engine* e, int32_t on) {
+  return guarded(e, [&] { e->eng->profile_enable(on != 0); });
+}
+int32_t msh_stream_profile_reset(msh_stream_engine* e) {
+  return guarded(e, [&] { e->eng->profile_reset(); });
+}
+int32_t msh_stream_profile_count(msh_stream_engine* e) {
+  int32_t n = 0;
+  const int32_t rc = guarded(e, [&] {
+    e->prof_cache = e->eng->profile_get();
+    n = (int32_t)e->prof_cache.size();
+  });
+  return rc == MSH_OK ? n : rc;
+}
+int32_t msh_stream_profile_get(msh_stream_engine* e, int32_t index, msh_profile_entry* out) {
+  if (e == nullptr || out == nullptr || index < 0 || index >= (int32_t)e->prof_cache.size()) return MSH_ERR_INVALID_ARGUMENT;
+  const msh::ProfEntry& p = e->prof_cache[index];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, p.name.c_str(), sizeof(out->name) - 1);
+  out->ms = p.ms;
+  out->launches = p.launches;
+  out->flops = p.flops;
+  out->bytes = p.bytes;
+  return MSH_OK;
 }
 int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what) {
   if (e == nullptr) return MSH_ERR_INVALID_ARGUMENT;

@@ -493,13 +493,19 @@ void StreamingEngine::process_audio(int n, const int* slots, const float* const*
   all.insert(all.end(), segB.begin(), segB.end());
   all.insert(all.end(), segC.begin(), segC.end());
   const StreamSeg* segs_d = stage(segs_, all);
-  stream_frames(audio_d, fj_d, (int)fj.size(), max_frames, k_scale_, frames_.as<bf16_t>(), stream_);
-  gemm_act(frames_.as<bf16_t>(), 96, lin_w_, nullptr, 1, 4 * P, De, 96, hid, nullptr, stream_);
-  copy_segments(segs_d, (int)segA.size(), stream_);
-  gemm_act(hid, 2 * De, conv1_w_, conv1_b_, 1, 2 * P - 2, 2 * De, 5 * De, c1o + (size_t)2 * 2 * De, nullptr, stream_);
-  copy_segments(segs_d + segA.size(), (int)segB.size(), stream_);
-  gemm_act(c1o, 4 * De, conv2_w_, conv2_b_, 0, P - 2, De, 10 * De, nullptr, fpk + (size_t)2 * De, stream_);
-  copy_segments(segs_d + segA.size() + segB.size(), (int)segC.size(), stream_);
+  {
+    // algorithmic: 80 -> De linear on 4P frames, conv1 (k5) on 2P rows, conv2 (k5) on P rows; bytes = samples in, features out
+    ScopeProfiler::Scope sc(&prof_, stream_, "stream_frontend",
+                            2.0 * 4 * P * De * 80 + 2.0 * 2 * P * 2 * De * 5 * De + 2.0 * P * De * 10 * De,
+                            (double)P * 320 * 4 + (double)P * De * 4);
+    stream_frames(audio_d, fj_d, (int)fj.size(), max_frames, k_scale_, frames_.as<bf16_t>(), stream_);
+    gemm_act(frames_.as<bf16_t>(), 96, lin_w_, nullptr, 1, 4 * P, De, 96, hid, nullptr, stream_);
+    copy_segments(segs_d, (int)segA.size(), stream_);
+    gemm_act(hid, 2 * De, conv1_w_, conv1_b_, 1, 2 * P - 2, 2 * De, 5 * De, c1o + (size_t)2 * 2 * De, nullptr, stream_);
+    copy_segments(segs_d + segA.size(), (int)segB.size(), stream_);
+    gemm_act(c1o, 4 * De, conv2_w_, conv2_b_, 0, P - 2, De, 10 * De, nullptr, fpk + (size_t)2 * De, stream_);
+    copy_segments(segs_d + segA.size() + segB.size(), (int)segC.size(), stream_);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,17 +590,43 @@ void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, i
   bf16_t* QKV = QKV_.as<bf16_t>();
   bf16_t* AO = AO_.as<bf16_t>();
   bf16_t* Z = Z_.as<bf16_t>();
+  using Sc = ScopeProfiler::Scope;
   for (int l = 0; l < cfg_.enc_layers; ++l) {
     const EncW& E = enc_[l];
-    layernorm_bf16(H, E.ln1, R, De, Y, nullptr, stream_);
-    gemm_act(Y, De, E.wqkv, nullptr, 0, R, 3 * De, De, QKV, nullptr, stream_);
-    stream_enc_attention(QKV, lo_d, hi_d, R, De, cfg_.encoder_heads, cfg_.windows[l].first, cfg_.windows[l].second, AO,
-                         stream_);
-    gemm_resid_f32(AO, De, E.wo, nullptr, R, De, De, H, stream_);
-    layernorm_bf16(H, E.ln2, R, De, Y, nullptr, stream_);
-    gemm_bias_gelu_bf16(Y, De, E.fc1, E.b1, R, Fe, De, Z, stream_);
-    gemm_resid_f32(Z, Fe, E.fc2, E.b2, R, De, Fe, H, stream_);
+    const double rd = (double)R * De;
+    {
+      Sc sc(&prof_, stream_, "senc_layernorm", 0, rd * 6);
+      layernorm_bf16(H, E.ln1, R, De, Y, nullptr, stream_);
+    }
+    {
+      Sc sc(&prof_, stream_, "senc_qkv_gemm", 2.0 * rd * 3 * De, rd * 2 * 4 + 6.0 * De * De);
+      gemm_act(Y, De, E.wqkv, nullptr, 0, R, 3 * De, De, QKV, nullptr, stream_);
+    }
+    {
+      const double keys = cfg_.windows[l].first + cfg_.windows[l].second + 1;
+      Sc sc(&prof_, stream_, "senc_window_attention", 4.0 * rd * keys, rd * 2 * 4);
+      stream_enc_attention(QKV, lo_d, hi_d, R, De, cfg_.encoder_heads, cfg_.windows[l].first, cfg_.windows[l].second, AO,
+                           stream_);
+    }
+    {
+      Sc sc(&prof_, stream_, "senc_oproj_gemm", 2.0 * rd * De, rd * (2 + 8) + 2.0 * De * De);
+      gemm_resid_f32(AO, De, E.wo, nullptr, R, De, De, H, stream_);
+    }
+    {
+      Sc sc(&prof_, stream_, "senc_layernorm", 0, rd * 6);
+      layernorm_bf16(H, E.ln2, R, De, Y, nullptr, stream_);
+    }
+    {
+      Sc sc(&prof_, stream_, "senc_fc1_gelu_gemm", 2.0 * rd * Fe, (double)R * (De + Fe) * 2 + 2.0 * De * Fe);
+      gemm_bias_gelu_bf16(Y, De, E.fc1, E.b1, R, Fe, De, Z, stream_);
+    }
+    {
+      Sc sc(&prof_, stream_, "senc_fc2_gemm", 2.0 * rd * Fe, (double)R * (Fe * 2 + De * 8) + 2.0 * De * Fe);
+      gemm_resid_f32(Z, Fe, E.fc2, E.b2, R, De, Fe, H, stream_);
+    }
   }
+  Sc sc_tail(&prof_, stream_, "stream_adapter_cross_kv", 2.0 * Nn * Dd * 2.0 * L * Dd + (proj_w_ != nullptr ? 2.0 * Nn * De * Dd : 0.0),
+             (double)Nn * Dd * (2 + 4.0 * L) + 4.0 * L * Dd * Dd);
   layernorm_bf16(H, enc_ln_, R, De, Y, Y32_.as<float>(), stream_);
   stream_adapter_in(Y32_.as<float>(), nrow_d, npos_d, Nn, De, pos_emb_, adp16_.as<bf16_t>(), adp32_.as<float>(),
                     stream_);
@@ -663,38 +695,58 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
   bf16_t* Z = Z_.as<bf16_t>();
   const RopeParams rp{rope_cos_, rope_sin_, rot_pairs_, cfg_.head_dim, Dd};
   const bool small = M <= 256;  // split-K decode kernel (16-row tiles) instead of 128-row MFMA tiles
+  // profiler groups: "sdec_*" for the one-row-per-stream AR steps (weight-streaming: bytes = the weights), "sver_*" for
+  // the wide verify pass (many rows per stream)
+  using Sc = ScopeProfiler::Scope;
+  const bool wide = runs_d != nullptr;
+  const double md = (double)M * Dd, wdd = 2.0 * Dd * Dd;
+  auto nm = [&](const char* ar, const char* ver) { return wide ? ver : ar; };
   for (int l = 0; l < L; ++l) {
     const DecW& W = dec_[l];
     // small passes: LayerNorm fused into the GEMM, q to its own buffer, k / v straight into the cache
-    if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
-      stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
-    } else {
-      layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
-      gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
-      stream_self_attention(QKV, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
+    {
+      Sc sc(&prof_, stream_, nm("sdec_qkv_self_attention", "sver_qkv_self_attention"), 2.0 * md * 3 * Dd, 3 * wdd + md * 12);
+      if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
+        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
+      } else {
+        layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
+        gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
+        stream_self_attention(QKV, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
+      }
     }
-    if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
-      gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
-    if (!(small && small_ln_gemm_bf16(H, W.wq_c_f, M, Dd, Dd, Q, stream_))) {
-      layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
-      gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+    {
+      Sc sc(&prof_, stream_, nm("sdec_proj_gemms", "sver_proj_gemms"), 2.0 * md * Dd * 2, 2 * wdd + md * 16);
+      if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
+        gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
+      if (!(small && small_ln_gemm_bf16(H, W.wq_c_f, M, Dd, Dd, Q, stream_))) {
+        layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
+        gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+      }
     }
     if (capture_probs_ != nullptr)  // word timestamps: this pass's cross-attention probabilities (cross_attention())
       stream_cross_probs(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, capture_ecap_, capture_probs_, stream_);
-    if (runs_d != nullptr)
-      stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
-    else
-      stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
-    if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
-      gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
-    if (!(small && small_ln_gemm_swiglu(H, W.fc1_f, W.b1, M, 2 * Fd, Dd, Z, stream_))) {
-      layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
-      gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+    {
+      Sc sc(&prof_, stream_, nm("sdec_cross_attention", "sver_cross_attention"), 0, pass_cross_bytes_ / L + md * 4);
+      if (runs_d != nullptr)
+        stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+      else
+        stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
     }
-    if (!(small && small_gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_)))
-      gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
+    {
+      Sc sc(&prof_, stream_, nm("sdec_crosso_mlp_gemms", "sver_crosso_mlp_gemms"), 2.0 * md * (Dd + 3.0 * Fd),
+            wdd + 6.0 * Dd * Fd + md * 16);
+      if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
+        gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
+      if (!(small && small_ln_gemm_swiglu(H, W.fc1_f, W.b1, M, 2 * Fd, Dd, Z, stream_))) {
+        layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
+        gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+      }
+      if (!(small && small_gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_)))
+        gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
+    }
   }
   // (an LN-fused head would redo the LayerNorm in each of its V / 64 column tiles: measured 46 vs 28 + 5 us)
+  Sc sc(&prof_, stream_, nm("sdec_lm_head", "sver_lm_head"), 2.0 * md * V, 2.0 * V * Dd + (pval != nullptr ? 0.0 : 4.0 * M * V));
   layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
   if (pval != nullptr) {   // nobody reads the logits of this pass: only each column tile's maximum leaves the GEMM
     gemm_argmax_partials(Y, Dd, head_w_, M, V, Dd, pval, pidx, stream_);
@@ -876,6 +928,11 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
   int n_runs = 0;
   const int2* runs_d = stage_runs(rs, &n_runs);
+  // algorithmic K / V bytes of a pass over all layers: every stream's memory once per pass (the run kernel's design), two
+  // tensors, bf16
+  double mem_rows = 0.0;
+  for (int sl : job_slot) mem_rows += st(sl).mem_len;
+  pass_cross_bytes_ = mem_rows * Dd * 2.0 * 2.0 * cfg_.depth;
   decoder_pass(M, rs_d, rp_d, logits_.as<float>(), runs_d, n_runs);
   // the biaser's bonuses go in before every token choice, the verify pass included (streaming-model.cpp:1241-1246,
   // 1304-1315); row t of a stream is conditioned on draft[0..t)
@@ -916,7 +973,8 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     const char* e = getenv("MSH_NO_GRAPH");
     return !(e != nullptr && e[0] == '1');
   }();
-  if (use_graph && max_budget > 0) {
+  const bool graph_now = use_graph && !prof_.on();   // event scopes cannot sit inside a replayed graph
+  if (graph_now && max_budget > 0) {
     char key[512];
     snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
              logits_.p, pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p,
@@ -955,7 +1013,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       MSH_HIP(hipStreamSynchronize(stream_));
       if (active <= 0) break;
     }
-    if (use_graph) MSH_HIP(hipGraphLaunch(ar_graph_, stream_));
+    if (graph_now) MSH_HIP(hipGraphLaunch(ar_graph_, stream_));
     else ar_step();
   }
   std::vector<SlotDev> sd(J);

@@ -77,6 +77,9 @@ class StreamingEngine {
   void get_features(int slot, float* out);  // [feature_count][De]
   int max_tokens_for(int slot) const;       // streaming-model.cpp:1217-1219
   void synchronize();
+  void profile_enable(bool on) { prof_.enable(on, stream_); }
+  void profile_reset() { prof_.reset(stream_); }
+  std::vector<ProfEntry> profile_get() { return prof_.get(stream_); }
   hipStream_t stream() const { return stream_; }
 
  private:
@@ -112,6 +115,11 @@ class StreamingEngine {
     bf16_t *wqkv_f, *wq_c_f, *fc1_f;  // LayerNorm scale folded in (LN-fused small-batch GEMMs of the AR steps)
   };
 
+  // per-kernel-group timing (profiler.h); while it is on, the AR steps run eagerly instead of from their hipGraph.
+  // pass_cross_bytes_: algorithmic K / V bytes of the decoder pass being enqueued (rows x their stream's memory), set by
+  // the callers of decoder_pass for the profiler
+  ScopeProfiler prof_;
+  double pass_cross_bytes_ = 0.0;
   hipGraphExec_t ar_graph_ = nullptr;  // one autoregressive decode step (decode_full), replayed
   std::string ar_key_;
   float* capture_probs_ = nullptr;  // set while cross_attention() runs its pass

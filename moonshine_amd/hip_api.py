@@ -97,6 +97,11 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_stream_decode_full": (i32, [vp, i32, vp, P(vp), vp, vp, vp, vp, i32, vp]),
         "msh_stream_set_bias": (i32, [vp, i32, vp, vp, vp, vp, vp, i32]),
         "msh_stream_query": (i32, [vp, i32, i32]),
+        "msh_stream_profile_enable": (i32, [vp, i32]),
+        "msh_stream_profile_reset": (i32, [vp]),
+        "msh_stream_profile_count": (i32, [vp]),
+        "msh_stream_profile_get": (i32, [vp, i32, P(ProfileEntry)]),
+        "msh_test_mlp_microbench": (C.c_float, [i32, i32, i32, i32, i32]),
         "msh_stream_get_memory": (i32, [vp, i32, vp]),
         "msh_stream_get_features": (i32, [vp, i32, vp]),
         "msh_host_tokens_to_text": (C.c_int64, [vp, u64, vp, u64, vp, u64]),
@@ -128,6 +133,8 @@ DECLARED_SYMBOLS = [
     "msh_stream_last_error", "msh_stream_info_get", "msh_stream_open", "msh_stream_close", "msh_stream_reset",
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens", "msh_stream_cross_attention",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
+    "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
+    "msh_test_mlp_microbench", "msh_test_mlp_run",
     "msh_stream_get_features",
 ]
 
@@ -461,6 +468,21 @@ class StreamEngine:
         off, tok, node, dep, bon = a(off, np.int32), a(tok, np.int32), a(node, np.int32), a(depth, np.int32), a(depth_bonus, np.float32)
         self._check(self.lib.msh_stream_set_bias(self.h, len(children), off.ctypes.data, tok.ctypes.data, node.ctypes.data,
                                                  dep.ctypes.data, bon.ctypes.data, bon.shape[0]))
+
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.msh_stream_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.msh_stream_profile_reset(self.h))
+
+    def profile(self) -> list[dict]:
+        n = self._check(self.lib.msh_stream_profile_count(self.h))
+        out = []
+        for i in range(n):
+            pe = ProfileEntry()
+            self._check(self.lib.msh_stream_profile_get(self.h, i, C.byref(pe)))
+            out.append({"name": pe.name.decode(), "ms": pe.ms, "launches": int(pe.launches), "flops": pe.flops, "bytes": pe.bytes})
+        return out
 
     def query(self, slot: int, what: int) -> int:
         return self._check(self.lib.msh_stream_query(self.h, slot, what))
