@@ -5,9 +5,18 @@
 // reference implementation byte for byte.  The reference sources are compiled where they lie under /root/reference/core
 // (nothing is copied into this repository) by oracle/build_ref.py into oracle/_ref/libmoonshine_ref_host.so:
 //   resampler.cpp, word-alignment.cpp, context-biaser.cpp, context-extractor.cpp, bin-tokenizer/bin-tokenizer.cpp,
-//   moonshine-utils/{debug-utils,string-utils,file-utils}.cpp
+//   moonshine-utils/{debug-utils,string-utils,file-utils}.cpp, voice-activity-detector.cpp
+// Two rows need a seam:
+//   * VoiceActivityDetector (core/voice-activity-detector.cpp:69-199) calls SileroVad::predict, whose implementation
+//     (core/silero-vad.cpp) is the ONNX Runtime driver.  The detector is compiled as it is; the SileroVad member functions
+//     are DEFINED HERE as a stub that hands out precomputed probabilities, one per hop -- the counterpart of
+//     msh_host_vad_segments_from_probs (the device-VAD path of batch calls feeds the detector the same way).
+//   * Transcriber::sanitize_text (core/transcriber.cpp:1489-1543) sits in a translation unit that needs the whole ORT
+//     model stack to link.  oracle/build_ref.py lifts that one function's text out of the reference file at build time
+//     into the git-ignored oracle/_ref/sanitize_text_extracted.inc (never committed, never edited), included below.
 // Every ref_host_* function below has the argument list of the msh_host_* function of include/moonshine_hip.h it checks.
 // The reference's arithmetic hot path (ONNX Runtime + .ort graphs) is NOT buildable here; see DESIGN.md section 4.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -19,7 +28,32 @@
 #include "context-extractor.h"             // core/context-extractor.h
 #include "debug-utils.h"                   // core/moonshine-utils/debug-utils.h (load_wav_data / save_wav_data)
 #include "resampler.h"                     // core/resampler.h
+#include "voice-activity-detector.h"       // core/voice-activity-detector.h (pulls in core/silero-vad.h + the ORT C header)
 #include "word-alignment.h"                // core/word-alignment.h
+
+#if __has_include("_ref/sanitize_text_extracted.inc")
+#define REF_HAS_SANITIZE 1
+namespace refx {
+struct Transcriber {   // the extracted definition is a static member function of this name
+  static std::string* sanitize_text(const char* text);
+};
+#include "_ref/sanitize_text_extracted.inc"
+}  // namespace refx
+#endif
+
+// ---- SileroVad stub: precomputed probabilities, one per predict() call, in order ----
+namespace {
+std::vector<float> g_probs;
+size_t g_prob_next = 0;
+}  // namespace
+SileroVad::SileroVad(int, int, float, int, int, int, float) {}
+SileroVad::~SileroVad() {}
+void SileroVad::predict(const std::vector<float>&, float* out_probability, int* out_flag) {
+  const float p = g_prob_next < g_probs.size() ? g_probs[g_prob_next] : 0.0f;
+  ++g_prob_next;
+  if (out_probability) *out_probability = p;
+  if (out_flag) *out_flag = p > 0.5f;
+}
 
 namespace {
 int64_t copy_out(const std::string& r, char* out, uint64_t cap) {
@@ -165,6 +199,50 @@ int64_t ref_host_resample(const float* in, uint64_t n, float in_rate, float out_
   const std::vector<float> r = resample_audio(std::vector<float>(in, in + n), in_rate, out_rate);
   if (out != nullptr) memcpy(out, r.data(), sizeof(float) * (r.size() < out_cap ? r.size() : (size_t)out_cap));
   return (int64_t)r.size();
+}
+
+// VoiceActivityDetector start / process_audio (in `chunk`-sample calls, chunk = 0: one call) / stop, with the Silero
+// probabilities of the hops supplied (ignored by the detector when threshold == 0).  out[4i..4i+3] = (round(start_time *
+// 16000), audio sample count, is_complete, FNV-1a of the segment's audio bytes); returns the segment count.
+int64_t ref_host_vad_segments(float threshold, int32_t window, int32_t hop, uint64_t look_behind, uint64_t max_segment,
+                              const float* audio, uint64_t n_samples, int32_t sample_rate, uint64_t chunk, const float* probs,
+                              uint64_t n_probs, int64_t* out, uint64_t max_segments) {
+  g_probs.assign(probs, probs + (probs ? n_probs : 0));
+  g_prob_next = 0;
+  VoiceActivityDetector vad(threshold, window, hop, (size_t)look_behind, (size_t)max_segment);
+  vad.start();
+  if (chunk == 0) chunk = n_samples ? n_samples : 1;
+  for (uint64_t i = 0; i < n_samples; i += chunk) vad.process_audio(audio + i, (size_t)((n_samples - i) < chunk ? (n_samples - i) : chunk), sample_rate);
+  vad.stop();
+  const std::vector<VoiceActivitySegment>* segs = vad.get_segments();
+  uint64_t k = 0;
+  for (const VoiceActivitySegment& s : *segs) {
+    if (k < max_segments) {
+      uint64_t h = 1469598103934665603ull;
+      const uint8_t* b = reinterpret_cast<const uint8_t*>(s.audio_data.data());
+      for (size_t i = 0; i < s.audio_data.size() * sizeof(float); ++i) h = (h ^ b[i]) * 1099511628211ull;
+      out[4 * k] = (int64_t)llround((double)s.start_time * 16000.0);
+      out[4 * k + 1] = (int64_t)s.audio_data.size();
+      out[4 * k + 2] = s.is_complete ? 1 : 0;
+      out[4 * k + 3] = (int64_t)h;
+    }
+    ++k;
+  }
+  return (int64_t)k;
+}
+
+// Transcriber::sanitize_text (core/transcriber.cpp:1489-1543), same return rule as msh_host_sanitize_utf8
+int64_t ref_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap) {
+#ifdef REF_HAS_SANITIZE
+  const std::string in(text, (size_t)n);   // the reference takes a C string: the tests keep NUL out of the input
+  std::string* r = refx::Transcriber::sanitize_text(in.c_str());
+  const int64_t len = copy_out(*r, out, out_cap);
+  delete r;
+  return len;
+#else
+  (void)text; (void)n; (void)out; (void)out_cap;
+  return -1;
+#endif
 }
 
 }  // extern "C"

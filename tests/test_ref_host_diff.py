@@ -247,3 +247,111 @@ def test_wav_io_identical(pair, tmp_path):
     bad.write_bytes(b"RIFF\x00\x00\x00\x00WAVEjunk")
     r = C.c_int32(0)
     assert all(f(str(bad).encode(), None, 0, C.addressof(r)) < 0 for f in pair.fns["load_wav"])
+
+
+def test_sanitize_text_identical(pair):
+    """Transcriber::sanitize_text (core/transcriber.cpp:1489-1543, lifted into oracle/_ref at build time) against
+    msh_host_sanitize_utf8 on random byte strings: valid UTF-8 of every length, truncated sequences at the end and in the
+    middle, stray continuation bytes, overlong-looking starts, 0xF5-0xFF -- byte for byte."""
+    ours = load_library().msh_host_sanitize_utf8
+    ref = C.CDLL(ref_library_path()).ref_host_sanitize_utf8
+    for f in (ours, ref):
+        f.restype, f.argtypes = i64, [C.c_char_p, u64, C.c_char_p, u64]
+    if ref(b"a", 1, C.create_string_buffer(8), 8) < 0:
+        pytest.skip("oracle/_ref was built without the sanitize_text extraction")
+    rng = np.random.default_rng(11)
+    pieces = [b"a", b"\xc3\xa9", b"\xe2\x82\xac", b"\xf0\x9f\x98\x80", b"\x80", b"\xbf", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\xf5", b"\xff",
+              b"\xc0\xaf", b"\xed\xa0\x80", b" "]
+    cases = [b"", b"\xf0\x9f", b"\xe2", b"plain ascii"]
+    for _ in range(1500):
+        if rng.random() < 0.5:
+            raw = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), int(rng.integers(0, 12))))
+        else:
+            raw = bytes(rng.integers(1, 256, int(rng.integers(0, 20))).tolist())   # (no NUL: the reference takes a C string)
+        cases.append(raw)
+    for raw in cases:
+        a, b = C.create_string_buffer(len(raw) + 8), C.create_string_buffer(len(raw) + 8)
+        na, nb = ours(raw, len(raw), a, len(a)), ref(raw, len(raw), b, len(b))
+        assert na == nb and a.raw[:na] == b.raw[:nb], raw
+
+
+def _fnv(x: np.ndarray) -> int:
+    h = 1469598103934665603
+    for byte in x.tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h - (1 << 64) if h >= (1 << 63) else h
+
+
+def test_vad_state_machine_identical(pair):
+    """VoiceActivityDetector (core/voice-activity-detector.cpp:69-199, compiled as it is; its SileroVad::predict stubbed with
+    the supplied per-hop probabilities) against the library's detector fed the same probabilities
+    (msh_host_vad_segments_from_probs, the host half of the device-VAD path) and, for threshold 0, against
+    msh_host_vad_segments with chunked feeding and other sample rates: segment starts, lengths, completion flags and the
+    segments' audio (hash) must be identical -- probability ring, look-behind, max-segment fade, start / continue / end."""
+    ours_lib = load_library()
+    refl = C.CDLL(ref_library_path())
+    ref = refl.ref_host_vad_segments
+    ref.restype = i64
+    ref.argtypes = [f32, i32, i32, u64, u64, vp, u64, i32, u64, vp, u64, vp, u64]
+    fp = ours_lib.msh_host_vad_segments_from_probs
+    fp.restype = i64
+    fp.argtypes = [C.c_char_p, u64, f32, i32, i32, u64, u64, u64, vp, u64, vp, u64, vp, u64]
+    f0 = ours_lib.msh_host_vad_segments
+    f0.restype = i64
+    f0.argtypes = [vp, u64, f32, i32, i32, u64, u64, u64, vp, u64, i32, u64, vp, u64]
+    rng = np.random.default_rng(5)
+    # the library's hook wants a Silero weights blob (the detector it builds is the Transcriber's); with the probabilities
+    # supplied the network itself never runs
+    import tempfile
+
+    from moonshine_amd.synth import make_silero_weights, save_safetensors
+
+    with tempfile.TemporaryDirectory() as d:
+        wp = os.path.join(d, "silero_vad.safetensors")
+        save_safetensors(wp, make_silero_weights(2))
+        blob = open(wp, "rb").read()
+
+    def ours_rows(bounds, k, audio16):
+        rows = []
+        for i in range(k):
+            s, cnt, comp = int(bounds[3 * i]), int(bounds[3 * i + 1]), int(bounds[3 * i + 2])
+            rows.append((s, cnt, comp, _fnv(audio16[s:s + cnt])))
+        return rows
+
+    checked = 0
+    for trial in range(60):
+        hop = 512   # (with Silero on, this build pins the hop to the network's 512-sample window and says so at load)
+        n = int(rng.integers(0, 40)) * hop + int(rng.integers(0, hop))
+        n += int(rng.integers(0, 8)) * 16000 if trial % 3 == 0 else 0
+        audio = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        window = int(rng.choice([1, 4, 16, 32]))
+        look = int(rng.choice([512, 4096, 8192]))   # (the reference shifts its look-behind ring by one hop in place: UB below one hop)
+        max_seg = int(rng.choice([0, 3 * 16000, 15 * 16000, 1600]))
+        thr = float(rng.choice([0.5, 0.3, 0.7]))
+        hops = n // hop
+        # speech-like probability tracks: runs of high / low values with noise, so that segments start and end
+        probs = np.clip(np.repeat(rng.random(hops // 7 + 2), 7)[:hops] * 1.2 - 0.1 + rng.normal(0, 0.1, hops), 0, 1).astype(np.float32)
+        outr = np.zeros(4 * 256, np.int64)
+        kr = ref(thr, window, hop, look, max_seg, audio.ctypes.data, n, 16000, 0, probs.ctypes.data, hops, outr.ctypes.data, 256)
+        outo = np.zeros(3 * 256, np.int64)
+        ko = fp(blob, len(blob), thr, window, hop, look, max_seg, 0, audio.ctypes.data, n, probs.ctypes.data, hops, outo.ctypes.data, 256)
+        assert ko == kr, (trial, ko, kr)
+        want = [tuple(int(v) for v in outr[4 * i:4 * i + 4]) for i in range(kr)]
+        assert ours_rows(outo, ko, audio) == want, trial
+        checked += kr
+    assert checked > 40   # the tracks do cut segments
+    # threshold 0 (all audio is speech): chunked feeding, other sample rates (the detector resamples), tiny max_segment
+    for trial in range(40):
+        rate = int(rng.choice([16000, 16000, 48000, 24000, 8000]))
+        n = int(rng.integers(0, 6 * rate))
+        audio = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        chunk = int(rng.choice([0, 160, 1000, 4096, 7777]))
+        look = int(rng.choice([512, 4096]))
+        max_seg = int(rng.choice([0, 16000, 15 * 16000]))
+        outr = np.zeros(4 * 256, np.int64)
+        kr = ref(0.0, 32, 512, look, max_seg, audio.ctypes.data, n, rate, chunk, None, 0, outr.ctypes.data, 256)
+        outo = np.zeros(3 * 256, np.int64)
+        ko = f0(None, 0, 0.0, 32, 512, look, max_seg, 0, audio.ctypes.data, n, rate, chunk if chunk else max(n, 1), outo.ctypes.data, 256)
+        assert ko == kr, (trial, rate, n, chunk, ko, kr)
+        for i in range(kr):   # the audio of a resampled segment lives inside the detector: compare starts / lengths / flags
+            assert tuple(int(v) for v in outo[3 * i:3 * i + 3]) == tuple(int(v) for v in outr[4 * i:4 * i + 3]), (trial, i)
