@@ -64,6 +64,13 @@ MSH_EXPORT int32_t msh_load_weights_file(msh_engine* e, const char* safetensors_
 MSH_EXPORT int32_t msh_load_weights_memory(msh_engine* e, const void* data, uint64_t size, int32_t model_arch);
 MSH_EXPORT int32_t msh_model_info_get(const msh_engine* e, msh_model_info* out);
 
+/* The checks of msh_load_weights_* without a GPU: parses the safetensors blob, validates every tensor the architecture
+ * needs (name, shape, dtype F32 / F16 / BF16), an optional `proj_out.weight` (must BE the tied embedding) and refuses tensors
+ * the loader does not know; *out receives the dimensions found.  On failure returns MSH_ERR_INVALID_ARGUMENT and writes the
+ * reason to err (NUL-terminated, at most err_cap bytes).  What tools/verify_real_checkpoint.py runs first on a download. */
+MSH_EXPORT int32_t msh_host_check_weights(const void* safetensors, uint64_t size, int32_t model_arch, msh_model_info* out,
+                                          char* err, uint64_t err_cap);
+
 /* Encoder (+ cross-attention K/V projection) over a batch of 16 kHz mono float clips.
  * pcm[i] points to n_samples[i] floats in host memory, or in device memory when pcm_on_device != 0.
  * Replaces the encoder ORT_RUN of reference core/moonshine-model.cpp:245-290, batched. */

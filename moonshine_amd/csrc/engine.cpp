@@ -190,6 +190,14 @@ void DevBuf::release() {
 }
 
 // ------------------------------------------------------------------------------------------------
+Engine::Engine(DryRun) : device_(-1), dry_run_(true) {}
+
+ModelConfig Engine::check_weights(const SafeTensors& st, int expect_arch) {
+  Engine e(DryRun{});
+  e.load_weights(st, expect_arch);
+  return e.cfg_;
+}
+
 Engine::Engine(int device) : device_(device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -216,6 +224,7 @@ Engine::Engine(int device) : device_(device) {
 }
 
 Engine::~Engine() {
+  if (dry_run_) return;   // nothing was ever allocated
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   groups_.clear();
@@ -244,6 +253,7 @@ void Engine::synchronize() {
 }
 
 void Engine::upload(const std::vector<float>& src, float** dst) {
+  if (dry_run_) return;
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
@@ -255,6 +265,7 @@ void Engine::upload(const std::vector<float>& src, float** dst) {
 }
 
 void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
+  if (dry_run_) return;
   std::vector<bf16_t> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
   void* p = nullptr;
@@ -272,6 +283,7 @@ void Engine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16
   if ((rows & 15) != 0 || (K & 31) != 0 || src.size() != (size_t)rows * K)
     throw std::runtime_error("decode weight [" + std::to_string(rows) + ", " + std::to_string(K) +
                              "] cannot be packed for the MFMA decode kernels (rows % 16, K % 32)");
+  if (dry_run_) return;
   std::vector<bf16_t> tmp(src.size());
   const int ks = K >> 5;
   for (int r = 0; r < rows; ++r)
@@ -315,8 +327,9 @@ void Engine::share_weights_from(const Engine& o) {
 
 // ------------------------------------------------------------------------------------------------
 void Engine::load_weights(const SafeTensors& st, int expect_arch) {
-  MSH_HIP(hipSetDevice(device_));
+  if (!dry_run_) MSH_HIP(hipSetDevice(device_));
   if (loaded_) throw std::runtime_error("weights already loaded");
+  st.used.clear();
   ModelConfig c;
   const StTensor& c1 = st.get("model.encoder.conv1.weight");
   if (c1.shape.size() != 3 || c1.shape[1] != 1 || c1.shape[2] != 127)
@@ -416,7 +429,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "mlp.fc2.bias", D), &L.b2);
     upload(vec(p + "input_layernorm.weight", D), &L.ln1);
     upload(vec(p + "post_attention_layernorm.weight", D), &L.ln2);
-    if (mlp_fused_supported(D, F)) {   // the same block once more, packed for the fused kernel (k_mlp.hip)
+    if (mlp_fused_supported(D, F) && !dry_run_) {   // the same block once more, packed for the fused kernel (k_mlp.hip)
       const std::vector<float> w1 = st.to_f32(p + "mlp.fc1.weight"), w2 = st.to_f32(p + "mlp.fc2.weight");
       const std::vector<float> g = vec(p + "post_attention_layernorm.weight", D), b1 = vec(p + "mlp.fc1.bias", F);
       std::vector<bf16_t> packed(mlp_packed_elems(D, F));
@@ -529,6 +542,30 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
   }
   upload(cs, &rope_cos_);
   upload(sn, &rope_sin_);
+  // The LM head is tied to the embedding (configuration_moonshine.py:103; the engine multiplies by embed_tokens).  A
+  // checkpoint may carry the alias `proj_out.weight` as well: accepted when it IS the embedding, refused when it is not --
+  // an untied head would otherwise be silently ignored.
+  if (st.has("proj_out.weight")) {
+    expect_shape("proj_out.weight", {V, D});
+    const std::vector<float> head = st.to_f32("proj_out.weight"), emb = st.to_f32("model.decoder.embed_tokens.weight");
+    for (size_t i = 0; i < head.size(); ++i)
+      if (head[i] != emb[i])
+        throw std::runtime_error("proj_out.weight differs from model.decoder.embed_tokens.weight: this engine implements the tied "
+                                 "LM head of the Moonshine configuration (tie_word_embeddings)");
+  }
+  // Anything else in the file is something this loader does not understand: say so instead of transcribing with half a
+  // model.  (Position buffers some exporters persist are the only benign extras known.)
+  {
+    std::string extra;
+    int n_extra = 0;
+    for (const std::string& name : st.unused()) {
+      if (name.size() >= 8 && name.compare(name.size() - 8, 8, "inv_freq") == 0) continue;
+      if (n_extra++ < 6) extra += (extra.empty() ? "" : ", ") + name;
+    }
+    if (n_extra > 0)
+      throw std::runtime_error(std::to_string(n_extra) + " tensor(s) in the checkpoint are not part of the Moonshine " + c.arch +
+                               " architecture this engine loads: " + extra + (n_extra > 6 ? ", ..." : ""));
+  }
   loaded_ = true;
 }
 

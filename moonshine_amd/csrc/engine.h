@@ -52,6 +52,9 @@ class Engine {
  public:
   explicit Engine(int device);
   ~Engine();
+  // Checkpoint validation without a GPU (msh_host_check_weights): runs load_weights with every upload skipped and returns
+  // the dimensions it found; throws what a real load would throw.
+  static ModelConfig check_weights(const SafeTensors& st, int expect_arch);
 
   void load_weights(const SafeTensors& st, int expect_arch /* -1 any, 0 tiny, 1 base */);
   // Use the weight buffers of a loaded engine on the same device (read-only; `owner` must outlive this engine).
@@ -129,6 +132,9 @@ class Engine {
   int device_;
   hipStream_t stream_ = nullptr;
   void* stream_probe_ = nullptr;
+  struct DryRun {};
+  explicit Engine(DryRun);   // no device: only load_weights' validation runs
+  bool dry_run_ = false;
   ModelConfig cfg_;
   bool loaded_ = false;
   std::vector<void*> weight_allocs_;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, 2) void enc_attention_kernel(const bf16_t*
   const int tile0 = blockIdx.x * tiles_per_wg;
   if (tile0 * 16 >= cm.rows) return;
   const int h = blockIdx.y;
-  const int T = cm.T, Tk = cm.Tk;
+  const int T = cm.T;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long ld = 2L * D;   // [row][q | k]

@@ -156,6 +156,36 @@ int32_t msh_model_info_get(const msh_engine* e, msh_model_info* out) {
   return MSH_OK;
 }
 
+int32_t msh_host_check_weights(const void* data, uint64_t size, int32_t model_arch, msh_model_info* out, char* err, uint64_t err_cap) {
+  if (err != nullptr && err_cap > 0) err[0] = 0;
+  try {
+    if (data == nullptr || size == 0) throw std::invalid_argument("null / empty checkpoint");
+    msh::SafeTensors st;
+    st.parse(static_cast<const uint8_t*>(data), (size_t)size);
+    const msh::ModelConfig c = msh::Engine::check_weights(st, model_arch);
+    if (out != nullptr) {
+      memset(out, 0, sizeof(*out));
+      out->hidden = c.hidden;
+      out->ffn = c.ffn;
+      out->enc_layers = c.enc_layers;
+      out->dec_layers = c.dec_layers;
+      out->heads = c.heads;
+      out->head_dim = c.head_dim();
+      out->vocab = c.vocab;
+      out->bos = c.bos;
+      out->eos = c.eos;
+      strncpy(out->arch, c.arch.c_str(), sizeof(out->arch) - 1);
+    }
+    return MSH_OK;
+  } catch (const std::exception& ex) {
+    if (err != nullptr && err_cap > 0) {
+      strncpy(err, ex.what(), (size_t)err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
 int32_t msh_encode(msh_engine* e, const float* const* pcm, const uint64_t* n_samples, uint32_t count,
                    int32_t pcm_on_device, float max_tokens_per_second) {
   return guarded(e, [&] {

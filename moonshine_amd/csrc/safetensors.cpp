@@ -272,7 +272,15 @@ void SafeTensors::load_file(const std::string& path) {
 const StTensor& SafeTensors::get(const std::string& name) const {
   auto it = tensors.find(name);
   if (it == tensors.end()) throw std::runtime_error("safetensors: missing tensor " + name);
+  used.insert(name);
   return it->second;
+}
+
+std::vector<std::string> SafeTensors::unused() const {
+  std::vector<std::string> out;
+  for (const auto& kv : tensors)
+    if (used.count(kv.first) == 0) out.push_back(kv.first);
+  return out;
 }
 
 std::vector<float> SafeTensors::to_f32(const std::string& name) const {
@@ -286,9 +294,11 @@ std::vector<float> SafeTensors::to_f32(const std::string& name) const {
       uint32_t u = ((uint32_t)s[i]) << 16;
       memcpy(&out[i], &u, 4);
     }
-  } else {
+  } else if (t.dtype == "F16") {
     const uint16_t* s = reinterpret_cast<const uint16_t*>(t.data);
     for (size_t i = 0; i < out.size(); ++i) out[i] = half_to_float(s[i]);
+  } else {
+    throw std::runtime_error("safetensors: tensor " + name + " has dtype " + t.dtype + "; the engine reads F32, F16 and BF16 weights");
   }
   return out;
 }
