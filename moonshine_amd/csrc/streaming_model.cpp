@@ -120,6 +120,7 @@ MoonshineStreamingState* MoonshineStreamingModel::create_state() {
   MoonshineStreamingState* s = new MoonshineStreamingState();
   s->owner = this;
   s->slot = slot;
+  ++states_live_;
   return s;
 }
 
@@ -127,6 +128,7 @@ void MoonshineStreamingModel::free_state(MoonshineStreamingState* state) {
   if (state == nullptr) return;
   std::lock_guard<std::mutex> lock(processing_mutex);
   msh_stream_close(engine, state->slot);
+  --states_live_;
   delete state;
 }
 

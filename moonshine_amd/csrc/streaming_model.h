@@ -42,6 +42,7 @@ struct MoonshineStreamingModel {
   MoonshineStreamingConfig config;
   std::string last_error;
   int device = 0, max_streams = 64, max_memory_frames = 2048;
+  int states_live_ = 0;
 
   MoonshineStreamingModel(int device, int max_streams, int max_memory_frames);
   ~MoonshineStreamingModel();
@@ -54,6 +55,10 @@ struct MoonshineStreamingModel {
 
   MoonshineStreamingState* create_state();          // reference :181
   void free_state(MoonshineStreamingState* state);
+  int states_in_use() {   // device slots held by live states (what the Transcriber balances streams over devices with)
+    std::lock_guard<std::mutex> lock(processing_mutex);
+    return states_live_;
+  }
   int reset_state(MoonshineStreamingState* state);   // MoonshineStreamingState::reset
 
   int process_audio_chunk(MoonshineStreamingState* state, const float* audio_chunk, size_t chunk_len,

@@ -428,7 +428,23 @@ void Transcriber::load_streaming_model() {
   // (word_timestamps: the reference swaps in decoder_kv_with_attention.ort here, core/transcriber.cpp:327-345; this engine
   //  computes the attention of the final token sequence on request, StreamingEngine::cross_attention)
   const int frames = (int)ceilf(opt_.max_stream_seconds * 50.0f);
-  streaming_model_.reset(new MoonshineStreamingModel(opt_.device, opt_.max_streams, frames));
+  std::vector<int> ids = opt_.device_ids;
+  if (ids.empty()) {
+    int n = opt_.num_gpus;
+    if (n < 0) n = msh_device_count() - opt_.device;   // every visible GPU from `device` on
+    if (n < 1) n = 1;
+    for (int i = 0; i < n; ++i) ids.push_back(opt_.device + i);
+  }
+  {
+    const int visible = msh_device_count();
+    for (int d : ids)
+      if (visible > 0 && (d < 0 || d >= visible))
+        throw std::runtime_error("GPU " + std::to_string(d) + " requested (options device / num_gpus / devices) but only " +
+                                 std::to_string(visible) + " visible");
+  }
+  streaming_model_.reset(new MoonshineStreamingModel(ids[0], opt_.max_streams, frames));
+  for (size_t i = 1; i < ids.size(); ++i)
+    streaming_more_.emplace_back(new MoonshineStreamingModel(ids[i], opt_.max_streams, frames));
   if (opt_.model_source == TranscriberOptions::FILES) {
     if (opt_.model_path.empty()) throw std::runtime_error("Model path is null");
     if (!is_dir_or_file(opt_.model_path))
@@ -445,9 +461,9 @@ void Transcriber::load_streaming_model() {
         throw std::runtime_error("Required model file does not exist at path '" + f + "'");
       }
     }
-    if (streaming_model_->load(opt_.model_path.c_str(), tok.c_str(), (int32_t)opt_.model_arch) != 0)
-      throw std::runtime_error("Failed to load streaming model from '" + opt_.model_path +
-                               "': " + streaming_model_->last_error);
+    for (MoonshineStreamingModel* m : streaming_models())   // replicated weights: every device reads the files itself
+      if (m->load(opt_.model_path.c_str(), tok.c_str(), (int32_t)opt_.model_arch) != 0)
+        throw std::runtime_error("Failed to load streaming model from '" + opt_.model_path + "': " + m->last_error);
   } else {
     auto get = [&](const char* name, std::vector<uint8_t>* owned, const uint8_t** p, size_t* n) {
       auto it = opt_.memory_files.find(name);
@@ -467,8 +483,9 @@ void Transcriber::load_streaming_model() {
     get(kWeightsName, &o1, &w, &wn);
     get(kTokenizerName, &o2, &t, &tn);
     get("streaming_config.json", &o3, &c, &cn);
-    if (streaming_model_->load_from_memory(w, wn, std::string((const char*)c, cn), t, tn, (int32_t)opt_.model_arch) != 0)
-      throw std::runtime_error("Failed to load streaming model from memory: " + streaming_model_->last_error);
+    for (MoonshineStreamingModel* m : streaming_models())
+      if (m->load_from_memory(w, wn, std::string((const char*)c, cn), t, tn, (int32_t)opt_.model_arch) != 0)
+        throw std::runtime_error("Failed to load streaming model from memory: " + m->last_error);
   }
 }
 
@@ -514,8 +531,8 @@ void Transcriber::set_keyterms(const std::vector<std::string>& keyterms) {
       if (!tokens.empty()) context_biaser_.add_token_sequence(tokens);
     }
   std::lock_guard<std::mutex> ml(model_mutex_);
-  if (streaming_model_->set_biaser(context_biaser_) != 0)
-    throw std::runtime_error("Failed to install the key terms: " + streaming_model_->last_error);
+  for (MoonshineStreamingModel* m : streaming_models())
+    if (m->set_biaser(context_biaser_) != 0) throw std::runtime_error("Failed to install the key terms: " + m->last_error);
   if (opt_.log_output_text)
     MSH_LOGF("Compiled %zu key terms for contextual biasing (boost %.2f)", keyterms.size(), context_biaser_.boost());
 }
@@ -532,7 +549,44 @@ Transcriber::~Transcriber() {
 // each segment, encode (final = the segment is complete), then decode from scratch -- with the previous
 // pass's tokens as a speculative draft when there is one -- and keep the tokens for the next pass.
 void Transcriber::transcribe_segments_with_streaming_model(std::vector<StreamingJob>& jobs) {
-  MoonshineStreamingModel* m = streaming_model_.get();
+  // Streams shard over the devices as clips do: a stream's device is fixed when its first line starts --
+  // the one holding the fewest lines -- and every device then runs its own batch of this round on its own host thread.
+  const std::vector<MoonshineStreamingModel*> models = streaming_models();
+  std::vector<std::vector<StreamingJob*>> part(models.size());
+  std::vector<int> load(models.size(), 0);
+  for (size_t d = 0; d < models.size(); ++d) load[d] = models[d]->states_in_use();
+  for (StreamingJob& j : jobs) {
+    size_t d = 0;
+    if (j.stream->sowner != nullptr) {
+      for (size_t k = 0; k < models.size(); ++k)
+        if (models[k] == j.stream->sowner) d = k;
+    } else {
+      for (size_t k = 1; k < models.size(); ++k)
+        if (load[k] < load[d]) d = k;
+      ++load[d];
+      j.stream->sowner = models[d];   // the state itself is created on that device by transcribe_segments_on_model
+    }
+    part[d].push_back(&j);
+  }
+  if (models.size() == 1) return transcribe_segments_on_model(models[0], part[0]);
+  std::vector<std::exception_ptr> errs(models.size());
+  std::vector<std::thread> threads;
+  for (size_t d = 0; d < models.size(); ++d) {
+    if (part[d].empty()) continue;
+    threads.emplace_back([&, d] {
+      try {
+        transcribe_segments_on_model(models[d], part[d]);
+      } catch (...) {
+        errs[d] = std::current_exception();
+      }
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  for (const std::exception_ptr& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+void Transcriber::transcribe_segments_on_model(MoonshineStreamingModel* m, std::vector<StreamingJob*>& jobs) {
   const MoonshineStreamingConfig& cfg = m->config;
   struct Work {
     StreamingJob* job;
@@ -543,7 +597,8 @@ void Transcriber::transcribe_segments_with_streaming_model(std::vector<Streaming
   std::vector<const float*> feed_audio;
   std::vector<size_t> feed_lens;
   std::vector<uint8_t> enc_final;
-  for (StreamingJob& j : jobs) {
+  for (StreamingJob* jp : jobs) {
+    StreamingJob& j = *jp;
     j.text.clear();
     TranscriberStream* s = j.stream;
     const std::vector<float>& audio = j.segment->audio;
@@ -939,7 +994,7 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
   // is a copy and everything is one wave.
   const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f && !use_device_vad;
-  const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams)
+  const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * 2
                                          : std::max<uint64_t>(count, 1);
   double seg_ms = 0.0;

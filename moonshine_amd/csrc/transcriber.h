@@ -205,7 +205,18 @@ class Transcriber {
   bool silero_device_failed_ = false;
   size_t vad_hard_cap_ = 0;                      // longest segment (samples) the engine behind this transcriber takes
   std::unique_ptr<MoonshineModel> model_;
-  std::unique_ptr<MoonshineStreamingModel> streaming_model_;
+  std::unique_ptr<MoonshineStreamingModel> streaming_model_;   // device 0 of the list (tokenizer, config, the biaser's owner)
+  // streaming architectures on more than one GPU (options num_gpus / devices): one model (engine + its slots, own copy of
+  // the weights) per further device.  A stream's line state lives on ONE device -- the one with the fewest lines when its
+  // first line starts -- so streams shard as clips do: no collective, per-device batches on per-device host threads.
+  std::vector<std::unique_ptr<MoonshineStreamingModel>> streaming_more_;
+  std::vector<MoonshineStreamingModel*> streaming_models() {
+    std::vector<MoonshineStreamingModel*> v;
+    if (streaming_model_) v.push_back(streaming_model_.get());
+    for (auto& m : streaming_more_) v.push_back(m.get());
+    return v;
+  }
+  void transcribe_segments_on_model(MoonshineStreamingModel* m, std::vector<StreamingJob*>& jobs);
   ContextBiaser context_biaser_;
   std::mutex context_biaser_mutex_;  // taken before model_mutex_ (reference core/transcriber.cpp:1394-1396)
   std::mutex model_mutex_, batch_mutex_, streams_mutex_;

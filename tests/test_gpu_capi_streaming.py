@@ -305,3 +305,42 @@ def test_streaming_arch_word_timestamps(model_dir, engine):
     finally:
         t.close()
         plain.close()
+
+
+def test_streams_sharded_over_devices_equal_one_device(model_dir):
+    """Options `devices` / `num_gpus` on a STREAMING architecture (streaming state is per segment, so streams
+    shard as clips do): one model -- engine, slots, own copy of the weights -- per listed GPU, a stream's line state placed
+    on the device holding the fewest lines, every device running its batch of an update on its own host thread, no
+    collective.  The box has one GPU, so the list names it twice: two engines, two slot pools, the same code path as two
+    GPUs.  Transcripts must equal the one-device run, for the batch call (incl. waves beyond one device's slot pool) and
+    for concurrent live streams updated in lock-step."""
+    clips = [make_audio(700 + i, n) for i, n in enumerate([32000, 40000, 1500, 52000, 16000 * 5 + 123, 24000, 61000])]
+    one = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0"})
+    want = [[l.text_bytes for l in r] for r in one.transcribe_batch_without_streaming(clips)]
+    two = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "devices": "0,0", "max_streams": "2"})
+    for _ in range(2):   # 7 clips on 2 x 2 slots: two waves; second call: slots handed back on both devices
+        got = [[l.text_bytes for l in r] for r in two.transcribe_batch_without_streaming(clips)]
+        assert got == want
+
+    def live(t, n_streams):
+        ids = [t.create_stream() for _ in range(n_streams)]
+        for s in ids:
+            t.start_stream(s)
+        texts = [[] for _ in ids]
+        for off in range(0, 48000, 8000):
+            for k, s in enumerate(ids):
+                t.add_audio(s, clips[k % len(clips)][off:off + 8000])
+            for k, s in enumerate(ids):
+                texts[k].append([l.text_bytes for l in t.transcribe_stream(s, api.FLAG_FORCE_UPDATE)])
+        for k, s in enumerate(ids):
+            t.stop_stream(s)
+            texts[k].append([l.text_bytes for l in t.transcribe_stream(s, api.FLAG_FORCE_UPDATE)])
+            t.free_stream(s)
+        return texts
+
+    two4 = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "devices": "0,0", "max_streams": "2"})
+    assert live(two4, 4) == live(one, 4)        # 4 live streams = 2 per device
+    with pytest.raises(api.MoonshineError):     # more GPUs than the box has: the load says so
+        api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "num_gpus": "2"})
+    for t in (one, two, two4):
+        t.close()
