@@ -67,25 +67,46 @@ int MoonshineModel::load_from_memory(const uint8_t* weights, size_t weights_size
   return 0;
 }
 
-int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx, const std::vector<const float*>& audio,
+int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx_in, const std::vector<const float*>& audio,
                               const std::vector<uint64_t>& lens, std::vector<std::vector<int32_t>>* ids) {
-  const uint32_t count = (uint32_t)idx.size();
+  const uint32_t count = (uint32_t)idx_in.size();
   if (count == 0) return 0;
+  // Longest first: a sub-batch decodes until its LAST clip is done, and a decode step costs about the same for 16 rows as
+  // for 256 (latency-bound GEMMs), so clips of similar length -- similar step budgets -- belong together.
+  std::vector<uint32_t> idx(idx_in);
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
   std::vector<const float*> pcm(count);
   std::vector<uint64_t> n(count);
-  size_t longest = 0;
   for (uint32_t i = 0; i < count; ++i) {
     pcm[i] = audio[idx[i]];
     n[i] = lens[idx[i]];
-    longest = std::max<size_t>(longest, (size_t)n[i]);
   }
-  const uint32_t chunk = (uint32_t)std::max(1, batch_clips);
+  const size_t longest = (size_t)n[0];
+  // Sub-batches are sized by AUDIO, not by clip count: batch_clips x 10 s of it (what a sub-batch of batch_clips full
+  // clips holds; the workspace and the HBM-bound part of a decode step scale with frames), at most 4 x batch_clips
+  // clips.  With the reference's default VAD a 2048-clip call turns into ~4100 segments of ~5 s: cut by count (256) that
+  // was 17 decode chains, by audio it is 9, each step of which costs little more.
+  const uint32_t clip_cap = (uint32_t)std::min<long>(4L * std::max(1, batch_clips), 1024);
+  const uint64_t audio_cap = (uint64_t)std::max(1, batch_clips) * 160000ull;
+  std::vector<std::pair<uint32_t, uint32_t>> cuts;   // [lo, lo + m)
+  for (uint32_t lo = 0; lo < count;) {
+    uint64_t sum = 0;
+    uint32_t m = 0;
+    while (lo + m < count && m < clip_cap) {
+      // the first batch_clips clips always go in (the old rule); further ones while the audio budget lasts
+      if (m >= (uint32_t)std::max(1, batch_clips) && sum + n[lo + m] > audio_cap) break;
+      sum += n[lo + m];
+      ++m;
+    }
+    cuts.push_back({lo, m});
+    lo += m;
+  }
   // rows wide enough for the step budget of the longest clip (the engine's rule: ceil(seconds * tokens/s)) + BOS
   const int32_t stride = (int32_t)ceilf((float)longest / 16000.0f * max_tokens_per_second) + 2;
   std::vector<int32_t> tokens((size_t)count * stride, 0), counts(count, 0);
-  if (count <= chunk || batches_in_flight <= 1) {
-    for (uint32_t lo = 0; lo < count; lo += chunk) {  // one sub-batch after the other on the engine itself
-      const uint32_t m = std::min(chunk, count - lo);
+  if (cuts.size() <= 1 || batches_in_flight <= 1) {
+    for (const auto& c : cuts) {  // one sub-batch after the other on the engine itself
+      const uint32_t lo = c.first, m = c.second;
       if (msh_encode(d.engine, pcm.data() + lo, n.data() + lo, m, 0, max_tokens_per_second) != MSH_OK) {
         MSH_LOGF("encoder failed on device %d: %s", d.device, msh_last_error(d.engine));
         return 1;
@@ -109,8 +130,8 @@ int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx, 
     }
     std::vector<int64_t> tickets;
     bool failed = false;
-    for (uint32_t lo = 0; lo < count; lo += chunk) {
-      const uint32_t m = std::min(chunk, count - lo);
+    for (const auto& c : cuts) {
+      const uint32_t lo = c.first, m = c.second;
       const int64_t t = msh_submit_transcribe_tokens(d.engine, pcm.data() + lo, n.data() + lo, m, 0, max_tokens_per_second, -1,
                                                      tokens.data() + (size_t)lo * stride, counts.data() + lo, stride);
       if (t < 0) {
@@ -540,6 +561,7 @@ void Transcriber::set_keyterms(const std::vector<std::string>& keyterms) {
 Transcriber::~Transcriber() {
   // streams own device slots of the streaming model: drop them before the model goes away
   streams_.clear();
+  if (batch_retire_.joinable()) batch_retire_.join();
   batch_streams_.clear();
   batch_stream_.reset();
   if (silero_device_ != nullptr) msh_silero_destroy(silero_device_);
@@ -917,8 +939,18 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
   auto t_phase = now();
-  batch_streams_.clear();
-  if (timing) MSH_LOGF("batch call: previous results freed in %.1f ms", ms_since(t_phase));
+  // The previous call's transcripts end here (moonshine-c-api.h: valid until the next call on the handle).  Freeing a
+  // few thousand streams and their lines' audio is ~100 ms of allocator work: it goes to a helper thread and this call
+  // starts at once.  Streams of a streaming model hold device slots the new streams need, so those are freed in place.
+  if (batch_retire_.joinable()) batch_retire_.join();
+  if (streaming_model_ || batch_streams_.size() < 64) {
+    batch_streams_.clear();
+  } else {
+    auto* old = new std::vector<std::unique_ptr<TranscriberStream>>(std::move(batch_streams_));
+    batch_streams_.clear();
+    batch_retire_ = std::thread([old] { delete old; });
+  }
+  if (timing) MSH_LOGF("batch call: previous results retired in %.1f ms", ms_since(t_phase));
   t_phase = now();
   std::vector<TranscriberStream*> streams;
   std::vector<std::vector<VadSegment>> segs(count);
@@ -993,9 +1025,11 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // model with Silero on is VAD-bound on the host (the network runs for every 32 ms hop of every clip): clips go in waves of
   // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
   // is a copy and everything is one wave.
-  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f && !use_device_vad;
+  // ... and with the network on the GPU (tens of milliseconds per thousand clips) the same pipeline, in waves of four
+  // sub-batches: the device VAD + the detectors' state machines of wave k + 1 run beside the transcription of wave k.
+  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
-                        : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * 2
+                        : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 4 : 2)
                                          : std::max<uint64_t>(count, 1);
   double seg_ms = 0.0;
   if (!pipelined) {
@@ -1008,8 +1042,10 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   } else {
     std::future<void> pending;   // the previous wave on the GPU
     try {
-      for (uint64_t w0 = 0; w0 < count; w0 += wave) {
-        const uint64_t w1 = std::min(count, w0 + wave);
+      // the first wave's segmentation has nothing to hide behind: keep it to one sub-batch of clips, then full waves
+      uint64_t w1 = 0;
+      for (uint64_t w0 = 0; w0 < count; w0 = w1) {
+        w1 = std::min(count, w0 + (w0 == 0 ? std::min<uint64_t>(wave, (uint64_t)std::max(1, opt_.batch_clips)) : wave));
         const auto ts = now();
         segment(w0, w1);
         seg_ms += ms_since(ts);

@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -222,6 +223,7 @@ class Transcriber {
   std::mutex model_mutex_, batch_mutex_, streams_mutex_;
   std::unique_ptr<TranscriberStream> batch_stream_;
   std::vector<std::unique_ptr<TranscriberStream>> batch_streams_;  // one per clip of the last batch call
+  std::thread batch_retire_;   // frees the previous batch call's streams beside the current call (guarded by batch_mutex_)
   std::map<int32_t, std::shared_ptr<TranscriberStream>> streams_;
   std::atomic<uint64_t> next_line_id_;
   int32_t next_stream_id_ = 1;
