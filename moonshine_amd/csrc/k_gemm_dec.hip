@@ -1,5 +1,6 @@
 // Decode-path GEMMs for gfx950 (M = batch rows, weights streamed): see the two kernels below.
 #include <stdlib.h>
+#include <string.h>
 
 #include "gemm_common.h"
 
@@ -323,6 +324,34 @@ void launch_fm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hip
 #undef MSH_FM_CASE
 }
 
+// FM operands at the streaming decoder's widths (AR steps of decode_full): K = decoder width or its ffn
+template <int TN, bool LN, class Epi, int TM = 1, int NW = 4>
+bool launch_sfm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  if ((N & 15) != 0) return false;
+  const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
+#define MSH_SFM_CASE(KK)                                                                                             \
+  case KK:                                                                                                           \
+    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
+                       (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
+    return true;
+  switch (K) {
+    MSH_SFM_CASE(96)
+    MSH_SFM_CASE(320)
+    MSH_SFM_CASE(640)
+    default: break;
+  }
+  if constexpr (!LN) {
+    switch (K) {
+      MSH_SFM_CASE(192)
+      MSH_SFM_CASE(1280)
+      MSH_SFM_CASE(2560)
+      default: break;
+    }
+  }
+#undef MSH_SFM_CASE
+  return false;
+}
+
 }  // namespace
 
 // Narrow outputs (N = decoder width) at streaming batch sizes give too few 16 x 32 tiles to occupy the chip (M = 64,
@@ -471,6 +500,54 @@ bool small_gemm_resid_f32(const bf16_t* A, long lda, const bf16_t* W, const floa
 }
 bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   return launch_dec_bf16<4>(A, lda, W, M, N, K, EpiF32{out, N}, s);
+}
+
+// ---- streaming decoder, AR steps: FM operands (weights packed at load, H / attention outputs / z in FM between the
+// kernels).  Per element the k-split and the MFMA order are those of the row-major forms above: bit-identical results. ----
+static int sfm_cfg(int digit, int dflt) {   // developer knob: MSH_SFM_CFG = digits (qkv, cross-q, fc1, resid), 0 = default
+  static const char* e = getenv("MSH_SFM_CFG");
+  if (e == nullptr || (int)strlen(e) <= digit || e[digit] == '0') return dflt;
+  return e[digit] - '0';
+}
+bool stream_fm_supported(int D, int F) {
+  const bool d_ok = D == 96 || D == 320 || D == 640, f_ok = F == 192 || F == 1280 || F == 2560;
+  return d_ok && f_ok;
+}
+bool stream_fm_qkv(const float* H, const bf16_t* Wfm, int M, int D, bf16_t* q_out, bf16_t* cacheK, bf16_t* cacheV,
+                   const int* row_slot, const int* row_pos, RopeParams rp, int layer, int L, int Scap, hipStream_t s) {
+  const EpiStreamQkv epi{q_out, cacheK, cacheV, row_slot, row_pos, rp, layer, L, Scap};
+  switch (sfm_cfg(0, M >= 32 ? 2 : 1)) {
+    case 1: return launch_sfm<1, true>(H, Wfm, M, 3 * D, D, epi, s);
+    case 4: return launch_sfm<4, true>(H, Wfm, M, 3 * D, D, epi, s);
+    default: return launch_sfm<2, true>(H, Wfm, M, 3 * D, D, epi, s);
+  }
+}
+bool stream_fm_ln_bf16(const float* H, const bf16_t* Wfm, int M, int N, int D, bf16_t* out, hipStream_t s) {
+  const EpiAct epi{out, nullptr, N, nullptr, 0};
+  if (sfm_cfg(1, few_tiles(M, N) ? 1 : 2) == 1) return launch_sfm<1, true>(H, Wfm, M, N, D, epi, s);
+  return launch_sfm<2, true>(H, Wfm, M, N, D, epi, s);
+}
+bool stream_fm_ln_swiglu(const float* H, const bf16_t* Wfm, const float* bias, int M, int F, int D, bf16_t* z,
+                         hipStream_t s) {
+  const EpiSwiGLUFm epi{z, F / 32, bias};
+  switch (sfm_cfg(2, M >= 32 ? 3 : 2)) {
+    case 1: return launch_sfm<1, true>(H, Wfm, M, 2 * F, D, epi, s);
+    case 3: return launch_sfm<4, true, EpiSwiGLUFm, 2>(H, Wfm, M, 2 * F, D, epi, s);
+    case 4: return launch_sfm<4, true>(H, Wfm, M, 2 * F, D, epi, s);
+    case 5: return launch_sfm<2, true, EpiSwiGLUFm, 2>(H, Wfm, M, 2 * F, D, epi, s);
+    default: return launch_sfm<2, true>(H, Wfm, M, 2 * F, D, epi, s);
+  }
+}
+template <bool BIAS>
+static bool stream_fm_resid_t(const bf16_t* A, const bf16_t* Wfm, const float* bias, int M, int N, int K, float* H,
+                              hipStream_t s) {
+  const EpiDecResidFm<BIAS> epi{H, N / 32, bias};
+  if (sfm_cfg(3, few_tiles(M, N) ? 1 : 2) == 1) return launch_sfm<1, false>(A, Wfm, M, N, K, epi, s);
+  return launch_sfm<2, false>(A, Wfm, M, N, K, epi, s);
+}
+bool stream_fm_resid(const bf16_t* A, const bf16_t* Wfm, const float* bias, int M, int N, int K, float* H, hipStream_t s) {
+  if ((N & 31) != 0) return false;
+  return bias != nullptr ? stream_fm_resid_t<true>(A, Wfm, bias, M, N, K, H, s) : stream_fm_resid_t<false>(A, Wfm, bias, M, N, K, H, s);
 }
 
 void dec_gemm_logits(const float* H, const bf16_t* E, int M, int V, int D, float* logits, hipStream_t s) {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
                                                              int layer, int L, int Scap,
                                                              const bf16_t* __restrict__ cacheK,
                                                              const bf16_t* __restrict__ cacheV,
-                                                             bf16_t* __restrict__ out) {
+                                                             bf16_t* __restrict__ out, int fm) {
   __shared__ float sq[4][128];
   __shared__ float sp[4][SELF_SMAX];
   __shared__ float part[4][16][128];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
   for (int d = lane; d < dh; d += 64) {
     float t = 0.f;
     for (int k = 0; k < G; ++k) t += part[w][k][d];
-    out[(long)row * D + head * dh + d] = f32_to_bf16(t * inv);
+    out[fm ? fm16(row, head * dh + d, D >> 5) : (long)row * D + head * dh + d] = f32_to_bf16(t * inv);
   }
 }
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
                                                                  int layer, int L, int Mcap,
                                                                  const bf16_t* __restrict__ crossKT,
                                                                  const bf16_t* __restrict__ crossVT,
-                                                                 bf16_t* __restrict__ out) {
+                                                                 bf16_t* __restrict__ out, int fm) {
   constexpr int DQ = DH / 4;
   __shared__ float sp[4][512];
   __shared__ float red[4][DQ][65];
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
     float acc = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) acc += red[wave][lane][i];
-    out[(long)row * D + h * DH + wave * DQ + lane] = f32_to_bf16(acc / l);
+    const int col = h * DH + wave * DQ + lane;
+    out[fm ? fm16(row, col, D >> 5) : (long)row * D + col] = f32_to_bf16(acc / l);
   }
 }
 
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16
                                                                       int heads, int layer, int L, int Mcap,
                                                                       const bf16_t* __restrict__ crossKT,
                                                                       const bf16_t* __restrict__ crossVT,
-                                                                      bf16_t* __restrict__ out) {
+                                                                      bf16_t* __restrict__ out, int fm) {
   __shared__ float sq[128];
   __shared__ float sp[CROSS_MMAX];
   __shared__ float red[8];
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16
     float a = 0.f;
     for (int j = lane; j < nk; j += 64) a += sp[j] * bf(crossVT[base + (long)d * Mcap + j]);
     a = wsum(a);
-    if (lane == 0) out[(long)row * D + head * dh + d] = f32_to_bf16(a * inv);
+    if (lane == 0) out[fm ? fm16(row, head * dh + d, D >> 5) : (long)row * D + head * dh + d] = f32_to_bf16(a * inv);
   }
 }
 
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 __global__ void verify_kernel(const DecJob* __restrict__ jobs, const int* __restrict__ pred,
                               const int* __restrict__ draft, SlotDev* __restrict__ slots, int* __restrict__ result,
                               int result_stride, int eos, const float* __restrict__ embed, int D, float* __restrict__ H,
-                              int* __restrict__ step_pos, int* __restrict__ n_active) {
+                              int* __restrict__ step_pos, int* __restrict__ n_active, int fm) {
   __shared__ int s_cur, s_fin;
   const DecJob job = jobs[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -634,7 +635,7 @@ __global__ void verify_kernel(const DecJob* __restrict__ jobs, const int* __rest
   __syncthreads();
   if (!s_fin) {
     const float* e = embed + (long)s_cur * D;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[fm ? fm32(blockIdx.x, d, D >> 5) : (long)blockIdx.x * D + d] = e[d];
   }
 }
 
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(128) void advance_partials_kernel(const DecJob* __r
                                                                int ntn, SlotDev* __restrict__ slots, int* __restrict__ result,
                                                                int result_stride, int eos, const float* __restrict__ embed,
                                                                int D, float* __restrict__ H, int* __restrict__ step_pos,
-                                                               int* __restrict__ n_active) {
+                                                               int* __restrict__ n_active, int fm) {
   __shared__ int s_cur, s_fin;
   __shared__ float bv[2];
   __shared__ int bi[2];
@@ -699,14 +700,14 @@ __global__ __launch_bounds__(128) void advance_partials_kernel(const DecJob* __r
   __syncthreads();
   if (!s_fin) {
     const float* e = embed + (long)s_cur * D;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[fm ? fm32(blockIdx.x, d, D >> 5) : (long)blockIdx.x * D + d] = e[d];
   }
 }
 
 __global__ void advance_kernel(const DecJob* __restrict__ jobs, const int* __restrict__ pred,
                                SlotDev* __restrict__ slots, int* __restrict__ result, int result_stride, int eos,
                                const float* __restrict__ embed, int D, float* __restrict__ H,
-                               int* __restrict__ step_pos, int* __restrict__ n_active) {
+                               int* __restrict__ step_pos, int* __restrict__ n_active, int fm) {
   __shared__ int s_cur, s_fin;
   const DecJob job = jobs[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -730,7 +731,7 @@ __global__ void advance_kernel(const DecJob* __restrict__ jobs, const int* __res
   __syncthreads();
   if (!s_fin) {
     const float* e = embed + (long)s_cur * D;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) H[(long)blockIdx.x * D + d] = e[d];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) H[fm ? fm32(blockIdx.x, d, D >> 5) : (long)blockIdx.x * D + d] = e[d];
   }
 }
 
@@ -874,29 +875,32 @@ void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* ro
   MSH_LAUNCH(self_append_kernel, dim3(M), dim3(128), 0, s, qkv, row_slot, row_pos, D, layer, L, Scap, cacheK,
                      cacheV);
   MSH_LAUNCH(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, qkv, 3 * D, row_slot, row_pos, M,
-                     D, heads, layer, L, Scap, cacheK, cacheV, out);
+                     D, heads, layer, L, Scap, cacheK, cacheV, out, 0);
 }
 void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
                                   int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
-                                  hipStream_t s) {
+                                  hipStream_t s, bool fm) {
   const int dh = D / heads;
   if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
     throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
   if (M <= 0) return;
+  if (fm && (D & 31) != 0) throw std::runtime_error("stream_self_attention: FM output needs D % 32 == 0");
   MSH_LAUNCH(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, q, D, row_slot, row_pos, M, D,
-                     heads, layer, L, Scap, cacheK, cacheV, out);
+                     heads, layer, L, Scap, cacheK, cacheV, out, fm ? 1 : 0);
 }
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
-                            hipStream_t s) {
+                            hipStream_t s, bool fm) {
   const int dh = D / heads;
   if (Mcap > CROSS_MMAX || dh > 128 || (dh & 3) != 0 || (Mcap & 7) != 0)
     throw std::runtime_error("stream_cross_attention: unsupported memory length or head_dim");
+  if (fm && (D & 31) != 0) throw std::runtime_error("stream_cross_attention: FM output needs D % 32 == 0");
   if (M <= 0) return;
+  const int fmi = fm ? 1 : 0;
 #define MSH_XATT(DHV)                                                                                                  \
   case DHV:                                                                                                            \
     MSH_LAUNCH(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
-                       layer, L, Mcap, crossK, crossV, out);                                                          \
+                       layer, L, Mcap, crossK, crossV, out, fmi);                                                     \
     break
   switch (dh) {
     MSH_XATT(16);
@@ -908,7 +912,7 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
     MSH_XATT(80);
     default:
       MSH_LAUNCH(cross_attention_generic_kernel, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,
-                         layer, L, Mcap, crossK, crossV, out);
+                         layer, L, Mcap, crossK, crossV, out, fmi);
   }
 #undef MSH_XATT
 }
@@ -953,23 +957,23 @@ void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s) 
 }
 void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* draft, SlotDev* slots, int* result,
                    int result_stride, int eos, const float* embed, int D, float* H, int* step_pos, int* n_active,
-                   hipStream_t s) {
+                   hipStream_t s, bool fm) {
   if (n_jobs <= 0) return;
   MSH_LAUNCH(verify_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, draft, slots, result, result_stride, eos,
-                     embed, D, H, step_pos, n_active);
+                     embed, D, H, step_pos, n_active, fm ? 1 : 0);
 }
 void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
-                    int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s) {
+                    int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s, bool fm) {
   if (n_jobs <= 0) return;
   MSH_LAUNCH(advance_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pred, slots, result, result_stride, eos, embed,
-                     D, H, step_pos, n_active);
+                     D, H, step_pos, n_active, fm ? 1 : 0);
 }
 void stream_advance_partials(const DecJob* jobs, int n_jobs, const float* pval, const int* pidx, int ntn, SlotDev* slots,
                              int* result, int result_stride, int eos, const float* embed, int D, float* H, int* step_pos,
-                             int* n_active, hipStream_t s) {
+                             int* n_active, hipStream_t s, bool fm) {
   if (n_jobs <= 0) return;
   MSH_LAUNCH(advance_partials_kernel, dim3(n_jobs), dim3(128), 0, s, jobs, pval, pidx, ntn, slots, result, result_stride, eos,
-             embed, D, H, step_pos, n_active);
+             embed, D, H, step_pos, n_active, fm ? 1 : 0);
 }
 void stream_bias_rows(BiasTrie trie, const int2* prefix, const int* tokens, const DecJob* jobs, const SlotDev* slots,
                       const int* result, int result_stride, int rows, float* logits, int V, hipStream_t s) {

@@ -120,6 +120,17 @@ bool small_ln_gemm_swiglu(const float* H, const bf16_t* Wf, const float* bias, i
                           hipStream_t s);
 bool small_ln_gemm_logits(const float* H, const bf16_t* Wf, int M, int N, int D, float* out, hipStream_t s);
 
+// The same AR-step GEMMs on FM operands (see the FM layouts above): Wfm = FM bf16 [N][K] (LayerNorm scale folded in for the
+// LN forms), H = FM fp32 [M16][D], A / z = FM bf16 [M16][K]; q_out / out stay row-major (the attention kernels read them).
+// False (nothing launched) when the width is not compiled: stream_fm_supported(D, F) is the load-time check.
+bool stream_fm_supported(int D, int F);
+bool stream_fm_qkv(const float* H, const bf16_t* Wfm, int M, int D, bf16_t* q_out, bf16_t* cacheK, bf16_t* cacheV,
+                   const int* row_slot, const int* row_pos, RopeParams rp, int layer, int L, int Scap, hipStream_t s);
+bool stream_fm_ln_bf16(const float* H, const bf16_t* Wfm, int M, int N, int D, bf16_t* out, hipStream_t s);
+bool stream_fm_ln_swiglu(const float* H, const bf16_t* Wfm, const float* bias, int M, int F, int D, bf16_t* z,
+                         hipStream_t s);
+bool stream_fm_resid(const bf16_t* A, const bf16_t* Wfm, const float* bias, int M, int N, int K, float* H, hipStream_t s);
+
 // LM head fused with the first stage of the argmax: per row and per 208-column tile the maximum logit and its
 // (lowest) column -> pval / pidx [M][gemm_argmax_tiles(N)]; the logits themselves are never written.
 int gemm_argmax_tiles(int N);

@@ -119,6 +119,24 @@ void StreamingEngine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   *dst = reinterpret_cast<bf16_t*>(p);
 }
 
+// bf16 upload of a [rows][K] matrix in the MFMA-fragment-major order of the decode GEMMs (kernels.h fm16)
+void StreamingEngine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst) {
+  if ((rows & 15) != 0 || (K & 31) != 0 || src.size() != (size_t)rows * K)
+    throw std::runtime_error("decoder weight [" + std::to_string(rows) + ", " + std::to_string(K) + "] cannot be packed fragment-major");
+  std::vector<bf16_t> tmp(src.size());
+  const int ks = K >> 5;
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < K; ++k) tmp[(size_t)fm16(r, k, ks)] = f32_to_bf16(src[(size_t)r * K + k]);
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+    p = device_alloc(tmp.size() * sizeof(bf16_t));
+  }
+  allocs_.push_back(p);
+  copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+  *dst = reinterpret_cast<bf16_t*>(p);
+}
+
 // Small descriptor arrays go host -> device on the engine stream.  The copy is issued from pageable memory
 // and the stream is drained before the host vector dies: these arrays are a few KiB and every public call
 // ends with a host-visible result anyway.
@@ -294,6 +312,10 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     upload_bf16(head, &head_wf_);
   }
   dec_.resize(L);
+  {
+    const char* e = getenv("MSH_STREAM_FM");   // developer switch: 0 = AR steps on the row-major operands
+    fm_ok_ = !(e != nullptr && e[0] == '0') && stream_fm_supported(Dd, Fd);
+  }
   std::vector<float> cross;
   for (int l = 0; l < L; ++l) {
     const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
@@ -308,13 +330,26 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
     {
       std::vector<float> qkv = cat({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, Dd, Dd);
       upload_bf16(qkv, &W.wqkv);
-      upload_bf16(fold(qkv, p + "input_layernorm.weight", 3 * Dd), &W.wqkv_f);
+      const std::vector<float> qkv_f = fold(qkv, p + "input_layernorm.weight", 3 * Dd);
+      upload_bf16(qkv_f, &W.wqkv_f);
       std::vector<float> qc = cat({p + "encoder_attn.q_proj.weight"}, Dd, Dd);
       upload_bf16(qc, &W.wq_c);
-      upload_bf16(fold(qc, p + "post_attention_layernorm.weight", Dd), &W.wq_c_f);
+      const std::vector<float> qc_f = fold(qc, p + "post_attention_layernorm.weight", Dd);
+      upload_bf16(qc_f, &W.wq_c_f);
+      if (fm_ok_) {
+        upload_bf16_fm(qkv_f, 3 * Dd, Dd, &W.wqkv_fm);
+        upload_bf16_fm(qc_f, Dd, Dd, &W.wq_c_fm);
+      }
     }
-    upload_bf16(cat({p + "self_attn.o_proj.weight"}, Dd, Dd), &W.wo);
-    upload_bf16(cat({p + "encoder_attn.o_proj.weight"}, Dd, Dd), &W.wo_c);
+    {
+      const std::vector<float> wo = cat({p + "self_attn.o_proj.weight"}, Dd, Dd), woc = cat({p + "encoder_attn.o_proj.weight"}, Dd, Dd);
+      upload_bf16(wo, &W.wo);
+      upload_bf16(woc, &W.wo_c);
+      if (fm_ok_) {
+        upload_bf16_fm(wo, Dd, Dd, &W.wo_fm);
+        upload_bf16_fm(woc, Dd, Dd, &W.wo_c_fm);
+      }
+    }
     std::vector<float> kv = cat({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"}, Dd, Dd);
     cross.insert(cross.end(), kv.begin(), kv.end());
     shape_is(p + "mlp.fc1.weight", {2 * Fd, Dd});
@@ -327,9 +362,15 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
       b1i[2 * j + 1] = b1[Fd + j];
     }
     upload_bf16(f1i, &W.fc1);
-    upload_bf16(fold(f1i, p + "final_layernorm.weight", 2 * Fd), &W.fc1_f);
+    const std::vector<float> f1f = fold(f1i, p + "final_layernorm.weight", 2 * Fd);
+    upload_bf16(f1f, &W.fc1_f);
     upload(b1i, &W.b1);
-    upload_bf16(cat({p + "mlp.fc2.weight"}, Dd, Fd), &W.fc2);
+    const std::vector<float> f2 = cat({p + "mlp.fc2.weight"}, Dd, Fd);
+    upload_bf16(f2, &W.fc2);
+    if (fm_ok_) {
+      upload_bf16_fm(f1f, 2 * Fd, Dd, &W.fc1_fm);
+      upload_bf16_fm(f2, Dd, Fd, &W.fc2_fm);
+    }
     upload(vec(p + "mlp.fc2.bias", Dd), &W.b2);
     upload(vec(p + "input_layernorm.weight", Dd), &W.ln1);
     upload(vec(p + "post_attention_layernorm.weight", Dd), &W.ln2);
@@ -679,14 +720,24 @@ const int2* StreamingEngine::stage_runs(const std::vector<int>& rs, int* n_runs)
   return stage(runs_, runs);
 }
 
+void StreamingEngine::reserve_decoder_buffers(int rows) {
+  const int Dd = cfg_.decoder_dim, Fd = cfg_.dec_ffn;
+  stepH_.reserve((size_t)rows * Dd * 4);
+  Y_.reserve((size_t)rows * Dd * 2);
+  QKV_.reserve((size_t)rows * 3 * Dd * 2);
+  AO_.reserve((size_t)rows * Dd * 2);
+  Q_.reserve((size_t)rows * Dd * 2);
+  Z_.reserve((size_t)rows * Fd * 2);
+}
+
+// fm: the pass runs on fragment-major operands (one row per stream, AR steps only): stepH_ is FM fp32 [M16][Dd], the
+// attention outputs and the MLP activation are FM bf16, weights are the *_fm copies -- every wave-level operand load of
+// the GEMMs is one contiguous 1 KiB run (kernels.h).  Results are bit-identical to the row-major pass.
 void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_pos, float* logits, const int2* runs_d,
-                                   int n_runs, float* pval, int* pidx) {
+                                   int n_runs, float* pval, int* pidx, bool fm) {
   const int Dd = cfg_.decoder_dim, L = cfg_.depth, Fd = cfg_.dec_ffn, V = cfg_.vocab_size;
-  Y_.reserve((size_t)M * Dd * 2);
-  QKV_.reserve((size_t)M * 3 * Dd * 2);
-  AO_.reserve((size_t)M * Dd * 2);
-  Q_.reserve((size_t)M * Dd * 2);
-  Z_.reserve((size_t)M * Fd * 2);
+  reserve_decoder_buffers(fm ? (M + 15) / 16 * 16 : M);
+  if (fm && (runs_d != nullptr || capture_probs_ != nullptr || !fm_ok_)) throw std::logic_error("decoder_pass: FM is for AR steps");
   float* H = stepH_.as<float>();
   bf16_t* Y = Y_.as<bf16_t>();
   bf16_t* QKV = QKV_.as<bf16_t>();
@@ -706,7 +757,11 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     // small passes: LayerNorm fused into the GEMM, q to its own buffer, k / v straight into the cache
     {
       Sc sc(&prof_, stream_, nm("sdec_qkv_self_attention", "sver_qkv_self_attention"), 2.0 * md * 3 * Dd, 3 * wdd + md * 12);
-      if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
+      if (fm) {
+        if (!stream_fm_qkv(H, W.wqkv_fm, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_))
+          throw std::logic_error("decoder_pass: FM qkv width not compiled");
+        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, true);
+      } else if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
         stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
       } else {
         layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
@@ -716,11 +771,16 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     }
     {
       Sc sc(&prof_, stream_, nm("sdec_proj_gemms", "sver_proj_gemms"), 2.0 * md * Dd * 2, 2 * wdd + md * 16);
-      if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
-        gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
-      if (!(small && small_ln_gemm_bf16(H, W.wq_c_f, M, Dd, Dd, Q, stream_))) {
-        layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
-        gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+      if (fm) {
+        if (!stream_fm_resid(AO, W.wo_fm, nullptr, M, Dd, Dd, H, stream_) || !stream_fm_ln_bf16(H, W.wq_c_fm, M, Dd, Dd, Q, stream_))
+          throw std::logic_error("decoder_pass: FM projection width not compiled");
+      } else {
+        if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
+          gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_);
+        if (!(small && small_ln_gemm_bf16(H, W.wq_c_f, M, Dd, Dd, Q, stream_))) {
+          layernorm_bf16(H, W.ln2, M, Dd, Y, nullptr, stream_);
+          gemm_act(Y, Dd, W.wq_c, nullptr, 0, M, Dd, Dd, Q, nullptr, stream_);
+        }
       }
     }
     if (capture_probs_ != nullptr)  // word timestamps: this pass's cross-attention probabilities (cross_attention())
@@ -730,24 +790,31 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       if (runs_d != nullptr)
         stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
       else
-        stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+        stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_, fm);
     }
     {
       Sc sc(&prof_, stream_, nm("sdec_crosso_mlp_gemms", "sver_crosso_mlp_gemms"), 2.0 * md * (Dd + 3.0 * Fd),
             wdd + 6.0 * Dd * Fd + md * 16);
-      if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
-        gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
-      if (!(small && small_ln_gemm_swiglu(H, W.fc1_f, W.b1, M, 2 * Fd, Dd, Z, stream_))) {
-        layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
-        gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+      if (fm) {
+        if (!stream_fm_resid(AO, W.wo_c_fm, nullptr, M, Dd, Dd, H, stream_) ||
+            !stream_fm_ln_swiglu(H, W.fc1_fm, W.b1, M, Fd, Dd, Z, stream_) || !stream_fm_resid(Z, W.fc2_fm, W.b2, M, Dd, Fd, H, stream_))
+          throw std::logic_error("decoder_pass: FM MLP width not compiled");
+      } else {
+        if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
+          gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_);
+        if (!(small && small_ln_gemm_swiglu(H, W.fc1_f, W.b1, M, 2 * Fd, Dd, Z, stream_))) {
+          layernorm_bf16(H, W.ln3, M, Dd, Y, nullptr, stream_);
+          gemm_swiglu_bf16(Y, Dd, W.fc1, W.b1, M, 2 * Fd, Dd, Z, stream_);
+        }
+        if (!(small && small_gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_)))
+          gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
       }
-      if (!(small && small_gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_)))
-        gemm_resid_f32(Z, Fd, W.fc2, W.b2, M, Dd, Fd, H, stream_);
     }
   }
   // (an LN-fused head would redo the LayerNorm in each of its V / 64 column tiles: measured 46 vs 28 + 5 us)
   Sc sc(&prof_, stream_, nm("sdec_lm_head", "sver_lm_head"), 2.0 * md * V, 2.0 * V * Dd + (pval != nullptr ? 0.0 : 4.0 * M * V));
-  layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
+  if (fm) dec_final_layernorm(H, dec_ln_, M, Dd, Y, stream_);   // FM in, row-major out (the LM head's A operand)
+  else layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
   if (pval != nullptr) {   // nobody reads the logits of this pass: only each column tile's maximum leaves the GEMM
     gemm_argmax_partials(Y, Dd, head_w_, M, V, Dd, pval, pidx, stream_);
     return;
@@ -913,7 +980,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   }
   const int J = (int)jobs.size(), M = (int)rs.size();
   if (J == 0) return;
-  stepH_.reserve((size_t)M * Dd * 4);
+  // AR steps (one row per stream) on fragment-major operands; every buffer is sized before the graph capture below
+  const bool fm = fm_ok_ && J <= 256;
+  reserve_decoder_buffers(std::max(M, (J + 15) / 16 * 16));
   logits_.reserve((size_t)M * V * 4);
   pred_.reserve((size_t)M * 4);
   steppos_.reserve((size_t)J * 4);
@@ -939,7 +1008,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   stream_bias_rows(bias_, prefix_d, draft_d, nullptr, nullptr, nullptr, 0, M, logits_.as<float>(), V, stream_);
   stream_argmax(logits_.as<float>(), M, V, pred_.as<int>(), stream_);
   stream_verify(jobs_d, J, pred_.as<int>(), draft_d, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd,
-                stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
+                stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_, fm);
   // One autoregressive step = ~100 short dependent kernels whose every argument is a device pointer (positions, ids and
   // stop flags live on the device): captured once per (row count, buffer addresses, trie) into a hipGraph and replayed -- an
   // eager launch costs the host >= 3.5 us per kernel, a graph node ~1.6 us of GPU time.
@@ -958,16 +1027,16 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   }
   auto ar_step = [&] {
     if (fused_head) {
-      decoder_pass(J, jslot_d, steppos_.as<int>(), nullptr, nullptr, 0, pval_.as<float>(), pidx_.as<int>());
+      decoder_pass(J, jslot_d, steppos_.as<int>(), nullptr, nullptr, 0, pval_.as<float>(), pidx_.as<int>(), fm);
       stream_advance_partials(jobs_d, J, pval_.as<float>(), pidx_.as<int>(), ntn, slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_,
-                              Dd, stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_);
+                              Dd, stepH_.as<float>(), steppos_.as<int>(), n_active_d_, stream_, fm);
       return;
     }
-    decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>());
+    decoder_pass(J, jslot_d, steppos_.as<int>(), logits_.as<float>(), nullptr, 0, nullptr, nullptr, fm);
     stream_bias_rows(bias_, nullptr, nullptr, jobs_d, slots_d_, result_, Scap_, J, logits_.as<float>(), V, stream_);
     stream_argmax(logits_.as<float>(), J, V, pred_.as<int>(), stream_);
     stream_advance(jobs_d, J, pred_.as<int>(), slots_d_, result_, Scap_, cfg_.eos_id, embed_f32_, Dd, stepH_.as<float>(),
-                   steppos_.as<int>(), n_active_d_, stream_);
+                   steppos_.as<int>(), n_active_d_, stream_, fm);
   };
   static const bool use_graph = [] {
     const char* e = getenv("MSH_NO_GRAPH");
@@ -978,7 +1047,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     char key[512];
     snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
              logits_.p, pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p,
-             (int)fused_head, pval_.p, pidx_.p);
+             (int)fused_head + 2 * (int)fm, pval_.p, pidx_.p);
     if (ar_graph_ == nullptr || ar_key_ != key) {
       if (ar_graph_ != nullptr) {
         MSH_HIP(hipGraphExecDestroy(ar_graph_));

@@ -93,13 +93,16 @@ class StreamingEngine {
   void check_slots(int n, const int* slots) const;
   void upload(const std::vector<float>& src, float** dst);
   void upload_bf16(const std::vector<float>& src, bf16_t** dst);
+  void upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst);
+  void reserve_decoder_buffers(int rows);
+  bool fm_ok_ = false;   // AR steps on FM operands
   template <class T>
   T* stage(DevBuf& buf, const std::vector<T>& host);  // async H2D of a small descriptor array
   // runs_d (optional): the pass's rows as runs of consecutive rows of one stream, for the shared-K/V cross-attention
   // pval / pidx (optional, then logits may be null): the LM head as the tiled GEMM whose epilogue keeps only each 128-column
   // tile's (max, lowest index) per row -- [M][gemm_argmax_tiles(V)] -- instead of M x V logits
   void decoder_pass(int M, const int* row_slot_d, const int* row_pos_d, float* logits, const int2* runs_d = nullptr,
-                    int n_runs = 0, float* pval = nullptr, int* pidx = nullptr);
+                    int n_runs = 0, float* pval = nullptr, int* pidx = nullptr, bool fm = false);
   // rows of `rs` (slot per row) -> runs of <= kCrossRunRows consecutive rows with the same slot, staged on the device;
   // nullptr when the pass has no run longer than one row (the auto-regressive steps) or the kernel does not cover the shape
   const int2* stage_runs(const std::vector<int>& rs, int* n_runs);
@@ -113,6 +116,9 @@ class StreamingEngine {
     float *ln1, *ln2, *ln3, *b1, *b2;
     bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;
     bf16_t *wqkv_f, *wq_c_f, *fc1_f;  // LayerNorm scale folded in (LN-fused small-batch GEMMs of the AR steps)
+    // the six AR-step weights in the fragment-major order of the decode GEMMs (kernels.h fm16), LayerNorm scales folded
+    // in where the GEMM is LN-fused; null when the widths are not FM-compiled (stream_fm_supported)
+    bf16_t *wqkv_fm = nullptr, *wo_fm = nullptr, *wq_c_fm = nullptr, *wo_c_fm = nullptr, *fc1_fm = nullptr, *fc2_fm = nullptr;
   };
 
   // per-kernel-group timing (profiler.h); while it is on, the AR steps run eagerly instead of from their hipGraph.

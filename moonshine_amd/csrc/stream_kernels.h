@@ -65,17 +65,19 @@ void stream_embed(const int* tokens, int M, const float* embed, int D, float* H,
 // append k / v of every row to the self cache [slot][L][Scap][D] at row_pos, then causal attention over [0, row_pos]
 void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* row_pos, int M, int D, int heads, int layer,
                            int L, int Scap, bf16_t* cacheK, bf16_t* cacheV, bf16_t* out, hipStream_t s);
-// same attention when k / v of the rows are already in the cache (written by the QKV GEMM epilogue): q [M,D] bf16
+// same attention when k / v of the rows are already in the cache (written by the QKV GEMM epilogue): q [M,D] bf16.
+// fm (here and below): `out` / `H` of the AR steps in the fragment-major layouts of kernels.h (fm16 / fm32, rows padded
+// to 16) -- the operand layout of the FM decode GEMMs that consume them
 void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
                                   int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
-                                  hipStream_t s);
+                                  hipStream_t s, bool fm = false);
 // cross-attention of every row over its stream's memory (keys [0, slots[slot].mem_len))
 // word timestamps: softmax probabilities of every (row, head) over the stream's memory frames -> out[row][layer][head][Ecap]
 void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads, int layer,
                         int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s);
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
-                            hipStream_t s);
+                            hipStream_t s, bool fm = false);
 // The same for runs of consecutive rows of one stream (runs[i] = {first row, rows <= kCrossRunRows}): a run's rows share one
 // pass over the stream's K / V.  Results equal stream_cross_attention's bit for bit.
 constexpr int kCrossRunRows = 4;
@@ -89,14 +91,15 @@ void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s);
 // self cache length, first continuation token; prepares row j of the step buffers (H, step_pos) for job j.
 void stream_verify(const DecJob* jobs, int n_jobs, const int* pred, const int* draft, SlotDev* slots, int* result,
                    int result_stride, int eos, const float* embed, int D, float* H, int* step_pos, int* n_active,
-                   hipStream_t s);
+                   hipStream_t s, bool fm = false);
 // one auto-regressive step of decode_full's loop (moonshine-streaming-model.cpp:1271-1288)
 void stream_advance(const DecJob* jobs, int n_jobs, const int* pred, SlotDev* slots, int* result, int result_stride,
-                    int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s);
+                    int eos, const float* embed, int D, float* H, int* step_pos, int* n_active, hipStream_t s,
+                    bool fm = false);
 // the same step from the per-tile (max, lowest index) pairs of gemm_argmax_partials (kernels.h): pval / pidx [n_jobs][ntn]
 void stream_advance_partials(const DecJob* jobs, int n_jobs, const float* pval, const int* pidx, int ntn, SlotDev* slots,
                              int* result, int result_stride, int eos, const float* embed, int D, float* H, int* step_pos,
-                             int* n_active, hipStream_t s);
+                             int* n_active, hipStream_t s, bool fm = false);
 // Contextual biasing (reference core/context-biaser.cpp:88-149): flat trie over token ids, children sorted by token.
 struct BiasTrie {
   const int* child_off;    // [n_nodes + 1]
