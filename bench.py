@@ -193,6 +193,7 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = msd.max_over_ranks(time.perf_counter() - t0, world, dev)
+    timed = dict(stats)   # the timed steps only (the profiled step below keeps counting into `stats`)
     # ---- per-kernel-group HIP-event times over one more step (the AR steps run eagerly while profiling) ----
     skernels, sroof = [], None
     if rank == 0 and not args.no_stream_profile:
@@ -229,9 +230,9 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
                                "arrives from host memory every update", "streams_per_gpu": S, "updates_per_stream": n_upd,
                    "parallelism": f"stream-sharded dp{world}"},
         "streaming": {"ms_per_update": round(elapsed / steps / n_upd * 1e3, 3),
-                      "frontend_ms_per_step": round(stats["frontend_ms"] / k, 2), "encode_ms_per_step": round(stats["encode_ms"] / k, 2),
-                      "decode_ms_per_step": round(stats["decode_ms"] / k, 2),
-                      "draft_acceptance": round(stats["accepted"] / max(stats["draft"], 1), 4),
+                      "frontend_ms_per_step": round(timed["frontend_ms"] / k, 2), "encode_ms_per_step": round(timed["encode_ms"] / k, 2),
+                      "decode_ms_per_step": round(timed["decode_ms"] / k, 2),
+                      "draft_acceptance": round(timed["accepted"] / max(timed["draft"], 1), 4),
                       "tokens_per_final_line": round(sum(len(t) for t in final_tokens) / S, 2),
                       "kernels": skernels, "roofline": sroof},
     }

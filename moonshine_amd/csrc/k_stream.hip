@@ -9,6 +9,8 @@
 
 #include <stdexcept>
 
+#include <stdlib.h>
+
 #include "stream_kernels.h"
 
 namespace msh {
@@ -212,6 +214,117 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
   }
 }
 
+// The same attention for the AR steps of decode_full (one new row per stream, at most SELF_AR_KEYS keys): one wave per
+// (row, head), and everything it needs -- the query, the head's cached K rows (one key per lane, a second one from 64 keys
+// on) and all V rows (16-byte chunks, staged through LDS) -- is requested in ONE batch of loads; self_attention_kernel
+// above walks K and then V in several dependent round trips (10.3 us per launch at 64 streams, all of it latency).
+// Arithmetic and summation order per output element are those of self_attention_kernel: scores as dot_row adds them, the
+// value sum in G interleaved partial sums (G = that kernel's key groups) added in group order.
+constexpr int SELF_AR_KEYS = 128;
+template <int DH>
+__global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __restrict__ q, const int* __restrict__ row_slot,
+                                                               const int* __restrict__ row_pos, int D, int heads, int layer,
+                                                               int L, int Scap, const bf16_t* __restrict__ cacheK,
+                                                               const bf16_t* __restrict__ cacheV, bf16_t* __restrict__ out,
+                                                               int fm) {
+  constexpr int C8 = DH / 8;                 // 16-byte chunks of a cached row
+  constexpr int VROW = DH + 8;               // LDS row stride (bf16): 16-byte aligned, rows 4 banks apart
+  constexpr int NV = (SELF_AR_KEYS * C8 + 63) / 64;
+  constexpr int TPK = DH / 4;
+  constexpr int G = 64 / TPK > 16 ? 16 : 64 / TPK;
+  constexpr int ND = (DH + 63) / 64;
+  __shared__ float sq[DH];
+  __shared__ float sp[SELF_AR_KEYS];
+  __shared__ __attribute__((aligned(16))) bf16_t sv[SELF_AR_KEYS * VROW];
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x / heads, head = blockIdx.x - row * heads;
+  int nk = row_pos[row] + 1;
+  nk = nk > SELF_AR_KEYS ? SELF_AR_KEYS : nk;   // the host only picks this kernel when the pass cannot get there
+  const long base = (((long)row_slot[row] * L + layer) * Scap) * D + head * DH;
+  // ---- every load of the wave ----
+  float qv[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int d = lane + 64 * i;
+    qv[i] = d < DH ? bf(q[(long)row * D + head * DH + d]) : 0.f;
+  }
+  uint4 kr[2][C8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int j = lane + 64 * t;
+    const bf16_t* kp = cacheK + base + (long)(j < nk ? j : 0) * D;
+#pragma unroll
+    for (int c = 0; c < C8; ++c) kr[t][c] = *reinterpret_cast<const uint4*>(kp + c * 8);
+  }
+  uint4 vr[NV];
+  const int nchunks = nk * C8;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    const int j = idx / C8, c = idx - j * C8;
+    vr[i] = idx < nchunks ? *reinterpret_cast<const uint4*>(cacheV + base + (long)j * D + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const float scale = rsqrtf((float)DH);
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+    if (lane + 64 * i < DH) sq[lane + 64 * i] = qv[i] * scale;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + 64 * i;
+    const int j = idx / C8, c = idx - j * C8;
+    if (idx < nchunks) *reinterpret_cast<uint4*>(&sv[j * VROW + c * 8]) = vr[i];
+  }
+  __syncthreads();
+  float sc[2], mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < C8; ++c) {
+      const uint4 r = kr[t][c];
+      const float* qq = &sq[c * 8];
+      acc += qq[0] * __uint_as_float(r.x << 16) + qq[1] * __uint_as_float(r.x & 0xffff0000u) +
+             qq[2] * __uint_as_float(r.y << 16) + qq[3] * __uint_as_float(r.y & 0xffff0000u);
+      acc += qq[4] * __uint_as_float(r.z << 16) + qq[5] * __uint_as_float(r.z & 0xffff0000u) +
+             qq[6] * __uint_as_float(r.w << 16) + qq[7] * __uint_as_float(r.w & 0xffff0000u);
+    }
+    sc[t] = lane + 64 * t < nk ? acc : -INFINITY;
+    mx = fmaxf(mx, sc[t]);
+  }
+  mx = wmax(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (lane + 64 * t < nk) {
+      const float e = __expf(sc[t] - mx);
+      sp[lane + 64 * t] = e;
+      sum += e;
+    }
+  }
+  const float inv = 1.0f / wsum(sum);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int d = lane + 64 * i;
+    if (d < DH) {
+      float part[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) part[g] = 0.f;
+      for (int j0 = 0; j0 < nk; j0 += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (j0 + g < nk) part[g] += sp[j0 + g] * bf(sv[(j0 + g) * VROW + d]);
+      }
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) t += part[g];
+      const int col = head * DH + d;
+      out[fm ? fm16(row, col, D >> 5) : (long)row * D + col] = f32_to_bf16(t * inv);
+    }
+  }
+}
+
 // Cross-attention: one workgroup per (row, head), its 4 waves split the head dim (the layout of the offline
 // dec_cross_attention_kernel).  K^T / V^T rows are keys-contiguous: lane l owns keys 8l..8l+7 of a 512-key chunk
 // and loads 16 bytes per head-dim row; wave w covers rows d in [w*dh/4, (w+1)*dh/4).  All 2*dh/4 loads of a chunk
@@ -252,10 +365,15 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
   for (int k0 = 0; k0 < nk; k0 += 512) {
     const int key = k0 + lane * 8;
     const bool in = key < nk;  // nk <= Mcap and Mcap % 8 == 0: an "in" lane's 8 keys are inside the row
+    // K and V rows of the chunk are requested together: one memory round trip per chunk (2 x DQ 16-byte loads in flight)
     su32x4 kr[DQ], vr[DQ];
 #pragma unroll
     for (int d = 0; d < DQ; ++d)
       kr[d] = in ? *reinterpret_cast<const su32x4*>(kt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int d = 0; d < DQ; ++d)
+      vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_sched_barrier(0);
     float sc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) sc[e] = 0.f;
@@ -267,10 +385,6 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
       sc[4] += qd[d] * s_lo(u.z); sc[5] += qd[d] * s_hi(u.z);
       sc[6] += qd[d] * s_lo(u.w); sc[7] += qd[d] * s_hi(u.w);
     }
-    __builtin_amdgcn_sched_barrier(0);  // the V rows are requested only now (K registers are dead)
-#pragma unroll
-    for (int d = 0; d < DQ; ++d)
-      vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
     if (k0 > 0) __syncthreads();
     *reinterpret_cast<float4*>(&sp[wave][lane * 8]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
     *reinterpret_cast<float4*>(&sp[wave][lane * 8 + 4]) = make_float4(sc[4], sc[5], sc[6], sc[7]);
@@ -879,12 +993,29 @@ void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* ro
 }
 void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
                                   int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
-                                  hipStream_t s, bool fm) {
+                                  hipStream_t s, bool fm, int max_keys) {
   const int dh = D / heads;
   if (Scap > SELF_SMAX || dh > 128 || (dh & 3) != 0 || (D & 7) != 0)
     throw std::runtime_error("stream_self_attention: unsupported cache length or head_dim");
   if (M <= 0) return;
   if (fm && (D & 31) != 0) throw std::runtime_error("stream_self_attention: FM output needs D % 32 == 0");
+  static const bool no_ar_kernel = [] {
+    const char* e = getenv("MSH_STREAM_SELF_AR");
+    return e != nullptr && e[0] == '0';
+  }();
+  if (max_keys > 0 && max_keys <= SELF_AR_KEYS && !no_ar_kernel && (dh == 24 || dh == 40 || dh == 80)) {
+#define MSH_SELF_AR(DHV)                                                                                              \
+  case DHV:                                                                                                           \
+    MSH_LAUNCH(self_attention_ar_kernel<DHV>, dim3(M * heads), dim3(64), 0, s, q, row_slot, row_pos, D, heads, layer, \
+               L, Scap, cacheK, cacheV, out, fm ? 1 : 0);                                                            \
+    return
+    switch (dh) {
+      MSH_SELF_AR(24);
+      MSH_SELF_AR(40);
+      MSH_SELF_AR(80);
+    }
+#undef MSH_SELF_AR
+  }
   MSH_LAUNCH(self_attention_kernel, dim3((M * heads + 3) / 4), dim3(256), 0, s, q, D, row_slot, row_pos, M, D,
                      heads, layer, L, Scap, cacheK, cacheV, out, fm ? 1 : 0);
 }

@@ -1,6 +1,9 @@
 #include "stream_engine.h"
 
+#include <chrono>
+
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -760,9 +763,11 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       if (fm) {
         if (!stream_fm_qkv(H, W.wqkv_fm, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_))
           throw std::logic_error("decoder_pass: FM qkv width not compiled");
-        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, true);
+        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, true,
+                                     ar_keys_bound_);
       } else if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
-        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_);
+        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, false,
+                                     wide ? 0 : ar_keys_bound_);
       } else {
         layernorm_bf16(H, W.ln1, M, Dd, Y, nullptr, stream_);
         gemm_qkv_rope_bf16(Y, Dd, W.wqkv, M, 3 * Dd, Dd, row_pos, rp, QKV, stream_);
@@ -939,6 +944,7 @@ void StreamingEngine::set_bias(int n_nodes, const int32_t* child_off, const int3
 void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const* drafts, const int* draft_lens,
                                   const int* max_tokens, int32_t* tokens_out, int32_t* counts_out, int tokens_stride,
                                   int32_t* accepted_out) {
+  const auto t_call = std::chrono::steady_clock::now();
   if (!loaded_) throw std::runtime_error("weights not loaded");
   check_slots(n, slots);
   if (n > 0 && (tokens_out == nullptr || counts_out == nullptr)) throw std::invalid_argument("null output");
@@ -947,7 +953,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   std::vector<int> rs, rpos, tok, draft_flat, job_slot, job_index;
   std::vector<int2> prefix;  // per wide-pass row: (offset into draft_flat, tokens before the row) for the biaser walk
   std::vector<DecJob> jobs;
-  int max_budget = 0;
+  int max_budget = 0, keys_bound = 0;
   for (int i = 0; i < n; ++i) {
     SlotHost& h = st(slots[i]);
     counts_out[i] = 0;
@@ -977,6 +983,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       prefix.push_back(make_int2(doff, t + 1));
     }
     max_budget = std::max(max_budget, budget);
+    keys_bound = std::max(keys_bound, 2 + std::max(dl, budget));   // BOS + draft / budget + the row being decoded
   }
   const int J = (int)jobs.size(), M = (int)rs.size();
   if (J == 0) return;
@@ -1025,6 +1032,11 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     pval_.reserve((size_t)J * ntn * sizeof(float));
     pidx_.reserve((size_t)J * ntn * sizeof(int));
   }
+  ar_keys_bound_ = keys_bound;   // lets the AR steps' self-attention take its one-round-trip form (<= 128 keys)
+  struct ClearBound {
+    int* p;
+    ~ClearBound() { *p = 0; }
+  } clear_bound{&ar_keys_bound_};
   auto ar_step = [&] {
     if (fused_head) {
       decoder_pass(J, jslot_d, steppos_.as<int>(), nullptr, nullptr, 0, pval_.as<float>(), pidx_.as<int>(), fm);
@@ -1047,7 +1059,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     char key[512];
     snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
              logits_.p, pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p,
-             (int)fused_head + 2 * (int)fm, pval_.p, pidx_.p);
+             (int)fused_head + 2 * (int)fm + 4 * (int)(keys_bound <= 128), pval_.p, pidx_.p);
     if (ar_graph_ == nullptr || ar_key_ != key) {
       if (ar_graph_ != nullptr) {
         MSH_HIP(hipGraphExecDestroy(ar_graph_));
@@ -1075,7 +1087,17 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       ar_key_ = key;
     }
   }
+  // developer timing (MSH_STREAM_TIMING=1): host clock around the verify pass and the AR loop, with the syncs that takes
+  static const bool timing = getenv("MSH_STREAM_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(now() - t).count(); };
+  if (timing) {
+    MSH_HIP(hipStreamSynchronize(stream_));
+    fprintf(stderr, "[moonshine] decode_full: %d streams, %d rows: staging + verify pass %.0f us\n", J, M, us_since(t_call));
+  }
+  const auto t_ar = now();
   int32_t active = 1;
+  int steps_run = 0;
   for (int step = 0; step < max_budget; ++step) {
     if (step % 8 == 0) {
       MSH_HIP(hipMemcpyAsync(&active, n_active_d_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
@@ -1084,6 +1106,13 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     }
     if (graph_now) MSH_HIP(hipGraphLaunch(ar_graph_, stream_));
     else ar_step();
+    ++steps_run;
+  }
+  if (timing) {
+    MSH_HIP(hipStreamSynchronize(stream_));
+    const double us = us_since(t_ar);
+    fprintf(stderr, "[moonshine] decode_full: %d AR steps in %.0f us = %.1f us per step (%s)\n", steps_run, us, us / std::max(steps_run, 1),
+             graph_now ? "graph" : "eager");
   }
   std::vector<SlotDev> sd(J);
   for (int j = 0; j < J; ++j)

@@ -96,6 +96,7 @@ class StreamingEngine {
   void upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst);
   void reserve_decoder_buffers(int rows);
   bool fm_ok_ = false;   // AR steps on FM operands
+  int ar_keys_bound_ = 0;  // while decode_full runs its AR steps: an upper bound of any row's key count (0 = unknown)
   template <class T>
   T* stage(DevBuf& buf, const std::vector<T>& host);  // async H2D of a small descriptor array
   // runs_d (optional): the pass's rows as runs of consecutive rows of one stream, for the shared-K/V cross-attention

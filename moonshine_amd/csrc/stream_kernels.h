@@ -67,10 +67,11 @@ void stream_self_attention(const bf16_t* qkv, const int* row_slot, const int* ro
                            int L, int Scap, bf16_t* cacheK, bf16_t* cacheV, bf16_t* out, hipStream_t s);
 // same attention when k / v of the rows are already in the cache (written by the QKV GEMM epilogue): q [M,D] bf16.
 // fm (here and below): `out` / `H` of the AR steps in the fragment-major layouts of kernels.h (fm16 / fm32, rows padded
-// to 16) -- the operand layout of the FM decode GEMMs that consume them
+// to 16) -- the operand layout of the FM decode GEMMs that consume them.  max_keys: an upper bound of row_pos + 1 over the
+// rows when the caller has one (0 = none): up to 128 keys the one-round-trip AR kernel runs (same arithmetic and order)
 void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const int* row_pos, int M, int D, int heads,
                                   int layer, int L, int Scap, const bf16_t* cacheK, const bf16_t* cacheV, bf16_t* out,
-                                  hipStream_t s, bool fm = false);
+                                  hipStream_t s, bool fm = false, int max_keys = 0);
 // cross-attention of every row over its stream's memory (keys [0, slots[slot].mem_len))
 // word timestamps: softmax probabilities of every (row, head) over the stream's memory frames -> out[row][layer][head][Ecap]
 void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads, int layer,
