@@ -187,6 +187,13 @@ MSH_EXPORT float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_
 MSH_EXPORT int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
                                     const float* b1, const float* w2, const float* b2);
 
+/* Developer / test hook: the encoder QKV panel kernel (LayerNorm + q | k with RoPE + V transposed, k_panel.hip) on R rows
+ * (R % 8 == 0) of synthetic data at width D (416 or 288); returns ms per launch (< 0 on error).  Non-null outputs receive the
+ * last launch's results as bf16 bit patterns (qk [R][2D], vt [D][R]) and the inputs used (h [R][D], w [3D][D] fp32, pos [R],
+ * pos < 0 = padding row) so that a test can recompute them (tests/test_gpu_panel.py). */
+MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h,
+                                    float* out_w, int32_t* out_pos);
+
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

@@ -147,6 +147,17 @@ float mlp_microbench(int R, int D, int F, int iters, int abl);
 void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
                     const float* b2);
 
+// ---------------- A-stationary panel GEMMs of the encoder (k_panel.hip) ----------------
+// Weights packed at load by pack_panel_weights (chunks of 32 output columns, MFMA-fragment order; gamma folded in when given).
+size_t panel_packed_elems(int N, int D);
+void pack_panel_weights(const float* w, const float* gamma, int N, int D, bf16_t* out);
+// encoder QKV: LayerNorm(H) * Wqkv^T; q | k with RoPE -> qk [R][2D] bf16, v -> vt [D][vt_ld] bf16 (transposed).
+// Replaces layernorm_bf16 + gemm_qkv_rope_bf16 + the swapped-operand V^T GEMM.  R % 8 == 0.
+bool qkv_panel_supported(int D, int head_dim, int rot_pairs);
+void qkv_panel(const float* H, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
+               long vt_ld, hipStream_t s);
+float qkv_panel_microbench(int R, int D, int iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h, float* out_w, int* out_pos);
+
 // ---------------- attention ----------------
 // encoder self-attention over the packed stream: qk [R,2D] bf16 (q | k, RoPE applied), vt = V^T [D][vt_ld] bf16 (row d,
 // stream rows contiguous; vt_ld >= R) -> out [R,D] bf16

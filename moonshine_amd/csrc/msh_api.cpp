@@ -347,6 +347,16 @@ float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_t iters, in
   }
 }
 
+float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h, float* out_w,
+                         int32_t* out_pos) {
+  try {
+    return msh::qkv_panel_microbench(R, D, iters, out_qk, out_vt, out_h, out_w, out_pos);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "qkv_panel: %s\n", ex.what());
+    return -1.0f;
+  }
+}
+
 int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma, const float* b1,
                          const float* w2, const float* b2) {
   try {
