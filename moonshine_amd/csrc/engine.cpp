@@ -418,8 +418,23 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
   for (int l = 0; l < c.enc_layers; ++l) {
     const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
     EncLayerW& L = enc_[l];
-    upload_bf16(fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}),
-                &L.wqkv);
+    {
+      const std::vector<float> qkv = fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"});
+      upload_bf16(qkv, &L.wqkv);
+      if (qkv_panel_supported(D, c.head_dim(), c.rot_pairs()) && !dry_run_) {
+        const std::vector<float> gam = vec(p + "input_layernorm.weight", D);
+        std::vector<bf16_t> packed(panel_packed_elems(3 * D, D));
+        pack_panel_weights(qkv.data(), gam.data(), 3 * D, D, packed.data());
+        void* dp = nullptr;
+        {
+          std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+          dp = device_alloc(packed.size() * sizeof(bf16_t));
+        }
+        weight_allocs_.push_back(dp);
+        copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+        L.qkv_panel = reinterpret_cast<bf16_t*>(dp);
+      }
+    }
     upload_bf16(fuse({p + "self_attn.o_proj.weight"}), &L.wo);
     expect_shape(p + "mlp.fc1.weight", {F, D});
     expect_shape(p + "mlp.fc2.weight", {D, F});
@@ -729,8 +744,9 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= x2_.reserve((2 * R + 8) * 2 * D * sizeof(bf16_t));
   moved |= H_.reserve(R * D * sizeof(float));
   moved |= Y_.reserve(R * D * sizeof(bf16_t));
-  moved |= QKV_.reserve(R * 2 * D * sizeof(bf16_t));                 // q | k rows of the current encoder layer
-  moved |= VTe_.reserve(((size_t)D * R + 64) * sizeof(bf16_t));          // its V^T [D][R]: keys contiguous
+  const size_t Rp = (R + 127) / 128 * 128;   // the panel kernel (k_panel.hip) stores whole 128-row panels: rows past R are padding
+  moved |= QKV_.reserve(Rp * 2 * D * sizeof(bf16_t));                // q | k rows of the current encoder layer
+  moved |= VTe_.reserve(((size_t)D * Rp + 64) * sizeof(bf16_t));         // its V^T [D][Rp]: keys contiguous
   moved |= AO_.reserve(R * D * sizeof(bf16_t));
   moved |= Z_.reserve(R * F * sizeof(bf16_t));
   moved |= ENC_.reserve(R * D * sizeof(bf16_t));
@@ -811,6 +827,11 @@ void Engine::run_encoder() {
   }
   RopeParams rp{rope_cos_, rope_sin_, cfg_.rot_pairs(), cfg_.head_dim(), D};
   // MSH_ENC_MLP=0: the MLP block as LayerNorm + two tiled GEMMs (A/B switch; the fused kernel is the default)
+  // developer switch (read per call, so that one test process can compare both paths): 0 = the tiled GEMMs, 2 = the panel
+  // kernel at any batch size
+  const char* qkv_env = getenv("MSH_ENC_QKV_PANEL");
+  const bool qkv_panel_on = !(qkv_env != nullptr && qkv_env[0] == '0');
+  const long qkv_panel_min_rows = (qkv_env != nullptr && qkv_env[0] == '2') ? 8 : 128 * 128;
   static const bool fused_mlp = [] {
     const char* e = getenv("MSH_ENC_MLP");
     return !(e != nullptr && e[0] == '0');
@@ -841,23 +862,32 @@ void Engine::run_encoder() {
   }
   for (int l = 0; l < cfg_.enc_layers; ++l) {
     const EncLayerW& W = enc_[l];
-    {
-      ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
-      layernorm_bf16(H_.as<float>(), W.ln1, R, D, Y_.as<bf16_t>(), nullptr, s);
-    }
-    {  // q | k with RoPE, row-major [R][2D]
-      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 2 * D, sT * D * 2 * 3);
-      gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 2 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
-    }
-    {  // v TRANSPOSED, as one plain GEMM with the operands swapped: V^T [D][R] = Wv [D][D] x Y^T -- the weight is the
-       // "activation" (4 row tiles), the R stream rows are the output columns, so the keys of a clip are contiguous in
-       // every row of the result: what the attention kernel's P.V wants as its MFMA operand
-      ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * D, sT * D * 2 * 2);
-      gemm_act(W.wqkv + (size_t)2 * D * D, D, Y_.as<bf16_t>(), nullptr, 0, D, (int)R, D, VTe_.as<bf16_t>(), nullptr, s);
+    long vt_ld = (long)R;
+    if (qkv_panel_on && W.qkv_panel != nullptr && R >= qkv_panel_min_rows && (R & 7) == 0) {
+      // LayerNorm + q | k with RoPE + V transposed in one A-stationary panel kernel (k_panel.hip); below about half a
+      // panel per CU the tiled GEMMs, whose tiles are smaller, fill the chip better
+      ProfScope p(this, "enc_qkv_panel", 2.0 * sT * D * 3 * D, sT * D * (4 + 6));
+      vt_ld = (long)((R + 127) / 128 * 128);
+      qkv_panel(H_.as<float>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s);
+    } else {
+      {
+        ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+        layernorm_bf16(H_.as<float>(), W.ln1, R, D, Y_.as<bf16_t>(), nullptr, s);
+      }
+      {  // q | k with RoPE, row-major [R][2D]
+        ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 2 * D, sT * D * 2 * 3);
+        gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 2 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
+      }
+      {  // v TRANSPOSED, as one plain GEMM with the operands swapped: V^T [D][R] = Wv [D][D] x Y^T -- the weight is the
+         // "activation" (4 row tiles), the R stream rows are the output columns, so the keys of a clip are contiguous in
+         // every row of the result: what the attention kernel's P.V wants as its MFMA operand
+        ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * D, sT * D * 2 * 2);
+        gemm_act(W.wqkv + (size_t)2 * D * D, D, Y_.as<bf16_t>(), nullptr, 0, D, (int)R, D, VTe_.as<bf16_t>(), nullptr, s);
+      }
     }
     {
       ProfScope p(this, "enc_attention", 4.0 * sT2 * D, sT * D * 2 * 4);
-      enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), (long)R, AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
+      enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
     }
     {
       ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));

@@ -41,6 +41,7 @@ struct EncLayerW {
   float *ln1, *ln2, *b1, *b2;
   bf16_t *wqkv, *wo, *fc1, *fc2;
   bf16_t* mlp = nullptr;   // fc1 (LayerNorm scale folded in) + b1 + fc2 packed for the fused MLP kernel (k_mlp.hip), or null
+  bf16_t* qkv_panel = nullptr;   // q | k | v with the LayerNorm scale folded in, packed for the panel kernel (k_panel.hip), or null
 };
 struct DecLayerW {
   float *ln1, *ln2, *ln3, *b1, *b2;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "gemm_common.h"
+#include "panel_rows.h"
 
 namespace msh {
 namespace {
@@ -56,23 +57,6 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-// 4 x 4 transpose inside every quad of lanes: in: lane r holds x[e] = (row r, column e); out: x[k] = (row k, column r)
-__device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
-  const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
-#pragma unroll
-  for (int p = 0; p < 4; p += 2) {
-    const float s = o1 ? x[p] : x[p + 1];
-    const float t = dpp_f<0xB1>(s);   // quad_perm [1, 0, 3, 2]
-    if (o1) x[p] = t; else x[p + 1] = t;
-  }
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const float s = o2 ? x[p] : x[p + 2];
-    const float t = dpp_f<0x4E>(s);   // quad_perm [2, 3, 0, 1]
-    if (o2) x[p] = t; else x[p + 2] = t;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Epilogue of the encoder QKV projection.  Sections of D columns: 0 = q, 1 = k (RoPE, row-major [R][2D] bf16), 2 = v
 // (transposed: vt[c][row], the P.V operand of enc_attention).  A lane's row position is fixed for the whole panel: its
@@ -90,16 +74,29 @@ struct EpiQkvPanel {
   struct Row {
     float cs[RP], sn[RP];
   };
-  __device__ void init(Row& r, int row) const {
+  // the RoPE factors of the wave's 32 rows: fetched with lanes running along the table rows (23 consecutive floats per row)
+  // into the wave's LDS scratch, then every lane picks up its row -- per-lane reads of the global table were 46 loads of
+  // 64 different lines each
+  __device__ void init(Row& r, int row0, int R, float* tab, int lane) const {
+    constexpr int TW = 2 * RP + 1;
+    int row = row0 + (lane & 31);
+    row = row < R ? row : R - 1;
     int pos = row_pos[row];
     pos = pos < 0 ? 0 : pos;
-    const float* c = cos_t + (long)pos * RP;
-    const float* s = sin_t + (long)pos * RP;
+    for (int idx = lane; idx < 32 * RP; idx += 64) {
+      const int rr = idx / RP, j = idx - rr * RP;
+      const int pr = __shfl(pos, rr, 64);
+      tab[rr * TW + j] = cos_t[(long)pr * RP + j];
+      tab[rr * TW + RP + j] = sin_t[(long)pr * RP + j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* mine = tab + (lane & 31) * TW;
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
-      r.cs[j] = c[j];
-      r.sn[j] = s[j];
+      r.cs[j] = mine[j];
+      r.sn[j] = mine[RP + j];
     }
+    __builtin_amdgcn_wave_barrier();
   }
   __device__ void init_dummy(Row& r, int lane) const {
 #pragma unroll
@@ -108,37 +105,63 @@ struct EpiQkvPanel {
       r.sn[j] = 0.25f * j;
     }
   }
-  // KIND 0 = a q / k section (sec = 0 / 1), KIND 1 = the v section.
-  // group Q (accumulator registers 4Q..4Q+3 = columns 32 C + 8 Q + 4 hh + 0..3 of the section) -> packed / transposed
-  template <int KIND, int C, int Q>
-  __device__ void compute(const f32x16& z, uint32_t (&pk)[8], const Row& r, int hh, int lane) const {
-    float x[4] = {z[4 * Q], z[4 * Q + 1], z[4 * Q + 2], z[4 * Q + 3]};
+  // KIND 0 = a q / k section (sec = 0 / 1), KIND 1 = the v section.  Group Q = accumulator registers 4Q..4Q+3 = columns
+  // 32 C + 8 Q + 4 hh + 0..3 of the section.  A group is finished in two halves (half A behind one MFMA, half B behind the
+  // next: short VALU bursts keep the matrix pipe fed), the values in between live in x.
+  template <int KIND, int C, int Q, int HALF>
+  __device__ void compute(const f32x16& z, float (&x)[4], uint32_t (&pk)[8], const Row& r, int hh, int lane) const {
+    if constexpr (HALF == 0) {
+      x[0] = z[4 * Q];
+      x[1] = z[4 * Q + 1];
+      x[2] = z[4 * Q + 2];
+      x[3] = z[4 * Q + 3];
+    }
     if constexpr (KIND == 0) {
       constexpr int d0 = (32 * C + 8 * Q) % DH, d1 = (32 * C + 8 * Q + 4) % DH;   // head-dim offset for hh = 0 / 1
-      sfor<2>([&](auto pc) {
-        constexpr int p = decltype(pc)::value, j0 = d0 / 2 + p, j1 = d1 / 2 + p;
-        float c0 = 1.f, s0 = 0.f, c1 = 1.f, s1 = 0.f;   // pairs beyond the rotary part pass through
-        if constexpr (j0 < RP) {
-          c0 = r.cs[j0];
-          s0 = r.sn[j0];
-        }
-        if constexpr (j1 < RP) {
-          c1 = r.cs[j1];
-          s1 = r.sn[j1];
-        }
+      constexpr int p = HALF, j0 = d0 / 2 + p, j1 = d1 / 2 + p;
+      float c0 = 1.f, s0 = 0.f, c1 = 1.f, s1 = 0.f;   // pairs beyond the rotary part pass through
+      if constexpr (j0 < RP) {
+        c0 = r.cs[j0];
+        s0 = r.sn[j0];
+      }
+      if constexpr (j1 < RP) {
+        c1 = r.cs[j1];
+        s1 = r.sn[j1];
+      }
+      if constexpr (j0 < RP || j1 < RP) {
         const float c = hh ? c1 : c0, s = hh ? s1 : s0;
         const float x0 = x[2 * p], x1 = x[2 * p + 1];
         x[2 * p] = x0 * c - x1 * s;
         x[2 * p + 1] = x1 * c + x0 * s;
-      });
+      }
+      pk[2 * Q + p] = pack_bf16x2(x[2 * p], x[2 * p + 1]);
     } else {
-      quad_transpose(x, lane);
+      // 4 x 4 transpose inside every quad of lanes (rows) in two exchange steps: afterwards lane r = lane & 3 holds column
+      // 8 Q + 4 hh + r for the quad's 4 rows
+      if constexpr (HALF == 0) {
+        const bool o1 = (lane & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const float t = dpp_f<0xB1>(o1 ? x[i] : x[i + 1]);   // quad_perm [1, 0, 3, 2]
+          if (o1) x[i] = t; else x[i + 1] = t;
+        }
+      } else {
+        const bool o2 = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float t = dpp_f<0x4E>(o2 ? x[i] : x[i + 2]);   // quad_perm [2, 3, 0, 1]
+          if (o2) x[i] = t; else x[i + 2] = t;
+        }
+        pk[2 * Q] = pack_bf16x2(x[0], x[1]);
+        pk[2 * Q + 1] = pack_bf16x2(x[2], x[3]);
+      }
     }
-    pk[2 * Q] = pack_bf16x2(x[0], x[1]);
-    pk[2 * Q + 1] = pack_bf16x2(x[2], x[3]);
   }
+  // Stores are UNCONDITIONAL (the kernel counts them in its vmcnt waits): rows past R land in the buffers' padding -- qk
+  // holds ceil(R / 128) * 128 rows and vt_ld >= that.
+  static constexpr int kMinStores = 2;   // the fewest store instructions a chunk issues
   template <int KIND, int C>
-  __device__ void store(uint32_t (&pk)[8], int sec, int row, int hh, int lane, int R) const {
+  __device__ void store(uint32_t (&pk)[8], int sec, int row, int hh, int lane) const {
     if constexpr (KIND == 0) {
       // swap32(a = group 2p, b = group 2p + 1): lane hh = 1's a (columns 16p + 4..7) <-> lane hh = 0's b (16p + 8..11);
       // afterwards hh = 0 holds columns 16p + 0..7 and hh = 1 columns 16p + 8..15: 16-byte stores
@@ -146,20 +169,15 @@ struct EpiQkvPanel {
       swap32(pk[1], pk[3]);
       swap32(pk[4], pk[6]);
       swap32(pk[5], pk[7]);
-      if (row < R) {
-        bf16_t* o = qk + (long)row * (2 * D) + sec * D + 32 * C + 8 * hh;
-        *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        *reinterpret_cast<uint4*>(o + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-      }
+      bf16_t* o = qk + (long)row * (2 * D) + sec * D + 32 * C + 8 * hh;
+      *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      *reinterpret_cast<uint4*>(o + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     } else {
-      // after the quad transpose lane r = lane & 3 holds column 8 Q + 4 hh + r for the quad's 4 rows
-      const int r0 = row & ~3;   // (the quad's first row; R is a multiple of 8: a quad is all in or all out)
-      if (r0 < R) {
+      const int r0 = row & ~3;   // the quad's first row
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = 32 * C + 8 * q + 4 * hh + (lane & 3);
-          *reinterpret_cast<uint2*>(vt + (long)c * vt_ld + r0) = make_uint2(pk[2 * q], pk[2 * q + 1]);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * C + 8 * q + 4 * hh + (lane & 3);
+        *reinterpret_cast<uint2*>(vt + (long)c * vt_ld + r0) = make_uint2(pk[2 * q], pk[2 * q + 1]);
       }
     }
   }
@@ -189,14 +207,6 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
   auto issue_piece = [&](const bf16_t* src, unsigned dst, int q) {
     if (q < PMAX - 1 || my_pieces == PMAX) dma16(src + (long)q * 2048, dst + (unsigned)q * 4096u);
   };
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const bf16_t* src = stage_src(s);
-    const unsigned dst = stage_dst(s);
-#pragma unroll
-    for (int q = 0; q < PMAX; ++q) issue_piece(src, dst, q);
-  }
-
   // ---- the wave's 32 x D activation block as the MFMA B operand: lane (mrow, hh) holds columns 16 s + 8 hh + 0..7 ----
   const int row = blockIdx.x * 128 + wave * 32 + mrow;
   const int lrow = row < R ? row : R - 1;
@@ -208,34 +218,35 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
       yf[s] = frag_of(p);
     }
   } else if constexpr (LN) {
-    const float* hp = reinterpret_cast<const float*>(Aptr) + (long)lrow * D + hh * 8;
-    const float k0 = hp[0];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(hp + s * 16), b = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+    // the wave's rows through LDS (panel_rows.h), twice: moments (shifted by the lane's first value, the two half rows merged
+    // with Chan's formula: no cancellation whatever the row's mean), then -- the block comes from L2 now -- the operand
+    using RV = RowsViaLds<D, (D >= 416 ? 4 : 3)>;
+    static_assert(4 * RV::BYTES <= (int)sizeof(lds), "the staging regions live in the (still empty) weight ring");
+    const unsigned roff = lds_base + (unsigned)(wave * RV::BYTES);
+    const unsigned char* rptr = reinterpret_cast<const unsigned char*>(lds) + wave * RV::BYTES;
+    const float* Hf = reinterpret_cast<const float*>(Aptr);
+    const int row0w = blockIdx.x * 128 + wave * 32;
+    float k0 = 0.f, s1 = 0.f, s2 = 0.f;
+    RV::run(Hf, row0w, R, roff, rptr, lane, [&](auto sc, const float4 a, const float4 b) {
+      if constexpr (decltype(sc)::value == 0) k0 = a.x;
       const float d0 = a.x - k0, d1 = a.y - k0, d2 = a.z - k0, d3 = a.w - k0, d4 = b.x - k0, d5 = b.y - k0, d6 = b.z - k0, d7 = b.w - k0;
       s1 += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
       s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
-    }
+    });
     constexpr float kHalf = D / 2;
     const float mean_l = k0 + s1 * (1.0f / kHalf), m2_l = s2 - s1 * s1 * (1.0f / kHalf);
     const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2_l, 32, 64);
     const float mean = 0.5f * (mean_l + mean_o), dm = mean_l - mean_o;
     const float var = (m2_l + m2_o + dm * dm * (0.5f * kHalf)) * (1.0f / D);
     const float rstd = rsqrtf(var + 1e-5f);
-    // second pass (the panel is in L2 now), in two halves: all of a row's loads in flight at once do not fit 256 registers
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s == KS / 2) __builtin_amdgcn_sched_barrier(0);
-      const float4 xa = *reinterpret_cast<const float4*>(hp + s * 16), xb = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+    RV::run(Hf, row0w, R, roff, rptr, lane, [&](auto sc, const float4 xa, const float4 xb) {
       uint4 p;
       p.x = pack_bf16x2((xa.x - mean) * rstd, (xa.y - mean) * rstd);
       p.y = pack_bf16x2((xa.z - mean) * rstd, (xa.w - mean) * rstd);
       p.z = pack_bf16x2((xb.x - mean) * rstd, (xb.y - mean) * rstd);
       p.w = pack_bf16x2((xb.z - mean) * rstd, (xb.w - mean) * rstd);
-      yf[s] = frag_of(p);
-    }
+      yf[decltype(sc)::value] = frag_of(p);
+    });
   } else {
     const bf16_t* ap = reinterpret_cast<const bf16_t*>(Aptr) + (long)lrow * D + hh * 8;
 #pragma unroll
@@ -245,8 +256,19 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
     }
   }
   typename Epi::Row rctx;
-  if constexpr ((ABL & 16) == 0) epi.init(rctx, lrow);
-  else epi.init_dummy(rctx, lane);
+  if constexpr ((ABL & 16) == 0) {
+    epi.init(rctx, blockIdx.x * 128 + wave * 32, R, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + wave * (int)(sizeof(lds) / 4)), lane);
+  } else {
+    epi.init_dummy(rctx, lane);
+  }
+  __syncthreads();   // every wave is done with its staging region: the weight ring may be filled
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {   // stages 0 and 1
+    const bf16_t* src = stage_src(s);
+    const unsigned dst = stage_dst(s);
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) issue_piece(src, dst, q);
+  }
 
   uint4 fr[PF];
   f32x16 za, zp;        // accumulator of the chunk being multiplied / of the finished chunk being stored
@@ -259,8 +281,10 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
   // One stage = the KS MFMAs of chunk j.  Beside them: the fragment ring (PF reads ahead, across stages), the finish of
   // chunk j - 1 (VALU, first half), ONE barrier in the middle (publishes stage j + 1, retires stage j - 1), then chunk
   // j - 1's stores and the DMAs of stage j + 2 into the retired buffer.  Order pinned as in k_mlp.hip.
-  // kp_c: kind of the PREVIOUS chunk (-1: there is none); sec_p: its section
-  auto stage = [&](int j, int buf, auto c_c, auto kp_c, int sec_p) {
+  // kp_c: kind of the PREVIOUS chunk (-1: there is none); sec_p: its section.  first_stores: this is the first stage whose
+  // predecessor issued stores (only then may the mid-stage wait leave stores in flight).
+  float xs[4];
+  auto stage = [&](int j, int buf, auto c_c, auto kp_c, int sec_p, bool prev_stored) {
     constexpr int C = decltype(c_c)::value, CP = (C + CT - 1) % CT, KP = decltype(kp_c)::value;
     const int nbuf = buf + 1 == NST ? 0 : buf + 1;
     const bf16_t* nsrc = stage_src(j + 2);
@@ -268,9 +292,10 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
     const uint4* st = lds + buf * (KS * 64) + lane;
     const uint4* stn = lds + nbuf * (KS * 64) + lane;
     constexpr int RO = (C * KS) % PF;   // ring slot of this stage's first step (the ring restarts with every section)
-    constexpr int DS = (KS - MID - 3) / PMAX > 0 ? (KS - MID - 3) / PMAX : 1;
-    constexpr int GS = (MID - 1) / 4;
-    static_assert(GS >= 1 && 1 + 3 * GS < MID, "the four finish groups must fit the first half of a stage");
+    constexpr int DS = (KS - MID - 4) / PMAX > 0 ? (KS - MID - 4) / PMAX : 1;
+    constexpr int STORE_AT = KS - 2;
+    static_assert(MID >= 9, "the eight finish half-groups sit behind steps 1..8 of the first half");
+    static_assert(MID + 1 + (PMAX - 1) * DS < STORE_AT, "the stores go behind the last DMA");
     sfor<KS>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
       if constexpr (f == 0) {
@@ -281,23 +306,32 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
       } else {
         za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(fr[(RO + f) % PF]), yf[f], za, 0, 0, 0);
       }
-      // finish of the previous chunk (VALU only): group Q behind step 1 + Q GS
-      if constexpr ((ABL & 2) == 0 && KP >= 0 && f >= 1 && (f - 1) % GS == 0 && (f - 1) / GS < 4) {
-        constexpr int Q = (f - 1) / GS;
-        epi.template compute<KP, CP, Q>(zp, pk, rctx, hh, lane);
-        asm volatile("" : "+v"(pk[2 * Q]), "+v"(pk[2 * Q + 1]));
+      // finish of the previous chunk (VALU only): half (f - 1) % 2 of group (f - 1) / 2 behind step f = 1..8
+      if constexpr ((ABL & 2) == 0 && KP >= 0 && f >= 1 && f <= 8) {
+        constexpr int Q = (f - 1) / 2, HALF = (f - 1) % 2;
+        epi.template compute<KP, CP, Q, HALF>(zp, xs, pk, rctx, hh, lane);
+        if constexpr (HALF == 0) asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]));
+        else asm volatile("" : "+v"(pk[2 * Q]), "+v"(pk[2 * Q + 1]));
       }
       if constexpr (f == MID) {
-        wait_vmcnt<0>();
+        // this wave's pieces of stage j + 1 were requested BEFORE the previous stage's stores: loads and stores retire in
+        // order, so the pieces are in once at most that chunk's stores are outstanding -- the stores themselves (hundreds
+        // of cycles of HBM write latency under load) are never waited for
+        if constexpr ((ABL & 32) != 0) {
+          wait_vmcnt<0>();
+        } else {
+          if (prev_stored) wait_vmcnt<Epi::kMinStores>();
+          else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
       }
-      if constexpr ((ABL & 1) == 0 && KP >= 0 && f == MID + 1) epi.template store<KP, CP>(pk, sec_p, row, hh, lane, R);
-      if constexpr ((ABL & 4) == 0 && f > MID + 1) {
+      if constexpr ((ABL & 4) == 0 && f > MID) {
         sfor<PMAX>([&](auto qc) {
-          constexpr int q = decltype(qc)::value, at = (MID + 2 + q * DS) < KS ? (MID + 2 + q * DS) : KS - 1;
+          constexpr int q = decltype(qc)::value, at = MID + 1 + q * DS;
           if constexpr (at == f) issue_piece(nsrc, ndst, q);
         });
       }
+      if constexpr ((ABL & 1) == 0 && KP >= 0 && f == STORE_AT) epi.template store<KP, CP>(pk, sec_p, row, hh, lane);
       if constexpr (f + PF < KS) fr[(RO + f) % PF] = st[(f + PF) * 64];
       else if constexpr (C + 1 < CT) fr[(RO + f) % PF] = stn[(f + PF - KS) * 64];   // next stage's first fragments (published at MID)
       __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +355,9 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
   // a section's chunks 1 .. CT - 1 (their previous chunk is in the same section)
   auto rest_of_section = [&](auto kind_c, int sec) {
     sfor<CT - 1>([&](auto cc) {
-      stage(j, buf, std::integral_constant<int, decltype(cc)::value + 1>{}, kind_c, sec);
+      constexpr int C = decltype(cc)::value + 1;
+      // stage j - 1 issued stores unless it was the very first stage
+      stage(j, buf, std::integral_constant<int, C>{}, kind_c, sec, C > 1 || sec > 0);
       advance();
     });
   };
@@ -330,27 +366,27 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
   __builtin_amdgcn_s_barrier();   // stages 0 and 1 are in the ring
   for (int sec = 0; sec < n0; ++sec) {
     ring_restart();
-    if (sec == 0) stage(j, buf, K0{}, KN{}, 0);
-    else stage(j, buf, K0{}, K0{}, sec - 1);
+    if (sec == 0) stage(j, buf, K0{}, KN{}, 0, false);
+    else stage(j, buf, K0{}, K0{}, sec - 1, true);
     advance();
     rest_of_section(K0{}, sec);
   }
   for (int sec = n0; sec < nsec; ++sec) {
     ring_restart();
-    if (sec == 0) stage(j, buf, K0{}, KN{}, 0);
-    else if (sec == n0) stage(j, buf, K0{}, K0{}, sec - 1);
-    else stage(j, buf, K0{}, K1{}, sec - 1);
+    if (sec == 0) stage(j, buf, K0{}, KN{}, 0, false);
+    else if (sec == n0) stage(j, buf, K0{}, K0{}, sec - 1, true);
+    else stage(j, buf, K0{}, K1{}, sec - 1, true);
     advance();
     rest_of_section(K1{}, sec);
   }
   wait_vmcnt<0>();   // trailing re-fetches must not outlive the workgroup's LDS
   // the last chunk
   if (n1 > 0) {
-    sfor<4>([&](auto qc) { epi.template compute<1, CT - 1, decltype(qc)::value>(zp, pk, rctx, hh, lane); });
-    epi.template store<1, CT - 1>(pk, nsec - 1, row, hh, lane, R);
+    sfor<8>([&](auto uc) { epi.template compute<1, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, hh, lane); });
+    epi.template store<1, CT - 1>(pk, nsec - 1, row, hh, lane);
   } else {
-    sfor<4>([&](auto qc) { epi.template compute<0, CT - 1, decltype(qc)::value>(zp, pk, rctx, hh, lane); });
-    epi.template store<0, CT - 1>(pk, nsec - 1, row, hh, lane, R);
+    sfor<8>([&](auto uc) { epi.template compute<0, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, hh, lane); });
+    epi.template store<0, CT - 1>(pk, nsec - 1, row, hh, lane);
   }
 }
 
@@ -369,7 +405,7 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
     switch (abl) {
       case 0: break;
 #define MSH_PABL(A) case A: MSH_LAUNCH((panel_gemm_kernel<D, true, E, A>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1); return;
-      MSH_PABL(1) MSH_PABL(2) MSH_PABL(3) MSH_PABL(4) MSH_PABL(7) MSH_PABL(8) MSH_PABL(16) MSH_PABL(24) MSH_PABL(31) MSH_PABL(27)
+      MSH_PABL(1) MSH_PABL(2) MSH_PABL(3) MSH_PABL(4) MSH_PABL(7) MSH_PABL(8) MSH_PABL(16) MSH_PABL(24) MSH_PABL(31) MSH_PABL(27) MSH_PABL(32)
 #undef MSH_PABL
       default: throw std::runtime_error("qkv_panel: ablation not compiled");
     }
@@ -441,30 +477,32 @@ float qkv_panel_microbench(int R, int D, int iters, uint16_t* out_qk, uint16_t* 
   MSH_HIP(hipMalloc(&Cd, cs.size() * 4));
   MSH_HIP(hipMalloc(&Sd, sn.size() * 4));
   MSH_HIP(hipMalloc(&Wd, packed.size() * 2));
-  MSH_HIP(hipMalloc(&QK, (size_t)R * 2 * D * 2));
-  MSH_HIP(hipMalloc(&VT, (size_t)D * R * 2));
+  const long Rp = (R + 127) / 128 * 128;   // rows past R are stored too (into the padding)
+  MSH_HIP(hipMalloc(&QK, (size_t)Rp * 2 * D * 2));
+  MSH_HIP(hipMalloc(&VT, (size_t)D * Rp * 2));
   MSH_HIP(hipMalloc(&Pd, (size_t)R * 4));
   MSH_HIP(hipMemcpy(Hd, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Cd, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Sd, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Wd, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Pd, pos.data(), (size_t)R * 4, hipMemcpyHostToDevice));
-  MSH_HIP(hipMemset(QK, 0, (size_t)R * 2 * D * 2));
-  MSH_HIP(hipMemset(VT, 0, (size_t)D * R * 2));
+  MSH_HIP(hipMemset(QK, 0, (size_t)Rp * 2 * D * 2));
+  MSH_HIP(hipMemset(VT, 0, (size_t)D * Rp * 2));
   const RopeParams rp{Cd, Sd, RP, DH, D};
-  qkv_panel(Hd, Wd, R, D, Pd, rp, QK, VT, R, 0);
+  qkv_panel(Hd, Wd, R, D, Pd, rp, QK, VT, Rp, 0);
   MSH_HIP(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   MSH_HIP(hipEventCreate(&e0));
   MSH_HIP(hipEventCreate(&e1));
   MSH_HIP(hipEventRecord(e0, 0));
-  for (int i = 0; i < iters; ++i) qkv_panel(Hd, Wd, R, D, Pd, rp, QK, VT, R, 0);
+  for (int i = 0; i < iters; ++i) qkv_panel(Hd, Wd, R, D, Pd, rp, QK, VT, Rp, 0);
   MSH_HIP(hipEventRecord(e1, 0));
   MSH_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   MSH_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (out_qk != nullptr) MSH_HIP(hipMemcpy(out_qk, QK, (size_t)R * 2 * D * 2, hipMemcpyDeviceToHost));
-  if (out_vt != nullptr) MSH_HIP(hipMemcpy(out_vt, VT, (size_t)D * R * 2, hipMemcpyDeviceToHost));
+  if (out_vt != nullptr)
+    MSH_HIP(hipMemcpy2D(out_vt, (size_t)R * 2, VT, (size_t)Rp * 2, (size_t)R * 2, D, hipMemcpyDeviceToHost));
   if (out_h != nullptr) memcpy(out_h, h.data(), h.size() * 4);
   if (out_w != nullptr) memcpy(out_w, w.data(), w.size() * 4);
   if (out_pos != nullptr) memcpy(out_pos, pos.data(), (size_t)R * 4);

@@ -75,3 +75,33 @@ def test_qkv_panel_speed_report(capsys):
     with capsys.disabled():
         print(f"\n[qkv panel] R = {R}: {ms:.3f} ms = {flops / ms / 1e9:.0f} TFLOP/s = {flops / ms / 1e9 / 2500:.3f} of the MFMA peak "
               f"(tiled: 0.33 ms + 0.048 ms LayerNorm)")
+
+
+@pytest.mark.parametrize("arch", ["base", "tiny"])
+def test_encoder_on_the_qkv_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch, arch):
+    """The whole encoder with the panel kernel forced on at a small ragged batch (it is the default from 16 k rows on,
+    where tests/test_gpu_parity.py::test_base_batch256_benchmark_path_vs_oracle runs it): last_hidden_state against the
+    ORACLE at the stated encoder tolerance, and against the tiled-GEMM path of the same engine."""
+    from oracle import moonshine_ref as ref
+    from oracle.weights import make_audio
+    from test_gpu_parity import _enc_check, _engine
+
+    e, w, cfg = _engine(tmp_path_factory, arch, 3)
+    lens = [160000, 48000, 159744, 100000, 7000, 31999]
+    clips = [make_audio(70 + i, n) for i, n in enumerate(lens)]
+    e.set_keep_encoder_output(True)
+    monkeypatch.setenv("MSH_ENC_QKV_PANEL", "2")
+    e.encode(clips)
+    panel = [e.encoder_output(i).copy() for i in range(len(clips))]
+    monkeypatch.setenv("MSH_ENC_QKV_PANEL", "0")
+    e.encode(clips)
+    tiled = [e.encoder_output(i).copy() for i in range(len(clips))]
+    worst = 0.0
+    for i in (0, 1, 4, 5):
+        want = ref.encoder_forward(w, cfg, clips[i])
+        r, _ = _enc_check(panel[i], want)
+        worst = max(worst, r)
+    for a, b in zip(panel, tiled):
+        assert a.shape == b.shape
+        _enc_check(a, b)
+    print(f"[{arch}] encoder with the QKV panel kernel: rel-RMS {worst:.2e} against the oracle")
