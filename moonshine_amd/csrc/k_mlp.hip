@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gemm_common.h"
+#include "panel_rows.h"
 
 namespace msh {
 namespace {
@@ -96,22 +97,40 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
   // ---- LayerNorm of this lane's row straight from the residual stream, kept as the fc1 B-operand ----
   // lane (mrow, hh) holds columns s*16 + hh*8 + 0..7 of row m0 + mrow for every k-step s: half a row
   const int row = blockIdx.x * 128 + wave * 32 + mrow;
-  const float* hp = H + (long)(row < R ? row : R - 1) * D + hh * 8;
   bf16x8 yf[KS];
   f32x16 oacc[CT];   // fc2 accumulators, started from the residual itself (below): H leaves HBM ONCE
   {
+    // The wave's 32 rows come through LDS (panel_rows.h: fetched with lanes running along the rows, read back in the operand
+    // pattern -- a lane reading its own row from global memory costs 64 cache-line lookups per load instruction), staged in
+    // the ring's third buffer, which is empty until the first stage's barrier.
+    constexpr int kPerWave = PIECES * 1024 / 4;   // bytes of the third ring buffer per wave
+    constexpr int SL = kPerWave >= 17 * 1024 ? 4 : kPerWave >= 13 * 1024 ? 3 : kPerWave >= 9 * 1024 ? 2 : kPerWave >= 5 * 1024 ? 1 : 0;
+    using RV = RowsViaLds<D, (SL > 0 ? SL : 1)>;
+    static_assert(SL == 0 || 4 * RV::BYTES <= PIECES * 1024, "the row staging must fit one ring buffer");
+    const unsigned roff = lds_base + (unsigned)(2 * PIECES * 1024 + wave * RV::BYTES);
+    const unsigned char* rptr = reinterpret_cast<const unsigned char*>(lds) + 2 * PIECES * 1024 + wave * RV::BYTES;
+    const int row0w = blockIdx.x * 128 + wave * 32;
+    auto for_rows = [&](auto&& f) {
+      if constexpr (SL > 0) {
+        RV::run(H, row0w, R, roff, rptr, lane, f);
+      } else {   // (a ring buffer too small to stage a slice: the lane reads its row itself)
+        const float* hp = H + (long)(row < R ? row : R - 1) * D + hh * 8;
+        static_for<KS>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          f(sc, *reinterpret_cast<const float4*>(hp + s * 16), *reinterpret_cast<const float4*>(hp + s * 16 + 4));
+        });
+      }
+    };
     // Pass 1: the row's moments, nothing kept (half a row is 208 fp32 values per lane: keeping them next to the bf16
     // operand and the accumulators they turn into does not fit the register file).  Shifted sums per lane half, merged
     // with the partner lane's (Chan): no cancellation whatever the row's mean.
-    const float k0 = hp[0];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(hp + s * 16), b = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+    float k0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for_rows([&](auto sc, const float4 a, const float4 b) {
+      if constexpr (decltype(sc)::value == 0) k0 = a.x;
       const float d0 = a.x - k0, d1 = a.y - k0, d2 = a.z - k0, d3 = a.w - k0, d4 = b.x - k0, d5 = b.y - k0, d6 = b.z - k0, d7 = b.w - k0;
       s1 += (d0 + d1) + (d2 + d3) + (d4 + d5) + (d6 + d7);
       s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
-    }
+    });
     constexpr float kHalf = D / 2;
     const float mean_l = k0 + s1 * (1.0f / kHalf), m2_l = s2 - s1 * s1 * (1.0f / kHalf);
     const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2_l, 32, 64);
@@ -123,9 +142,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
     // layout wants lane hh to hold columns 8g + 4hh + 0..3 of every group of 8: lane 0 keeps its first four of each eight
     // and takes lane 1's first four, lane 1 keeps its last four and takes lane 0's -- one v_permlane32_swap per register
     // pair (lanes l and l + 32 are the two halves of a row).
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 xa = *reinterpret_cast<const float4*>(hp + s * 16), xb = *reinterpret_cast<const float4*>(hp + s * 16 + 4);
+    for_rows([&](auto sc, const float4 xa, const float4 xb) {
+      constexpr int s = decltype(sc)::value;
       uint4 p;
       p.x = pack_bf16x2((xa.x - mean) * rstd, (xa.y - mean) * rstd);
       p.y = pack_bf16x2((xa.z - mean) * rstd, (xa.w - mean) * rstd);
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
         oacc[s >> 1][4 * (2 * (s & 1)) + e] = a[e];
         oacc[s >> 1][4 * (2 * (s & 1) + 1) + e] = b[e];
       }
-    }
+    });
   }
 
   bf16x8 zb0, zb1;   // gelu(fc1) of the previous chunk: the two 16-deep k-steps of fc2's B operand
