@@ -954,9 +954,31 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   t_phase = now();
   std::vector<TranscriberStream*> streams;
   std::vector<std::vector<VadSegment>> segs(count);
-  for (uint64_t i = 0; i < count; ++i) {
-    batch_streams_.emplace_back(new_stream(-1));
-    streams.push_back(batch_streams_.back().get());
+  batch_streams_.resize(count);
+  streams.resize(count);
+  {
+    // (a stream = a detector with its buffers: ~5 us each, created on a few threads when there are thousands)
+    const unsigned nt = count >= 512 ? std::min(8u, effective_cpus()) : 1u;
+    std::vector<std::exception_ptr> errs(nt);
+    auto make = [&](unsigned t) {
+      try {
+        for (uint64_t i = t; i < count; i += nt) {
+          batch_streams_[i].reset(new_stream(-1));
+          streams[i] = batch_streams_[i].get();
+        }
+      } catch (...) {
+        errs[t] = std::current_exception();
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(make, t);
+    make(0);
+    for (auto& x : th) x.join();
+    for (auto& e : errs)
+      if (e) {
+        batch_streams_.clear();
+        std::rethrow_exception(e);
+      }
   }
   if (timing) MSH_LOGF("batch call: %llu streams created in %.1f ms", (unsigned long long)count, ms_since(t_phase));
   t_phase = now();
@@ -1043,6 +1065,8 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     std::future<void> pending;   // the previous wave on the GPU
     try {
       // the first wave's segmentation has nothing to hide behind: keep it to one sub-batch of clips, then full waves
+      // (waves growing 256 / 512 / 1024 measured slower -- 475 against 413 ms for 2048 clips: every wave is its own set of
+      // sub-batches with its own tail)
       uint64_t w1 = 0;
       for (uint64_t w0 = 0; w0 < count; w0 = w1) {
         w1 = std::min(count, w0 + (w0 == 0 ? std::min<uint64_t>(wave, (uint64_t)std::max(1, opt_.batch_clips)) : wave));
