@@ -78,6 +78,7 @@ GROUPS = {  # bench.py kernel group -> kernel-name pattern
     "dec_cross_attention": r"dec_cross_attention_kernel", "dec_self_attention": r"dec_self_attention_kernel",
     "enc_attention": r"enc_attention_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
     "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiGnBiasGeluBf16", "enc_fc1_gelu_gemm": r"gemm_astat_kernel.*EpiBiasGeluBf16",
+    "enc_mlp_fused": r"mlp_fused_kernel", "enc_qkv_panel": r"panel_gemm_kernel", "cross_kv_gemm": r"EpiCrossKV",
 }
 out = {}
 for name in ("fetch", "write"):
@@ -105,3 +106,10 @@ for g, pat in GROUPS.items():
     print(g, res["groups"][g])
 json.dump(res, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
 PY
+
+# streaming workload (BASELINE config 5): kernel stats of one timed step
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sprof_${TAG} -o s -- python $R/bench.py --workload streaming --steps 1 --warmup 1 --no-stream-profile > $R/gpurun_out/${TAG}_stream_traced.json 2> /dev/null)
+f=$(find /tmp/sprof_${TAG} -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_streaming.csv && head -6 "$f" | cut -c1-160
+timeout 300 python tools/mlp_microbench.py > gpurun_out/${TAG}_mlp_fused_ablations.txt 2>&1; tail -3 gpurun_out/${TAG}_mlp_fused_ablations.txt
+timeout 300 python tools/panel_microbench.py > gpurun_out/${TAG}_qkv_panel_ablations.txt 2>&1; head -3 gpurun_out/${TAG}_qkv_panel_ablations.txt
