@@ -1047,11 +1047,12 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // model with Silero on is VAD-bound on the host (the network runs for every 32 ms hop of every clip): clips go in waves of
   // two sub-batches and the GPU transcribes wave k while the host threads segment wave k + 1.  Without Silero segmentation
   // is a copy and everything is one wave.
-  // ... and with the network on the GPU (tens of milliseconds per thousand clips) the same pipeline, in waves of four
-  // sub-batches: the device VAD + the detectors' state machines of wave k + 1 run beside the transcription of wave k.
+  // ... and with the network on the GPU (tens of milliseconds per thousand clips) the same pipeline, in waves of eight
+  // sub-batches after a first wave of one: the device VAD + the detectors' state machines of wave k + 1 run beside the
+  // transcription of wave k, and there are few wave boundaries (each one is a tail of half-empty sub-batches on the GPU).
   const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
-                        : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 4 : 2)
+                        : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 8 : 2)
                                          : std::max<uint64_t>(count, 1);
   double seg_ms = 0.0;
   if (!pipelined) {
