@@ -430,6 +430,7 @@ float mlp_microbench(int R, int D, int F, int iters, int abl) {
       case 32: return launch_mlp<416, 32>(H, Wp, B2, R, F, 0);
       case 67: return launch_mlp<416, 67>(H, Wp, B2, R, F, 0);
       case 195: return launch_mlp<416, 195>(H, Wp, B2, R, F, 0);
+      case 199: return launch_mlp<416, 199>(H, Wp, B2, R, F, 0);
       default: throw std::runtime_error("mlp_microbench: bad ablation");
     }
   };

@@ -12,8 +12,9 @@
 //     MFMAs of the next chunk and stored behind that chunk's barrier;
 //   * 78 KiB of LDS and < 256 registers: TWO workgroups per CU, so one's LayerNorm prologue / stores overlap the other's
 //     MFMAs and the two waves per SIMD interleave their dependent accumulator chains.
-// Instances: encoder QKV (LayerNorm + q | k with RoPE row-major + V transposed), cross-attention K / V of all decoder
-// layers (bf16 rows in, K^T / V^T out).
+// Instance so far: the encoder QKV projection (LayerNorm + q | k with RoPE row-major + V transposed).  The kernel is
+// written against an epilogue interface (sections of D columns of two compile-time kinds) so that the other K = D
+// projections can follow (cross-attention K / V of all decoder layers: its transposed store is the kind-1 path).
 #include <stdlib.h>
 
 #include <stdexcept>
@@ -70,7 +71,6 @@ struct EpiQkvPanel {
   const int* row_pos;
   const float* cos_t;  // [pos][RP]
   const float* sin_t;
-  static constexpr int kSections = 3;
   struct Row {
     float cs[RP], sn[RP];
   };
