@@ -187,6 +187,11 @@ MSH_EXPORT float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_
 MSH_EXPORT int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
                                     const float* b1, const float* w2, const float* b2);
 
+/* Test hook: the same kernel with the attention output projection in front (h += ao wo^T first, ao [R][D], wo [D][D] fp32,
+ * both rounded to bf16 inside), as the encoder runs it from 16 k rows on. */
+MSH_EXPORT int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
+                                          const float* b1, const float* w2, const float* b2, const float* ao, const float* wo);
+
 /* Developer / test hook: the encoder QKV panel kernel (LayerNorm + q | k with RoPE + V transposed, k_panel.hip) on R rows
  * (R % 8 == 0) of synthetic data at width D (416 or 288); returns ms per launch (< 0 on error).  Non-null outputs receive the
  * last launch's results as bf16 bit patterns (qk [R][2D], vt [D][R]) and the inputs used (h [R][D], w [3D][D] fp32, pos [R],

@@ -447,8 +447,10 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     if (mlp_fused_supported(D, F) && !dry_run_) {   // the same block once more, packed for the fused kernel (k_mlp.hip)
       const std::vector<float> w1 = st.to_f32(p + "mlp.fc1.weight"), w2 = st.to_f32(p + "mlp.fc2.weight");
       const std::vector<float> g = vec(p + "post_attention_layernorm.weight", D), b1 = vec(p + "mlp.fc1.bias", F);
-      std::vector<bf16_t> packed(mlp_packed_elems(D, F));
-      pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data());
+      // (with the attention output projection in front: the kernel forms H + AO Wo^T in its accumulators first)
+      const std::vector<float> wo = fuse({p + "self_attn.o_proj.weight"});
+      std::vector<bf16_t> packed(mlp_packed_elems(D, F, true));
+      pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data(), wo.data());
       void* dp = nullptr;
       {
         std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
@@ -832,10 +834,11 @@ void Engine::run_encoder() {
   const char* qkv_env = getenv("MSH_ENC_QKV_PANEL");
   const bool qkv_panel_on = !(qkv_env != nullptr && qkv_env[0] == '0');
   const long qkv_panel_min_rows = (qkv_env != nullptr && qkv_env[0] == '2') ? 8 : 128 * 128;
-  static const bool fused_mlp = [] {
-    const char* e = getenv("MSH_ENC_MLP");
-    return !(e != nullptr && e[0] == '0');
-  }();
+  // developer switch (per call): 0 = tiled GEMMs, 2 = the MLP block alone in the fused kernel behind a tiled o-proj,
+  // 3 = o-proj + MLP fused at any batch size; default 1 = o-proj + MLP fused from 32 k rows on
+  const char* mlp_env = getenv("MSH_ENC_MLP");
+  const int fused_mlp = mlp_env == nullptr ? 1 : (mlp_env[0] == '0' ? 0 : mlp_env[0] == '2' ? 2 : 1);
+  const long mlp_min_rows = (mlp_env != nullptr && mlp_env[0] == '3') ? 1 : 128 * 256;
 
   {
     ProfScope p(this, "pack_audio", 0, sN * 4 + 384.0 * R * 2);
@@ -889,16 +892,23 @@ void Engine::run_encoder() {
       ProfScope p(this, "enc_attention", 4.0 * sT2 * D, sT * D * 2 * 4);
       enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
     }
+    // (a panel is 128 rows and a CU holds one: below ~one panel per CU the tiled GEMMs, whose tiles are 8x smaller, fill
+    // the chip better -- 13,568 rows: fused 0.104 ms, tiled 0.082 + LayerNorm; 32,768 rows: 0.124 against 0.16)
+    const bool mlp_fused_now = fused_mlp != 0 && W.mlp != nullptr && R >= mlp_min_rows;
+    if (mlp_fused_now && fused_mlp == 1) {
+      // o-proj + residual + LayerNorm + fc1 + GELU + fc2 + residual in ONE kernel: H is read once and written once per layer
+      // for both blocks, the [R][F] intermediate never exists (k_mlp.hip)
+      ProfScope p(this, "enc_oproj_mlp_fused", 2.0 * sT * D * D + 4.0 * sT * D * F, sT * D * (2 + 8));
+      mlp_fused_oproj(H_.as<float>(), AO_.as<bf16_t>(), W.mlp, W.b2, R, D, F, s);
+      continue;
+    }
     {
       ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));
       gemm_resid_f32(AO_.as<bf16_t>(), D, W.wo, nullptr, R, D, D, H_.as<float>(), s);
     }
-    // (a panel is 128 rows and a CU holds one: below ~one panel per CU the tiled GEMMs, whose tiles are 8x smaller, fill
-    // the chip better -- 13,568 rows: fused 0.104 ms, tiled 0.082 + LayerNorm; 32,768 rows: 0.124 against 0.16)
-    if (fused_mlp && W.mlp != nullptr && R >= 128 * 256) {
-      // LayerNorm + fc1 + GELU + fc2 + residual in one kernel: the [R][F] intermediate never exists (k_mlp.hip)
+    if (mlp_fused_now) {   // MSH_ENC_MLP=2: the MLP block alone in the fused kernel (its stages follow the o-proj ones)
       ProfScope p(this, "enc_mlp_fused", 4.0 * sT * D * F, sT * D * 8);
-      mlp_fused(H_.as<float>(), W.mlp, W.b2, R, D, F, s);
+      mlp_fused(H_.as<float>(), W.mlp + (size_t)((D / 32 + 1) / 2) * (D / 8 + 1) * 512, W.b2, R, D, F, s);
       continue;
     }
     {

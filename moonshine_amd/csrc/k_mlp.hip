@@ -65,18 +65,23 @@ __device__ __forceinline__ void static_for(Body&& body) {
 // of one chain (correct), bit 3 = ring of 2 fragment registers instead of 4 (correct), bit 4 = a stage's DMAs issued
 // together behind the barrier instead of spread over the MFMAs that follow it (correct), bit 5 = no stages at all
 // (LayerNorm prologue + residual epilogue only), bit 6 = no fragment reads, bit 7 = no workgroup barrier.
-template <int D, int ABL = 0>
+// OP: the attention output projection of the layer rides in front: H' = H + AO Wo^T is formed in the fc2 accumulators
+// (NOP extra stages of two 32-column tiles each at the head of Wp, AO [R][D] bf16 as their B operand), LayerNorm is then
+// taken from those registers, and H is read ONCE and written once per layer for o-proj + MLP together.
+template <int D, int ABL = 0, bool OP = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H, const bf16_t* __restrict__ Wp,
-                                                           const float* __restrict__ b2, int R, int NC) {
+                                                           const float* __restrict__ b2, int R, int NC,
+                                                           const bf16_t* __restrict__ AO) {
   using G = MlpGeom<D>;
   constexpr int KS = G::KS, CT = G::CT, WP = G::WP, PIECES = G::PIECES, NST = G::NST, PMAX = G::PMAX;
+  constexpr int NOP = OP ? (CT + 1) / 2 : 0;   // o-proj stages
   __shared__ __attribute__((aligned(16))) uint4 lds[NST * PIECES * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, mrow = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int my_pieces = (PIECES - wave + 3) / 4;   // wave-uniform: pieces wave, wave + 4, ...; PMAX or PMAX - 1
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
-  const int nstages = NC + 1;
+  const int nstages = NOP + NC + 1;
 
   // piece q of this wave for stage `st` into ring buffer `buf` (a stage past the end re-fetches the last one into a
   // buffer nobody reads any more: the issue / wait pattern is the same for every stage)
@@ -121,6 +126,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
         });
       }
     };
+    if constexpr (OP) {
+      // only the residual is taken here (one pass): LayerNorm follows the o-proj stages, from registers
+      for_rows([&](auto sc, const float4 xa, const float4 xb) {
+        constexpr int s = decltype(sc)::value;
+        float a[4] = {xa.x, xa.y, xa.z, xa.w}, b[4] = {xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          oacc[s >> 1][4 * (2 * (s & 1)) + e] = a[e];
+          oacc[s >> 1][4 * (2 * (s & 1) + 1) + e] = b[e];
+        }
+      });
+    } else {
     // Pass 1: the row's moments, nothing kept (half a row is 208 fp32 values per lane: keeping them next to the bf16
     // operand and the accumulators they turn into does not fit the register file).  Shifted sums per lane half, merged
     // with the partner lane's (Chan): no cancellation whatever the row's mean.
@@ -166,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
         oacc[s >> 1][4 * (2 * (s & 1) + 1) + e] = b[e];
       }
     });
+    }
   }
 
   bf16x8 zb0, zb1;   // gelu(fc1) of the previous chunk: the two 16-deep k-steps of fc2's B operand
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
     // DMA piece q of this wave goes behind step MID + 1 + q * DS (all behind MID with ABL bit 4)
     constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / PMAX > 0 ? (NF - MID - 2) / PMAX : 1);
     const int nbuf = buf + 1 == NST ? 0 : buf + 1;           // stage j + 1
-    const bf16_t* nsrc = stage_src(j + 2);
+    const bf16_t* nsrc = stage_src(NOP + j + 2);
     const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);   // stage j + 2 goes where stage j - 1 was
     const uint4* st = lds + buf * (PIECES * 64) + lane;
     const uint4* stn = lds + nbuf * (PIECES * 64) + next_f0 * 64 + lane;
@@ -294,6 +314,87 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
     }
     __builtin_amdgcn_sched_barrier(0);
     int buf = 0;
+    if constexpr (OP) {
+      // ---- o-proj: stage I holds the Wo fragments of output tiles 2I and 2I + 1 (k-step major inside a tile); the B operand
+      // is the wave's AO block, the accumulators are fc2's and already hold the residual ----
+      bf16x8 yao[KS];
+      {
+        const bf16_t* ap = AO + (long)(row < R ? row : R - 1) * D + hh * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+          const uint4 p = *reinterpret_cast<const uint4*>(ap + s2 * 16);
+          yao[s2] = as_frag(p);
+        }
+      }
+      static_for<NOP>([&](auto ic) {
+        constexpr int I = decltype(ic)::value, T0 = 2 * I, T1 = 2 * I + 1 < CT ? 2 * I + 1 : CT - 1;   // (a missing last tile: zero weights)
+        constexpr int NF = 2 * KS, MID = NF / 2;
+        static_assert(NF % PF == 0, "an o-proj stage must leave the fragment ring's phase unchanged");
+        constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / PMAX > 0 ? (NF - MID - 2) / PMAX : 1);
+        const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+        const bf16_t* nsrc = stage_src(I + 2);
+        const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);
+        const uint4* st = lds + buf * (PIECES * 64) + lane;
+        const uint4* stn = lds + nbuf * (PIECES * 64) + lane;
+        static_for<NF>([&](auto fc) {
+          constexpr int f = decltype(fc)::value, T = f < KS ? T0 : T1, s2 = f % KS;
+          oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[f % PF]), yao[s2], oacc[T], 0, 0, 0);
+          if constexpr (f == MID) {
+            if constexpr ((ABL & 1) == 0) wait_vmcnt<0>();
+            if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();
+          }
+          if constexpr ((ABL & 1) == 0 && f > MID) {
+            static_for<PMAX>([&](auto qc) {
+              constexpr int q = decltype(qc)::value, at = (MID + 1 + q * DS) < NF ? (MID + 1 + q * DS) : NF - 1;
+              if constexpr (at == f) issue_piece(nsrc, ndst, q);
+            });
+          }
+          if constexpr (f + PF < NF) fr[f % PF] = st[(f + PF) * 64];
+          else fr[f % PF] = stn[(f + PF - NF) * 64];   // the next stage's first fragments (published at MID)
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        buf = nbuf;
+      });
+      // ---- LayerNorm of H' from the accumulators: this lane holds half a row (columns 32t + 8q + 4hh + e) ----
+      {
+        const float k0 = oacc[0][0];
+        float s1 = 0.f, s2v = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = oacc[t][r] - k0;
+            s1 += d;
+            s2v += d * d;
+          }
+        constexpr float kHalf = D / 2;
+        const float mean_l = k0 + s1 * (1.0f / kHalf), m2_l = s2v - s1 * s1 * (1.0f / kHalf);
+        const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2_l, 32, 64);
+        const float mean = 0.5f * (mean_l + mean_o), dm = mean_l - mean_o;
+        const float var = (m2_l + m2_o + dm * dm * (0.5f * kHalf)) * (1.0f / D);
+        const float rstd = rsqrtf(var + 1e-5f);
+        // back to the operand layout (columns 16s + 8hh + 0..7): the swap of the prologue is its own inverse
+        static_for<KS>([&](auto sc) {
+          constexpr int s3 = decltype(sc)::value, t = s3 >> 1, q0 = 2 * (s3 & 1);
+          float a[4], b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = oacc[t][4 * q0 + e];
+            b[e] = oacc[t][4 * (q0 + 1) + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
+          uint4 p;
+          p.x = pack_bf16x2((a[0] - mean) * rstd, (a[1] - mean) * rstd);
+          p.y = pack_bf16x2((a[2] - mean) * rstd, (a[3] - mean) * rstd);
+          p.z = pack_bf16x2((b[0] - mean) * rstd, (b[1] - mean) * rstd);
+          p.w = pack_bf16x2((b[2] - mean) * rstd, (b[3] - mean) * rstd);
+          yf[s3] = as_frag(p);
+        });
+      }
+      load_bias(buf);   // b1 of chunk 0 (its stage was published at the last o-proj stage's barrier)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     stage(0, buf, std::integral_constant<int, 0>{}, NC > 1 ? 0 : KS);
     for (int j = 1; j < NC; ++j) {
       buf = buf + 1 == NST ? 0 : buf + 1;
@@ -324,23 +425,48 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
 
 template <int D, int ABL = 0>
 void launch_mlp(float* H, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s) {
-  MSH_LAUNCH((mlp_fused_kernel<D, ABL>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32);
+  MSH_LAUNCH((mlp_fused_kernel<D, ABL, false>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, (const bf16_t*)nullptr);
+}
+template <int D>
+void launch_mlp_o(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s) {
+  MSH_LAUNCH((mlp_fused_kernel<D, 0, true>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, AO);
 }
 
 }  // namespace
 
 bool mlp_fused_supported(int D, int F) { return (D == 416 || D == 288 || D == 64) && F % 32 == 0 && F >= 32; }
 
-size_t mlp_packed_elems(int D, int F) { return (size_t)(F / 32 + 1) * (D / 8 + 1) * 512; }
+size_t mlp_packed_elems(int D, int F, bool with_oproj) {
+  return (size_t)(F / 32 + 1 + (with_oproj ? (D / 32 + 1) / 2 : 0)) * (D / 8 + 1) * 512;
+}
 
 // Host-side packing (once, at load).  w1 [F][D] (gamma is folded in here), b1 [F], w2 [D][F] -> (F/32 + 1) stages of
 // (D/8 + 1) KiB: stage j = { W1 fragments of hidden rows 32j..32j+31 (k-step s: lane l holds row 32j + (l & 31), columns
 // 16s + 8(l >> 5) + 0..7) | W2 fragments of chunk j-1 (tile t, k-step u: lane l holds output row 32t + (l & 31), hidden
 // columns 32(j-1) + 8(2u + (e >> 2)) + 4(l >> 5) + (e & 3) for e = 0..7 -- the order the 32x32 accumulator layout hands
 // gelu(fc1) over in) | 32 floats of b1 }.  Stage 0 has no W2 part and stage F/32 no W1 part (zeros).
-void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out) {
+// wo (nullable) [D][D]: the attention output projection; its (CT + 1) / 2 stages come first: stage I = { Wo fragments of
+// output tile 2I, k-steps 0..KS-1 | of tile 2I + 1 (zeros when there is none) | 32 + ... floats of zeros }.
+void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out,
+                      const float* wo) {
   const int KS = D / 16, CT = D / 32, WP = KS + 2 * CT, PIECES = WP + 1, NC = F / 32;
   const bf16_t zero = f32_to_bf16(0.f);
+  if (wo != nullptr) {
+    const int NOP = (CT + 1) / 2;
+    for (int I = 0; I < NOP; ++I) {
+      bf16_t* stage = out + (size_t)I * PIECES * 512;
+      for (int h2 = 0; h2 < 2; ++h2)
+        for (int s = 0; s < KS; ++s)
+          for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+              const int t = 2 * I + h2, n = 32 * t + (l & 31), k = 16 * s + 8 * (l >> 5) + e;
+              stage[((size_t)(h2 * KS + s) * 64 + l) * 8 + e] = t < CT ? f32_to_bf16(wo[(size_t)n * D + k]) : zero;
+            }
+      float* bias = reinterpret_cast<float*>(stage + (size_t)WP * 512);
+      for (int i = 0; i < 256; ++i) bias[i] = 0.f;
+    }
+    out += (size_t)NOP * PIECES * 512;
+  }
   for (int j = 0; j <= NC; ++j) {
     bf16_t* stage = out + (size_t)j * PIECES * 512;
     for (int s = 0; s < KS; ++s)
@@ -361,6 +487,16 @@ void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, cons
   }
 }
 
+void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s) {
+  if (R <= 0) return;
+  switch (D) {
+    case 416: return launch_mlp_o<416>(H, AO, Wp, b2, R, F, s);
+    case 288: return launch_mlp_o<288>(H, AO, Wp, b2, R, F, s);
+    case 64: return launch_mlp_o<64>(H, AO, Wp, b2, R, F, s);
+    default: throw std::runtime_error("mlp_fused_oproj: unsupported hidden size");
+  }
+}
+
 void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s) {
   if (R <= 0) return;
   switch (D) {
@@ -373,21 +509,30 @@ void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F,
 
 // Test hook (tests/test_gpu_mlp.py): packs the weights and runs the kernel once on h [R][D] (host, in / out).
 void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
-                    const float* b2) {
+                    const float* b2, const float* ao, const float* wo) {
   if (!mlp_fused_supported(D, F)) throw std::runtime_error("mlp_fused: unsupported shape");
-  std::vector<bf16_t> packed(mlp_packed_elems(D, F));
-  pack_mlp_weights(w1, gamma, b1, w2, D, F, packed.data());
+  const bool op = ao != nullptr && wo != nullptr;
+  std::vector<bf16_t> packed(mlp_packed_elems(D, F, op));
+  pack_mlp_weights(w1, gamma, b1, w2, D, F, packed.data(), op ? wo : nullptr);
   float *H = nullptr, *B2 = nullptr;
-  bf16_t* Wp = nullptr;
+  bf16_t *Wp = nullptr, *AOd = nullptr;
+  if (op) {
+    std::vector<bf16_t> a16((size_t)R * D);
+    for (size_t i = 0; i < a16.size(); ++i) a16[i] = f32_to_bf16(ao[i]);
+    MSH_HIP(hipMalloc(&AOd, a16.size() * 2));
+    MSH_HIP(hipMemcpy(AOd, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+  }
   MSH_HIP(hipMalloc(&H, (size_t)R * D * 4));
   MSH_HIP(hipMalloc(&B2, (size_t)D * 4));
   MSH_HIP(hipMalloc(&Wp, packed.size() * 2));
   MSH_HIP(hipMemcpy(H, h, (size_t)R * D * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(B2, b2, (size_t)D * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Wp, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
-  mlp_fused(H, Wp, B2, R, D, F, 0);
+  if (op) mlp_fused_oproj(H, AOd, Wp, B2, R, D, F, 0);
+  else mlp_fused(H, Wp, B2, R, D, F, 0);
   MSH_HIP(hipDeviceSynchronize());
   MSH_HIP(hipMemcpy(h, H, (size_t)R * D * 4, hipMemcpyDeviceToHost));
+  if (AOd != nullptr) (void)hipFree(AOd);
   (void)hipFree(H);
   (void)hipFree(B2);
   (void)hipFree(Wp);
@@ -407,8 +552,8 @@ float mlp_microbench(int R, int D, int F, int iters, int abl) {
   for (auto& v : b1) v = rnd() * 0.1f;
   for (auto& v : b2) v = rnd() * 0.1f;
   for (auto& v : h) v = rnd();
-  std::vector<bf16_t> packed(mlp_packed_elems(D, F));
-  pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data());
+  std::vector<bf16_t> packed(mlp_packed_elems(D, F, false));
+  pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data(), nullptr);
   float *H = nullptr, *B2 = nullptr;
   bf16_t* Wp = nullptr;
   MSH_HIP(hipMalloc(&H, h.size() * 4));

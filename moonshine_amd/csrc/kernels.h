@@ -140,12 +140,16 @@ void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int
 // ---------------- encoder MLP block as one kernel (k_mlp.hip) ----------------
 // H[R][D] fp32 += fc2(gelu(fc1(LayerNorm(H)) + b1)) + b2, in place; Wp from pack_mlp_weights (LayerNorm scale folded in).
 bool mlp_fused_supported(int D, int F);
-size_t mlp_packed_elems(int D, int F);
-void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out);
+size_t mlp_packed_elems(int D, int F, bool with_oproj = false);
+void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, const float* w2, int D, int F, bf16_t* out,
+                      const float* wo = nullptr);
 void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s);
+// the same with the attention output projection in front: H += AO Wo^T first (AO [R][D] bf16, Wp packed with wo), then the
+// MLP block on the result -- replaces gemm_resid_f32 (o-proj) + mlp_fused
+void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s);
 float mlp_microbench(int R, int D, int F, int iters, int abl);
 void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
-                    const float* b2);
+                    const float* b2, const float* ao = nullptr, const float* wo = nullptr);
 
 // ---------------- A-stationary panel GEMMs of the encoder (k_panel.hip) ----------------
 // Weights packed at load by pack_panel_weights (chunks of 32 output columns, MFMA-fragment order; gamma folded in when given).

@@ -368,6 +368,17 @@ int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float*
   }
 }
 
+int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma, const float* b1,
+                               const float* w2, const float* b2, const float* ao, const float* wo) {
+  try {
+    msh::mlp_fused_host(h, R, D, F, w1, gamma, b1, w2, b2, ao, wo);
+    return MSH_OK;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "mlp_oproj_run: %s\n", ex.what());
+    return MSH_ERR_UNKNOWN;
+  }
+}
+
 // ---- Silero VAD on the device ----
 struct msh_silero {
   msh::SileroDevice* dev = nullptr;

@@ -134,7 +134,7 @@ DECLARED_SYMBOLS = [
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens", "msh_stream_cross_attention",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
-    "msh_test_mlp_microbench", "msh_test_mlp_run", "msh_test_qkv_panel",
+    "msh_test_mlp_microbench", "msh_test_mlp_run", "msh_test_mlp_oproj_run", "msh_test_qkv_panel",
     "msh_stream_get_features",
 ]
 

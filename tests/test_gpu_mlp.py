@@ -47,3 +47,45 @@ def test_fused_mlp_block_vs_oracle(D, F, R):
     assert relrms <= 6e-3, relrms
     assert float(np.abs(err).max()) <= 6e-2
     assert np.isfinite(got).all()
+
+
+def _run_o(h, w1, g, b1, w2, b2, ao, wo):
+    lib = load_library()
+    fp = C.POINTER(C.c_float)
+    lib.msh_test_mlp_oproj_run.restype = C.c_int32
+    lib.msh_test_mlp_oproj_run.argtypes = [fp, C.c_int32, C.c_int32, C.c_int32] + [fp] * 7
+    out = np.ascontiguousarray(h, np.float32).copy()
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (w1, g, b1, w2, b2, ao, wo)]
+    R, D = out.shape
+    rc = lib.msh_test_mlp_oproj_run(out.ctypes.data_as(fp), R, D, w1.shape[0], *[a.ctypes.data_as(fp) for a in arrs])
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("D,F,R", [(64, 256, 40), (64, 256, 129), (288, 1152, 300), (416, 1664, 424), (416, 1664, 1000), (416, 64, 33)])
+def test_fused_oproj_mlp_block_vs_oracle(D, F, R):
+    """The same kernel with the attention output projection in front (hf modeling_moonshine.py:382-411: hidden = residual +
+    o_proj(attn); hidden = hidden + mlp(LayerNorm(hidden))): H' = H + AO Wo^T formed in the accumulators, LayerNorm taken from
+    those registers.  The attention output is compared as the kernel sees it (bf16)."""
+    rng = np.random.default_rng(7 * D + F + R)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    wo = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (rng.standard_normal(F) * 0.1).astype(np.float32)
+    b2 = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    h = rng.standard_normal((R, D)).astype(np.float32) * 2.0
+    h[:: 7] += 300.0
+    ao = rng.standard_normal((R, D)).astype(np.float32)
+    got = _run_o(h, w1, g, b1, w2, b2, ao, wo)
+    u = np.ascontiguousarray(ao, np.float32).view(np.uint32).astype(np.uint64)
+    ao16 = (((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)).view(np.float32)
+    h1 = h + ao16 @ wo.T
+    y = ref.layer_norm_nobias(h1, g)
+    want = (h1 + ref.gelu(y @ w1.T + b1) @ w2.T + b2).astype(np.float32)
+    err = got - want
+    blk = want - h
+    relrms = float(np.sqrt((err ** 2).mean()) / np.sqrt((blk ** 2).mean()))
+    assert relrms <= 6e-3, relrms
+    assert float(np.abs(err).max()) <= 8e-2     # two bf16 GEMM chains in a row
+    assert np.isfinite(got).all()

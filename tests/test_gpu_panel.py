@@ -79,7 +79,7 @@ def test_qkv_panel_speed_report(capsys):
 
 @pytest.mark.parametrize("arch", ["base", "tiny"])
 def test_encoder_on_the_qkv_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch, arch):
-    """The whole encoder with the panel kernel forced on at a small ragged batch (it is the default from 16 k rows on,
+    """The whole encoder with the panel kernels (QKV panel, fused o-proj + MLP) forced on at a small ragged batch (they are the default from 16 k / 32 k rows on,
     where tests/test_gpu_parity.py::test_base_batch256_benchmark_path_vs_oracle runs it): last_hidden_state against the
     ORACLE at the stated encoder tolerance, and against the tiled-GEMM path of the same engine."""
     from oracle import moonshine_ref as ref
@@ -91,9 +91,11 @@ def test_encoder_on_the_qkv_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch
     clips = [make_audio(70 + i, n) for i, n in enumerate(lens)]
     e.set_keep_encoder_output(True)
     monkeypatch.setenv("MSH_ENC_QKV_PANEL", "2")
+    monkeypatch.setenv("MSH_ENC_MLP", "3")          # and the fused o-proj + MLP kernel at any size
     e.encode(clips)
     panel = [e.encoder_output(i).copy() for i in range(len(clips))]
     monkeypatch.setenv("MSH_ENC_QKV_PANEL", "0")
+    monkeypatch.setenv("MSH_ENC_MLP", "0")
     e.encode(clips)
     tiled = [e.encoder_output(i).copy() for i in range(len(clips))]
     worst = 0.0
