@@ -296,7 +296,7 @@ def roofline_entry(p):
     ridge = PEAK_TFLOPS_BF16 * 1e12 / (PEAK_HBM_GBS * 1e9)
     # the LDS-tiled GEMMs / attention are matrix-core work by construction; everything else is a stream
     mfma_kernel = (p["name"].startswith(("conv", "enc_", "senc_")) and p["name"].endswith(("_gemm", "attention", "_fused", "_panel"))
-                   or p["name"] in ("cross_kv_gemm", "stream_frontend", "stream_adapter_cross_kv") or p["name"].startswith("sver_") and "cross" not in p["name"])
+                   or p["name"] in ("cross_kv_gemm", "cross_kv_panel", "stream_frontend", "stream_adapter_cross_kv") or p["name"].startswith("sver_") and "cross" not in p["name"])
     if flops_per > 0 and (mfma_kernel or intensity >= ridge):
         ach = flops_per / (ms_per * 1e-3) / 1e12
         return {"kernel": p["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",

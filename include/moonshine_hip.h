@@ -168,7 +168,8 @@ MSH_EXPORT int64_t msh_submit_transcribe_tokens(msh_engine* e, const float* cons
 MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
 
 /* Test hook: copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
- * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]) to host memory; returns the buffer's
+ * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]; "cross_k", "cross_v": K^T / V^T of the last
+ * msh_encode, [layers][hidden * keys] at 2 bytes (bf16) or 1 byte (fp8) per key) to host memory; returns the buffer's
  * size in bytes, -1 on error.  No reference counterpart (ORT owns these tensors there). */
 MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
 /* Developer hook: self-test of the library's device allocator (odd sizes, pageable copies, interior slices); 0 = ok.

@@ -317,6 +317,7 @@ void Engine::share_weights_from(const Engine& o) {
   enc_ = o.enc_;
   dec_ = o.dec_;
   embed_bf16_ = o.embed_bf16_, embed_head_folded_ = o.embed_head_folded_, cross_kv_w_ = o.cross_kv_w_;
+  cross_kv_panel_w_ = o.cross_kv_panel_w_;
   embed_f32_ = o.embed_f32_, dec_ln_ = o.dec_ln_;
   kv_qscale_ = o.kv_qscale_, kv_dq_ = o.kv_dq_;
   kv_fp8_ = o.kv_fp8_;
@@ -519,6 +520,19 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
+  if (cross_kv_panel_supported(D) && !dry_run_) {   // the same weight packed for the panel kernel (k_panel.hip)
+    const int Lc = c.dec_layers;
+    std::vector<bf16_t> packed(panel_packed_elems(Lc * 2 * D, D));
+    pack_panel_weights(cross.data(), nullptr, Lc * 2 * D, D, packed.data());
+    void* dp = nullptr;
+    {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      dp = device_alloc(packed.size() * sizeof(bf16_t));
+    }
+    weight_allocs_.push_back(dp);
+    copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+    cross_kv_panel_w_ = reinterpret_cast<bf16_t*>(dp);
+  }
   {
     // Scales of the optional fp8 (e4m3) cross K / V (set_kv_dtype): column n of the cross-KV GEMM is w_n . enc with
     // enc = LayerNorm(x) * gamma, so |value| <= |w_n|_2 * sqrt(D) * max|gamma| whatever the audio (Cauchy-Schwarz on a
@@ -929,8 +943,16 @@ void Engine::run_encoder() {
     layernorm_bf16(H_.as<float>(), enc_ln_, R, D, ENC_.as<bf16_t>(), keep_enc_f32_ ? ENC32_.as<float>() : nullptr, s);
   }
   {  // cross-attention K/V of all decoder layers in one GEMM, written as K^T / V^T for the decode stream
-    ProfScope p(this, "cross_kv_gemm", 2.0 * sT * D * 2 * D * L, sT * D * 2 + sT * D * 2.0 * L * 2);
-    if (kv_fp8_)
+    // The panel kernel's cross-KV instance is OFF unless asked for (MSH_ENC_CROSS_KV_PANEL=2): at 256 x 10 s it measured
+    // 1.01 ms against 0.93 ms for the A-stationary tiled kernel -- this GEMM writes 1.42 GB of K^T / V^T per batch and is
+    // bound by that, not by its operand traffic.  Its parity test keeps the instance honest.
+    const char* ckv_env = getenv("MSH_ENC_CROSS_KV_PANEL");
+    const bool ckv_panel = cross_kv_panel_w_ != nullptr && ckv_env != nullptr && ckv_env[0] == '2';
+    ProfScope p(this, ckv_panel ? "cross_kv_panel" : "cross_kv_gemm", 2.0 * sT * D * 2 * D * L, sT * D * 2 + sT * D * 2.0 * L * 2);
+    if (ckv_panel)
+      cross_kv_panel(ENC_.as<bf16_t>(), cross_kv_panel_w_, (int)R, D, L, row_clip_.as<int>(), clips, (long)D * kv_keys_,
+                     kv_fp8_ ? kv_qscale_ : nullptr, KT_.p, VT_.p, s);
+    else if (kv_fp8_)
       gemm_cross_kv_fp8(ENC_.as<bf16_t>(), D, cross_kv_w_, R, L * 2 * D, D, row_clip_.as<int>(), clips, D, (long)D * kv_keys_,
                         kv_qscale_, KT_.as<uint8_t>(), VT_.as<uint8_t>(), s);
     else
@@ -1016,6 +1038,12 @@ double Engine::profile_cross_attention_ms(int rounds) {
 
 size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
   MSH_HIP(hipSetDevice(device_));
+  if (name == "cross_k" || name == "cross_v") {   // K^T / V^T of the last encode(): [layers][D * keys] at kv_bytes() per key
+    const size_t size = (size_t)cfg_.dec_layers * cfg_.hidden * kv_keys_ * kv_bytes();
+    MSH_HIP(hipStreamSynchronize(stream_));
+    if (dst != nullptr && bytes > 0) copy_blocking(dst, name == "cross_k" ? KT_.p : VT_.p, std::min(bytes, size), hipMemcpyDeviceToHost);
+    return size;
+  }
   if (groups_.empty()) throw std::runtime_error("debug_read: no decode() yet");
   DecodeGroup& g = *groups_[0];
   const int dh = cfg_.head_dim();

@@ -146,6 +146,7 @@ class Engine {
   std::vector<EncLayerW> enc_;
   std::vector<DecLayerW> dec_;
   bf16_t *embed_bf16_ = nullptr, *embed_head_folded_ = nullptr, *cross_kv_w_ = nullptr;
+  bf16_t* cross_kv_panel_w_ = nullptr;   // the fused cross K/V weight packed for the panel kernel (k_panel.hip), or null
   float *embed_f32_ = nullptr, *dec_ln_ = nullptr;
   float *rope_cos_ = nullptr, *rope_sin_ = nullptr;
   int rope_max_pos_ = 0;

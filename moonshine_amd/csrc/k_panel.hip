@@ -109,7 +109,7 @@ struct EpiQkvPanel {
   // 32 C + 8 Q + 4 hh + 0..3 of the section.  A group is finished in two halves (half A behind one MFMA, half B behind the
   // next: short VALU bursts keep the matrix pipe fed), the values in between live in x.
   template <int KIND, int C, int Q, int HALF>
-  __device__ void compute(const f32x16& z, float (&x)[4], uint32_t (&pk)[8], const Row& r, int hh, int lane) const {
+  __device__ void compute(const f32x16& z, float (&x)[4], uint32_t (&pk)[8], const Row& r, int /*sec*/, int hh, int lane) const {
     if constexpr (HALF == 0) {
       x[0] = z[4 * Q];
       x[1] = z[4 * Q + 1];
@@ -161,7 +161,7 @@ struct EpiQkvPanel {
   // holds ceil(R / 128) * 128 rows and vt_ld >= that.
   static constexpr int kMinStores = 2;   // the fewest store instructions a chunk issues
   template <int KIND, int C>
-  __device__ void store(uint32_t (&pk)[8], int sec, int row, int hh, int lane) const {
+  __device__ void store(uint32_t (&pk)[8], const Row&, int sec, int row, int hh, int lane) const {
     if constexpr (KIND == 0) {
       // swap32(a = group 2p, b = group 2p + 1): lane hh = 1's a (columns 16p + 4..7) <-> lane hh = 0's b (16p + 8..11);
       // afterwards hh = 0 holds columns 16p + 0..7 and hh = 1 columns 16p + 8..15: 16-byte stores
@@ -179,6 +179,91 @@ struct EpiQkvPanel {
         const int c = 32 * C + 8 * q + 4 * hh + (lane & 3);
         *reinterpret_cast<uint2*>(vt + (long)c * vt_ld + r0) = make_uint2(pk[2 * q], pk[2 * q + 1]);
       }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the cross-attention K / V projection of ALL decoder layers: section sec = 2 * layer + (0 = K, 1 = V), every
+// section stored TRANSPOSED into K^T / V^T [layer][clip][c][t] (keys contiguous: what the decode kernel streams), zeros
+// for keys past the clip's frame count, nothing for rows past its padded key count.  After the quad transpose a lane
+// holds 4 consecutive keys of one column: 8-byte stores (bf16), 4-byte stores (fp8: value * qscale[column], e4m3).
+template <int D, bool FP8>
+struct EpiCrossKvPanel {
+  void* KT;
+  void* VT;
+  const int* row_clip;
+  const ClipMeta* clips;
+  long layer_stride;      // elements (= bytes for fp8) per layer: D * total keys
+  const float* qscale;    // [L * 2 * D], fp8 only
+  static constexpr int kMinStores = 0;   // stores are conditional: the mid-stage wait is a full vmcnt(0)
+  struct Row {
+    int t0, T, Tk;   // first key of the lane's quad within its clip, the clip's frames and padded key count
+    long off;        // kv_start * D + t0
+  };
+  __device__ void init(Row& r, int row0, int R, float*, int lane) const {
+    const int row = row0 + (lane & 31);
+    const ClipMeta cm = clips[row_clip[row < R ? row : R - 1]];
+    r.t0 = (row & ~3) - cm.row_start;   // (a row past R lands past the last clip's keys and is never stored)
+    r.T = cm.T;
+    r.Tk = cm.Tk;
+    r.off = (long)cm.kv_start * D + r.t0;
+  }
+  __device__ void init_dummy(Row& r, int lane) const {
+    r.t0 = lane & 28;
+    r.T = 400;
+    r.Tk = 0;
+    r.off = 0;
+  }
+  template <int KIND, int C, int Q, int HALF>
+  __device__ void compute(const f32x16& z, float (&x)[4], uint32_t (&pk)[8], const Row& r, int sec, int hh, int lane) const {
+    if constexpr (HALF == 0) {
+      x[0] = z[4 * Q];
+      x[1] = z[4 * Q + 1];
+      x[2] = z[4 * Q + 2];
+      x[3] = z[4 * Q + 3];
+      const bool o1 = (lane & 1) != 0;
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const float t = dpp_f<0xB1>(o1 ? x[i] : x[i + 1]);
+        if (o1) x[i] = t; else x[i + 1] = t;
+      }
+    } else {
+      const bool o2 = (lane & 2) != 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float t = dpp_f<0x4E>(o2 ? x[i] : x[i + 2]);
+        if (o2) x[i] = t; else x[i + 2] = t;
+      }
+      // the lane now holds keys t0 .. t0 + 3 of column 32 C + 8 Q + 4 hh + (lane & 3); padding keys are exact zeros
+      if constexpr (!FP8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = r.t0 + k < r.T ? x[k] : 0.f;
+        pk[2 * Q] = pack_bf16x2(x[0], x[1]);
+        pk[2 * Q + 1] = pack_bf16x2(x[2], x[3]);
+      } else {
+        const float qs = qscale[sec * D + 32 * C + 8 * Q + 4 * hh + (lane & 3)];
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = r.t0 + k < r.T ? fminf(fmaxf(x[k] * qs, -448.f), 448.f) : 0.f;   // (the cvt does not saturate)
+        int p = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], p, true);
+        pk[2 * Q] = (uint32_t)p;
+        pk[2 * Q + 1] = 0u;
+      }
+    }
+  }
+  template <int KIND, int C>
+  __device__ void store(uint32_t (&pk)[8], const Row& r, int sec, int row, int hh, int lane) const {
+    (void)row;
+    if (r.t0 >= r.Tk) return;
+    const int layer = sec >> 1, which = sec & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 32 * C + 8 * q + 4 * hh + (lane & 3);
+      const long at = layer * layer_stride + r.off + (long)c * r.Tk;
+      if constexpr (!FP8) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(which ? VT : KT) + at) = make_uint2(pk[2 * q], pk[2 * q + 1]);
+      else *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(which ? VT : KT) + at) = pk[2 * q];
     }
   }
 };
@@ -309,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
       // finish of the previous chunk (VALU only): half (f - 1) % 2 of group (f - 1) / 2 behind step f = 1..8
       if constexpr ((ABL & 2) == 0 && KP >= 0 && f >= 1 && f <= 8) {
         constexpr int Q = (f - 1) / 2, HALF = (f - 1) % 2;
-        epi.template compute<KP, CP, Q, HALF>(zp, xs, pk, rctx, hh, lane);
+        epi.template compute<KP, CP, Q, HALF>(zp, xs, pk, rctx, sec_p, hh, lane);
         if constexpr (HALF == 0) asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]));
         else asm volatile("" : "+v"(pk[2 * Q]), "+v"(pk[2 * Q + 1]));
       }
@@ -331,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
           if constexpr (at == f) issue_piece(nsrc, ndst, q);
         });
       }
-      if constexpr ((ABL & 1) == 0 && KP >= 0 && f == STORE_AT) epi.template store<KP, CP>(pk, sec_p, row, hh, lane);
+      if constexpr ((ABL & 1) == 0 && KP >= 0 && f == STORE_AT) epi.template store<KP, CP>(pk, rctx, sec_p, row, hh, lane);
       if constexpr (f + PF < KS) fr[(RO + f) % PF] = st[(f + PF) * 64];
       else if constexpr (C + 1 < CT) fr[(RO + f) % PF] = stn[(f + PF - KS) * 64];   // next stage's first fragments (published at MID)
       __builtin_amdgcn_sched_barrier(0);
@@ -382,11 +467,11 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
   wait_vmcnt<0>();   // trailing re-fetches must not outlive the workgroup's LDS
   // the last chunk
   if (n1 > 0) {
-    sfor<8>([&](auto uc) { epi.template compute<1, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, hh, lane); });
-    epi.template store<1, CT - 1>(pk, nsec - 1, row, hh, lane);
+    sfor<8>([&](auto uc) { epi.template compute<1, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, nsec - 1, hh, lane); });
+    epi.template store<1, CT - 1>(pk, rctx, nsec - 1, row, hh, lane);
   } else {
-    sfor<8>([&](auto uc) { epi.template compute<0, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, hh, lane); });
-    epi.template store<0, CT - 1>(pk, nsec - 1, row, hh, lane);
+    sfor<8>([&](auto uc) { epi.template compute<0, CT - 1, decltype(uc)::value / 2, decltype(uc)::value % 2>(zp, xs, pk, rctx, nsec - 1, hh, lane); });
+    epi.template store<0, CT - 1>(pk, rctx, nsec - 1, row, hh, lane);
   }
 }
 
@@ -413,7 +498,34 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
   MSH_LAUNCH((panel_gemm_kernel<D, true, E>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1);
 }
 
+template <int D, bool FP8>
+void launch_cross_kv_panel(const bf16_t* A, const bf16_t* Wp, int R, int L, const int* row_clip, const ClipMeta* clips,
+                           long layer_stride, const float* qscale, void* KT, void* VT, hipStream_t s) {
+  using E = EpiCrossKvPanel<D, FP8>;
+  E epi{KT, VT, row_clip, clips, layer_stride, qscale};
+  MSH_LAUNCH((panel_gemm_kernel<D, false, E>), dim3((R + 127) / 128), dim3(256), 0, s, A, Wp, epi, R, 0, 2 * L);
+}
+
 }  // namespace
+
+bool cross_kv_panel_supported(int D) { return D == 416 || D == 288; }
+
+// K^T / V^T of all L decoder layers from the encoder output A [R][D] bf16; Wp = pack_panel_weights of the fused
+// [L * 2 * D][D] weight; qscale non-null = e4m3 output (layer_stride then in bytes)
+void cross_kv_panel(const bf16_t* A, const bf16_t* Wp, int R, int D, int L, const int* row_clip, const ClipMeta* clips,
+                    long layer_stride, const float* qscale, void* KT, void* VT, hipStream_t s) {
+  if (R <= 0) return;
+  const bool fp8 = qscale != nullptr;
+  switch (D) {
+    case 416:
+      return fp8 ? launch_cross_kv_panel<416, true>(A, Wp, R, L, row_clip, clips, layer_stride, qscale, KT, VT, s)
+                 : launch_cross_kv_panel<416, false>(A, Wp, R, L, row_clip, clips, layer_stride, qscale, KT, VT, s);
+    case 288:
+      return fp8 ? launch_cross_kv_panel<288, true>(A, Wp, R, L, row_clip, clips, layer_stride, qscale, KT, VT, s)
+                 : launch_cross_kv_panel<288, false>(A, Wp, R, L, row_clip, clips, layer_stride, qscale, KT, VT, s);
+    default: throw std::runtime_error("cross_kv_panel: unsupported width");
+  }
+}
 
 bool qkv_panel_supported(int D, int head_dim, int rot_pairs) {
   return (D == 416 && head_dim == 52 && rot_pairs == 23) || (D == 288 && head_dim == 36 && rot_pairs == 16);

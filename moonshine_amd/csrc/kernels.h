@@ -160,6 +160,12 @@ void pack_panel_weights(const float* w, const float* gamma, int N, int D, bf16_t
 bool qkv_panel_supported(int D, int head_dim, int rot_pairs);
 void qkv_panel(const float* H, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
                long vt_ld, hipStream_t s);
+// cross-attention K^T / V^T of all L decoder layers on the same kernel: A = encoder output [R][D] bf16, Wp packed from the
+// fused [L * 2 * D][D] weight (no gamma); qscale non-null = e4m3 bytes (value * qscale[column]), layer_stride in bytes then.
+// Replaces gemm_cross_kv / gemm_cross_kv_fp8 at large batches.
+bool cross_kv_panel_supported(int D);
+void cross_kv_panel(const bf16_t* A, const bf16_t* Wp, int R, int D, int L, const int* row_clip, const ClipMeta* clips,
+                    long layer_stride, const float* qscale, void* KT, void* VT, hipStream_t s);
 float qkv_panel_microbench(int R, int D, int iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h, float* out_w, int* out_pos);
 
 // ---------------- attention ----------------

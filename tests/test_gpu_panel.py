@@ -107,3 +107,38 @@ def test_encoder_on_the_qkv_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch
         assert a.shape == b.shape
         _enc_check(a, b)
     print(f"[{arch}] encoder with the QKV panel kernel: rel-RMS {worst:.2e} against the oracle")
+
+
+@pytest.mark.parametrize("arch,kv", [("base", "bf16"), ("base", "fp8"), ("tiny", "bf16")])
+def test_cross_kv_on_the_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch, arch, kv):
+    """Cross-attention K^T / V^T of all decoder layers written by the panel kernel (forced on at a small ragged batch; the
+    default from 16 k rows on, where the batch-256 oracle tests run it): teacher-forced decoder logits against the ORACLE at
+    the stated tolerance, and the K^T / V^T buffers themselves against the same engine's tiled cross-KV GEMM (the same
+    products summed in a different order: equal up to a bf16 / e4m3 step on a small fraction of the elements, zero padding
+    keys at the same places)."""
+    from oracle import moonshine_ref as ref
+    from oracle.weights import make_audio
+    from test_gpu_parity import LOGIT_MAXABS, _engine, _teacher_logit_check
+
+    e, w, cfg = _engine(tmp_path_factory, arch, 5)
+    if kv == "fp8":
+        e.set_kv_dtype("fp8")
+    clips = [make_audio(90 + i, n) for i, n in enumerate([160000, 52000, 159744, 3000, 100000])]
+    monkeypatch.setenv("MSH_ENC_CROSS_KV_PANEL", "2")
+    _teacher_logit_check(e, w, cfg, [clips[1], clips[4]], 6)
+    e.encode(clips)
+    kp, vp = e.debug_read("cross_k").copy(), e.debug_read("cross_v").copy()
+    monkeypatch.setenv("MSH_ENC_CROSS_KV_PANEL", "0")
+    e.encode(clips)
+    kt, vt = e.debug_read("cross_k").copy(), e.debug_read("cross_v").copy()
+    assert kp.shape == kt.shape and kp.size > 0
+    if kv == "bf16":
+        f = lambda b: (b.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+        for a, b in ((f(kp), f(kt)), (f(vp), f(vt))):
+            assert np.isfinite(a).all()
+            # the same products summed in a different order, rounded to bf16: equal up to one bf16 step on a small fraction
+            assert float(np.abs(a - b).max()) <= 2.0 ** -6 * max(1.0, float(np.abs(b).max())), float(np.abs(a - b).max())
+            assert float((a != b).mean()) < 0.05
+            assert ((a == 0) == (b == 0)).all()          # the zero padding keys sit at the same places
+    else:
+        assert float((kp != kt).mean()) < 0.05 and float((vp != vt).mean()) < 0.05      # e4m3 bytes
