@@ -217,6 +217,13 @@ Engine::Engine(int device) : device_(device) {
     MSH_HIP(hipMemsetAsync(stream_probe_, 0, 256, stream_));
     MSH_HIP(hipStreamSynchronize(stream_));
   }
+  if (const char* sk = getenv("MSH_ALLOC_SKEW_KB")) {   // developer probe: shift every later allocation of this engine (placement sensitivity)
+    const long kb = atol(sk);
+    if (kb > 0) {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      weight_allocs_.push_back(device_alloc((size_t)kb << 10));
+    }
+  }
   const char* ng = getenv("MSH_NO_GRAPH");
   if (ng != nullptr && ng[0] == '1') use_graph_ = false;
   const char* dg = getenv("MSH_DEC_GROUPS");
@@ -520,7 +527,10 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
-  if (cross_kv_panel_supported(D) && !dry_run_) {   // the same weight packed for the panel kernel (k_panel.hip)
+  // the same weight packed for the panel kernel (k_panel.hip): only when that instance is asked for (it is off by default,
+  // see run_encoder)
+  const char* ckv_load_env = getenv("MSH_ENC_CROSS_KV_PANEL");
+  if (cross_kv_panel_supported(D) && !dry_run_ && ckv_load_env != nullptr && ckv_load_env[0] == '2') {
     const int Lc = c.dec_layers;
     std::vector<bf16_t> packed(panel_packed_elems(Lc * 2 * D, D));
     pack_panel_weights(cross.data(), nullptr, Lc * 2 * D, D, packed.data());
