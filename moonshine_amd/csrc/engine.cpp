@@ -527,6 +527,13 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
+  if (const char* gap = getenv("MSH_ALLOC_GAP_KB")) {   // developer probe: a dummy block between the weights and the workspaces
+    const long kb = atol(gap);
+    if (kb > 0 && !dry_run_) {
+      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+      weight_allocs_.push_back(device_alloc((size_t)kb << 10));
+    }
+  }
   // the same weight packed for the panel kernel (k_panel.hip): only when that instance is asked for (it is off by default,
   // see run_encoder)
   const char* ckv_load_env = getenv("MSH_ENC_CROSS_KV_PANEL");
