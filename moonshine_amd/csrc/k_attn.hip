@@ -576,9 +576,12 @@ __global__ __launch_bounds__(256, FP8 ? MSH_FP8_ATT_OCC : 2) void dec_cross_atte
 #pragma unroll
     for (int d = 0; d < DQ; ++d) qd[d] = qp[d];
   }
+  // (fp8: the K scales are multiplied into q only BEHIND the first chunk's K / V requests: as a statement up here the
+  // multiply made the wave wait for q and the scales before it issued a single K / V load -- one more memory round trip)
+  float kq[FP8 ? DQ : 1];
   if constexpr (FP8) {
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) qd[d] *= kdq[h * DH + wave * DQ + d];
+    for (int d = 0; d < DQ; ++d) kq[d] = kdq[h * DH + wave * DQ + d];
   }
   float opart[DQ];
 #pragma unroll
@@ -605,6 +608,10 @@ __global__ __launch_bounds__(256, FP8 ? MSH_FP8_ATT_OCC : 2) void dec_cross_atte
         vr[d] = u32x4{t.x, t.y, 0u, 0u};
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (k0 == 0) {
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) qd[d] *= kq[d];
+      }
 #pragma unroll
       for (int d = 0; d < DQ; ++d) {
         const f32x2 k01 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].x, false), k23 = __builtin_amdgcn_cvt_pk_f32_fp8(kr[d].x, true);
