@@ -342,14 +342,17 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
                                                                  int layer, int L, int Mcap,
                                                                  const bf16_t* __restrict__ crossKT,
                                                                  const bf16_t* __restrict__ crossVT,
-                                                                 bf16_t* __restrict__ out, int fm) {
+                                                                 bf16_t* __restrict__ out, int fm,
+                                                                 const int* __restrict__ row_mem) {
   constexpr int DQ = DH / 4;
   __shared__ float sp[4][512];
   __shared__ float red[4][DQ][65];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int row = blockIdx.x, h = blockIdx.y;
   const int slot = row_slot[row];
-  const int nk = slots[slot].mem_len;
+  // row_mem (optional): the rows' memory lengths as the host knows them -- read beside row_slot instead of behind it
+  // (row -> slot -> slots[slot].mem_len is two dependent loads in front of the first K / V request)
+  const int nk = row_mem != nullptr ? row_mem[row] : slots[slot].mem_len;
   const long base = (((long)slot * L + layer) * D + h * DH + wave * DQ) * Mcap;
   const bf16_t* kt = crossKT + base;
   const bf16_t* vt = crossVT + base;
@@ -1021,7 +1024,7 @@ void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const in
 }
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
-                            hipStream_t s, bool fm) {
+                            hipStream_t s, bool fm, const int* row_mem) {
   const int dh = D / heads;
   if (Mcap > CROSS_MMAX || dh > 128 || (dh & 3) != 0 || (Mcap & 7) != 0)
     throw std::runtime_error("stream_cross_attention: unsupported memory length or head_dim");
@@ -1031,7 +1034,7 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
 #define MSH_XATT(DHV)                                                                                                  \
   case DHV:                                                                                                            \
     MSH_LAUNCH(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
-                       layer, L, Mcap, crossK, crossV, out, fmi);                                                     \
+                       layer, L, Mcap, crossK, crossV, out, fmi, row_mem);                                            \
     break
   switch (dh) {
     MSH_XATT(16);

@@ -795,7 +795,8 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       if (runs_d != nullptr)
         stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
       else
-        stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_, fm);
+        stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_, fm,
+                               ar_row_mem_d_);
     }
     {
       Sc sc(&prof_, stream_, nm("sdec_crosso_mlp_gemms", "sver_crosso_mlp_gemms"), 2.0 * md * (Dd + 3.0 * Fd),
@@ -999,6 +1000,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   const int* draft_d = stage(draft_, draft_flat);
   const DecJob* jobs_d = stage(decjobs_, jobs);
   const int* jslot_d = stage(newslot_, job_slot);
+  std::vector<int> job_mem(job_slot.size());
+  for (size_t j = 0; j < job_slot.size(); ++j) job_mem[j] = st(job_slot[j]).mem_len;
+  const int* jmem_d = stage(jobmem_, job_mem);   // the AR rows' memory lengths (fixed for the whole decode_full)
   MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
   const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
@@ -1033,10 +1037,15 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     pidx_.reserve((size_t)J * ntn * sizeof(int));
   }
   ar_keys_bound_ = keys_bound;   // lets the AR steps' self-attention take its one-round-trip form (<= 128 keys)
+  ar_row_mem_d_ = jmem_d;        // and their cross-attention read the memory length beside the slot index
   struct ClearBound {
     int* p;
-    ~ClearBound() { *p = 0; }
-  } clear_bound{&ar_keys_bound_};
+    const int** q;
+    ~ClearBound() {
+      *p = 0;
+      *q = nullptr;
+    }
+  } clear_bound{&ar_keys_bound_, &ar_row_mem_d_};
   auto ar_step = [&] {
     if (fused_head) {
       decoder_pass(J, jslot_d, steppos_.as<int>(), nullptr, nullptr, 0, pval_.as<float>(), pidx_.as<int>(), fm);
@@ -1057,9 +1066,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   const bool graph_now = use_graph && !prof_.on();   // event scopes cannot sit inside a replayed graph
   if (graph_now && max_budget > 0) {
     char key[512];
-    snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
+    snprintf(key, sizeof(key), "%d:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%p:%d:%p:%d:%p:%p:%p", J, (void*)jslot_d, (void*)jobs_d, steppos_.p,
              logits_.p, pred_.p, stepH_.p, Y_.p, QKV_.p, AO_.p, Q_.p, Z_.p, (void*)result_, bias_.n_nodes, (void*)bias_off_.p,
-             (int)fused_head + 2 * (int)fm + 4 * (int)(keys_bound <= 128), pval_.p, pidx_.p);
+             (int)fused_head + 2 * (int)fm + 4 * (int)(keys_bound <= 128), pval_.p, pidx_.p, (void*)jmem_d);
     if (ar_graph_ == nullptr || ar_key_ != key) {
       if (ar_graph_ != nullptr) {
         MSH_HIP(hipGraphExecDestroy(ar_graph_));

@@ -97,6 +97,7 @@ class StreamingEngine {
   void reserve_decoder_buffers(int rows);
   bool fm_ok_ = false;   // AR steps on FM operands
   int ar_keys_bound_ = 0;  // while decode_full runs its AR steps: an upper bound of any row's key count (0 = unknown)
+  const int* ar_row_mem_d_ = nullptr;   // ... and the rows' memory lengths on the device (null outside the AR steps)
   template <class T>
   T* stage(DevBuf& buf, const std::vector<T>& host);  // async H2D of a small descriptor array
   // runs_d (optional): the pass's rows as runs of consecutive rows of one stream, for the shared-K/V cross-attention
@@ -160,7 +161,7 @@ class StreamingEngine {
 
   // workspace (grow-only)
   DevBuf audio_, frames_, hidden_, c1out_, feat_pk_, segs_, jobs_, H_, Y_, Y32_, QKV_, AO_, Z_, Q_, rowlo_, rowhi_,
-      newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_,
+      newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_, jobmem_,
       logits_, pred_, draft_, decjobs_, stepH_, steppos_;
   DevBuf runs_, pval_, pidx_;
   DevBuf bias_off_, bias_tok_, bias_node_, bias_depth_, bias_bonus_, bias_prefix_;

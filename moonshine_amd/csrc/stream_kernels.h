@@ -78,7 +78,7 @@ void stream_cross_probs(const bf16_t* q, const int* row_slot, const SlotDev* slo
                         int L, int Mcap, const bf16_t* crossK, int Ecap, float* out, hipStream_t s);
 void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev* slots, int M, int D, int heads,
                             int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
-                            hipStream_t s, bool fm = false);
+                            hipStream_t s, bool fm = false, const int* row_mem = nullptr);
 // The same for runs of consecutive rows of one stream (runs[i] = {first row, rows <= kCrossRunRows}): a run's rows share one
 // pass over the stream's K / V.  Results equal stream_cross_attention's bit for bit.
 constexpr int kCrossRunRows = 4;
