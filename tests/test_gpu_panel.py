@@ -98,6 +98,20 @@ def test_encoder_on_the_qkv_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch
     monkeypatch.setenv("MSH_ENC_MLP", "0")
     e.encode(clips)
     tiled = [e.encoder_output(i).copy() for i in range(len(clips))]
+    if arch == "base":
+        # MSH_ENC_MLP=2: the MLP block alone in the fused kernel (its stages follow the o-proj stages in the packed weights);
+        # it only engages from 32 k rows on, so this batch is 80 x 10 s
+        big = [make_audio(200 + i, 160000) for i in range(80)]
+        e.set_keep_encoder_output(True)
+        monkeypatch.setenv("MSH_ENC_MLP", "2")
+        e.encode(big)
+        a = [e.encoder_output(i).copy() for i in (0, 41, 79)]
+        monkeypatch.setenv("MSH_ENC_MLP", "1")
+        e.encode(big)
+        b = [e.encoder_output(i).copy() for i in (0, 41, 79)]
+        for x, y in zip(a, b):
+            _enc_check(x, y)
+        _enc_check(a[1], ref.encoder_forward(w, cfg, big[41]))
     worst = 0.0
     for i in (0, 1, 4, 5):
         want = ref.encoder_forward(w, cfg, clips[i])

@@ -38,6 +38,8 @@ pass() { # name counters...
   tail -1 /tmp/pmc_${TAG}_$name.log | cut -c1-160
 }
 pass fetch FETCH_SIZE
+# (rocprofv3 itself has crashed in this pass on some boxes: one retry)
+[ -z "$(find /tmp/pmc_${TAG}_fetch -name '*counter_collection.csv' 2>/dev/null | head -1)" ] && pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
 [ -x tools/build/dec_gemm_timeline ] && tools/build/dec_gemm_timeline > gpurun_out/${TAG}_dec_gemm_timeline.txt 2>&1
