@@ -490,7 +490,7 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
     switch (abl) {
       case 0: break;
 #define MSH_PABL(A) case A: MSH_LAUNCH((panel_gemm_kernel<D, true, E, A>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1); return;
-      MSH_PABL(1) MSH_PABL(2) MSH_PABL(3) MSH_PABL(4) MSH_PABL(7) MSH_PABL(8) MSH_PABL(16) MSH_PABL(24) MSH_PABL(31) MSH_PABL(27) MSH_PABL(32)
+      MSH_PABL(1) MSH_PABL(2) MSH_PABL(3) MSH_PABL(4) MSH_PABL(8) MSH_PABL(16) MSH_PABL(32)
 #undef MSH_PABL
       default: throw std::runtime_error("qkv_panel: ablation not compiled");
     }

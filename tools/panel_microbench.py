@@ -18,9 +18,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         print(f"abl {os.environ.get('MSH_PANEL_ABL', '0'):>3}  R = {R:7d} ({R / 128 / 256:.2f} rounds of 256 panels)  {ms:.3f} ms = "
               f"{2.0 * R * 416 * 1248 / ms / 1e9:.0f} TFLOP/s")
     sys.exit(0)
-NAMES = {0: "product", 1: "no stores", 2: "no finish arithmetic", 3: "no finish, no stores", 4: "no DMA", 7: "MFMAs + prologue only",
-         8: "no LayerNorm loads", 16: "no RoPE factor loads", 24: "no prologue loads", 31: "MFMAs only", 27: "MFMAs + DMA only"}
-for a in ([int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 7, 8, 16, 24, 27, 31]):
+NAMES = {0: "product", 1: "no stores", 2: "no finish arithmetic", 3: "no finish, no stores", 4: "no DMA",
+         8: "no LayerNorm loads", 16: "no RoPE factor loads", 32: "full vmcnt(0) at the mid-stage wait"}
+for a in ([int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 8, 16, 32]):
     env = dict(os.environ, MSH_PANEL_ABL=str(a))
     rows = "32768,65536,106496" if a == 0 else "65536"
     out = subprocess.run([sys.executable, __file__, "--one", rows], env=env, capture_output=True, text=True)
