@@ -537,8 +537,10 @@ def main():
         kr.update(ms_per_launch=round(ms, 5), achieved=round(ach, 1 if kr["unit"] == "GB/s" else 2), frac=round(ach / kr["peak"], 4),
                   total_ms=round(ms * kr["launches_per_step"], 3), timed_in="replayed hipGraph chain of this kernel only")
     kernels.sort(key=lambda r: -r["total_ms"])
+    absorbed = "dec_ctx_resid_gemm" in chain   # k_xattn.hip: the cross-attention's output side is the wide-K context GEMM
     decode_step_us = {"sum_of_chain_costs": round(sum(chain.get(k, 0.0) * n for k, n in (
-        ("dec_qkv_gemm", 8), ("dec_self_attention", 8), ("dec_proj_resid_gemm", 16), ("dec_crossq_gemm", 8), ("dec_cross_attention", 8),
+        ("dec_qkv_gemm", 8), ("dec_self_attention", 8), ("dec_proj_resid_gemm", 8 if absorbed else 16), ("dec_ctx_resid_gemm", 8),
+        ("dec_crossq_gemm", 8), ("dec_cross_attention", 8),
         ("dec_fc1_swiglu_gemm", 8), ("dec_fc2_resid_gemm", 8), ("dec_final_layernorm", 1), ("dec_lm_head_gemm", 1),
         ("dec_argmax_advance", 1))) * 1e3, 1), "per_kernel_us": {k: round(v * 1e3, 2) for k, v in sorted(chain.items())}}
     # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (tools/gpu_final.sh), so
@@ -741,6 +743,9 @@ def main():
                    # steps are independent batches; up to this many are in flight per GPU (own stream + workspace each),
                    # the timed region still contains exactly `steps` complete passes
                    "batches_in_flight": F, "ids_match_serial_pass": ids_match,
+                   # form of the decoder's cross-attention on this run (msh_set_cross_mode, automatic by batch size):
+                   # "absorbed" = one pass over the encoder output for all heads (k_xattn.hip), "kv" = K^T / V^T stream
+                   "cross_attention": "absorbed" if absorbed else "kv",
                    # the strict one-batch-at-a-time figure and the drop-in call under the reference's default options, here
                    # as well so that a reader of `config` alone sees them
                    "serial_steps_value": serial["value"] if serial else None,

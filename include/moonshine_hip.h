@@ -200,6 +200,23 @@ MSH_EXPORT int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_
 MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h,
                                     float* out_w, int32_t* out_pos);
 
+/* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  0 = automatic: from
+ * MSH_XATTN_MIN_BATCH (default 128) clips per batch on, the "absorbed" form -- the key projection moved onto the query
+ * (qt_h = Wk_h^T q_h) and the value projection onto the output projection (Wo_h Wv_h), so that a decode step reads the
+ * encoder output ONCE per layer for all heads instead of K^T and V^T: half the bytes of the kernel that bounds batched
+ * decode and no cross-K/V projection in the encoder (k_xattn.hip); below that the classic K^T / V^T stream.  1 = always
+ * classic.  2 = absorbed whenever the architecture supports it (8 heads, hidden 288 / 416).  Word-timestamp capture and
+ * kv_dtype = fp8 always use the classic form.  Applies to the next msh_encode; set it before msh_set_batches_in_flight. */
+MSH_EXPORT int32_t msh_set_cross_mode(msh_engine* e, int32_t mode);
+/* 1 if the batch encoded last decodes with the absorbed form, else 0. */
+MSH_EXPORT int32_t msh_cross_absorbed(const msh_engine* e);
+/* Test / developer hook: the absorbed cross-attention kernel alone.  M clips, clip b = Ts[b] rows of `enc` [R][D] (fp32,
+ * rounded to bf16 inside) from row row_starts[b]; qt [M][8 * D] fp32 (scores = qt_h . enc[t], already in the exp2 domain);
+ * ctx_out [M][8 * D] fp32 receives the kernel's bf16 output (softmax_t(qt_h . enc[t]) weighted sum of the rows, per head).
+ * D = 416 or 288.  Returns ms per launch over `iters` launches (0 = a single untimed launch), < 0 on error. */
+MSH_EXPORT float msh_test_cross_absorbed(const float* qt, const float* enc, int64_t R, const int32_t* Ts,
+                                         const int32_t* row_starts, int32_t M, int32_t D, float* ctx_out, int32_t iters);
+
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

@@ -35,6 +35,15 @@ UtilStreams& util_streams() {
 }
 }  // namespace
 
+// smallest batch that decodes with the absorbed cross-attention when the mode is automatic (Engine::set_cross_mode)
+int xattn_min_batch() {
+  static const int v = [] {
+    const char* e = getenv("MSH_XATTN_MIN_BATCH");
+    return e != nullptr ? atoi(e) : 128;
+  }();
+  return v;
+}
+
 int trace_launch_level() {
   static const int level = [] {
     const char* e = getenv("MSH_TRACE_LAUNCH");
@@ -328,6 +337,7 @@ void Engine::share_weights_from(const Engine& o) {
   embed_f32_ = o.embed_f32_, dec_ln_ = o.dec_ln_;
   kv_qscale_ = o.kv_qscale_, kv_dq_ = o.kv_dq_;
   kv_fp8_ = o.kv_fp8_;
+  cross_mode_ = o.cross_mode_;
   rope_cos_ = o.rope_cos_, rope_sin_ = o.rope_sin_;
   rope_max_pos_ = o.rope_max_pos_;
   loaded_ = true;  // weight_allocs_ stays empty: the owner frees
@@ -505,9 +515,43 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       upload_bf16_fm(wq, D, D, &L.wq_c);
       upload_bf16(wq, &L.wq_c_rm);
     }
-    upload_bf16_fm(fuse({p + "encoder_attn.o_proj.weight"}), D, D, &L.wo_c);
+    const std::vector<float> wo_c = fuse({p + "encoder_attn.o_proj.weight"});
+    upload_bf16_fm(wo_c, D, D, &L.wo_c);
     std::vector<float> kv = fuse({p + "encoder_attn.k_proj.weight", p + "encoder_attn.v_proj.weight"});
     cross.insert(cross.end(), kv.begin(), kv.end());
+    if (cross_absorbed_supported(D, c.heads) && !dry_run_) {
+      // Absorbed cross-attention (k_xattn.hip): the key projection moves onto the query, the value projection onto the
+      // output projection, so that the attention itself runs over the encoder output.  Products in fp32, rounded once.
+      //   wqk[(h, d)][k] = scale * sum_j Wk[h j][d] * Wq'[h j][k]      (Wq' = Wq * diag(gamma), scale = log2(e) / sqrt(dh))
+      //   wvo[n][(h, d)] = sum_j Wo[n][h j] * Wv[h j][d]
+      const int Hn = c.heads, dh = D / Hn;
+      const std::vector<float> wqf = fold(fuse({p + "encoder_attn.q_proj.weight"}), p + "post_attention_layernorm.weight", D);
+      const float scale = 1.4426950408889634f / sqrtf((float)dh);
+      std::vector<float> wqk((size_t)Hn * D * D, 0.f), wvo((size_t)D * Hn * D, 0.f);
+      const float* Wk = kv.data();
+      const float* Wv = kv.data() + (size_t)D * D;
+      msh_host::parallel_for((size_t)Hn, [&](size_t h) {
+        for (int j = 0; j < dh; ++j) {
+          const float* wkrow = Wk + (size_t)(h * dh + j) * D;
+          const float* wqrow = wqf.data() + (size_t)(h * dh + j) * D;
+          for (int d = 0; d < D; ++d) {
+            const float a = wkrow[d] * scale;
+            float* o = wqk.data() + ((size_t)h * D + d) * D;
+            for (int k = 0; k < D; ++k) o[k] += a * wqrow[k];
+          }
+        }
+        for (int n = 0; n < D; ++n) {
+          float* o = wvo.data() + (size_t)n * Hn * D + h * D;
+          for (int j = 0; j < dh; ++j) {
+            const float a = wo_c[(size_t)n * D + h * dh + j];
+            const float* wvrow = Wv + (size_t)(h * dh + j) * D;
+            for (int d = 0; d < D; ++d) o[d] += a * wvrow[d];
+          }
+        }
+      });
+      upload_bf16_fm(wqk, Hn * D, D, &L.wqk);
+      upload_bf16_fm(wvo, D, Hn * D, &L.wvo);
+    }
     expect_shape(p + "mlp.fc1.weight", {2 * F, D});
     expect_shape(p + "mlp.fc2.weight", {D, F});
     std::vector<float> w = st.to_f32(p + "mlp.fc1.weight"), b = vec(p + "mlp.fc1.bias", 2 * F);
@@ -787,8 +831,15 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= gn_part_.reserve((size_t)count * 64 * sizeof(float2));
   moved |= gn_stats_.reserve(count * sizeof(float2));
   moved |= gn_table_.reserve((size_t)count * 2 * D * sizeof(float));
-  moved |= KT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
-  moved |= VT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
+  // Cross-attention form of this batch (k_xattn.hip): absorbed = the decode steps attend over ENC_ itself and no K^T / V^T
+  // is projected.  One workgroup per clip: it needs a batch that fills the chip, the classic form (8 workgroups per clip)
+  // stays for small batches, for the word-timestamp capture (which reads K^T) and for fp8 keys.
+  absorbed_ = !dec_.empty() && dec_[0].wqk != nullptr && !capture_cross_ && !kv_fp8_ &&
+              (cross_mode_ == 2 || (cross_mode_ == 0 && (int)count >= xattn_min_batch()));
+  if (!absorbed_) {
+    moved |= KT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
+    moved |= VT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
+  }
   if (moved) ++ws_gen_;
 
   // clip pointers: stage host PCM into one device buffer, or use the caller's device pointers
@@ -959,7 +1010,7 @@ void Engine::run_encoder() {
     ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
     layernorm_bf16(H_.as<float>(), enc_ln_, R, D, ENC_.as<bf16_t>(), keep_enc_f32_ ? ENC32_.as<float>() : nullptr, s);
   }
-  {  // cross-attention K/V of all decoder layers in one GEMM, written as K^T / V^T for the decode stream
+  if (!absorbed_) {  // cross-attention K/V of all decoder layers in one GEMM, written as K^T / V^T for the decode stream
     // The panel kernel's cross-KV instance is OFF unless asked for (MSH_ENC_CROSS_KV_PANEL=2): at 256 x 10 s it measured
     // 1.01 ms against 0.93 ms for the A-stationary tiled kernel -- this GEMM writes 1.42 GB of K^T / V^T per batch and is
     // bound by that, not by its operand traffic.  Its parity test keeps the instance honest.
@@ -1036,6 +1087,10 @@ double Engine::profile_cross_attention_ms(int rounds) {
   auto sweep = [&] {
     for (int l = 0; l < L; ++l) {
       const int ll = same_layer ? 0 : l;
+      if (absorbed_) {   // every layer reads the same encoder output (that IS the decode step's access pattern)
+        dec_cross_absorbed(g.dq.as<float>(), ENC_.as<bf16_t>(), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
+        continue;
+      }
       dec_cross_attention(g.dq.as<float>(), kv_layer(KT_, ll), kv_layer(VT_, ll), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads,
                           g.dao.as<bf16_t>(), stream_, kdq(ll), vdq(ll));
     }
@@ -1056,6 +1111,7 @@ double Engine::profile_cross_attention_ms(int rounds) {
 size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
   MSH_HIP(hipSetDevice(device_));
   if (name == "cross_k" || name == "cross_v") {   // K^T / V^T of the last encode(): [layers][D * keys] at kv_bytes() per key
+    if (absorbed_) throw std::runtime_error("debug_read: the last batch used the absorbed cross-attention, K^T / V^T were not written");
     const size_t size = (size_t)cfg_.dec_layers * cfg_.hidden * kv_keys_ * kv_bytes();
     MSH_HIP(hipStreamSynchronize(stream_));
     if (dst != nullptr && bytes > 0) copy_blocking(dst, name == "cross_k" ? KT_.p : VT_.p, std::min(bytes, size), hipMemcpyDeviceToHost);
@@ -1127,7 +1183,23 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
     }();
     const bf16_t* KTl = kv_layer(KT_, l);
     const bf16_t* VTl = kv_layer(VT_, l);
-    if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
+    if (absorbed_) {
+      // k_xattn.hip: qt = LN(h) Wqk^T (all heads' keys-side queries, D wide each), one pass over the encoder output for the
+      // attention of all heads, then h += ctx Wvo^T
+      if (on(3)) {
+        ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * 4.0 * (1 + Hh));
+        dec_gemm_ln_f32(dH, W.wqk, M, Hh * D, D, dq, s);
+      }
+      if (on(4)) {
+        // both products on all 16 MFMA columns (high / low halves of 8 heads); bytes: E once, qt in, ctx out
+        ProfScope p(this, "dec_cross_attention", 2.0 * 2.0 * sT * D * 16, sT * D * 2.0 + M * D * Hh * 6.0);
+        dec_cross_absorbed(dq, ENC_.as<bf16_t>(), clips, M, D, Hh, dao, s);
+      }
+      if (on(5)) {
+        ProfScope p(this, "dec_ctx_resid_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * (2.0 * Hh + 8.0));
+        dec_gemm_resid(dao, W.wvo, nullptr, M, D, Hh * D, dH, s);
+      }
+    } else if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
       if (on(4)) {
         ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
@@ -1146,7 +1218,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         dec_cross_attention(dq, KTl, VTl, clips, M, D, Hh, dao, s, kdq(l), vdq(l));
       }
     }
-    if (on(5)) {
+    if (on(5) && !absorbed_) {
       ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
       dec_gemm_resid(dao, W.wo_c, nullptr, M, D, D, dH, s);
     }
@@ -1235,7 +1307,8 @@ void Engine::profile_decode_chain(int reps) {
       MSH_HIP(hipStreamSynchronize(g.stream));
       float ms = 0.f;
       MSH_HIP(hipEventElapsedTime(&ms, a, b));
-      const std::string name = std::string("chain_") + names[id];
+      // (absorbed cross-attention: group 5 is the wide-K context GEMM, a different kernel from the self-attention o-proj)
+      const std::string name = std::string("chain_") + (id == 5 && absorbed_ ? "dec_ctx_resid_gemm" : names[id]);
       auto it = prof_idx_.find(name);
       if (it == prof_idx_.end()) {
         prof_idx_[name] = (int)prof_.size();
@@ -1313,8 +1386,9 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     bool moved = false;
     const size_t M16 = (size_t)round_up(M, 16);  // the FM buffers hold whole 16-row MFMA tiles (kernels.h)
     moved |= g.dH.reserve(M16 * D * sizeof(float));
-    moved |= g.dq.reserve((size_t)M * D * sizeof(float));
-    moved |= g.dao.reserve(M16 * D * sizeof(bf16_t));
+    const int xw = absorbed_ ? Hh : 1;   // absorbed cross-attention: the query and the context are `heads` rows of D per clip
+    moved |= g.dq.reserve((size_t)M * D * xw * sizeof(float));
+    moved |= g.dao.reserve(M16 * D * xw * sizeof(bf16_t));
     moved |= g.dz.reserve(M16 * F * sizeof(bf16_t));
     moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
     moved |= g.logits.reserve((size_t)M * V * sizeof(float));
@@ -1361,7 +1435,8 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(ws_gen_) + ":" +
                               std::to_string(g.gen) + ":" + std::to_string(Smax_) + ":" + std::to_string(stride) + ":" +
                               std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
-                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" + std::to_string(kv_fp8_);
+                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" + std::to_string(kv_fp8_) + ":" +
+                              std::to_string(absorbed_);
       if (g.graph == nullptr || g.key != key) {
         if (g.graph) {
           MSH_HIP(hipGraphExecDestroy(g.graph));

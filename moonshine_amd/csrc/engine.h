@@ -47,6 +47,10 @@ struct DecLayerW {
   float *ln1, *ln2, *ln3, *b1, *b2;
   bf16_t *wqkv, *wo, *wq_c, *wo_c, *fc1, *fc2;  // MFMA-fragment-major (kernels.h fm16)
   bf16_t* wq_c_rm;                              // cross-q again, row-major (fused-q attention kernel, small batches)
+  // absorbed cross-attention (k_xattn.hip), FM, or null when the shape is not supported:
+  //   wqk [heads * D][D]  rows (h, d) = softmax scale * sum_j Wk[h j][d] * (Wq[h j][:] * gamma)   (query side, LayerNorm fused)
+  //   wvo [D][heads * D]  columns (h, d) = sum_j Wo[:][h j] * Wv[h j][d]                          (output side, residual update)
+  bf16_t *wqk = nullptr, *wvo = nullptr;
 };
 
 class Engine {
@@ -85,8 +89,21 @@ class Engine {
   // returns the three dimensions.
   void set_capture_cross_attention(bool on) {
     if (on && kv_fp8_) throw std::invalid_argument("cross-attention capture (word timestamps) needs kv_dtype = bf16");
+    if (on && absorbed_) encoded_ = false;   // the capture reads K^T, which the absorbed form never writes: encode again
     capture_cross_ = on;
   }
+  // How the decoder's cross-attention runs (k_xattn.hip): 0 = automatic (the absorbed form -- one pass over the encoder
+  // output, no cross K/V -- from xattn_min_batch() clips on, the classic K^T / V^T stream below), 1 = always classic,
+  // 2 = absorbed whenever the shape supports it.  Applies to the next encode; lanes take it when they are created.
+  void set_cross_mode(int mode) {
+    if (mode < 0 || mode > 2) throw std::invalid_argument("cross mode: 0 = auto, 1 = projected K/V, 2 = absorbed");
+    if (mode != cross_mode_) {
+      cross_mode_ = mode;
+      encoded_ = false;
+    }
+  }
+  int cross_mode() const { return cross_mode_; }
+  bool cross_absorbed() const { return absorbed_; }   // of the batch encoded last
   // cross K^T / V^T storage: bf16 (default) or e4m3 bytes with per-column scales fixed at load; applies to the next encode.
   // Lanes (batches in flight) take the setting when they are created.
   void set_kv_fp8(bool on) {
@@ -160,6 +177,8 @@ class Engine {
   bool encoded_ = false, keep_enc_f32_ = false;
   bool capture_cross_ = false;
   bool kv_fp8_ = false;
+  int cross_mode_ = 0;
+  bool absorbed_ = false;   // the encoded batch decodes with the absorbed cross-attention: K^T / V^T were not written
   float *kv_qscale_ = nullptr, *kv_dq_ = nullptr;   // [L * 2D]: e4m3 scale of every cross-KV column and its inverse
   size_t kv_bytes() const { return kv_fp8_ ? 1 : 2; }
   const bf16_t* kv_layer(const DevBuf& b, int l) const {

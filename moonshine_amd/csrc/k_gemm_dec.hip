@@ -392,7 +392,12 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
 }
 void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
   EpiF32 epi{out, N};
-  if (few_tiles(M, N))
+  // N = heads * D (the keys-side queries of the absorbed cross-attention, k_xattn.hip): fc1's shape, fc1's tiles
+  if (N >= 2048 && M >= 192 && N % 128 == 0)
+    launch_fm<8, true, EpiF32, 2>(H, W, M, N, D, epi, s);
+  else if (N >= 2048 && M >= 96)
+    launch_fm<4, true>(H, W, M, N, D, epi, s);
+  else if (few_tiles(M, N))
     launch_fm<1, true>(H, W, M, N, D, epi, s);
   else
     launch_fm<2, true>(H, W, M, N, D, epi, s);
@@ -414,10 +419,40 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
   else
     launch_fm<2, true>(H, W, M, 2 * F, D, epi, s);
 }
+// K = heads * D (the context of the absorbed cross-attention, k_xattn.hip): 72 / 104 k-steps, split over EIGHT waves so that a
+// wave's up-front load phase stays at 13 k-steps of W and A (the 4-wave form would hold 26 x (TN + 1) fragments in registers).
+template <int TN, class Epi>
+static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+  if ((N & 15) != 0) throw std::runtime_error("gemm_dec (FM, wide K): N must be a multiple of 16");
+  const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
+  switch (K) {
+    case 3328:
+      MSH_LAUNCH((gemm_dec_kernel<104, TN, false, Epi, 1, true, 8>), dim3(m_tiles * n_tiles), dim3(512), 0, s, (const void*)A,
+                 (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);
+      return;
+    case 2304:
+      MSH_LAUNCH((gemm_dec_kernel<72, TN, false, Epi, 1, true, 8>), dim3(m_tiles * n_tiles), dim3(512), 0, s, (const void*)A,
+                 (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);
+      return;
+    default: throw std::runtime_error("gemm_dec (FM, wide K): unsupported K " + std::to_string(K));
+  }
+}
+static int wide_k_tn() {   // developer knob: column tiles per workgroup of the wide-K residual GEMM (1 or 2)
+  static const int v = [] {
+    const char* e = getenv("MSH_XATTN_G2_TN");
+    return e != nullptr && e[0] == '1' ? 1 : 2;
+  }();
+  return v;
+}
 template <bool BIAS>
 static void dec_gemm_resid_t(const bf16_t* A, const bf16_t* W, const float* bias, int M, int N, int K, float* H,
                              hipStream_t s) {
   EpiDecResidFm<BIAS> epi{H, N / 32, bias};
+  if (K == 3328 || K == 2304) {
+    if (wide_k_tn() == 1 || few_tiles(M, N)) launch_fm_wide_k<1>(A, W, M, N, K, epi, s);
+    else launch_fm_wide_k<2>(A, W, M, N, K, epi, s);
+    return;
+  }
   if (narrow_small_batch(M) || few_tiles(M, N))
     launch_fm<1, false>(A, W, M, N, K, epi, s);
   else

@@ -181,6 +181,17 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                          int heads, bf16_t* out, hipStream_t s, const float* kdq = nullptr, const float* vdq = nullptr);
 
+// Absorbed form (k_xattn.hip): the attention of all heads of a clip in ONE pass over the encoder output `enc` [R][D] bf16
+// (clip b's T frames start at row clips[b].row_start).  qt [M][heads * D] fp32 = the keys-side queries of the heads (from
+// dec_gemm_ln_f32 with the merged weight Wqk, softmax scale and log2(e) folded in) -> ctx [M16][heads * D] bf16 in FM, the A
+// operand of dec_gemm_resid with the merged weight Wvo (K = heads * D).  heads == 8, D in {416, 288}.
+bool cross_absorbed_supported(int D, int heads);
+void dec_cross_absorbed(const float* qt, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
+                        hipStream_t s);
+float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const int* Ts, const int* row_starts, int M, int D,
+                          float* ctx_out, int iters);
+int xattn_min_batch();
+
 // same with the query projection fused in: H = fp32 residual stream (FM), Wq = cross-q weight [D,D] ROW-MAJOR with the
 // LayerNorm scale folded in (replaces dec_gemm_ln_f32 + dec_cross_attention)
 // cross-attention probabilities of the current step (word timestamps): out[clip][layer][head][pos][Tcap] fp32, frames

@@ -232,6 +232,15 @@ int32_t msh_set_kv_dtype(msh_engine* e, int32_t dtype) {
   });
 }
 
+int32_t msh_set_cross_mode(msh_engine* e, int32_t mode) {
+  return guarded(e, [&] {
+    if (e->pipe) throw std::invalid_argument("msh_set_cross_mode: set it before msh_set_batches_in_flight (lanes take it at creation)");
+    e->eng->set_cross_mode(mode);
+  });
+}
+
+int32_t msh_cross_absorbed(const msh_engine* e) { return e != nullptr && e->eng->cross_absorbed() ? 1 : 0; }
+
 int32_t msh_get_encoder_output(msh_engine* e, uint32_t clip, float* out) {
   return guarded(e, [&] {
     if (out == nullptr || clip >= e->eng->batch_count()) throw std::invalid_argument("bad clip index / null output");
@@ -376,6 +385,16 @@ int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const 
   } catch (const std::exception& ex) {
     fprintf(stderr, "mlp_oproj_run: %s\n", ex.what());
     return MSH_ERR_UNKNOWN;
+  }
+}
+
+float msh_test_cross_absorbed(const float* qt, const float* enc, int64_t R, const int32_t* Ts, const int32_t* row_starts,
+                              int32_t M, int32_t D, float* ctx_out, int32_t iters) {
+  try {
+    return msh::cross_absorbed_host(qt, enc, (long)R, Ts, row_starts, M, D, ctx_out, iters);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "cross_absorbed: %s\n", ex.what());
+    return -1.0f;
   }
 }
 

@@ -1,0 +1,211 @@
+"""Absorbed cross-attention (moonshine_amd/csrc/k_xattn.hip, msh_set_cross_mode): the decoder attends over the ENCODER
+OUTPUT itself -- the key projection moved onto the query, the value projection onto the output projection -- so a decode
+step reads T x D bf16 per clip and layer once for all heads instead of K^T and V^T (half the bytes of the kernel that bounds
+batched decode), and the encoder projects no cross K/V at all.  It is the same function as the reference's
+graph (transformers modeling_moonshine.py:265-330, reference core/moonshine-model.cpp:380-517 for the loop) in exact
+arithmetic, rounds at different points in bf16, and is held here to the SAME gates as the classic path: the kernel alone
+against numpy, then the parity bodies of tests/test_gpu_parity.py / test_gpu_long_parity.py re-run with the form forced on
+(logits max-abs <= 5e-2, ids where the oracle's margin > 0.1, HF goldens, the benchmarked 256 x 10 s configuration)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import test_gpu_parity as tp
+from oracle import moonshine_ref as ref
+from oracle.weights import ARCHS, make_audio, make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+    return r.view(np.float32).reshape(x.shape)
+
+
+def _run_kernel(qt, enc, Ts, starts, D, iters=0):
+    from moonshine_amd.hip_api import load_library
+
+    lib = load_library()
+    M = len(Ts)
+    qt = np.ascontiguousarray(qt, np.float32)
+    enc = np.ascontiguousarray(enc, np.float32)
+    Ts = np.asarray(Ts, np.int32)
+    starts = np.asarray(starts, np.int32)
+    out = np.zeros((M, 8 * D), np.float32)
+    ms = lib.msh_test_cross_absorbed(qt.ctypes.data, enc.ctypes.data, enc.shape[0], Ts.ctypes.data, starts.ctypes.data, M, D,
+                                     out.ctypes.data, iters)
+    assert ms >= 0, "kernel launch failed"
+    return out.reshape(M, 8, D), ms
+
+
+def _numpy_ctx(qt, enc16, Ts, starts, D):
+    """softmax over the clip's frames of qt_h . enc[t] (base-2 exponent, the kernel's domain), weighted sum of the rows."""
+    M = len(Ts)
+    out = np.zeros((M, 8, D), np.float64)
+    for b in range(M):
+        E = enc16[starts[b]:starts[b] + Ts[b]].astype(np.float64)
+        s = qt[b].reshape(8, D).astype(np.float64) @ E.T
+        p = np.exp2(s - s.max(axis=1, keepdims=True))
+        out[b] = (p / p.sum(axis=1, keepdims=True)) @ E
+    return out
+
+
+@pytest.mark.parametrize("D", [416, 288])
+def test_kernel_vs_numpy_ragged(D):
+    """Frame counts around every boundary of the kernel: one frame, one short of / exactly / one past a 16-key tile, fewer
+    tiles than waves, the 10 s clip (415), a long clip (many rounds of the LDS ring), rows starting at odd offsets.  The
+    random rows make any transposition or mis-assigned lane visible."""
+    rng = np.random.default_rng(5)
+    Ts = [1, 15, 16, 17, 33, 63, 64, 65, 415, 129, 1000, 7, 48, 415, 96, 2]
+    starts, row = [], 3
+    for t in Ts:
+        starts.append(row)
+        row += t + int(rng.integers(0, 9))
+    R = row + 5
+    enc = rng.standard_normal((R, D)).astype(np.float32)
+    enc[:, ::7] *= 3.0
+    enc16 = _bf16_round(enc)
+    qt = (rng.standard_normal((len(Ts), 8 * D)) * (2.5 / np.sqrt(D))).astype(np.float32)
+    got, _ = _run_kernel(qt, enc, Ts, starts, D)
+    want = _numpy_ctx(qt, enc16, Ts, starts, D)
+    err = np.abs(got - want)
+    tol = 2.0 ** -8 * np.abs(want) + 2e-3    # the output is bf16: half an ulp relative, plus the products' own error
+    worst = float((err - tol).max())
+    assert worst <= 0, (worst, float(err.max()), np.unravel_index(np.argmax(err - tol), err.shape))
+
+
+def test_kernel_sharp_and_flat_scores():
+    """Softmax extremes: one dominating key late in the clip (the running reference must move after many tiles were
+    accumulated), scores growing steadily along the clip (the reference moves again and again), and all-equal scores."""
+    D = 416
+    rng = np.random.default_rng(9)
+    T = 415
+    enc = rng.standard_normal((T, D)).astype(np.float32)
+    enc16 = _bf16_round(enc)
+    qt = np.zeros((3, 8 * D), np.float32)
+    # clip 0: head h looks for row 400 - 10 h: qt = c * that row -> score ~ c |row|^2 >> others
+    for h in range(8):
+        qt[0, h * D:(h + 1) * D] = enc16[400 - 10 * h] * (40.0 / D)
+    # clip 1: scores rise along the clip: qt . enc[t] = t / 4 through a planted coordinate
+    enc2 = enc.copy()
+    enc2[:, 0] = np.arange(T) / 64.0
+    # clip 2: zeros -> uniform average
+    encs = np.concatenate([enc, enc2, enc], axis=0)
+    qt[1, 0::D] = 16.0
+    got, _ = _run_kernel(qt, encs, [T, T, T], [0, T, 2 * T], D)
+    want = _numpy_ctx(qt, _bf16_round(encs), [T, T, T], [0, T, 2 * T], D)
+    err = np.abs(got - want)
+    tol = 2.0 ** -8 * np.abs(want) + 2e-3
+    assert float((err - tol).max()) <= 0, float(err.max())
+
+
+def test_kernel_rate_at_the_benchmark_shape():
+    """256 clips x 415 frames at D = 416 (BASELINE config 3): prints the kernel's rate; the bound is only a smoke alarm."""
+    D, T, M = 416, 415, 256
+    rng = np.random.default_rng(1)
+    rows = 424
+    enc = rng.standard_normal((M * rows, D)).astype(np.float32)
+    qt = (rng.standard_normal((M, 8 * D)) * (2.0 / np.sqrt(D))).astype(np.float32)
+    Ts, starts = [T] * M, [b * rows for b in range(M)]
+    got, ms = _run_kernel(qt, enc, Ts, starts, D, iters=50)
+    want = _numpy_ctx(qt[:2], _bf16_round(enc), Ts[:2], starts[:2], D)
+    assert float(np.abs(got[:2] - want).max()) <= 2e-2
+    mb = M * (T * D * 2 + 8 * D * 6) / 1e6
+    print(f"\n[absorbed cross-attention] {M} x {T} frames: {ms * 1e3:.1f} us per launch, {mb:.1f} MB = {mb / ms / 1e3:.2f} TB/s")
+    assert ms < 0.08
+
+
+# ---------------------------------------------------------------- the engine with the form forced on
+def _absorbed_engine(tmp_path_factory, arch, seed=0, weights=None):
+    e, w, cfg = tp._engine(tmp_path_factory, arch, seed, weights)
+    e.set_cross_mode("absorbed")
+    return e, w, cfg
+
+
+@pytest.fixture(scope="module")
+def base_x(tmp_path_factory):
+    return _absorbed_engine(tmp_path_factory, "base")
+
+
+@pytest.fixture(scope="module")
+def tiny_x(tmp_path_factory):
+    return _absorbed_engine(tmp_path_factory, "tiny")
+
+
+@pytest.mark.parametrize("case", ["base_10s", "base_vadtrunc"])
+def test_base_against_hf_golden_absorbed(base_x, case, golden_dir):
+    tp.test_base_against_hf_golden(base_x, case, golden_dir)
+    assert base_x[0].cross_absorbed()
+
+
+def test_tiny_against_hf_golden_absorbed(tiny_x, golden_dir):
+    e, w, cfg = tiny_x
+    g = np.load(os.path.join(golden_dir, "golden_tiny_2s.npz"))
+    audio = make_audio(int(g["clip"]), int(g["n_samples"]))
+    e.encode([audio])
+    assert e.cross_absorbed()
+    gold = g["tokens"].astype(np.int32)
+    steps = len(gold) - 1
+    toks, logits = e.decode(forced_steps=steps, teacher=gold[None, :], want_logits=steps)
+    for i in range(steps):
+        assert float(np.abs(logits[i, 0][g["logit_idx"][i]] - g["logit_val"][i]).max()) <= tp.LOGIT_MAXABS
+
+
+def test_tiny_ragged_teacher_forced_vs_oracle_absorbed(tiny_x):
+    """Ragged tiny batch (frame counts off every tile boundary, one very short clip), 12 teacher-forced steps against the
+    oracle at the default tolerances."""
+    e, w, cfg = tiny_x
+    clips = [make_audio(20 + i, n) for i, n in enumerate([16000, 30000, 12345, 9000, 40007, 1300])]
+    worst, flips = tp._teacher_logit_check(e, w, cfg, clips, 12)
+    assert e.cross_absorbed()
+    print(f"\ntiny ragged, absorbed: logits max-abs {worst:.3e}, {flips} near-tie flips")
+
+
+def test_base_ragged_batch_vs_oracle_absorbed(base_x):
+    e, w, cfg = base_x
+    lens = [160000, 48000, 159744, 100000]
+    clips = [make_audio(50 + i, n) for i, n in enumerate(lens)]
+    worst, flips = tp._teacher_logit_check(e, w, cfg, [clips[1], clips[3]], 8)
+    assert e.cross_absorbed()
+    print(f"\nbase ragged, absorbed: logits max-abs {worst:.3e}, {flips} near-tie flips")
+
+
+def test_long_clip_absorbed(tiny_x):
+    """30 s and 44 s clips (T = 1249 / 1850: dozens of rounds of the LDS ring per wave) with 100 forced steps."""
+    e, w, cfg = tiny_x
+    clips = [make_audio(70, 480000), make_audio(71, 710400), make_audio(72, 20000)]
+    worst, flips = tp._teacher_logit_check(e, w, cfg, clips, 100)
+    assert e.cross_absorbed()
+    print(f"\ntiny long clips, absorbed: logits max-abs {worst:.3e}, {flips} near-tie flips")
+
+
+def test_base_batch256_benchmark_path_vs_oracle_absorbed(base_x):
+    """The benchmarked configuration (base, 256 x 10 s, 65 forced steps) on the absorbed path, against the oracle, with the
+    tolerances of the classic path's own test."""
+    tp.test_base_batch256_benchmark_path_vs_oracle(base_x)
+    assert base_x[0].cross_absorbed()
+
+
+def test_automatic_mode_picks_the_form_by_batch_size(tmp_path_factory):
+    """Mode 0: absorbed from MSH_XATTN_MIN_BATCH (128) clips on, the classic stream below; the word-timestamp capture and
+    fp8 keys always use the classic form; a batch's ids do not depend on which clips share it within one form."""
+    e, w, cfg = tp._engine(tmp_path_factory, "tiny", 3)
+    clips = [make_audio(300 + i, 16000 + 37 * i) for i in range(130)]
+    e.encode(clips[:8])
+    assert not e.cross_absorbed()
+    small = e.decode(forced_steps=6)[0]
+    e.encode(clips)
+    assert e.cross_absorbed()
+    big = e.decode(forced_steps=6)[0]
+    agree = sum(a == b for a, b in zip(small, big[:8]))
+    assert agree >= 6, (small, big[:8])   # two roundings of the same function: near-ties may flip, nothing else
+    e.set_cross_mode("absorbed")
+    forced = e.transcribe_tokens(clips[:8], forced_steps=6)
+    assert forced == big[:8]              # absorbed at batch 8 == absorbed inside the batch of 130
+    e.set_cross_mode("kv")
+    assert e.transcribe_tokens(clips[:8], forced_steps=6) == small
+    e.encode(clips)
+    assert not e.cross_absorbed()
