@@ -1088,7 +1088,7 @@ double Engine::profile_cross_attention_ms(int rounds) {
     for (int l = 0; l < L; ++l) {
       const int ll = same_layer ? 0 : l;
       if (absorbed_) {   // every layer reads the same encoder output (that IS the decode step's access pattern)
-        dec_cross_absorbed(g.dq.as<float>(), ENC_.as<bf16_t>(), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
+        dec_cross_absorbed(g.dq.as<bf16_t>(), ENC_.as<bf16_t>(), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads, g.dao.as<bf16_t>(), stream_);
         continue;
       }
       dec_cross_attention(g.dq.as<float>(), kv_layer(KT_, ll), kv_layer(VT_, ll), clips_d_.as<ClipMeta>(), g.M, D, cfg_.heads,
@@ -1188,12 +1188,12 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       // attention of all heads, then h += ctx Wvo^T
       if (on(3)) {
         ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * 4.0 * (1 + Hh));
-        dec_gemm_ln_f32(dH, W.wqk, M, Hh * D, D, dq, s);
+        dec_gemm_ln_qt(dH, W.wqk, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
       }
       if (on(4)) {
         // both products on all 16 MFMA columns (high / low halves of 8 heads); bytes: E once, qt in, ctx out
         ProfScope p(this, "dec_cross_attention", 2.0 * 2.0 * sT * D * 16, sT * D * 2.0 + M * D * Hh * 6.0);
-        dec_cross_absorbed(dq, ENC_.as<bf16_t>(), clips, M, D, Hh, dao, s);
+        dec_cross_absorbed(reinterpret_cast<const bf16_t*>(dq), ENC_.as<bf16_t>(), clips, M, D, Hh, dao, s);
       }
       if (on(5)) {
         ProfScope p(this, "dec_ctx_resid_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * (2.0 * Hh + 8.0));

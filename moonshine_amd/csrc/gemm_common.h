@@ -535,6 +535,30 @@ struct EpiF32 {
   }
 };
 
+// Keys-side queries of the absorbed cross-attention (k_xattn.hip): column n = head * D + d of row m (a clip) goes out as
+// TWO bf16 values, x rounded and the rounding residual x - bf16(x), in the order the attention kernel's score product takes
+// its B operand, k-step by k-step: qf[clip][d / 32][16 rows][4][8] with row = head (value) or head + 8 (residual) and the
+// 32 features of a k-step contiguous per row -- a lane (row, kg) of that kernel loads its 16 bytes at (row * 4 + kg) * 16 of
+// the k-step's KiB (the wave's load is the whole KiB), and a 16-column tile of this GEMM lands in one 32-byte run per clip.
+struct EpiQtFrag {
+  bf16_t* qf;
+  int D;   // model width; N = heads * D, D % 32 == 0
+  struct Pre {};
+  __device__ Pre pre(int, int) const { return Pre{}; }
+  __device__ void n4p(int m, int n, f32x4 v, const Pre&) const { n4(m, n, v); }
+  __device__ void n4(int m, int n, f32x4 v) const {
+    const int h = n / D, d = n - h * D;
+    bf16_t* frag = qf + ((size_t)m * (D >> 5) + (d >> 5)) * 512 + (d & 31);
+    uint2 hi, lo;
+    hi.x = pack_bf16x2(v[0], v[1]);
+    hi.y = pack_bf16x2(v[2], v[3]);
+    lo.x = pack_bf16x2(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack_bf16x2(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(frag + h * 32) = hi;
+    *reinterpret_cast<uint2*>(frag + (h + 8) * 32) = lo;
+  }
+};
+
 // rows of W / bias interleaved as (value_j, gate_j): modeling_moonshine.py:92-96 chunk order
 struct EpiSwiGLU {
   bf16_t* z;

@@ -392,13 +392,19 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
 }
 void dec_gemm_ln_f32(const float* H, const bf16_t* W, int M, int N, int D, float* out, hipStream_t s) {
   EpiF32 epi{out, N};
-  // N = heads * D (the keys-side queries of the absorbed cross-attention, k_xattn.hip): fc1's shape, fc1's tiles
-  if (N >= 2048 && M >= 192 && N % 128 == 0)
-    launch_fm<8, true, EpiF32, 2>(H, W, M, N, D, epi, s);
-  else if (N >= 2048 && M >= 96)
-    launch_fm<4, true>(H, W, M, N, D, epi, s);
-  else if (few_tiles(M, N))
+  if (few_tiles(M, N))
     launch_fm<1, true>(H, W, M, N, D, epi, s);
+  else
+    launch_fm<2, true>(H, W, M, N, D, epi, s);
+}
+void dec_gemm_ln_qt(const float* H, const bf16_t* W, int M, int heads, int D, bf16_t* qf, hipStream_t s) {
+  // N = heads * D: fc1's shape, fc1's tiles (see dec_gemm_ln_swiglu)
+  const int N = heads * D;
+  EpiQtFrag epi{qf, D};
+  if (M >= 192 && N % 128 == 0)
+    launch_fm<8, true, EpiQtFrag, 2>(H, W, M, N, D, epi, s);
+  else if (M >= 96)
+    launch_fm<4, true>(H, W, M, N, D, epi, s);
   else
     launch_fm<2, true>(H, W, M, N, D, epi, s);
 }

@@ -19,8 +19,7 @@
 // bf16 where the classic form rounded P V), and it is held to the same parity gates (tests/test_gpu_xattn.py).
 //
 // Kernel: one workgroup per clip, 4 waves.  Wave w owns the 16-key tiles w, w + 4, ... of the clip, each fetched by
-// global_load_lds_dwordx4 into a wave-private 2-slot LDS ring (rows at a pitch of 2D + 32 bytes: conflict-free for both
-// read patterns below), and keeps its own online-softmax state -- no barrier inside the loop.  Per tile:
+// global_load_lds_dwordx4 into a wave-private 3-slot LDS ring (rows at a pitch of 2D + 16 bytes), and keeps its own online-softmax state -- no barrier inside the loop.  Per tile:
 //   S^T [16 keys x 16]   = E_tile (A: rows = keys, ds_read_b128) x Qt^T (B: columns 0-7 = high halves of the 8 heads' qt,
 //                          8-15 = low halves; resident in registers), MFMA 16x16x32, D/32 steps;
 //   hi + lo columns added (DPP row rotate), fp32 online softmax per head column, P split hi / lo the same way;
@@ -30,6 +29,7 @@
 // fragment-major A operand of the residual GEMM (kernels.h fm16, K = heads * D).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "gemm_common.h"
@@ -40,20 +40,25 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
-template <int D>
+template <int D, int NWAVES, int NS>
 struct XaCfg {
+  static constexpr int NW = NWAVES;                        // waves per workgroup: tile i of the clip belongs to wave i % NW
   static constexpr int KS = D / 32;                        // k-steps of the score product
   static constexpr int DT = D / 16;                        // 16-row tiles of the context product
-  static constexpr int ROWB = D * 2 + 32;                  // LDS row pitch in bytes (= 96 mod 256 for D = 416 and 288)
-  static constexpr int TILE = 16 * ROWB;                   // bytes a 16-key tile occupies
-  static constexpr int PIECES = (TILE + 1023) / 1024;      // 1 KiB DMA instructions per tile
-  static constexpr int SLOT = PIECES * 1024;
-  static constexpr int NSLOT = (160 * 1024 / 4 / SLOT) >= 3 ? 3 : 2;
-  static constexpr int RING = 4 * NSLOT * SLOT;
-  static constexpr int MERGE = 4 * 8 * D * 4 + 4 * 8 * 8;  // [wave][head][D] fp32 + [wave][head] {m, l}
+  // A ring slot is the tile as it lies in memory: 16 rows of 2 D bytes, exactly D / 32 KiB -- one DMA piece per KiB, the
+  // same lane offset for every piece.  (Both read patterns below see 2-way bank conflicts at this pitch, a few cycles per
+  // tile; a padded pitch costs per-lane address tables and, at D = 416, the twelfth slot.)
+  static constexpr int ROWB = D * 2;
+  static constexpr int TILE = 16 * ROWB;
+  static constexpr int PIECES = TILE / 1024;
+  static constexpr int SLOT = TILE;
+  static constexpr int NSLOT = NS;
+  static constexpr int RING = NW * NSLOT * SLOT;
+  static constexpr int MST = D + 4;                        // floats per (wave, head) row of the merge area (padded: bank spread)
+  static constexpr int MERGE = NW * 8 * MST * 4 + NW * 8 * 8;  // [wave][head][MST] fp32 + [wave][head] {m, l}
   static constexpr int LDS = RING > MERGE ? RING : MERGE;
-  static_assert(D % 32 == 0, "D must be a multiple of 32");
-  static_assert(ROWB % 256 == 96, "row pitch chosen for conflict-free ds_read_b128 / ds_read_b64_tr_b16");
+  static_assert(D % 32 == 0 && TILE % 1024 == 0, "a tile must be whole KiB pieces");
+  static_assert(NS >= 1 && NS <= 3, "ring depth");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -81,14 +86,66 @@ __device__ __forceinline__ float bf16_round(float x) {   // x rounded to bf16 (R
   return __uint_as_float(pack_bf16x2(x, 0.f) << 16);
 }
 
+// One 16-key tile of E -> one ring slot: PIECES x buffer_load_dwordx4 ... lds (1 KiB each: lane l writes 16 bytes at
+// M0 + 16 l).  The lane's byte offset (16 l) is one VGPR, the piece's offset inside the clip is the SGPR soffset and its LDS
+// address is M0, both stepped by SALU adds: per piece two scalar adds and one VMEM issue, no vector arithmetic.  M0 is
+// restored inside the statement.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#define MSH_XA_P "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], 0x400\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+#define MSH_XA_HEAD "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+#define MSH_XA_TAIL "s_mov_b32 m0, %[keep]"
+template <int P>
+__device__ __forceinline__ void dma_tile(int vo, i32x4_t rs, int so, unsigned lds);
+template <>
+__device__ __forceinline__ void dma_tile<13>(int vo, i32x4_t rs, int so, unsigned lds) {
+  unsigned keep;
+  asm volatile(MSH_XA_HEAD MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P
+                   MSH_XA_P MSH_XA_TAIL
+               : [keep] "=&s"(keep), [so] "+s"(so)
+               : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds)
+               : "memory", "scc");
+}
+template <>
+__device__ __forceinline__ void dma_tile<9>(int vo, i32x4_t rs, int so, unsigned lds) {
+  unsigned keep;
+  asm volatile(MSH_XA_HEAD MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_TAIL
+               : [keep] "=&s"(keep), [so] "+s"(so)
+               : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds)
+               : "memory", "scc");
+}
+#undef MSH_XA_P
+#undef MSH_XA_HEAD
+#undef MSH_XA_TAIL
+// one piece with its own lane offsets (the ragged last tile of a clip)
+__device__ __forceinline__ void dma_piece(int vo, i32x4_t rs, int so, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+               "s_mov_b32 m0, %[keep]"
+               : [keep] "=&s"(keep)
+               : [vo] "v"(vo), [rs] "s"(rs), [so] "s"(so), [lds] "s"(lds)
+               : "memory");
+}
+
 // TR = true: the context product's A fragments come from ds_read_b64_tr_b16; false: four 2-byte reads per fragment (the
-// plain formulation of the same gather, kept as the check of the transposing read: MSH_XATTN_TR=0)
-template <int D, bool TR>
-__global__ __launch_bounds__(256, 2) void dec_cross_absorbed_kernel(const float* __restrict__ qt,      // [M][8 * D]
-                                                               const bf16_t* __restrict__ enc,    // [R][D]
-                                                               const ClipMeta* __restrict__ clips,
-                                                               bf16_t* __restrict__ ctx) {       // FM [M16][8 * D]
-  using C = XaCfg<D>;
+// plain formulation of the same gather, kept as the check of the transposing read: MSH_XATTN_CFG=40).
+// ABL (developer ablations, tools/gpu_r4e.sh; garbage results): 1 = no DMA (the products run on whatever the LDS holds),
+// 2 = no products / softmax (the tiles are only fetched and waited for), 4 = no merge / output, 8 = no output pass,
+// 16 = no merge writes, 32 / 64 = one k-step / one row tile per group of the score / context product.
+template <int D, bool TR, int NWAVES, int NS, int ABL = 0>
+__global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(const bf16_t* __restrict__ qf,     // [M][D / 32][16][32]
+                                                                          const bf16_t* __restrict__ enc,    // [R][D]
+                                                                          const ClipMeta* __restrict__ clips,
+                                                                          bf16_t* __restrict__ ctx,         // FM [M16][8 * D]
+                                                                          unsigned long long* __restrict__ dbg) {
+  using C = XaCfg<D, NWAVES, NS>;
+  // ABL & 128: wave time stamps (s_memtime, shader clock) into dbg[(block * NW + wave) * 16 + point]
+#define MSH_XA_TL(i)                                                                                              \
+  do {                                                                                                            \
+    if constexpr ((ABL & 128) != 0)                                                                               \
+      if ((threadIdx.x & 63) == 0) dbg[((size_t)blockIdx.x * NWAVES + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  MSH_XA_TL(0);
+  constexpr int NW = C::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,65 +153,47 @@ __global__ __launch_bounds__(256, 2) void dec_cross_absorbed_kernel(const float*
   const ClipMeta cm = clips[b];
   const int T = cm.T;
   const int n_tiles = (T + 15) >> 4;
-  const char* ebase = reinterpret_cast<const char*>(enc + (long)cm.row_start * D);
-  const unsigned ring = lds_offset_of(smem) + (unsigned)wave * (C::NSLOT * C::SLOT);
-
-  // byte offset (within a tile's 16 x D block of E) that DMA piece j of this lane fetches; pad lanes re-read offset 0
-  int goff[C::PIECES];
-#pragma unroll
-  for (int j = 0; j < C::PIECES; ++j) {
-    const unsigned o = (unsigned)(j * 1024 + lane * 16);
-    const unsigned r = o / (unsigned)C::ROWB, c = o - r * (unsigned)C::ROWB;
-    goff[j] = (r < 16u && c < (unsigned)(D * 2)) ? (int)(r * (unsigned)(D * 2) + c) : 0;
+  // buffer descriptor over the clip's T rows of E (raw buffer: byte offsets)
+  i32x4_t rs;
+  {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(enc + (long)cm.row_start * D);
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    rs[2] = __builtin_amdgcn_readfirstlane(T * D * 2);
+    rs[3] = 0x00020000;
   }
+  const unsigned ring = lds_offset_of(smem) + (unsigned)wave * (C::NSLOT * C::SLOT);   // this wave's slots
+  const int lane16 = lane * 16;
   auto issue_tile = [&](int tile, int slot) {
-    const char* src = ebase + (long)tile * (16 * D * 2);
+    if constexpr ((ABL & 1) != 0) return;
+    const int so = tile * C::TILE;
     const unsigned dst = ring + (unsigned)slot * C::SLOT;
     if (tile * 16 + 16 <= T) {
-#pragma unroll
-      for (int j = 0; j < C::PIECES; ++j) dma16(src + goff[j], dst + (unsigned)j * 1024u);
+      dma_tile<C::PIECES>(lane16, rs, so, dst);
     } else {   // last tile of a clip whose frame count is not a multiple of 16: rows past the end re-read the last valid row
-      const int last = T - 1 - tile * 16;   // >= 0
+      const unsigned last = (unsigned)(T - 1 - tile * 16);
 #pragma unroll
       for (int j = 0; j < C::PIECES; ++j) {
-        const unsigned o = (unsigned)(j * 1024 + lane * 16);
+        const unsigned o = (unsigned)(j * 1024 + lane16);
         unsigned r = o / (unsigned)C::ROWB;
         const unsigned c = o - r * (unsigned)C::ROWB;
-        const bool ok = r < 16u && c < (unsigned)(D * 2);
-        r = r < (unsigned)last ? r : (unsigned)last;
-        dma16(src + (ok ? (int)(r * (unsigned)(D * 2) + c) : 0), dst + (unsigned)j * 1024u);
+        r = r < last ? r : last;
+        dma_piece((int)(r * (unsigned)C::ROWB + c), rs, so, dst + (unsigned)j * 1024u);
       }
     }
   };
   // the first NSLOT tiles of this wave go out before anything else
 #pragma unroll
   for (int sl = 0; sl < C::NSLOT; ++sl)
-    if (wave + 4 * sl < n_tiles) issue_tile(wave + 4 * sl, sl);
+    if (wave + NW * sl < n_tiles) issue_tile(wave + NW * sl, sl);
 
-  // B operand of the score product: column li = head (li & 7), high half (li < 8) or low half of qt; k = kg * 8 .. + 8
+  // B operand of the score product: column li = head (li & 7), value (li < 8) or rounding residual (li >= 8) of the head's
+  // keys-side query, k = kg * 8 .. + 8 -- already in that order in memory (EpiQtFrag): one contiguous KiB per wave load
   bf16x8 qfrag[C::KS];
-  {
-    const float* qrow = qt + ((long)b * 8 + (li & 7)) * D + kg * 8;
-    float4 qa[C::KS], qb[C::KS];
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      qa[ks] = *reinterpret_cast<const float4*>(qrow + ks * 32);
-      qb[ks] = *reinterpret_cast<const float4*>(qrow + ks * 32 + 4);
-    }
-    // low-half lanes keep x - bf16(x), high-half lanes x itself (branch-free: the subtrahend is scaled by 0 or 1)
-    const float lo = li >= 8 ? 1.0f : 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      float x[8] = {qa[ks].x, qa[ks].y, qa[ks].z, qa[ks].w, qb[ks].x, qb[ks].y, qb[ks].z, qb[ks].w};
-      uint4 u;
-      uint32_t* up = reinterpret_cast<uint32_t*>(&u);
-#pragma unroll
-      for (int e = 0; e < 8; e += 2)
-        up[e >> 1] = pack_bf16x2(fmaf(-lo, bf16_round(x[e]), x[e]), fmaf(-lo, bf16_round(x[e + 1]), x[e + 1]));
-      qfrag[ks] = *reinterpret_cast<bf16x8*>(&u);
-    }
-  }
-
+  for (int ks = 0; ks < C::KS; ++ks)
+    qfrag[ks] = *reinterpret_cast<const bf16x8*>(qf + (((size_t)b * C::KS + ks) * 64 + (li * 4 + kg)) * 8);
+  MSH_XA_TL(1);   // qfrag built (its loads waited for)
   f32x4 acc[C::DT];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -167,30 +206,80 @@ __global__ __launch_bounds__(256, 2) void dec_cross_absorbed_kernel(const float*
 
   int slot = 0;
 #pragma unroll 1
-  for (int tile = wave; tile < n_tiles; tile += 4) {
-    if constexpr (C::NSLOT == 2) {
-      if (tile + 4 < n_tiles) wait_vmcnt<C::PIECES>();
+  for (int tile = wave; tile < n_tiles; tile += NW) {
+    // tiles of this wave still in flight BEHIND this one: up to NSLOT - 1
+    if constexpr ((ABL & 1) != 0) {
+    } else if constexpr (C::NSLOT == 1) {
+      wait_vmcnt<0>();
+    } else if constexpr (C::NSLOT == 2) {
+      if (tile + NW < n_tiles) wait_vmcnt<C::PIECES>();
       else wait_vmcnt<0>();
     } else {
-      if (tile + 8 < n_tiles) wait_vmcnt<2 * C::PIECES>();
-      else if (tile + 4 < n_tiles) wait_vmcnt<C::PIECES>();
+      if (tile + 2 * NW < n_tiles) wait_vmcnt<2 * C::PIECES>();
+      else if (tile + NW < n_tiles) wait_vmcnt<C::PIECES>();
       else wait_vmcnt<0>();
     }
+    if (tile == wave) MSH_XA_TL(2);   // first tile landed
     const char* sbase = smem + (size_t)wave * (C::NSLOT * C::SLOT) + (size_t)slot * C::SLOT;
-
-    // ---- scores: S^T[key][col] over D, two accumulation chains ----
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(sbase + a1_off + ks * 64);
-      if (ks & 1) s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qfrag[ks], s1, 0, 0, 0);
-      else s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qfrag[ks], s0, 0, 0, 0);
+    if constexpr ((ABL & 2) != 0) {
+      if (tile + NW * C::NSLOT < n_tiles) issue_tile(tile + NW * C::NSLOT, slot);
+      slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+      continue;
     }
+
+    // ---- scores: S^T[key][col] over D.  The A fragments (rows = keys) are requested in three groups ahead of the MFMAs
+    // that consume them, FOUR accumulation chains: a read that lands in the registers an MFMA is still reading, or an MFMA
+    // waiting on its predecessor's result, is what the first version of this loop spent most of its time in. ----
+    constexpr int KSE = (ABL & 32) != 0 ? 3 : C::KS;
+    constexpr int P0 = (KSE + 2) / 3, P1 = (KSE + 1) / 3, P2 = KSE / 3;
+    auto read_s = [&](int ks) { return *reinterpret_cast<const bf16x8*>(sbase + a1_off + ks * 64); };
+    bf16x8 e0[P0], e1[P1], e2[P2];
+#pragma unroll
+    for (int i = 0; i < P0; ++i) e0[i] = read_s(i);
+#pragma unroll
+    for (int i = 0; i < P1; ++i) e1[i] = read_s(P0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 sc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P0; ++i) sc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e0[i], qfrag[i], sc[i & 3], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < P2; ++i) e2[i] = read_s(P0 + P1 + i);
+    // ---- context: C^T[d][col] += E_tile^T x P^T, the A fragments read in four groups: group g + 1 is requested before
+    // group g's MFMAs are issued, the first group before the softmax arithmetic (it does not depend on it) ----
+    constexpr int DTE = (ABL & 64) != 0 ? 4 : C::DT;
+    constexpr int G0 = (DTE + 3) / 4, G1 = (DTE + 2) / 4, G2 = (DTE + 1) / 4, G3 = DTE / 4;
+    auto read_a = [&](int dt) {
+      s16x4 a;
+      if constexpr (TR) {
+        a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sbase + a2_off + dt * 32));
+      } else {
+        const char* g = sbase + a2_off + dt * 32;
+        a[0] = *reinterpret_cast<const short*>(g);
+        a[1] = *reinterpret_cast<const short*>(g + C::ROWB);
+        a[2] = *reinterpret_cast<const short*>(g + 2 * C::ROWB);
+        a[3] = *reinterpret_cast<const short*>(g + 3 * C::ROWB);
+      }
+      return a;
+    };
+    s16x4 a0[G0], a1[G1], a2[G2], a3[G3];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < P1; ++i)
+      sc[(P0 + i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e1[i], qfrag[P0 + i], sc[(P0 + i) & 3], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G0; ++i) a0[i] = read_a(i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < P2; ++i)
+      sc[(P0 + P1 + i) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e2[i], qfrag[P0 + P1 + i], sc[(P0 + P1 + i) & 3], 0, 0, 0);
+    if (tile == wave) MSH_XA_TL(3);   // score MFMAs issued
     float s[4];
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = s0[r] + s1[r];
+      const float v = (sc[0][r] + sc[1][r]) + (sc[2][r] + sc[3][r]);
       const float t = v + dpp_ror8(v);   // high-half column + low-half column of the same head
       s[r] = (tile * 16 + kg * 4 + r < T) ? t : -INFINITY;
       mx = fmaxf(mx, s[r]);
@@ -220,34 +309,50 @@ __global__ __launch_bounds__(256, 2) void dec_cross_absorbed_kernel(const float*
       u.y = pack_bf16x2(fmaf(-lo_lane, bf16_round(p[2]), p[2]), fmaf(-lo_lane, bf16_round(p[3]), p[3]));
       pfrag = *reinterpret_cast<s16x4*>(&u);
     }
-    // ---- context: C^T[d][col] += E_tile^T x P^T ----
+    if (tile == wave) MSH_XA_TL(4);   // softmax done
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) {
-      s16x4 a;
-      if constexpr (TR) {
-        a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sbase + a2_off + dt * 32));
-      } else {
-        const char* g = sbase + a2_off + dt * 32;
-        a[0] = *reinterpret_cast<const short*>(g);
-        a[1] = *reinterpret_cast<const short*>(g + C::ROWB);
-        a[2] = *reinterpret_cast<const short*>(g + 2 * C::ROWB);
-        a[3] = *reinterpret_cast<const short*>(g + 3 * C::ROWB);
-      }
-      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, pfrag, acc[dt], 0, 0, 0);
-    }
+    for (int i = 0; i < G1; ++i) a1[i] = read_a(G0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G0; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0[i], pfrag, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G2; ++i) a2[i] = read_a(G0 + G1 + i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G1; ++i) acc[G0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1[i], pfrag, acc[G0 + i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G3; ++i) a3[i] = read_a(G0 + G1 + G2 + i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G2; ++i)
+      acc[G0 + G1 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2[i], pfrag, acc[G0 + G1 + i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G3; ++i)
+      acc[G0 + G1 + G2 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a3[i], pfrag, acc[G0 + G1 + G2 + i], 0, 0, 0);
+    if (tile == wave) MSH_XA_TL(5);   // context MFMAs issued
     // the slot is free once every read of it has returned: fetch the tile NSLOT rounds ahead into it
-    if (tile + 4 * C::NSLOT < n_tiles) {
+    if (tile + NW * C::NSLOT < n_tiles) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_tile(tile + 4 * C::NSLOT, slot);
+      issue_tile(tile + NW * C::NSLOT, slot);
     }
+    if (tile == wave) MSH_XA_TL(6);   // next tile requested
+    if (tile == wave + NW) MSH_XA_TL(7);   // second tile of the wave finished
     slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
   }
 
-  // ---- merge the four waves ----
+  if constexpr ((ABL & 4) != 0) {
+    float keep = l_part;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) keep += (acc[dt][0] + acc[dt][1]) + (acc[dt][2] + acc[dt][3]);
+    if (keep == 12345.f) ctx[threadIdx.x] = (bf16_t)1;   // keeps every accumulator alive, never true in practice
+    return;
+  }
+  // ---- merge the waves ----
+  MSH_XA_TL(8);    // loop done
   const float l_wave = xa_rows_sum(l_part);   // all four key groups of the column
   __syncthreads();                             // every wave is done with its ring: the merge area overlays it
-  float* mc = reinterpret_cast<float*>(smem);                 // [wave][head][D]
-  float2* ml = reinterpret_cast<float2*>(smem + 4 * 8 * D * 4);   // [wave][head]
+  float* mc = reinterpret_cast<float*>(smem);                               // [wave][head][MST]
+  float2* ml = reinterpret_cast<float2*>(smem + NW * 8 * C::MST * 4);       // [wave][head]
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) {
     float4 v;
@@ -255,71 +360,117 @@ __global__ __launch_bounds__(256, 2) void dec_cross_absorbed_kernel(const float*
     v.y = acc[dt][1] + dpp_ror8(acc[dt][1]);
     v.z = acc[dt][2] + dpp_ror8(acc[dt][2]);
     v.w = acc[dt][3] + dpp_ror8(acc[dt][3]);
-    if (li < 8) *reinterpret_cast<float4*>(mc + ((size_t)(wave * 8 + li) * D + dt * 16 + kg * 4)) = v;
+    if constexpr ((ABL & 16) == 0)
+      if (li < 8) *reinterpret_cast<float4*>(mc + ((size_t)(wave * 8 + li) * C::MST + dt * 16 + kg * 4)) = v;
+    if constexpr ((ABL & 16) != 0)
+      if (v.x == 12345.f) ctx[0] = 1;
   }
+  MSH_XA_TL(9);    // first barrier passed, partials written
   if (lane < 8) ml[wave * 8 + lane] = make_float2(m_run, l_wave);
   __syncthreads();
+  MSH_XA_TL(10);   // second barrier passed
   constexpr int CHUNKS = 8 * D / 8;   // 16-byte output chunks of the clip's row
-  for (int ch = threadIdx.x; ch < CHUNKS; ch += 256) {
+  if constexpr ((ABL & 8) != 0) return;
+  for (int ch = threadIdx.x; ch < CHUNKS; ch += 64 * NW) {
     const int h = ch / (D / 8), d0 = (ch - h * (D / 8)) * 8;
-    const float2 e0 = ml[h], e1 = ml[8 + h], e2 = ml[16 + h], e3 = ml[24 + h];
-    float m = fmaxf(fmaxf(e0.x, e1.x), fmaxf(e2.x, e3.x));
+    float mw[NW], f[NW];
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      mw[w] = ml[w * 8 + h].x;
+      m = fmaxf(m, mw[w]);
+    }
     m = m > -INFINITY ? m : 0.f;   // a clip without frames: every weight 0, output 0
-    const float f0 = __builtin_amdgcn_exp2f(e0.x - m), f1 = __builtin_amdgcn_exp2f(e1.x - m);
-    const float f2 = __builtin_amdgcn_exp2f(e2.x - m), f3 = __builtin_amdgcn_exp2f(e3.x - m);
-    const float l = (f0 * e0.y + f1 * e1.y) + (f2 * e2.y + f3 * e3.y);
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      f[w] = __builtin_amdgcn_exp2f(mw[w] - m);
+      l += f[w] * ml[w * 8 + h].y;
+    }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float o[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const float4 c0 = *reinterpret_cast<const float4*>(mc + (size_t)(0 * 8 + h) * D + d0 + half * 4);
-      const float4 c1 = *reinterpret_cast<const float4*>(mc + (size_t)(1 * 8 + h) * D + d0 + half * 4);
-      const float4 c2 = *reinterpret_cast<const float4*>(mc + (size_t)(2 * 8 + h) * D + d0 + half * 4);
-      const float4 c3 = *reinterpret_cast<const float4*>(mc + (size_t)(3 * 8 + h) * D + d0 + half * 4);
-      o[half * 4 + 0] = ((f0 * c0.x + f1 * c1.x) + (f2 * c2.x + f3 * c3.x)) * inv;
-      o[half * 4 + 1] = ((f0 * c0.y + f1 * c1.y) + (f2 * c2.y + f3 * c3.y)) * inv;
-      o[half * 4 + 2] = ((f0 * c0.z + f1 * c1.z) + (f2 * c2.z + f3 * c3.z)) * inv;
-      o[half * 4 + 3] = ((f0 * c0.w + f1 * c1.w) + (f2 * c2.w + f3 * c3.w)) * inv;
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float4 c0 = *reinterpret_cast<const float4*>(mc + (size_t)(w * 8 + h) * C::MST + d0);
+      const float4 c1 = *reinterpret_cast<const float4*>(mc + (size_t)(w * 8 + h) * C::MST + d0 + 4);
+      o[0] += f[w] * c0.x; o[1] += f[w] * c0.y; o[2] += f[w] * c0.z; o[3] += f[w] * c0.w;
+      o[4] += f[w] * c1.x; o[5] += f[w] * c1.y; o[6] += f[w] * c1.z; o[7] += f[w] * c1.w;
     }
     uint4 u;
-    u.x = pack_bf16x2(o[0], o[1]);
-    u.y = pack_bf16x2(o[2], o[3]);
-    u.z = pack_bf16x2(o[4], o[5]);
-    u.w = pack_bf16x2(o[6], o[7]);
+    u.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+    u.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+    u.z = pack_bf16x2(o[4] * inv, o[5] * inv);
+    u.w = pack_bf16x2(o[6] * inv, o[7] * inv);
     *reinterpret_cast<uint4*>(ctx + fm16(b, h * D + d0, 8 * D / 32)) = u;
   }
+  MSH_XA_TL(11);   // output stores issued
+#undef MSH_XA_TL
 }
 
-bool xattn_use_tr() {
-  static const bool on = [] {
-    const char* e = getenv("MSH_XATTN_TR");
-    return !(e != nullptr && e[0] == '0');
+// Shape of the workgroup (developer knob MSH_XATTN_CFG = <waves><slots>): 81 = eight waves with one ring slot each (default:
+// a wave that sits in the back-pressure of its own DMA issue does not keep the CU from computing -- seven others are there --
+// and 106 KiB of LDS leave room for another kernel's workgroup on the CU), 43 / 42 = four waves with three / two slots each;
+// 40 = 42 with the context product's fragments gathered by 2-byte reads instead of ds_read_b64_tr_b16 (the check of that read).
+int xattn_cfg() {
+  static const int v = [] {
+    const char* e = getenv("MSH_XATTN_CFG");
+    const int c = e != nullptr ? atoi(e) : 81;
+    return c == 43 || c == 42 || c == 40 ? c : 81;
   }();
-  return on;
+  return v;
 }
 
-template <int D>
-void launch_absorbed(const float* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s) {
-  using C = XaCfg<D>;
+template <int D, bool TR, int NWAVES, int NS, int ABL = 0>
+void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s,
+                         unsigned long long* dbg = nullptr) {
+  using C = XaCfg<D, NWAVES, NS>;
   static const bool attr = [] {
-    MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-    MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, false>),
+    MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     return true;
   }();
   (void)attr;
-  if (xattn_use_tr())
-    MSH_LAUNCH((dec_cross_absorbed_kernel<D, true>), dim3(M), dim3(256), C::LDS, s, qt, enc, clips, ctx);
-  else
-    MSH_LAUNCH((dec_cross_absorbed_kernel<D, false>), dim3(M), dim3(256), C::LDS, s, qt, enc, clips, ctx);
+  MSH_LAUNCH((dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL>), dim3(M), dim3(64 * NWAVES), C::LDS, s, qt, enc, clips, ctx, dbg);
+}
+template <int D>
+void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s) {
+  static const int abl = [] {
+    const char* e = getenv("MSH_XATTN_ABL");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  if constexpr (D == 416) {
+    switch (abl) {
+      case 1: return launch_absorbed_cfg<D, true, 8, 1, 1>(qt, enc, clips, M, ctx, s);
+      case 2: return launch_absorbed_cfg<D, true, 8, 1, 2>(qt, enc, clips, M, ctx, s);
+      case 4: return launch_absorbed_cfg<D, true, 8, 1, 4>(qt, enc, clips, M, ctx, s);
+      case 6: return launch_absorbed_cfg<D, true, 8, 1, 6>(qt, enc, clips, M, ctx, s);
+      case 3: return launch_absorbed_cfg<D, true, 8, 1, 3>(qt, enc, clips, M, ctx, s);
+      case 7: return launch_absorbed_cfg<D, true, 8, 1, 7>(qt, enc, clips, M, ctx, s);
+      case 10: return launch_absorbed_cfg<D, true, 8, 1, 10>(qt, enc, clips, M, ctx, s);
+      case 26: return launch_absorbed_cfg<D, true, 8, 1, 26>(qt, enc, clips, M, ctx, s);
+      case 11: return launch_absorbed_cfg<D, true, 8, 1, 11>(qt, enc, clips, M, ctx, s);
+      case 27: return launch_absorbed_cfg<D, true, 8, 1, 27>(qt, enc, clips, M, ctx, s);
+      case 33: return launch_absorbed_cfg<D, true, 8, 1, 33>(qt, enc, clips, M, ctx, s);
+      case 65: return launch_absorbed_cfg<D, true, 8, 1, 65>(qt, enc, clips, M, ctx, s);
+      case 97: return launch_absorbed_cfg<D, true, 8, 1, 97>(qt, enc, clips, M, ctx, s);
+      default: break;
+    }
+  }
+  switch (xattn_cfg()) {
+    case 43: return launch_absorbed_cfg<D, true, 4, 3>(qt, enc, clips, M, ctx, s);
+    case 42: return launch_absorbed_cfg<D, true, 4, 2>(qt, enc, clips, M, ctx, s);
+    case 40: return launch_absorbed_cfg<D, false, 4, 2>(qt, enc, clips, M, ctx, s);
+    default: return launch_absorbed_cfg<D, true, 8, 1>(qt, enc, clips, M, ctx, s);
+  }
 }
 
 }  // namespace
 
 bool cross_absorbed_supported(int D, int heads) { return heads == 8 && (D == 416 || D == 288); }
 
-void dec_cross_absorbed(const float* qt, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
+void dec_cross_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
                         hipStream_t s) {
   if (!cross_absorbed_supported(D, heads)) throw std::runtime_error("dec_cross_absorbed: unsupported shape");
   if (D == 416) launch_absorbed<416>(qt, enc, clips, M, ctx, s);
@@ -341,14 +492,25 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
     cm[b].T = Ts[b];
   }
   const int M16 = (M + 15) / 16 * 16;
-  float* dq = nullptr;
+  // the queries in the operand order the GEMM epilogue writes (gemm_common.h EpiQtFrag): value and rounding residual
+  std::vector<bf16_t> qf16((size_t)M * 8 * D * 2);
+  for (int b = 0; b < M; ++b)
+    for (int h = 0; h < 8; ++h)
+      for (int d = 0; d < D; ++d) {
+        const float x = qt[((size_t)b * 8 + h) * D + d];
+        const bf16_t hi = f32_to_bf16(x);
+        const size_t frag = ((size_t)b * (D / 32) + d / 32) * 512 + d % 32;
+        qf16[frag + h * 32] = hi;
+        qf16[frag + (h + 8) * 32] = f32_to_bf16(x - bf16_to_f32(hi));
+      }
+  bf16_t* dq = nullptr;
   bf16_t *de = nullptr, *dc = nullptr;
   ClipMeta* dm = nullptr;
   MSH_HIP(hipMalloc(&dq, (size_t)M * 8 * D * 4));
   MSH_HIP(hipMalloc(&de, e16.size() * 2));
   MSH_HIP(hipMalloc(&dc, (size_t)M16 * 8 * D * 2));
   MSH_HIP(hipMalloc(&dm, (size_t)M * sizeof(ClipMeta)));
-  MSH_HIP(hipMemcpy(dq, qt, (size_t)M * 8 * D * 4, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(dq, qf16.data(), qf16.size() * 2, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(de, e16.data(), e16.size() * 2, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(dm, cm.data(), (size_t)M * sizeof(ClipMeta), hipMemcpyHostToDevice));
   MSH_HIP(hipMemset(dc, 0, (size_t)M16 * 8 * D * 2));
@@ -367,6 +529,34 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
     ms /= (float)iters;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b2);
+  }
+  if (const char* tl = getenv("MSH_XATTN_TIMELINE"); tl != nullptr && tl[0] == '1' && D == 416) {
+    // developer: per-wave s_memtime stamps of the default shape (tools/xattn_microbench.py prints nothing else for it)
+    const size_t n = (size_t)M * 8 * 16;
+    unsigned long long* dd = nullptr;
+    MSH_HIP(hipMalloc(&dd, n * 8));
+    MSH_HIP(hipMemset(dd, 0, n * 8));
+    for (int rep = 0; rep < 3; ++rep) launch_absorbed_cfg<416, true, 8, 1, 128>(dq, de, dm, M, dc, 0, dd);
+    MSH_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(n);
+    MSH_HIP(hipMemcpy(h.data(), dd, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dd);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < (size_t)M * 8; ++w) {
+      t0 = std::min(t0, h[w * 16]);
+      t1 = std::max(t1, h[w * 16 + 11]);
+    }
+    static const char* names[12] = {"start", "qfrag", "tile0 landed", "scores issued", "softmax", "context issued", "next dma issued",
+                                    "2nd tile done", "loop done", "barrier1+writes", "barrier2", "stores issued"};
+    fprintf(stderr, "[xattn timeline] %d clips: first start -> last end %llu cycles\n", M, t1 - t0);
+    for (int i = 0; i < 12; ++i) {
+      std::vector<unsigned long long> v;
+      for (size_t w = 0; w < (size_t)M * 8; ++w)
+        if (h[w * 16 + i] != 0) v.push_back(h[w * 16 + i] - t0);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      fprintf(stderr, "  %-18s min %7llu  p50 %7llu  max %7llu  (%zu waves)\n", names[i], v.front(), v[v.size() / 2], v.back(), v.size());
+    }
   }
   std::vector<bf16_t> c16((size_t)M16 * 8 * D);
   MSH_HIP(hipMemcpy(c16.data(), dc, c16.size() * 2, hipMemcpyDeviceToHost));

@@ -182,11 +182,13 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
                          int heads, bf16_t* out, hipStream_t s, const float* kdq = nullptr, const float* vdq = nullptr);
 
 // Absorbed form (k_xattn.hip): the attention of all heads of a clip in ONE pass over the encoder output `enc` [R][D] bf16
-// (clip b's T frames start at row clips[b].row_start).  qt [M][heads * D] fp32 = the keys-side queries of the heads (from
-// dec_gemm_ln_f32 with the merged weight Wqk, softmax scale and log2(e) folded in) -> ctx [M16][heads * D] bf16 in FM, the A
-// operand of dec_gemm_resid with the merged weight Wvo (K = heads * D).  heads == 8, D in {416, 288}.
+// (clip b's T frames start at row clips[b].row_start).  qf = the keys-side queries of the heads, LN(h) Wqk^T with the merged
+// weight Wqk (softmax scale and log2(e) folded in), as dec_gemm_ln_qt writes them: [M][D / 32][16][32] bf16, value and rounding
+// residual in the score product's operand order (gemm_common.h EpiQtFrag) -> ctx [M16][heads * D] bf16 in FM, the A operand
+// of dec_gemm_resid with the merged weight Wvo (K = heads * D).  heads == 8, D in {416, 288}.
 bool cross_absorbed_supported(int D, int heads);
-void dec_cross_absorbed(const float* qt, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
+void dec_gemm_ln_qt(const float* H, const bf16_t* W, int M, int heads, int D, bf16_t* qf, hipStream_t s);
+void dec_cross_absorbed(const bf16_t* qf, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
                         hipStream_t s);
 float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const int* Ts, const int* row_starts, int M, int D,
                           float* ctx_out, int iters);
