@@ -201,7 +201,7 @@ MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_
                                     float* out_w, int32_t* out_pos);
 
 /* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  0 = automatic: from
- * MSH_XATTN_MIN_BATCH (default 128) clips per batch on, the "absorbed" form -- the key projection moved onto the query
+ * MSH_XATTN_MIN_BATCH (default 192) clips per batch on, the "absorbed" form -- the key projection moved onto the query
  * (qt_h = Wk_h^T q_h) and the value projection onto the output projection (Wo_h Wv_h), so that a decode step reads the
  * encoder output ONCE per layer for all heads instead of K^T and V^T: half the bytes of the kernel that bounds batched
  * decode and no cross-K/V projection in the encoder (k_xattn.hip); below that the classic K^T / V^T stream.  1 = always

@@ -39,7 +39,19 @@ UtilStreams& util_streams() {
 int xattn_min_batch() {
   static const int v = [] {
     const char* e = getenv("MSH_XATTN_MIN_BATCH");
-    return e != nullptr ? atoi(e) : 128;
+    // one workgroup per clip: below ~200 clips most of the chip idles through the kernel and its two wider GEMMs cost more
+    // than the halved stream saves (measured at 64 / 128 / 256 clips x 10 s: 8.7 / 12.0 / 17.8 us against 9 / 15 / 28.9)
+    return e != nullptr ? atoi(e) : 192;
+  }();
+  return v;
+}
+
+// decode steps per graph replay in the steady state of the decode loop (MSH_DEC_GRAPH_STEPS; 1 = one replay per step)
+int graph_steps() {
+  static const int v = [] {
+    const char* e = getenv("MSH_DEC_GRAPH_STEPS");
+    const int n = e != nullptr ? atoi(e) : 8;
+    return n == 1 || n == 2 || n == 4 || n == 8 ? n : 8;
   }();
   return v;
 }
@@ -1056,12 +1068,14 @@ struct Engine::DecodeGroup {
   bool fused_argmax = false;  // LM head writes per-tile (max, index) pairs instead of logits
   DecodeState state{};        // of the last decode() (profile_decode_chain replays its kernels)
   bool has_state = false;
-  hipGraphExec_t graph = nullptr;
+  hipGraphExec_t graph = nullptr;     // one decode step
+  hipGraphExec_t graph_n = nullptr;   // graph_steps() consecutive steps in one replay (the loop's steady state)
   std::string key;
   uint64_t gen = 0;
   int32_t n_active_h = 0;
   ~DecodeGroup() {
     if (graph) (void)hipGraphExecDestroy(graph);
+    if (graph_n) (void)hipGraphExecDestroy(graph_n);
     DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher,
                       &pval, &pidx};
     for (DevBuf* b : bufs) b->release();
@@ -1438,33 +1452,43 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
                               std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" + std::to_string(kv_fp8_) + ":" +
                               std::to_string(absorbed_);
       if (g.graph == nullptr || g.key != key) {
-        if (g.graph) {
-          MSH_HIP(hipGraphExecDestroy(g.graph));
-          g.graph = nullptr;
-        }
+        for (hipGraphExec_t* ge : {&g.graph, &g.graph_n})
+          if (*ge) {
+            MSH_HIP(hipGraphExecDestroy(*ge));
+            *ge = nullptr;
+          }
         g.key.clear();
-        hipGraph_t gr = nullptr;
-        std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-        MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        try {
-          decode_step_enqueue(g);
-          if (g.fused_argmax)
-            decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
-                                    g.dH.as<float>(), g.stream);
-          else
-            decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
-        } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
-          (void)hipStreamEndCapture(g.stream, &gr);
-          if (gr != nullptr) (void)hipGraphDestroy(gr);
-          throw;
-        }
-        MSH_HIP(hipStreamEndCapture(g.stream, &gr));
-        const hipError_t inst = hipGraphInstantiate(&g.graph, gr, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(gr);
-        if (inst != hipSuccess) {
-          g.graph = nullptr;
-          MSH_HIP(inst);
-        }
+        // nothing step-dependent is a kernel argument (position, counters and ids live in device memory), so n consecutive
+        // steps captured into ONE graph are n times the same nodes: the loop below replays that one wherever n whole steps
+        // are left -- one graph launch (its start / end packets and the gap between two replays) per n steps instead of per step
+        auto capture = [&](int n_steps, hipGraphExec_t* out) {
+          hipGraph_t gr = nullptr;
+          std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+          MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+          try {
+            for (int r = 0; r < n_steps; ++r) {
+              decode_step_enqueue(g);
+              if (g.fused_argmax)
+                decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
+                                        g.dH.as<float>(), g.stream);
+              else
+                decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+            }
+          } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
+            (void)hipStreamEndCapture(g.stream, &gr);
+            if (gr != nullptr) (void)hipGraphDestroy(gr);
+            throw;
+          }
+          MSH_HIP(hipStreamEndCapture(g.stream, &gr));
+          const hipError_t inst = hipGraphInstantiate(out, gr, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(gr);
+          if (inst != hipSuccess) {
+            *out = nullptr;
+            MSH_HIP(inst);
+          }
+        };
+        capture(1, &g.graph);
+        if (graph_steps() > 1) capture(graph_steps(), &g.graph_n);
         g.key = key;
       }
     }
@@ -1474,11 +1498,17 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
   }
 
   int steps_run = 0;
+  const int gsteps = graph_steps();   // 8 = the interval at which the host looks at the active-clip counter anyway
   for (int i = 0; i < steps; ++i) {
+    // a whole block of steps in one replay: from a block boundary, when that many steps are left (the reference loop stops
+    // at EOS / budget per clip -- finished clips are masked on the device, the host only checks between blocks)
+    const bool block = !eager && gsteps > 1 && (i % gsteps) == 0 && i + gsteps <= steps;
     for (int gi = 0; gi < ngroups; ++gi) {
       DecodeGroup& g = *groups_[gi];
       if (g.n_active_h <= 0) continue;
-      if (!eager) {
+      if (block && g.graph_n != nullptr) {
+        MSH_HIP(hipGraphLaunch(g.graph_n, g.stream));
+      } else if (!eager) {
         MSH_HIP(hipGraphLaunch(g.graph, g.stream));
       } else {
         decode_step_enqueue(g);
@@ -1496,7 +1526,12 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
         }
       }
     }
-    ++steps_run;
+    if (block) {
+      steps_run += gsteps;
+      i += gsteps - 1;
+    } else {
+      ++steps_run;
+    }
     if (!forced && ((i & 7) == 7) && i + 1 < steps) {
       int alive = 0;
       for (int gi = 0; gi < ngroups; ++gi) {

@@ -93,7 +93,7 @@ class Engine {
     capture_cross_ = on;
   }
   // How the decoder's cross-attention runs (k_xattn.hip): 0 = automatic (the absorbed form -- one pass over the encoder
-  // output, no cross K/V -- from xattn_min_batch() clips on, the classic K^T / V^T stream below), 1 = always classic,
+  // output, no cross K/V -- from xattn_min_batch() = 192 clips on, the classic K^T / V^T stream below), 1 = always classic,
   // 2 = absorbed whenever the shape supports it.  Applies to the next encode; lanes take it when they are created.
   void set_cross_mode(int mode) {
     if (mode < 0 || mode > 2) throw std::invalid_argument("cross mode: 0 = auto, 1 = projected K/V, 2 = absorbed");

@@ -57,7 +57,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_dec_kernel(const void* __restric
   __shared__ float2 stat[NW][16 * TM];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = (blockIdx.x / n_tiles) * (16 * TM), n0 = (blockIdx.x % n_tiles) * (16 * TN);
+  // Block -> tile.  n_tiles > 0: XCD-aware order (launch grid dec_grid()): workgroup b runs on XCD b % 8 (observed placement,
+  // used for speed only), and column tile nt is given to XCD nt % 8 with ALL its row tiles -- every weight byte then crosses
+  // the fabric into ONE XCD's L2 instead of into four to eight of them (the decode weights, 77-88 MB per step, never stay in
+  // the 4 MB L2s from one step to the next: each GEMM starts L2-cold and its first round trip is the fabric's).  Blocks
+  // beyond an XCD's share exit at once.  n_tiles < 0: plain row-major order over -n_tiles column tiles (MSH_DEC_XCD=0).
+  int mt_, nt_;
+  if (n_tiles > 0) {
+    const int m_tiles = (M + 16 * TM - 1) / (16 * TM);
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int cnt = (n_tiles - x + 7) >> 3;   // column tiles with nt % 8 == x
+    if (i >= cnt * m_tiles) return;
+    const int c = i / m_tiles;
+    mt_ = i - c * m_tiles;
+    nt_ = x + 8 * c;
+  } else {
+    n_tiles = -n_tiles;
+    mt_ = blockIdx.x / n_tiles;
+    nt_ = blockIdx.x - mt_ * n_tiles;
+  }
+  const int m0 = mt_ * (16 * TM), n0 = nt_ * (16 * TN);
   MSH_TL(0);
   int gm[TM];
 #pragma unroll
@@ -269,12 +288,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_dec_kernel(const void* __restric
   MSH_TL(6);
 }
 
+static bool dec_xcd_order() {
+  static const bool on = [] {
+    const char* e = getenv("MSH_DEC_XCD");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+// launch grid and the n_tiles argument of gemm_dec_kernel (see "Block -> tile" there)
+static inline unsigned dec_grid(int m_tiles, int n_tiles) {
+  return dec_xcd_order() ? 8u * (unsigned)((n_tiles + 7) / 8) * (unsigned)m_tiles : (unsigned)(m_tiles * n_tiles);
+}
+static inline int dec_ntiles_arg(int n_tiles) { return dec_xcd_order() ? n_tiles : -n_tiles; }
+
 template <int KS, int TN, bool LN, class Epi, int TM = 1>
 void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W, int M, int N, Epi epi,
                     hipStream_t s) {
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
-  MSH_LAUNCH((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(m_tiles * n_tiles), dim3(256), 0, s, A, lda, gamma, W,
-                     M, N, n_tiles, epi);
+  MSH_LAUNCH((gemm_dec_kernel<KS, TN, LN, Epi, TM>), dim3(dec_grid(m_tiles, n_tiles)), dim3(256), 0, s, A, lda, gamma, W,
+                     M, N, dec_ntiles_arg(n_tiles), epi);
 }
 static int dec_tm2_threshold() {
   static int thr = [] {
@@ -309,8 +341,8 @@ void launch_fm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hip
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
 #define MSH_FM_CASE(KK)                                                                                              \
   case KK:                                                                                                           \
-    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
-                       (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
+    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(dec_grid(m_tiles, n_tiles)), dim3(64 * NW), 0, s, A, \
+                       (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);                       \
     return;
   switch (K) {
     MSH_FM_CASE(416)
@@ -331,8 +363,8 @@ bool launch_sfm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hi
   const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
 #define MSH_SFM_CASE(KK)                                                                                             \
   case KK:                                                                                                           \
-    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(m_tiles * n_tiles), dim3(64 * NW), 0, s, A, \
-                       (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);                                       \
+    MSH_LAUNCH((gemm_dec_kernel<KK / 32, TN, LN, Epi, TM, true, NW>), dim3(dec_grid(m_tiles, n_tiles)), dim3(64 * NW), 0, s, A, \
+                       (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);                       \
     return true;
   switch (K) {
     MSH_SFM_CASE(96)
@@ -433,12 +465,12 @@ static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int
   const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
   switch (K) {
     case 3328:
-      MSH_LAUNCH((gemm_dec_kernel<104, TN, false, Epi, 1, true, 8>), dim3(m_tiles * n_tiles), dim3(512), 0, s, (const void*)A,
-                 (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);
+      MSH_LAUNCH((gemm_dec_kernel<104, TN, false, Epi, 1, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
+                 (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);
       return;
     case 2304:
-      MSH_LAUNCH((gemm_dec_kernel<72, TN, false, Epi, 1, true, 8>), dim3(m_tiles * n_tiles), dim3(512), 0, s, (const void*)A,
-                 (long)0, (const float*)nullptr, W, M, N, n_tiles, epi);
+      MSH_LAUNCH((gemm_dec_kernel<72, TN, false, Epi, 1, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
+                 (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);
       return;
     default: throw std::runtime_error("gemm_dec (FM, wide K): unsupported K " + std::to_string(K));
   }
@@ -446,7 +478,7 @@ static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int
 static int wide_k_tn() {   // developer knob: column tiles per workgroup of the wide-K residual GEMM (1 or 2)
   static const int v = [] {
     const char* e = getenv("MSH_XATTN_G2_TN");
-    return e != nullptr && e[0] == '1' ? 1 : 2;
+    return e != nullptr && e[0] == '2' ? 2 : 1;   // measured at M = 256: 6.6 us (416 workgroups) against 7.4 (208)
   }();
   return v;
 }

@@ -190,10 +190,10 @@ def test_base_batch256_benchmark_path_vs_oracle_absorbed(base_x):
 
 
 def test_automatic_mode_picks_the_form_by_batch_size(tmp_path_factory):
-    """Mode 0: absorbed from MSH_XATTN_MIN_BATCH (128) clips on, the classic stream below; the word-timestamp capture and
+    """Mode 0: absorbed from MSH_XATTN_MIN_BATCH (192) clips on, the classic stream below; the word-timestamp capture and
     fp8 keys always use the classic form; a batch's ids do not depend on which clips share it within one form."""
     e, w, cfg = tp._engine(tmp_path_factory, "tiny", 3)
-    clips = [make_audio(300 + i, 16000 + 37 * i) for i in range(130)]
+    clips = [make_audio(300 + i, 16000 + 37 * i) for i in range(200)]
     e.encode(clips[:8])
     assert not e.cross_absorbed()
     small = e.decode(forced_steps=6)[0]
@@ -204,8 +204,48 @@ def test_automatic_mode_picks_the_form_by_batch_size(tmp_path_factory):
     assert agree >= 6, (small, big[:8])   # two roundings of the same function: near-ties may flip, nothing else
     e.set_cross_mode("absorbed")
     forced = e.transcribe_tokens(clips[:8], forced_steps=6)
-    assert forced == big[:8]              # absorbed at batch 8 == absorbed inside the batch of 130
+    assert forced == big[:8]              # absorbed at batch 8 == absorbed inside the batch of 200
     e.set_cross_mode("kv")
     assert e.transcribe_tokens(clips[:8], forced_steps=6) == small
     e.encode(clips)
     assert not e.cross_absorbed()
+    # the word-timestamp capture reads K^T: it always gets the classic form, and switching it on re-encodes
+    e.set_cross_mode("absorbed")
+    e.encode(clips[:4])
+    assert e.cross_absorbed()
+    e.lib.msh_set_capture_cross_attention(e.h, 1)
+    e.encode(clips[:4])
+    assert not e.cross_absorbed()
+    e.lib.msh_set_capture_cross_attention(e.h, 0)
+
+
+def test_decode_gemm_tile_order_and_graph_blocking_do_not_change_ids(tmp_path_factory):
+    """Two launch-side choices of this round must be invisible in the results: the XCD-aware block -> tile order of the decode
+    GEMMs (MSH_DEC_XCD) and the eight-steps-per-replay decode graph (MSH_DEC_GRAPH_STEPS).  Both are read once per process, so
+    the comparison runs in child processes: same weights, same clips, 19 free-running steps (two blocks of eight plus three
+    single steps), all four combinations must give identical ids."""
+    import json
+    import subprocess
+    import sys
+
+    code = (
+        "import json, sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import tempfile\n"
+        "from moonshine_amd.hip_api import Engine\n"
+        "from moonshine_amd.synth import ARCHS, make_audio, make_weights, save_safetensors\n"
+        "cfg = ARCHS['tiny']; w = make_weights(cfg, 5)\n"
+        "d = tempfile.mkdtemp(); p = os.path.join(d, 'model.safetensors')\n"
+        "save_safetensors(p, w, {'arch': cfg.name, 'heads': str(cfg.heads)})\n"
+        "e = Engine(0); e.load_weights_file(p)\n"
+        "clips = [make_audio(900 + i, 20000 + 811 * i) for i in range(40)]\n"
+        "print(json.dumps(e.transcribe_tokens(clips, forced_steps=19)))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for xcd in ("1", "0"):
+        for gs in ("8", "1"):
+            env = dict(os.environ, MSH_DEC_XCD=xcd, MSH_DEC_GRAPH_STEPS=gs)
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert all(o == outs[0] for o in outs[1:])
