@@ -40,7 +40,7 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
-template <int D, int NWAVES, int NS>
+template <int D, int NWAVES, int NS, int XSLOTS = 0>
 struct XaCfg {
   static constexpr int NW = NWAVES;                        // waves per workgroup: tile i of the clip belongs to wave i % NW
   static constexpr int KS = D / 32;                        // k-steps of the score product
@@ -53,10 +53,24 @@ struct XaCfg {
   static constexpr int PIECES = TILE / 1024;
   static constexpr int SLOT = TILE;
   static constexpr int NSLOT = NS;
-  static constexpr int RING = NW * NSLOT * SLOT;
-  static constexpr int MST = D + 4;                        // floats per (wave, head) row of the merge area (padded: bank spread)
-  static constexpr int MERGE = NW * 8 * MST * 4 + NW * 8 * 8;  // [wave][head][MST] fp32 + [wave][head] {m, l}
-  static constexpr int LDS = RING > MERGE ? RING : MERGE;
+  // XS > 0 (with NS = 1): waves 0 .. XS - 1 own TWO slots, the others one.  The tiles of a clip rarely divide evenly (10 s:
+  // 26 tiles on 8 waves), and with one slot each the waves that hold the extra tile fetch it alone in a last, latency-bound
+  // round; with a second slot they request it while the others request their last one.
+  static constexpr int XS = XSLOTS;
+  static constexpr int RING = (NW * NSLOT + XS) * SLOT;
+  static_assert(XS == 0 || NS == 1, "extra slots go with the one-slot ring");
+  static_assert(XS <= NW, "at most one extra slot per wave");
+  // byte offset of wave w's ring (wave-uniform)
+  __host__ __device__ static constexpr int wring_off(int w) { return XS > 0 ? (w < XS ? 2 * w : w + XS) * SLOT : w * NSLOT * SLOT; }
+  // Merge area: a wave's fp32 partial context [8 heads][D] is exactly one ring slot (16 rows x 2 D bytes = 8 x D x 4), so
+  // every wave overlays ITS OWN ring with it -- no barrier between the last tile's reads and the partial's writes, and the
+  // waves that own one tile less than the others have written theirs before the last tiles land.  The heads' rows start
+  // on the same bank (D * 4 bytes = a multiple of 128), so column c of head h is kept at c ^ (h << 2): a 16-lane group of
+  // the 8-byte writes then covers 32 distinct banks, and the output pass's 16-byte reads stay aligned.
+  static constexpr int MST = D;
+  static constexpr int ML = RING;                          // [wave][head] {m, l} behind the ring
+  static constexpr int LDS = RING + NW * 8 * 8;
+  static_assert(8 * MST * 4 <= NSLOT * SLOT, "a wave's partial must fit its own ring");
   static_assert(D % 32 == 0 && TILE % 1024 == 0, "a tile must be whole KiB pieces");
   static_assert(NS >= 1 && NS <= 3, "ring depth");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -128,16 +142,16 @@ __device__ __forceinline__ void dma_piece(int vo, i32x4_t rs, int so, unsigned l
 
 // TR = true: the context product's A fragments come from ds_read_b64_tr_b16; false: four 2-byte reads per fragment (the
 // plain formulation of the same gather, kept as the check of the transposing read: MSH_XATTN_CFG=40).
-// ABL (developer ablations, tools/gpu_r4e.sh; garbage results): 1 = no DMA (the products run on whatever the LDS holds),
+// ABL (developer ablations, tools/gpu_r4r.sh; garbage results): 1 = no DMA (the products run on whatever the LDS holds),
 // 2 = no products / softmax (the tiles are only fetched and waited for), 4 = no merge / output, 8 = no output pass,
-// 16 = no merge writes, 32 / 64 = one k-step / one row tile per group of the score / context product.
-template <int D, bool TR, int NWAVES, int NS, int ABL = 0>
+// 16 = no merge writes, 32 / 64 = one k-step / one row tile per group of the score / context product, 128 = time stamps.
+template <int D, bool TR, int NWAVES, int NS, int ABL = 0, int XS = 0>
 __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(const bf16_t* __restrict__ qf,     // [M][D / 32][16][32]
                                                                           const bf16_t* __restrict__ enc,    // [R][D]
-                                                                          const ClipMeta* __restrict__ clips,
+                                                                          const ClipMeta* __restrict__ clips, int M, int xcd_group,
                                                                           bf16_t* __restrict__ ctx,         // FM [M16][8 * D]
                                                                           unsigned long long* __restrict__ dbg) {
-  using C = XaCfg<D, NWAVES, NS>;
+  using C = XaCfg<D, NWAVES, NS, XS>;
   // ABL & 128: wave time stamps (s_memtime, shader clock) into dbg[(block * NW + wave) * 16 + point]
 #define MSH_XA_TL(i)                                                                                              \
   do {                                                                                                            \
@@ -149,7 +163,16 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x;
+  // Block -> clip.  xcd_group: the 16 clips of an output row tile (16 consecutive rows of the fragment-major context, whose
+  // 128-byte lines interleave 16-byte pieces of all 16 rows) run on ONE XCD (workgroup i runs on XCD i % 8: observed
+  // placement, used for speed only), so the pieces meet in that XCD's L2 and leave it as whole lines; in plain order the
+  // 16 writers of a line sit on 8 XCDs and every L2 writes back its own masked copy of every line at the kernel's end.
+  int b = blockIdx.x;
+  if (xcd_group != 0) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    b = ((x + 8 * (i >> 4)) << 4) + (i & 15);
+    if (b >= M) return;
+  }
   const ClipMeta cm = clips[b];
   const int T = cm.T;
   const int n_tiles = (T + 15) >> 4;
@@ -162,7 +185,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
     rs[2] = __builtin_amdgcn_readfirstlane(T * D * 2);
     rs[3] = 0x00020000;
   }
-  const unsigned ring = lds_offset_of(smem) + (unsigned)wave * (C::NSLOT * C::SLOT);   // this wave's slots
+  const int wring = __builtin_amdgcn_readfirstlane(C::wring_off(wave));
+  const unsigned ring = lds_offset_of(smem) + (unsigned)wring;   // this wave's slots
+  const int nslot = XS > 0 ? (wave < XS ? 2 : 1) : C::NSLOT;      // wave-uniform
   const int lane16 = lane * 16;
   auto issue_tile = [&](int tile, int slot) {
     if constexpr ((ABL & 1) != 0) return;
@@ -184,8 +209,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
   };
   // the first NSLOT tiles of this wave go out before anything else
 #pragma unroll
-  for (int sl = 0; sl < C::NSLOT; ++sl)
-    if (wave + NW * sl < n_tiles) issue_tile(wave + NW * sl, sl);
+  for (int sl = 0; sl < (XS > 0 ? 2 : C::NSLOT); ++sl)
+    if (sl < nslot && wave + NW * sl < n_tiles) issue_tile(wave + NW * sl, sl);
 
   // B operand of the score product: column li = head (li & 7), value (li < 8) or rounding residual (li >= 8) of the head's
   // keys-side query, k = kg * 8 .. + 8 -- already in that order in memory (EpiQtFrag): one contiguous KiB per wave load
@@ -209,6 +234,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
   for (int tile = wave; tile < n_tiles; tile += NW) {
     // tiles of this wave still in flight BEHIND this one: up to NSLOT - 1
     if constexpr ((ABL & 1) != 0) {
+    } else if constexpr (XS > 0) {
+      if (nslot == 2 && tile + NW < n_tiles) wait_vmcnt<C::PIECES>();
+      else wait_vmcnt<0>();
     } else if constexpr (C::NSLOT == 1) {
       wait_vmcnt<0>();
     } else if constexpr (C::NSLOT == 2) {
@@ -220,10 +248,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
       else wait_vmcnt<0>();
     }
     if (tile == wave) MSH_XA_TL(2);   // first tile landed
-    const char* sbase = smem + (size_t)wave * (C::NSLOT * C::SLOT) + (size_t)slot * C::SLOT;
+    const char* sbase = smem + wring + (size_t)slot * C::SLOT;
     if constexpr ((ABL & 2) != 0) {
-      if (tile + NW * C::NSLOT < n_tiles) issue_tile(tile + NW * C::NSLOT, slot);
-      slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+      if (tile + NW * nslot < n_tiles) issue_tile(tile + NW * nslot, slot);
+      slot = slot + 1 == nslot ? 0 : slot + 1;
       continue;
     }
 
@@ -331,13 +359,13 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
       acc[G0 + G1 + G2 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a3[i], pfrag, acc[G0 + G1 + G2 + i], 0, 0, 0);
     if (tile == wave) MSH_XA_TL(5);   // context MFMAs issued
     // the slot is free once every read of it has returned: fetch the tile NSLOT rounds ahead into it
-    if (tile + NW * C::NSLOT < n_tiles) {
+    if (tile + NW * nslot < n_tiles) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue_tile(tile + NW * C::NSLOT, slot);
+      issue_tile(tile + NW * nslot, slot);
     }
     if (tile == wave) MSH_XA_TL(6);   // next tile requested
     if (tile == wave + NW) MSH_XA_TL(7);   // second tile of the wave finished
-    slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+    slot = slot + 1 == nslot ? 0 : slot + 1;
   }
 
   if constexpr ((ABL & 4) != 0) {
@@ -350,25 +378,31 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
   // ---- merge the waves ----
   MSH_XA_TL(8);    // loop done
   const float l_wave = xa_rows_sum(l_part);   // all four key groups of the column
-  __syncthreads();                             // every wave is done with its ring: the merge area overlays it
-  float* mc = reinterpret_cast<float*>(smem);                               // [wave][head][MST]
-  float2* ml = reinterpret_cast<float2*>(smem + NW * 8 * C::MST * 4);       // [wave][head]
+  // (the wave's own LDS operations run in order: its last tile's reads are ahead of these writes, and it has no DMA in flight)
+  float* mine = reinterpret_cast<float*>(smem + wring);   // [head][MST], column c at c ^ (head << 2)
+  float2* ml = reinterpret_cast<float2*>(smem + C::ML);                     // [wave][head]
+  {
+    const int hh = li & 7;
+    const int sw = hh << 2;
 #pragma unroll
-  for (int dt = 0; dt < C::DT; ++dt) {
-    float4 v;
-    v.x = acc[dt][0] + dpp_ror8(acc[dt][0]);
-    v.y = acc[dt][1] + dpp_ror8(acc[dt][1]);
-    v.z = acc[dt][2] + dpp_ror8(acc[dt][2]);
-    v.w = acc[dt][3] + dpp_ror8(acc[dt][3]);
-    if constexpr ((ABL & 16) == 0)
-      if (li < 8) *reinterpret_cast<float4*>(mc + ((size_t)(wave * 8 + li) * C::MST + dt * 16 + kg * 4)) = v;
-    if constexpr ((ABL & 16) != 0)
-      if (v.x == 12345.f) ctx[0] = 1;
+    for (int dt = 0; dt < C::DT; ++dt) {
+      // high-half column + low-half column of the head: both lanes (li, li ^ 8) then hold the four sums, the lower lane
+      // stores the first two, the upper one the last two
+      const float v0 = acc[dt][0] + dpp_ror8(acc[dt][0]);
+      const float v1 = acc[dt][1] + dpp_ror8(acc[dt][1]);
+      const float v2 = acc[dt][2] + dpp_ror8(acc[dt][2]);
+      const float v3 = acc[dt][3] + dpp_ror8(acc[dt][3]);
+      const float2 w2 = li < 8 ? make_float2(v0, v1) : make_float2(v2, v3);
+      const int c = dt * 16 + kg * 4 + (li < 8 ? 0 : 2);
+      if constexpr ((ABL & 16) == 0) *reinterpret_cast<float2*>(mine + hh * C::MST + (c ^ sw)) = w2;
+      if constexpr ((ABL & 16) != 0)
+        if (w2.x == 12345.f) ctx[0] = 1;
+    }
   }
-  MSH_XA_TL(9);    // first barrier passed, partials written
   if (lane < 8) ml[wave * 8 + lane] = make_float2(m_run, l_wave);
+  MSH_XA_TL(9);    // partials written
   __syncthreads();
-  MSH_XA_TL(10);   // second barrier passed
+  MSH_XA_TL(10);   // barrier passed
   constexpr int CHUNKS = 8 * D / 8;   // 16-byte output chunks of the clip's row
   if constexpr ((ABL & 8) != 0) return;
   for (int ch = threadIdx.x; ch < CHUNKS; ch += 64 * NW) {
@@ -391,10 +425,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const int sw = h << 2;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float4 c0 = *reinterpret_cast<const float4*>(mc + (size_t)(w * 8 + h) * C::MST + d0);
-      const float4 c1 = *reinterpret_cast<const float4*>(mc + (size_t)(w * 8 + h) * C::MST + d0 + 4);
+      const float* row = reinterpret_cast<const float*>(smem + C::wring_off(w)) + h * C::MST;
+      const float4 c0 = *reinterpret_cast<const float4*>(row + (d0 ^ sw));
+      const float4 c1 = *reinterpret_cast<const float4*>(row + ((d0 + 4) ^ sw));
       o[0] += f[w] * c0.x; o[1] += f[w] * c0.y; o[2] += f[w] * c0.z; o[3] += f[w] * c0.w;
       o[4] += f[w] * c1.x; o[5] += f[w] * c1.y; o[6] += f[w] * c1.z; o[7] += f[w] * c1.w;
     }
@@ -409,30 +445,38 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
 #undef MSH_XA_TL
 }
 
-// Shape of the workgroup (developer knob MSH_XATTN_CFG = <waves><slots>): 81 = eight waves with one ring slot each (default:
-// a wave that sits in the back-pressure of its own DMA issue does not keep the CU from computing -- seven others are there --
-// and 106 KiB of LDS leave room for another kernel's workgroup on the CU), 43 / 42 = four waves with three / two slots each;
-// 40 = 42 with the context product's fragments gathered by 2-byte reads instead of ds_read_b64_tr_b16 (the check of that read).
+// Shape of the workgroup (developer knob MSH_XATTN_CFG): 84 = eight waves, one ring slot each plus a second one for waves
+// 0-3 (default; 156 KiB of LDS -- the kernel's 246 registers per lane keep other kernels off its CUs anyway); 81 = eight
+// waves with one slot each (a wave that sits in the back-pressure of its own DMA issue does not keep the CU from
+// computing: seven others are there); 43 / 42 = four waves with three / two slots each; 40 = 42 with the context product's
+// fragments gathered by 2-byte reads instead of ds_read_b64_tr_b16 (the check of that read).
 int xattn_cfg() {
   static const int v = [] {
     const char* e = getenv("MSH_XATTN_CFG");
-    const int c = e != nullptr ? atoi(e) : 81;
-    return c == 43 || c == 42 || c == 40 ? c : 81;
+    const int c = e != nullptr ? atoi(e) : 84;
+    return c == 81 || c == 43 || c == 42 || c == 40 ? c : 84;
   }();
   return v;
 }
 
-template <int D, bool TR, int NWAVES, int NS, int ABL = 0>
+template <int D, bool TR, int NWAVES, int NS, int ABL = 0, int XS = 0>
 void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s,
                          unsigned long long* dbg = nullptr) {
-  using C = XaCfg<D, NWAVES, NS>;
+  using C = XaCfg<D, NWAVES, NS, XS>;
   static const bool attr = [] {
-    MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL>),
+    MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL, XS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     return true;
   }();
   (void)attr;
-  MSH_LAUNCH((dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL>), dim3(M), dim3(64 * NWAVES), C::LDS, s, qt, enc, clips, ctx, dbg);
+  // MSH_XATTN_XCD=0: plain block -> clip order (developer knob; see "Block -> clip" in the kernel)
+  static const bool group = [] {
+    const char* e = getenv("MSH_XATTN_XCD");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  const unsigned grid = group ? 128u * (unsigned)(((M + 15) / 16 + 7) / 8) : (unsigned)M;
+  MSH_LAUNCH((dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL, XS>), dim3(grid), dim3(64 * NWAVES), C::LDS, s, qt, enc, clips, M,
+             group ? 1 : 0, ctx, dbg);
 }
 template <int D>
 void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s) {
@@ -442,19 +486,11 @@ void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips,
   }();
   if constexpr (D == 416) {
     switch (abl) {
-      case 1: return launch_absorbed_cfg<D, true, 8, 1, 1>(qt, enc, clips, M, ctx, s);
-      case 2: return launch_absorbed_cfg<D, true, 8, 1, 2>(qt, enc, clips, M, ctx, s);
-      case 4: return launch_absorbed_cfg<D, true, 8, 1, 4>(qt, enc, clips, M, ctx, s);
-      case 6: return launch_absorbed_cfg<D, true, 8, 1, 6>(qt, enc, clips, M, ctx, s);
-      case 3: return launch_absorbed_cfg<D, true, 8, 1, 3>(qt, enc, clips, M, ctx, s);
-      case 7: return launch_absorbed_cfg<D, true, 8, 1, 7>(qt, enc, clips, M, ctx, s);
-      case 10: return launch_absorbed_cfg<D, true, 8, 1, 10>(qt, enc, clips, M, ctx, s);
-      case 26: return launch_absorbed_cfg<D, true, 8, 1, 26>(qt, enc, clips, M, ctx, s);
-      case 11: return launch_absorbed_cfg<D, true, 8, 1, 11>(qt, enc, clips, M, ctx, s);
-      case 27: return launch_absorbed_cfg<D, true, 8, 1, 27>(qt, enc, clips, M, ctx, s);
-      case 33: return launch_absorbed_cfg<D, true, 8, 1, 33>(qt, enc, clips, M, ctx, s);
-      case 65: return launch_absorbed_cfg<D, true, 8, 1, 65>(qt, enc, clips, M, ctx, s);
-      case 97: return launch_absorbed_cfg<D, true, 8, 1, 97>(qt, enc, clips, M, ctx, s);
+      case 1: return launch_absorbed_cfg<D, true, 8, 1, 1, 4>(qt, enc, clips, M, ctx, s);
+      case 2: return launch_absorbed_cfg<D, true, 8, 1, 2, 4>(qt, enc, clips, M, ctx, s);
+      case 4: return launch_absorbed_cfg<D, true, 8, 1, 4, 4>(qt, enc, clips, M, ctx, s);
+      case 6: return launch_absorbed_cfg<D, true, 8, 1, 6, 4>(qt, enc, clips, M, ctx, s);
+      case 10: return launch_absorbed_cfg<D, true, 8, 1, 10, 4>(qt, enc, clips, M, ctx, s);
       default: break;
     }
   }
@@ -462,7 +498,8 @@ void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips,
     case 43: return launch_absorbed_cfg<D, true, 4, 3>(qt, enc, clips, M, ctx, s);
     case 42: return launch_absorbed_cfg<D, true, 4, 2>(qt, enc, clips, M, ctx, s);
     case 40: return launch_absorbed_cfg<D, false, 4, 2>(qt, enc, clips, M, ctx, s);
-    default: return launch_absorbed_cfg<D, true, 8, 1>(qt, enc, clips, M, ctx, s);
+    case 81: return launch_absorbed_cfg<D, true, 8, 1>(qt, enc, clips, M, ctx, s);
+    default: return launch_absorbed_cfg<D, true, 8, 1, 0, 4>(qt, enc, clips, M, ctx, s);
   }
 }
 
@@ -532,30 +569,40 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
   }
   if (const char* tl = getenv("MSH_XATTN_TIMELINE"); tl != nullptr && tl[0] == '1' && D == 416) {
     // developer: per-wave s_memtime stamps of the default shape (tools/xattn_microbench.py prints nothing else for it)
-    const size_t n = (size_t)M * 8 * 16;
+    const size_t nb = 128u * (size_t)(((M + 15) / 16 + 7) / 8) + (size_t)M;   // blocks of either block -> clip order
+    const size_t n = nb * 8 * 16;
     unsigned long long* dd = nullptr;
     MSH_HIP(hipMalloc(&dd, n * 8));
     MSH_HIP(hipMemset(dd, 0, n * 8));
-    for (int rep = 0; rep < 3; ++rep) launch_absorbed_cfg<416, true, 8, 1, 128>(dq, de, dm, M, dc, 0, dd);
+    launch_absorbed_cfg<416, true, 8, 1, 128, 4>(dq, de, dm, M, dc, 0, dd);   // warm (code object, caches)
+    MSH_HIP(hipDeviceSynchronize());
+    MSH_HIP(hipMemset(dd, 0, n * 8));
+    launch_absorbed_cfg<416, true, 8, 1, 128, 4>(dq, de, dm, M, dc, 0, dd);
     MSH_HIP(hipDeviceSynchronize());
     std::vector<unsigned long long> h(n);
     MSH_HIP(hipMemcpy(h.data(), dd, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(dd);
-    unsigned long long t0 = ~0ull, t1 = 0;
-    for (size_t w = 0; w < (size_t)M * 8; ++w) {
-      t0 = std::min(t0, h[w * 16]);
-      t1 = std::max(t1, h[w * 16 + 11]);
-    }
+    // the shader clocks of different XCDs have different origins: every workgroup's stamps are taken relative to the
+    // earliest start among its own waves
     static const char* names[12] = {"start", "qfrag", "tile0 landed", "scores issued", "softmax", "context issued", "next dma issued",
-                                    "2nd tile done", "loop done", "barrier1+writes", "barrier2", "stores issued"};
-    fprintf(stderr, "[xattn timeline] %d clips: first start -> last end %llu cycles\n", M, t1 - t0);
+                                    "2nd tile done", "loop done", "partials written", "barrier", "stores issued"};
+    std::vector<std::vector<unsigned long long>> pts(12);
+    for (size_t blk = 0; blk < nb; ++blk) {
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < 8; ++w)
+        if (h[(blk * 8 + w) * 16] != 0) t0 = std::min(t0, h[(blk * 8 + w) * 16]);
+      if (t0 == ~0ull) continue;
+      for (int w = 0; w < 8; ++w)
+        for (int i = 0; i < 12; ++i)
+          if (h[(blk * 8 + w) * 16 + i] != 0) pts[i].push_back(h[(blk * 8 + w) * 16 + i] - t0);
+    }
+    fprintf(stderr, "[xattn timeline] %d clips, shader cycles since the workgroup's first wave started\n", M);
     for (int i = 0; i < 12; ++i) {
-      std::vector<unsigned long long> v;
-      for (size_t w = 0; w < (size_t)M * 8; ++w)
-        if (h[w * 16 + i] != 0) v.push_back(h[w * 16 + i] - t0);
+      std::vector<unsigned long long>& v = pts[i];
       if (v.empty()) continue;
       std::sort(v.begin(), v.end());
-      fprintf(stderr, "  %-18s min %7llu  p50 %7llu  max %7llu  (%zu waves)\n", names[i], v.front(), v[v.size() / 2], v.back(), v.size());
+      fprintf(stderr, "  %-18s min %7llu  p10 %7llu  p50 %7llu  p90 %7llu  max %7llu  (%zu waves)\n", names[i], v.front(), v[v.size() / 10],
+              v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
     }
   }
   std::vector<bf16_t> c16((size_t)M16 * 8 * D);
