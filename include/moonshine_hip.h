@@ -217,6 +217,13 @@ MSH_EXPORT int32_t msh_cross_absorbed(const msh_engine* e);
 MSH_EXPORT float msh_test_cross_absorbed(const float* qt, const float* enc, int64_t R, const int32_t* Ts,
                                          const int32_t* row_starts, int32_t M, int32_t D, float* ctx_out, int32_t iters);
 
+/* Test / developer hook: the two-stage query kernel of the absorbed form alone (k_crossq.hip).  x [M][D] fp32 (residual
+ * stream rows), wq [D][D] = the scaled, LayerNorm-folded query projection with rows (head, j), wk [D][D] the key projection
+ * with rows (head, j); qt_out [M][8 * D] fp32 receives qt_h = Wk_h^T (wq_h LN(x)) per head (value + rounding residual of the
+ * kernel's split-bf16 output).  D = 416 or 288.  Returns ms per launch over `iters` launches (0 = one untimed launch), < 0 on error. */
+MSH_EXPORT float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out,
+                                  int32_t iters);
+
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

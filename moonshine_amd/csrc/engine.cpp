@@ -35,6 +35,16 @@ UtilStreams& util_streams() {
 }
 }  // namespace
 
+// developer knob MSH_XATTN_QT=1 (at load AND at run time): the keys-side queries of the absorbed cross-attention from the
+// merged weight Wqk (one wide decode GEMM) instead of the two-stage kernel (k_crossq.hip)
+int xattn_qt_mode() {   // 0 = two-stage kernel, 1 = merged weight, 2 = two-stage kernel with the merged weight uploaded as well (probe)
+  static const int v = [] {
+    const char* e = getenv("MSH_XATTN_QT");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  return v;
+}
+bool xattn_merged_qt() { return xattn_qt_mode() == 1; }
 // smallest batch that decodes with the absorbed cross-attention when the mode is automatic (Engine::set_cross_mode)
 int xattn_min_batch() {
   static const int v = [] {
@@ -280,14 +290,38 @@ void Engine::synchronize() {
   MSH_HIP(hipStreamSynchronize(stream_));
 }
 
+// Weights come out of a few large slabs instead of one hipMalloc each: ~150 tensors of 1.6 KB .. 2.8 MB would otherwise be ~150
+// separate mappings of odd sizes, and where they land decides how large the page-table fragments behind them are.  (The
+// decode step walks ~100 MB of weights next to ~300 MB of caches; round 3 and round 4 both saw the SAME binaries run 15-25 %
+// slower in some processes than in others)  256-byte aligned like hipMalloc's results.  MSH_WEIGHT_ARENA=0
+// or the guard allocator (every buffer its own mapping, that is its point): one allocation per tensor as before.
+void* Engine::weight_alloc(size_t bytes) {
+  static const bool arena = [] {
+    const char* e = getenv("MSH_WEIGHT_ARENA");
+    return !(e != nullptr && e[0] == '0') && !guard_alloc_enabled();
+  }();
+  constexpr size_t kSlab = (size_t)64 << 20;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+  if (!arena || bytes > kSlab / 2) {
+    void* p = device_alloc(bytes);
+    weight_allocs_.push_back(p);
+    return p;
+  }
+  if (slab_ == nullptr || slab_used_ + bytes > kSlab) {
+    slab_ = static_cast<char*>(device_alloc(kSlab));
+    weight_allocs_.push_back(slab_);
+    slab_used_ = 0;
+  }
+  void* p = slab_ + slab_used_;
+  slab_used_ += bytes;
+  return p;
+}
+
 void Engine::upload(const std::vector<float>& src, float** dst) {
   if (dry_run_) return;
-  void* p = nullptr;
-  {
-    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    p = device_alloc(src.size() * sizeof(float));
-  }
-  weight_allocs_.push_back(p);
+  void* p = weight_alloc(src.size() * sizeof(float));
   copy_blocking(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<float*>(p);
 }
@@ -296,12 +330,7 @@ void Engine::upload_bf16(const std::vector<float>& src, bf16_t** dst) {
   if (dry_run_) return;
   std::vector<bf16_t> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
-  void* p = nullptr;
-  {
-    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    p = device_alloc(tmp.size() * sizeof(bf16_t));
-  }
-  weight_allocs_.push_back(p);
+  void* p = weight_alloc(tmp.size() * sizeof(bf16_t));
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
 }
@@ -316,12 +345,7 @@ void Engine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16
   const int ks = K >> 5;
   for (int r = 0; r < rows; ++r)
     for (int k = 0; k < K; ++k) tmp[(size_t)fm16(r, k, ks)] = f32_to_bf16(src[(size_t)r * K + k]);
-  void* p = nullptr;
-  {
-    std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-    p = device_alloc(tmp.size() * sizeof(bf16_t));
-  }
-  weight_allocs_.push_back(p);
+  void* p = weight_alloc(tmp.size() * sizeof(bf16_t));
   copy_blocking(p, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
   *dst = reinterpret_cast<bf16_t*>(p);
 }
@@ -455,12 +479,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
         const std::vector<float> gam = vec(p + "input_layernorm.weight", D);
         std::vector<bf16_t> packed(panel_packed_elems(3 * D, D));
         pack_panel_weights(qkv.data(), gam.data(), 3 * D, D, packed.data());
-        void* dp = nullptr;
-        {
-          std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-          dp = device_alloc(packed.size() * sizeof(bf16_t));
-        }
-        weight_allocs_.push_back(dp);
+        void* dp = weight_alloc(packed.size() * sizeof(bf16_t));
         copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
         L.qkv_panel = reinterpret_cast<bf16_t*>(dp);
       }
@@ -481,12 +500,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       const std::vector<float> wo = fuse({p + "self_attn.o_proj.weight"});
       std::vector<bf16_t> packed(mlp_packed_elems(D, F, true));
       pack_mlp_weights(w1.data(), g.data(), b1.data(), w2.data(), D, F, packed.data(), wo.data());
-      void* dp = nullptr;
-      {
-        std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-        dp = device_alloc(packed.size() * sizeof(bf16_t));
-      }
-      weight_allocs_.push_back(dp);
+      void* dp = weight_alloc(packed.size() * sizeof(bf16_t));
       copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
       L.mlp = reinterpret_cast<bf16_t*>(dp);
     }
@@ -561,8 +575,20 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
           }
         }
       });
-      upload_bf16_fm(wqk, Hn * D, D, &L.wqk);
+      if (!crossq2_supported(D, Hn) || xattn_qt_mode() != 0) upload_bf16_fm(wqk, Hn * D, D, &L.wqk);
       upload_bf16_fm(wvo, D, Hn * D, &L.wvo);
+      if (crossq2_supported(D, Hn)) {   // the factors of wqk, kept apart (k_crossq.hip)
+        std::vector<float> w1((size_t)Hn * 64 * D, 0.f);
+        for (int h = 0; h < Hn; ++h)
+          for (int j = 0; j < dh; ++j)
+            for (int k = 0; k < D; ++k) w1[((size_t)h * 64 + j) * D + k] = scale * wqf[(size_t)(h * dh + j) * D + k];
+        upload_bf16_fm(w1, Hn * 64, D, &L.wq1);
+        std::vector<bf16_t> w2((size_t)Hn * (D / 16) * 2 * 64 * 8);
+        pack_crossq_wk(Wk, D, Hn, w2.data());
+        void* dp = weight_alloc(w2.size() * sizeof(bf16_t));
+        copy_blocking(dp, w2.data(), w2.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
+        L.wk2 = reinterpret_cast<bf16_t*>(dp);
+      }
     }
     expect_shape(p + "mlp.fc1.weight", {2 * F, D});
     expect_shape(p + "mlp.fc2.weight", {D, F});
@@ -597,12 +623,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     const int Lc = c.dec_layers;
     std::vector<bf16_t> packed(panel_packed_elems(Lc * 2 * D, D));
     pack_panel_weights(cross.data(), nullptr, Lc * 2 * D, D, packed.data());
-    void* dp = nullptr;
-    {
-      std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-      dp = device_alloc(packed.size() * sizeof(bf16_t));
-    }
-    weight_allocs_.push_back(dp);
+    void* dp = weight_alloc(packed.size() * sizeof(bf16_t));
     copy_blocking(dp, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
     cross_kv_panel_w_ = reinterpret_cast<bf16_t*>(dp);
   }
@@ -846,7 +867,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   // Cross-attention form of this batch (k_xattn.hip): absorbed = the decode steps attend over ENC_ itself and no K^T / V^T
   // is projected.  One workgroup per clip: it needs a batch that fills the chip, the classic form (8 workgroups per clip)
   // stays for small batches, for the word-timestamp capture (which reads K^T) and for fp8 keys.
-  absorbed_ = !dec_.empty() && dec_[0].wqk != nullptr && !capture_cross_ && !kv_fp8_ &&
+  absorbed_ = !dec_.empty() && dec_[0].wvo != nullptr && !capture_cross_ && !kv_fp8_ &&
               (cross_mode_ == 2 || (cross_mode_ == 0 && (int)count >= xattn_min_batch()));
   if (!absorbed_) {
     moved |= KT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
@@ -1173,7 +1194,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
   for (int b = 0; b < M; ++b) sT += clips_h_[g.first + b].T;
   const double w_dd = 2.0 * D * D;  // bytes of a [D, D] bf16 weight
   // chain profiling (profile_decode_chain): enqueue only the kernel group `step_only_`
-  auto on = [&](int id) { return step_only_ < 0 || step_only_ == id; };
+  auto on = [&](int id) { return step_mask_ != 0 ? ((step_mask_ >> id) & 1u) != 0 : (step_only_ < 0 || step_only_ == id); };
   for (int l = 0; l < cfg_.dec_layers; ++l) {
     const DecLayerW& W = dec_[l];
     bf16_t* cK = g.cacheK.as<bf16_t>() + l * cache_layer;
@@ -1202,7 +1223,8 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       // attention of all heads, then h += ctx Wvo^T
       if (on(3)) {
         ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * 4.0 * (1 + Hh));
-        dec_gemm_ln_qt(dH, W.wqk, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
+        if (W.wq1 != nullptr && !xattn_merged_qt()) dec_crossq2(dH, W.wq1, W.wk2, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
+        else dec_gemm_ln_qt(dH, W.wqk, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
       }
       if (on(4)) {
         // both products on all 16 MFMA columns (high / low halves of 8 heads); bytes: E once, qt in, ctx out
@@ -1333,6 +1355,53 @@ void Engine::profile_decode_chain(int reps) {
       prof_[it->second].launches += 2ull * launches;
     }
     MSH_HIP(hipGraphExecDestroy(ge));
+  }
+  // Developer: MSH_CHAIN_MASKS = comma-separated bit masks of kernel groups (bit i = group i of `names`, per layer): each
+  // mask is timed as its own replayed chain ("chainmask_<mask>", ms per decode STEP in `ms / launches * groups-in-mask * 8`
+  // terms: launches counts the graph's nodes) -- what a SEQUENCE of different kernels costs, against the sum of its members.
+  if (const char* masks = getenv("MSH_CHAIN_MASKS")) {
+    std::string list(masks);
+    size_t pos = 0;
+    while (pos < list.size()) {
+      const size_t comma = list.find(',', pos);
+      const std::string tok = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+      pos = comma == std::string::npos ? list.size() : comma + 1;
+      const unsigned mask = (unsigned)strtoul(tok.c_str(), nullptr, 0) & 0xffu;
+      if (mask == 0) continue;
+      hipGraph_t gr = nullptr;
+      hipGraphExec_t ge = nullptr;
+      size_t n_nodes = 0;
+      {
+        std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
+        MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        step_mask_ = mask;
+        for (int r = 0; r < reps; ++r) decode_step_enqueue(g);
+        step_mask_ = 0;
+        MSH_HIP(hipStreamEndCapture(g.stream, &gr));
+        MSH_HIP(hipGraphGetNodes(gr, nullptr, &n_nodes));
+        MSH_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        MSH_HIP(hipGraphDestroy(gr));
+      }
+      if (n_nodes > 0) {
+        MSH_HIP(hipGraphLaunch(ge, g.stream));
+        MSH_HIP(hipEventRecord(a, g.stream));
+        MSH_HIP(hipGraphLaunch(ge, g.stream));
+        MSH_HIP(hipGraphLaunch(ge, g.stream));
+        MSH_HIP(hipEventRecord(b, g.stream));
+        MSH_HIP(hipStreamSynchronize(g.stream));
+        float ms = 0.f;
+        MSH_HIP(hipEventElapsedTime(&ms, a, b));
+        const std::string name = "chainmask_" + tok;
+        if (prof_idx_.find(name) == prof_idx_.end()) {
+          prof_idx_[name] = (int)prof_.size();
+          prof_.push_back(ProfEntry{name, 0, 0, 0, 0});
+        }
+        ProfEntry& pe = prof_[prof_idx_[name]];
+        pe.ms += ms;
+        pe.launches += 2ull * n_nodes;
+      }
+      MSH_HIP(hipGraphExecDestroy(ge));
+    }
   }
   event_pool_.push_back(a);
   event_pool_.push_back(b);

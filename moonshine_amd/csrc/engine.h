@@ -51,6 +51,9 @@ struct DecLayerW {
   //   wqk [heads * D][D]  rows (h, d) = softmax scale * sum_j Wk[h j][d] * (Wq[h j][:] * gamma)   (query side, LayerNorm fused)
   //   wvo [D][heads * D]  columns (h, d) = sum_j Wo[:][h j] * Wv[h j][d]                          (output side, residual update)
   bf16_t *wqk = nullptr, *wvo = nullptr;
+  // the two factors of wqk for the two-stage query kernel (k_crossq.hip): scale * Wq * diag(gamma) as FM [heads * 64][D]
+  // and Wk in pack_crossq_wk's order; wqk itself is then only uploaded on request (MSH_XATTN_QT=1, the merged-weight GEMM)
+  bf16_t *wq1 = nullptr, *wk2 = nullptr;
 };
 
 class Engine {
@@ -143,6 +146,7 @@ class Engine {
   void plan_batch(const uint64_t* n_samples, uint32_t count, float max_tokens_per_second);
   void run_encoder();
   void decode_step_enqueue(DecodeGroup& g);
+  void* weight_alloc(size_t bytes);
   void upload(const std::vector<float>& src, float** dst);
   void upload_bf16(const std::vector<float>& src, bf16_t** dst);
   void upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16_t** dst);
@@ -156,6 +160,8 @@ class Engine {
   ModelConfig cfg_;
   bool loaded_ = false;
   std::vector<void*> weight_allocs_;
+  char* slab_ = nullptr;      // weight_alloc: the slab being filled
+  size_t slab_used_ = 0;
 
   // weights
   bf16_t *conv1_w_ = nullptr, *conv2_w_ = nullptr, *conv3_w_ = nullptr;
@@ -207,6 +213,7 @@ class Engine {
   // profiling
   bool prof_on_ = false;
   int step_only_ = -1;  // decode_step_enqueue: enqueue only this kernel group (profile_decode_chain)
+  unsigned step_mask_ = 0;  // != 0: enqueue the kernel groups whose bit is set (profile_decode_chain, MSH_CHAIN_MASKS)
   struct ProfRec {
     int idx;
     hipEvent_t a, b;

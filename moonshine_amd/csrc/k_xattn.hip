@@ -79,6 +79,13 @@ struct XaCfg {
 __device__ __forceinline__ float dpp_ror8(float v) {   // value of lane (l ^ 8) within every row of 16 lanes
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
 }
+// x + (x of lane ^ 8) in one VALU operation (the compiler keeps a v_mov_b32_dpp and a v_add_f32 apart once a select sits
+// between them)
+__device__ __forceinline__ float add_ror8(float v) {
+  float r;
+  asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+  return r;
+}
 // reductions across the four 16-lane rows of a wave (lane ^ 16, lane ^ 32): v_permlane{16,32}_swap, pure VALU
 __device__ __forceinline__ float xa_rows_max(float v) {
   const unsigned u = __float_as_uint(v);
@@ -388,10 +395,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
     for (int dt = 0; dt < C::DT; ++dt) {
       // high-half column + low-half column of the head: both lanes (li, li ^ 8) then hold the four sums, the lower lane
       // stores the first two, the upper one the last two
-      const float v0 = acc[dt][0] + dpp_ror8(acc[dt][0]);
-      const float v1 = acc[dt][1] + dpp_ror8(acc[dt][1]);
-      const float v2 = acc[dt][2] + dpp_ror8(acc[dt][2]);
-      const float v3 = acc[dt][3] + dpp_ror8(acc[dt][3]);
+      const float v0 = add_ror8(acc[dt][0]);
+      const float v1 = add_ror8(acc[dt][1]);
+      const float v2 = add_ror8(acc[dt][2]);
+      const float v3 = add_ror8(acc[dt][3]);
       const float2 w2 = li < 8 ? make_float2(v0, v1) : make_float2(v2, v3);
       const int c = dt * 16 + kg * 4 + (li < 8 ? 0 : 2);
       if constexpr ((ABL & 16) == 0) *reinterpret_cast<float2*>(mine + hh * C::MST + (c ^ sw)) = w2;

@@ -188,6 +188,12 @@ void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, con
 // of dec_gemm_resid with the merged weight Wvo (K = heads * D).  heads == 8, D in {416, 288}.
 bool cross_absorbed_supported(int D, int heads);
 void dec_gemm_ln_qt(const float* H, const bf16_t* W, int M, int heads, int D, bf16_t* qf, hipStream_t s);
+// The same queries from the two factors of Wqk (k_crossq.hip): W1 = scale * Wq * diag(gamma) as FM [heads * 64][D] (a head's
+// rows padded to 64 with zeros), W2 = Wk in the order pack_crossq_wk writes; same output order.
+bool crossq2_supported(int D, int heads);
+void pack_crossq_wk(const float* Wk, int D, int heads, bf16_t* out);   // out: heads * (D / 16) * 1024 elements
+void dec_crossq2(const float* H, const bf16_t* W1, const bf16_t* W2, int M, int heads, int D, bf16_t* qf, hipStream_t s);
+float crossq2_host(const float* x, const float* wq, const float* wk, int M, int D, float* qt_out, int iters);
 void dec_cross_absorbed(const bf16_t* qf, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
                         hipStream_t s);
 float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const int* Ts, const int* row_starts, int M, int D,

@@ -388,6 +388,15 @@ int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const 
   }
 }
 
+float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out, int32_t iters) {
+  try {
+    return msh::crossq2_host(x, wq, wk, M, D, qt_out, iters);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "crossq2: %s\n", ex.what());
+    return -1.0f;
+  }
+}
+
 float msh_test_cross_absorbed(const float* qt, const float* enc, int64_t R, const int32_t* Ts, const int32_t* row_starts,
                               int32_t M, int32_t D, float* ctx_out, int32_t iters) {
   try {

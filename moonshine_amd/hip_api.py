@@ -70,6 +70,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_set_cross_mode": (i32, [vp, i32]),
         "msh_cross_absorbed": (i32, [vp]),
         "msh_test_cross_absorbed": (C.c_float, [vp, vp, C.c_int64, vp, vp, i32, i32, vp, i32]),
+        "msh_test_crossq2": (C.c_float, [vp, vp, vp, i32, i32, vp, i32]),
         "msh_profile_enable": (i32, [vp, i32]),
         "msh_profile_reset": (i32, [vp]),
         "msh_profile_count": (i32, [vp]),
@@ -138,7 +139,7 @@ DECLARED_SYMBOLS = [
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
     "msh_test_mlp_microbench", "msh_test_mlp_run", "msh_test_mlp_oproj_run", "msh_test_qkv_panel",
-    "msh_set_cross_mode", "msh_cross_absorbed", "msh_test_cross_absorbed",
+    "msh_set_cross_mode", "msh_cross_absorbed", "msh_test_cross_absorbed", "msh_test_crossq2",
     "msh_stream_get_features",
 ]
 

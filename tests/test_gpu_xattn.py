@@ -119,6 +119,55 @@ def test_kernel_rate_at_the_benchmark_shape():
 
 
 # ---------------------------------------------------------------- the engine with the form forced on
+@pytest.mark.parametrize("D,M", [(416, 256), (416, 37), (288, 64), (416, 1)])
+def test_two_stage_query_kernel_vs_numpy(D, M):
+    """k_crossq.hip alone: qt_h = Wk_h^T (Wq_h' LN(x)) from the two factors, against float64 numpy on the bf16-rounded weights.
+    Rows with a large common offset and an outlier feature exercise the LayerNorm; M = 37 / 1 leave a ragged last row tile.
+    The kernel rounds LN(x) to bf16 (like every decode GEMM) and keeps q and its output as two bf16 halves: the bound is
+    that of one bf16 operand rounding over K = D."""
+    from moonshine_amd.hip_api import load_library
+
+    lib = load_library()
+    rng = np.random.default_rng(D + M)
+    dh = D // 8
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    x += rng.standard_normal((M, 1)).astype(np.float32) * 3.0   # per-row offset
+    x[:, 5] += 20.0                                              # an outlier feature
+    wq = (rng.standard_normal((D, D)) / np.sqrt(D) * (1.4427 / np.sqrt(dh))).astype(np.float32)
+    wk = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    out = np.zeros((M, 8 * D), np.float32)
+    ms = lib.msh_test_crossq2(x.ctypes.data, wq.ctypes.data, wk.ctypes.data, M, D, out.ctypes.data, 0)
+    assert ms >= 0, "kernel launch failed"
+    xd = x.astype(np.float64)
+    ln = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-5)
+    q = ln @ _bf16_round(wq).astype(np.float64).T                                  # [M][D] = (h, j)
+    wk16 = _bf16_round(wk).astype(np.float64)
+    want = np.einsum("mhj,hjd->mhd", q.reshape(M, 8, dh), wk16.reshape(8, dh, D))   # [M][8][D]
+    got = out.reshape(M, 8, D).astype(np.float64)
+    err = np.abs(got - want).max()
+    scale = np.abs(want).max()
+    assert err <= 6e-3 * scale, f"max abs err {err:.3e} against a range of {scale:.3e}"
+    # and as tight as the merged-weight form the kernel replaces: relative RMS error
+    rel = np.sqrt(((got - want) ** 2).mean() / (want ** 2).mean())
+    assert rel <= 3e-3, f"relative RMS error {rel:.3e}"
+
+
+def test_two_stage_query_kernel_rate():
+    """Informational: per-launch time of the query kernel at the benchmark shape (256 rows), back-to-back launches."""
+    from moonshine_amd.hip_api import load_library
+
+    lib = load_library()
+    D, M = 416, 256
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    wq = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    wk = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    out = np.zeros((M, 8 * D), np.float32)
+    ms = lib.msh_test_crossq2(x.ctypes.data, wq.ctypes.data, wk.ctypes.data, M, D, out.ctypes.data, 300)
+    assert ms > 0
+    print(f"\n[two-stage crossq] M = {M}: {ms * 1e3:.2f} us per launch back to back")
+
+
 def _absorbed_engine(tmp_path_factory, arch, seed=0, weights=None):
     e, w, cfg = tp._engine(tmp_path_factory, arch, seed, weights)
     e.set_cross_mode("absorbed")
