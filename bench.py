@@ -547,9 +547,13 @@ def main():
     # the figure is read from the committed summary of the last such run on this workload, not measured live.
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path) and B == 256 and args.arch == "base":
-        pmc = json.load(open(pmc_path)).get("groups", {})
+        pmc_all = json.load(open(pmc_path))
+        pmc = pmc_all.get("groups", {})
+        pmc_form = pmc_all.get("cross_attention", "kv")   # which form of the decode cross-attention the counters were taken on
         for kr in kernels:
             if kr["kernel"] in pmc:
+                if kr["kernel"] in ("dec_cross_attention", "dec_crossq_gemm", "dec_ctx_resid_gemm") and pmc_form != ("absorbed" if absorbed else "kv"):
+                    continue
                 kr["traffic"] = round(pmc[kr["kernel"]]["traffic_bytes_per_launch"], 1)
     dominant = dict(kernels[0])
     prof_total = sum(p["ms"] for p in prof)

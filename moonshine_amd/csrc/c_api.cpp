@@ -91,6 +91,14 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
       else if (t == "fp8" || t == "fp8_e4m3" || t == "e4m3") o->kv_dtype = 1;
       else throw std::runtime_error("kv_dtype must be bf16 or fp8, got '" + v + "'");
     }
+    else if (k == "cross_attention") {   // additive: auto (default) | kv | absorbed (msh_set_cross_mode)
+      std::string t = v;
+      for (char& ch : t) ch = (char)tolower((unsigned char)ch);
+      if (t == "auto") o->cross_attention = 0;
+      else if (t == "kv" || t == "projected") o->cross_attention = 1;
+      else if (t == "absorbed") o->cross_attention = 2;
+      else throw std::runtime_error("cross_attention must be auto, kv or absorbed, got '" + v + "'");
+    }
     else if (k == "batch_clips" || k == "max_batch_size") o->batch_clips = parse_int32(v);  // additive (batch calls; SURVEY 8b names it max_batch_size)
     else if (k == "num_gpus") o->num_gpus = parse_int32(v);                         // additive: shard batch calls over GPUs device .. device+n-1 (-1 = all)
     else if (k == "devices") {                                                      // additive: explicit GPU list, e.g. "0,1,2,3"

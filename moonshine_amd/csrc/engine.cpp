@@ -1222,8 +1222,11 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       // k_xattn.hip: qt = LN(h) Wqk^T (all heads' keys-side queries, D wide each), one pass over the encoder output for the
       // attention of all heads, then h += ctx Wvo^T
       if (on(3)) {
-        ProfScope p(this, "dec_crossq_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * 4.0 * (1 + Hh));
-        if (W.wq1 != nullptr && !xattn_merged_qt()) dec_crossq2(dH, W.wq1, W.wk2, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
+        const bool two_stage = W.wq1 != nullptr && !xattn_merged_qt();
+        // bytes: the weight(s) once + the residual rows in + the split-bf16 queries out; two-stage: both factors padded to 64 rows per head
+        ProfScope p(this, "dec_crossq_gemm", two_stage ? 2.0 * 2.0 * M * D * 64.0 * Hh : 2.0 * M * D * D * Hh,
+                    (two_stage ? 2.0 * Hh * 64.0 * D * 2.0 : w_dd * Hh) + M * D * 4.0 * (1 + Hh));
+        if (two_stage) dec_crossq2(dH, W.wq1, W.wk2, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
         else dec_gemm_ln_qt(dH, W.wqk, M, Hh, D, reinterpret_cast<bf16_t*>(dq), s);
       }
       if (on(4)) {

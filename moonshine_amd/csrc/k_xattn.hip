@@ -112,31 +112,32 @@ __device__ __forceinline__ float bf16_round(float x) {   // x rounded to bf16 (R
 // address is M0, both stepped by SALU adds: per piece two scalar adds and one VMEM issue, no vector arithmetic.  M0 is
 // restored inside the statement.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#define MSH_XA_P "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], 0x400\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
-#define MSH_XA_HEAD "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds\n\t"
+#define MSH_XA_P(POL) "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], 0x400\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds" POL "\n\t"
+#define MSH_XA_HEAD(POL) "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds" POL "\n\t"
 #define MSH_XA_TAIL "s_mov_b32 m0, %[keep]"
-template <int P>
-__device__ __forceinline__ void dma_tile(int vo, i32x4_t rs, int so, unsigned lds);
-template <>
-__device__ __forceinline__ void dma_tile<13>(int vo, i32x4_t rs, int so, unsigned lds) {
+#define MSH_XA_13(POL) MSH_XA_HEAD(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) \
+    MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_TAIL
+#define MSH_XA_9(POL) MSH_XA_HEAD(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) \
+    MSH_XA_P(POL) MSH_XA_TAIL
+// NT: the non-temporal cache policy on the stream (every byte of a clip is read once per launch, by one CU)
+template <int P, bool NT>
+__device__ __forceinline__ void dma_tile(int vo, i32x4_t rs, int so, unsigned lds) {
+  static_assert(P == 13 || P == 9, "pieces per tile");
   unsigned keep;
-  asm volatile(MSH_XA_HEAD MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P
-                   MSH_XA_P MSH_XA_TAIL
-               : [keep] "=&s"(keep), [so] "+s"(so)
-               : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds)
-               : "memory", "scc");
-}
-template <>
-__device__ __forceinline__ void dma_tile<9>(int vo, i32x4_t rs, int so, unsigned lds) {
-  unsigned keep;
-  asm volatile(MSH_XA_HEAD MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_P MSH_XA_TAIL
-               : [keep] "=&s"(keep), [so] "+s"(so)
-               : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds)
-               : "memory", "scc");
+  if constexpr (P == 13 && NT)
+    asm volatile(MSH_XA_13(" nt") : [keep] "=&s"(keep), [so] "+s"(so) : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds) : "memory", "scc");
+  else if constexpr (P == 13)
+    asm volatile(MSH_XA_13("") : [keep] "=&s"(keep), [so] "+s"(so) : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds) : "memory", "scc");
+  else if constexpr (NT)
+    asm volatile(MSH_XA_9(" nt") : [keep] "=&s"(keep), [so] "+s"(so) : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds) : "memory", "scc");
+  else
+    asm volatile(MSH_XA_9("") : [keep] "=&s"(keep), [so] "+s"(so) : [vo] "v"(vo), [rs] "s"(rs), [lds] "s"(lds) : "memory", "scc");
 }
 #undef MSH_XA_P
 #undef MSH_XA_HEAD
 #undef MSH_XA_TAIL
+#undef MSH_XA_13
+#undef MSH_XA_9
 // one piece with its own lane offsets (the ragged last tile of a clip)
 __device__ __forceinline__ void dma_piece(int vo, i32x4_t rs, int so, unsigned lds) {
   unsigned keep;
@@ -151,7 +152,8 @@ __device__ __forceinline__ void dma_piece(int vo, i32x4_t rs, int so, unsigned l
 // plain formulation of the same gather, kept as the check of the transposing read: MSH_XATTN_CFG=40).
 // ABL (developer ablations, tools/gpu_r4r.sh; garbage results): 1 = no DMA (the products run on whatever the LDS holds),
 // 2 = no products / softmax (the tiles are only fetched and waited for), 4 = no merge / output, 8 = no output pass,
-// 16 = no merge writes, 32 / 64 = one k-step / one row tile per group of the score / context product, 128 = time stamps.
+// 16 = no merge writes, 32 / 64 = one k-step / one row tile per group of the score / context product, 128 = time stamps, 256 = non-temporal stream
+// (correct results: a candidate, not an ablation).
 template <int D, bool TR, int NWAVES, int NS, int ABL = 0, int XS = 0>
 __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(const bf16_t* __restrict__ qf,     // [M][D / 32][16][32]
                                                                           const bf16_t* __restrict__ enc,    // [R][D]
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
     const int so = tile * C::TILE;
     const unsigned dst = ring + (unsigned)slot * C::SLOT;
     if (tile * 16 + 16 <= T) {
-      dma_tile<C::PIECES>(lane16, rs, so, dst);
+      dma_tile<C::PIECES, (ABL & 256) != 0>(lane16, rs, so, dst);
     } else {   // last tile of a clip whose frame count is not a multiple of 16: rows past the end re-read the last valid row
       const unsigned last = (unsigned)(T - 1 - tile * 16);
 #pragma unroll
@@ -498,6 +500,8 @@ void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips,
       case 4: return launch_absorbed_cfg<D, true, 8, 1, 4, 4>(qt, enc, clips, M, ctx, s);
       case 6: return launch_absorbed_cfg<D, true, 8, 1, 6, 4>(qt, enc, clips, M, ctx, s);
       case 10: return launch_absorbed_cfg<D, true, 8, 1, 10, 4>(qt, enc, clips, M, ctx, s);
+      case 256: return launch_absorbed_cfg<D, true, 8, 1, 256, 4>(qt, enc, clips, M, ctx, s);
+      case 262: return launch_absorbed_cfg<D, true, 8, 1, 262, 4>(qt, enc, clips, M, ctx, s);
       default: break;
     }
   }

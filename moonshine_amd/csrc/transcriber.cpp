@@ -397,6 +397,10 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   model_->batch_clips = opt_.batch_clips;
   model_->batches_in_flight = opt_.batches_in_flight;
   model_->word_timestamps = opt_.word_timestamps;
+  if (opt_.cross_attention != 0)
+    for (MoonshineModel::DeviceShard& d : model_->devices)
+      if (msh_set_cross_mode(d.engine, opt_.cross_attention) != MSH_OK)
+        throw std::runtime_error(std::string("cross_attention: ") + msh_last_error(d.engine));
   if (opt_.kv_dtype != 0) {
     if (opt_.word_timestamps) throw std::runtime_error("kv_dtype=fp8 cannot be combined with word_timestamps (the capture reads bf16 keys)");
     for (MoonshineModel::DeviceShard& d : model_->devices)

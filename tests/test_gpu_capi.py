@@ -392,3 +392,28 @@ def test_config1_beckett_wav_through_the_c_api(tiny, tiny_dir, engine):
             checked += 1
     assert checked >= (len(toks) - 1) // 2
     assert [l.text_bytes for l in tiny.transcribe_without_streaming(audio)] == [want]   # deterministic
+
+
+def test_cross_attention_option(tiny_dir, engine):
+    """Additive load option `cross_attention` (auto | kv | absorbed -> msh_set_cross_mode): a bad value fails the load; with
+    `absorbed` the batch call decodes over the encoder output itself (k_xattn.hip) and its token ids agree with the engine's
+    own absorbed decode of the same clips (the numerics of that form against the oracle: tests/test_gpu_xattn.py)."""
+    with pytest.raises(Exception):
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "sideways"})
+    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
+    clips = [make_audio(60 + i, n) for i, n in enumerate([16000, 48000, 30720, 80384])]
+    clips = [c[: (len(c) // 512) * 512] for c in clips]
+    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "absorbed"})
+    try:
+        got = t.transcribe_batch_without_streaming(clips)
+    finally:
+        t.close()
+    engine.set_cross_mode("absorbed")
+    try:
+        want_ids = engine.transcribe_tokens(clips)
+        assert engine.cross_absorbed()
+    finally:
+        engine.set_cross_mode("auto")
+    for lines, ids in zip(got, want_ids):
+        assert len(lines) == 1
+        assert lines[0].text_bytes == host_ref.sanitize_text(host_ref.tokens_to_text(vocab, ids))
