@@ -63,6 +63,23 @@ __device__ __forceinline__ float rows_sum(float v) {
   auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
+// Full-wave reductions without the LDS crossbar: four DPP row rotations inside the 16-lane rows, then the row swaps above.
+// Every lane ends with the result.  (Fixed order: deterministic; not the order of wave_max / wave_sum.)
+#define MSH_DPP_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, true))
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, MSH_DPP_ROR(v, 8));
+  v = fmaxf(v, MSH_DPP_ROR(v, 4));
+  v = fmaxf(v, MSH_DPP_ROR(v, 2));
+  v = fmaxf(v, MSH_DPP_ROR(v, 1));
+  return rows_max(v);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += MSH_DPP_ROR(v, 8);
+  v += MSH_DPP_ROR(v, 4);
+  v += MSH_DPP_ROR(v, 2);
+  v += MSH_DPP_ROR(v, 1);
+  return rows_sum(v);
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -83,10 +100,12 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 // ------------------------------------------------------------------------------------------------
 constexpr int KB = 64;        // keys per LDS block
 constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: 16-byte aligned rows, conflict-free ds_read_b64)
-constexpr int EQT = 4;        // query tiles of 16 per wave
+constexpr int EQT_DEFAULT = 4;        // query tiles of 16 per wave
 
-template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void enc_attention_kernel(const bf16_t* __restrict__ qk,
+// EQT = query tiles per wave: 4 (232 registers: two 4-wave workgroups per CU), or 2 (fewer accumulators: three workgroups per
+// CU, twice as many workgroups stage the keys of a (clip, head) -- MSH_ENC_ATT_EQT=2)
+template <int DH, int NW, int EQT = EQT_DEFAULT>
+__global__ __launch_bounds__(64 * NW, EQT == 2 ? 3 : 2) void enc_attention_kernel(const bf16_t* __restrict__ qk,
                                                                 const bf16_t* __restrict__ vt, long vt_ld,
                                                                 bf16_t* __restrict__ out,
                                                                 const ClipMeta* __restrict__ clips, int D,
@@ -225,10 +244,17 @@ __global__ __launch_bounds__(64 * NW, 2) void enc_attention_kernel(const bf16_t*
 #pragma unroll
       for (int s = 0; s < 2; ++s) kf[kt][s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
     }
+    // (a tile that does no work keeps zero P fragments: the P.V product below runs over all EQT tiles without a branch per
+    // MFMA -- guarded one by one, each of its 32 MFMAs per key block sat in a basic block of its own)
     bf16x8 pf[EQT][2];
 #pragma unroll
     for (int qi = 0; qi < EQT; ++qi) {
-      if (!act[qi]) continue;
+      if (!act[qi]) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        pf[qi][0] = *reinterpret_cast<const bf16x8*>(&z);
+        pf[qi][1] = *reinterpret_cast<const bf16x8*>(&z);
+        continue;
+      }
       f32x4 st[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -299,8 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void enc_attention_kernel(const bf16_t*
         uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
 #pragma unroll
         for (int qi = 0; qi < EQT; ++qi)
-          if (act[qi])
-            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[qi][ks], o[qi][dt], 0, 0, 0);
+          o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[qi][ks], o[qi][dt], 0, 0, 0);
       }
     }
   }
@@ -441,13 +466,13 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
       }
       s1 = a;
     }
-    const float m_new = fmaxf(m_run, wave_max(fmaxf(s0, s1)));
+    const float m_new = fmaxf(m_run, wave_max_dpp(fmaxf(s0, s1)));
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first block: exp2(-inf) = 0
     m_run = m_new;
     const float p0 = __builtin_amdgcn_exp2f(s0 - m_new), p1 = __builtin_amdgcn_exp2f(s1 - m_new);   // masked keys: 0
     sc[wave][lane] = p0;
     if (lane < KB - 64) sc[wave][lane + 64] = p1;
-    l_run = l_run * alpha + wave_sum(p0 + p1);
+    l_run = l_run * alpha + wave_sum_dpp(p0 + p1);
     __builtin_amdgcn_wave_barrier();
     // P.V: lane = (key group g, 4-dim piece); group g walks keys g, g + G, ...
     acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
@@ -757,9 +782,13 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
     const char* e = getenv("MSH_ENC_ATT_WIDE");
     return e != nullptr && e[0] == '1';
   }();
+  static const bool two_tiles = [] {
+    const char* e = getenv("MSH_ENC_ATT_EQT");
+    return e != nullptr && e[0] == '2';
+  }();
   const int ntiles = (max_rows + 15) / 16;
   const bool wide = wide_wg && ntiles > 16 && ntiles <= 28;
-  const int slots = wide ? 28 : 16;
+  const int slots = wide ? 28 : (two_tiles ? 8 : 16);
   const int gx = (ntiles + slots - 1) / slots;
   const int tiles_per_wg = (ntiles + gx - 1) / gx;
   dim3 grid(gx, heads, n_clips);
@@ -768,6 +797,8 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
   case DHV:                                                                                                                 \
     if (wide)                                                                                                               \
       MSH_LAUNCH((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
+    else if (two_tiles)                                                                                                     \
+      MSH_LAUNCH((enc_attention_kernel<DHV, 4, 2>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);    \
     else                                                                                                                    \
       MSH_LAUNCH((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
     break
