@@ -112,8 +112,8 @@ __device__ __forceinline__ float bf16_round(float x) {   // x rounded to bf16 (R
 // address is M0, both stepped by SALU adds: per piece two scalar adds and one VMEM issue, no vector arithmetic.  M0 is
 // restored inside the statement.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#define MSH_XA_P(POL) "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], 0x400\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds" POL "\n\t"
-#define MSH_XA_HEAD(POL) "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds" POL "\n\t"
+#define MSH_XA_P(POL) "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], 0x400\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen" POL " lds\n\t"
+#define MSH_XA_HEAD(POL) "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen" POL " lds\n\t"
 #define MSH_XA_TAIL "s_mov_b32 m0, %[keep]"
 #define MSH_XA_13(POL) MSH_XA_HEAD(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) \
     MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_P(POL) MSH_XA_TAIL
