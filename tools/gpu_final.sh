@@ -34,7 +34,7 @@ with open(sys.argv[1]) as src, gzip.open(sys.argv[2], "wt") as dst:
 PYT
 pass() { # name counters...
   local name=$1; shift
-  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api > /tmp/pmc_${TAG}_$name.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- python $R/bench.py --in-flight 1 --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api --no-fp8 > /tmp/pmc_${TAG}_$name.log 2>&1)
   tail -1 /tmp/pmc_${TAG}_$name.log | cut -c1-160
 }
 pass fetch FETCH_SIZE

@@ -19,4 +19,4 @@ out = np.zeros((M, 8 * D), np.float32)
 lib = load_library()
 ms = lib.msh_test_cross_absorbed(qt.ctypes.data, enc.ctypes.data, enc.shape[0], Ts.ctypes.data, starts.ctypes.data, M, D, out.ctypes.data, 200)
 mb = M * (T * D * 2 + 8 * D * 6) / 1e6
-print(f"abl={os.environ.get('MSH_XATTN_ABL', '0')} cfg={os.environ.get('MSH_XATTN_CFG', '81')} M={M} T={T}: {ms * 1e3:.2f} us per launch, {mb / ms / 1e3:.2f} TB/s")
+print(f"abl={os.environ.get('MSH_XATTN_ABL', '0')} cfg={os.environ.get('MSH_XATTN_CFG', '84')} M={M} T={T}: {ms * 1e3:.2f} us per launch, {mb / ms / 1e3:.2f} TB/s")
