@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include <atomic>
+
 #include "host_utils.h"
 
 #include <mutex>
@@ -199,23 +201,42 @@ void zero_blocking(void* p, size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Developer probe MSH_BUF_SKEW_KB=n: the k-th workspace allocation of the process starts (k mod 8) * n KiB into its
+// device allocation.  Large hipMalloc results share their alignment, so streams that walk two buffers at the same pace (a
+// kernel's input rows and its output rows) keep the same low address bits for the whole launch; where that puts both on
+// the same memory channel depends on the physical pages behind them.  (The probe answers whether the box-to-box spread of
+// the encoder panel kernels, DESIGN.md 3b / 3c, is that.)
+static size_t buf_skew_bytes() {
+  static const size_t kb = [] {
+    const char* e = getenv("MSH_BUF_SKEW_KB");
+    const long v = e != nullptr ? atol(e) : 0;
+    return (size_t)(v > 0 && !guard_alloc_enabled() ? v : 0);
+  }();
+  if (kb == 0) return 0;
+  static std::atomic<unsigned> counter{0};
+  return (size_t)(counter.fetch_add(1) % 8u) * kb * 1024;
+}
 bool DevBuf::reserve(size_t bytes) {
   if (bytes <= cap && p != nullptr) return false;
   // a little slack so ragged batches do not thrash (none under the guard allocator: it would hide over-reads)
   size_t want = guard_alloc_enabled() ? bytes : bytes + bytes / 8 + 256;
+  const size_t skew = buf_skew_bytes();
   std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-  void* np = device_alloc(want);
+  void* nr = device_alloc(want + skew);
+  void* np = static_cast<char*>(nr) + skew;
   // The zero-fill must be complete before the first kernel or copy on an engine stream writes the new buffer (a plain
   // hipMemset is asynchronous null-stream work those streams do not wait for: seen as rare garbage logits).
   zero_blocking(np, want);
-  if (p) device_free(p);
+  if (raw) device_free(raw);
+  raw = nr;
   p = np;
   cap = want;
   return true;
 }
 void DevBuf::release() {
   std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-  if (p) device_free(p);
+  if (raw) device_free(raw);
+  raw = nullptr;
   p = nullptr;
   cap = 0;
 }

@@ -29,6 +29,7 @@ struct ModelConfig {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  void* raw = nullptr;   // the allocation p lies in (p = raw + a skew, see reserve)
   bool reserve(size_t bytes);  // returns true if reallocated (contents lost, zero-filled)
   void release();
   template <class T>
