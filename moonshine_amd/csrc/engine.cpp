@@ -47,6 +47,15 @@ int xattn_qt_mode() {   // 0 = two-stage kernel, 1 = merged weight, 2 = two-stag
   return v;
 }
 bool xattn_merged_qt() { return xattn_qt_mode() == 1; }
+// the absorbed cross-attention's encoder rows with the non-temporal policy: by default when the engine is one of several lanes
+// on the GPU; MSH_XATTN_NT=0 / 1 forces it off / on (developer knob)
+bool xattn_stream_nt(bool shared_gpu) {
+  static const int forced = [] {
+    const char* e = getenv("MSH_XATTN_NT");
+    return e != nullptr ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  return forced >= 0 ? forced != 0 : shared_gpu;
+}
 // smallest batch that decodes with the absorbed cross-attention when the mode is automatic (Engine::set_cross_mode)
 int xattn_min_batch() {
   static const int v = [] {
@@ -1253,7 +1262,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       if (on(4)) {
         // both products on all 16 MFMA columns (high / low halves of 8 heads); bytes: E once, qt in, ctx out
         ProfScope p(this, "dec_cross_attention", 2.0 * 2.0 * sT * D * 16, sT * D * 2.0 + M * D * Hh * 6.0);
-        dec_cross_absorbed(reinterpret_cast<const bf16_t*>(dq), ENC_.as<bf16_t>(), clips, M, D, Hh, dao, s);
+        dec_cross_absorbed(reinterpret_cast<const bf16_t*>(dq), ENC_.as<bf16_t>(), clips, M, D, Hh, dao, s, xattn_stream_nt(shared_gpu_));
       }
       if (on(5)) {
         ProfScope p(this, "dec_ctx_resid_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * (2.0 * Hh + 8.0));

@@ -107,6 +107,9 @@ class Engine {
     }
   }
   int cross_mode() const { return cross_mode_; }
+  // this engine is one of several lanes that decode at the same time on one GPU (BatchPipeline): its once-per-launch streams
+  // go with the non-temporal policy (kernels.h dec_cross_absorbed)
+  void set_shared_gpu(bool on) { shared_gpu_ = on; }
   bool cross_absorbed() const { return absorbed_; }   // of the batch encoded last
   // cross K^T / V^T storage: bf16 (default) or e4m3 bytes with per-column scales fixed at load; applies to the next encode.
   // Lanes (batches in flight) take the setting when they are created.
@@ -185,6 +188,7 @@ class Engine {
   bool capture_cross_ = false;
   bool kv_fp8_ = false;
   int cross_mode_ = 0;
+  bool shared_gpu_ = false;
   bool absorbed_ = false;   // the encoded batch decodes with the absorbed cross-attention: K^T / V^T were not written
   float *kv_qscale_ = nullptr, *kv_dq_ = nullptr;   // [L * 2D]: e4m3 scale of every cross-KV column and its inverse
   size_t kv_bytes() const { return kv_fp8_ ? 1 : 2; }

@@ -754,6 +754,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+__device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_base) {   // the same with the non-temporal policy
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

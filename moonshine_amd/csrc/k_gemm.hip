@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 // fragment reads and drains vmcnt(0) before every ds_read (cdna_hip_programming.md section 5).
 // ------------------------------------------------------------------------------------------------
 // ABL (microbenchmark ablations, 0 in the product): bit 0 = no DMA after the prologue, bit 1 = no MFMA,
-// bit 2 = no fragment reads, bit 3 = no epilogue stores, bit 4 = direct (unstaged) stores; ABL >> 8 = b + 1: workgroups whose id has bit b set start
+// bit 2 = no fragment reads, bit 3 = no epilogue stores, bit 4 = direct (unstaged) stores, bit 5 = the W stream non-temporal
+// (not an ablation: correct results, used by the LM head under MSH_LMHEAD_NT=1); ABL >> 8 = b + 1: workgroups whose id has bit b set start
 // ~10 us late (probe for co-resident workgroups running their main loops and epilogues in lockstep).
 template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) void gemm_tiled_dma_kernel(const bf16_t* __restrict__ A, long lda,
@@ -209,7 +210,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) v
     const unsigned sb = (unsigned)(kt % NSTAGE) * (STAGE_SLOTS * 16u);
 #pragma unroll
     for (int i = 0; i < PMAX; ++i)
-      if (i < my_pieces) dma16(src[i] + (kt << 5), dst[i] + sb);
+      if (i < my_pieces) {
+        if constexpr ((ABL & 32) != 0) {   // W pieces with the non-temporal policy (a weight read once per launch: the LM head)
+          if (wave + NW * i >= PA) dma16_nt(src[i] + (kt << 5), dst[i] + sb);
+          else dma16(src[i] + (kt << 5), dst[i] + sb);
+        } else {
+          dma16(src[i] + (kt << 5), dst[i] + sb);
+        }
+      }
   };
   // wait until at most `stages` of this wave's k-slices are still in flight
   auto wait_stages = [&](int stages) {
@@ -352,12 +360,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) v
   }
 }
 
-template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi>
+template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
 void launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   constexpr int BM = 16 * NW * TM, BN = 16 * TN;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   const int nblocks = ntm * ntn;
-  MSH_LAUNCH((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
+  MSH_LAUNCH((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi, ABL>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
                      W, M, N, K, ntn, nblocks, epi);
 }
 
@@ -664,8 +672,16 @@ int gemm_argmax_tiles(int N) { return (N + 16 * kArgmaxTN - 1) / (16 * kArgmaxTN
 void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* pval, int* pidx,
                           hipStream_t s) {
   if ((K & 31) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_argmax_partials: unsupported shape");
-  launch_tiled_dma_cfg<4, 2, kArgmaxTN, 3, true, EpiArgmaxPartial>(A, lda, W, M, N, K,
-                                                                   EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
+  static const bool w_nt = [] {   // developer probe: the 27 MB embedding with the non-temporal policy
+    const char* e = getenv("MSH_LMHEAD_NT");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (w_nt)
+    launch_tiled_dma_cfg<4, 2, kArgmaxTN, 3, true, EpiArgmaxPartial, 32>(A, lda, W, M, N, K,
+                                                                         EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
+  else
+    launch_tiled_dma_cfg<4, 2, kArgmaxTN, 3, true, EpiArgmaxPartial>(A, lda, W, M, N, K,
+                                                                     EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
 }
 void gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiF32{out, N}, s);

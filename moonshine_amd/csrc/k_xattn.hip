@@ -488,7 +488,7 @@ void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* cl
              group ? 1 : 0, ctx, dbg);
 }
 template <int D>
-void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s) {
+void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s, bool stream_nt) {
   static const int abl = [] {
     const char* e = getenv("MSH_XATTN_ABL");
     return e != nullptr ? atoi(e) : 0;
@@ -510,7 +510,10 @@ void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips,
     case 42: return launch_absorbed_cfg<D, true, 4, 2>(qt, enc, clips, M, ctx, s);
     case 40: return launch_absorbed_cfg<D, false, 4, 2>(qt, enc, clips, M, ctx, s);
     case 81: return launch_absorbed_cfg<D, true, 8, 1>(qt, enc, clips, M, ctx, s);
-    default: return launch_absorbed_cfg<D, true, 8, 1, 0, 4>(qt, enc, clips, M, ctx, s);
+    default:
+      // ABL bit 256 = the encoder rows with the non-temporal policy (correct results; see dec_cross_absorbed)
+      if (stream_nt) return launch_absorbed_cfg<D, true, 8, 1, 256, 4>(qt, enc, clips, M, ctx, s);
+      return launch_absorbed_cfg<D, true, 8, 1, 0, 4>(qt, enc, clips, M, ctx, s);
   }
 }
 
@@ -519,10 +522,10 @@ void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips,
 bool cross_absorbed_supported(int D, int heads) { return heads == 8 && (D == 416 || D == 288); }
 
 void dec_cross_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
-                        hipStream_t s) {
+                        hipStream_t s, bool stream_nt) {
   if (!cross_absorbed_supported(D, heads)) throw std::runtime_error("dec_cross_absorbed: unsupported shape");
-  if (D == 416) launch_absorbed<416>(qt, enc, clips, M, ctx, s);
-  else launch_absorbed<288>(qt, enc, clips, M, ctx, s);
+  if (D == 416) launch_absorbed<416>(qt, enc, clips, M, ctx, s, stream_nt);
+  else launch_absorbed<288>(qt, enc, clips, M, ctx, s, stream_nt);
 }
 
 // Test / microbenchmark hook (msh_test_cross_absorbed): M clips of Ts[b] frames, qt [M][8 D] fp32, enc rows as fp32
@@ -562,7 +565,7 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
   MSH_HIP(hipMemcpy(de, e16.data(), e16.size() * 2, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(dm, cm.data(), (size_t)M * sizeof(ClipMeta), hipMemcpyHostToDevice));
   MSH_HIP(hipMemset(dc, 0, (size_t)M16 * 8 * D * 2));
-  dec_cross_absorbed(dq, de, dm, M, D, 8, dc, 0);
+  dec_cross_absorbed(dq, de, dm, M, D, 8, dc, 0, false);
   MSH_HIP(hipDeviceSynchronize());
   float ms = 0.f;
   if (iters > 0) {
@@ -570,7 +573,7 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
     MSH_HIP(hipEventCreate(&a));
     MSH_HIP(hipEventCreate(&b2));
     MSH_HIP(hipEventRecord(a, 0));
-    for (int i = 0; i < iters; ++i) dec_cross_absorbed(dq, de, dm, M, D, 8, dc, 0);
+    for (int i = 0; i < iters; ++i) dec_cross_absorbed(dq, de, dm, M, D, 8, dc, 0, false);
     MSH_HIP(hipEventRecord(b2, 0));
     MSH_HIP(hipEventSynchronize(b2));
     MSH_HIP(hipEventElapsedTime(&ms, a, b2));

@@ -194,8 +194,11 @@ bool crossq2_supported(int D, int heads);
 void pack_crossq_wk(const float* Wk, int D, int heads, bf16_t* out);   // out: heads * (D / 16) * 1024 elements
 void dec_crossq2(const float* H, const bf16_t* W1, const bf16_t* W2, int M, int heads, int D, bf16_t* qf, hipStream_t s);
 float crossq2_host(const float* x, const float* wq, const float* wk, int M, int D, float* qt_out, int iters);
+// stream_nt: the encoder rows with the non-temporal cache policy -- with one batch on the GPU the rows of a clip are re-read by the
+// next layer out of the memory-side cache and the default policy is right; with several batches in flight (lanes) the lanes'
+// encoder outputs together do not fit it and only displace the weights every lane shares: +4.7 % overlapped throughput
 void dec_cross_absorbed(const bf16_t* qf, const bf16_t* enc, const ClipMeta* clips, int M, int D, int heads, bf16_t* ctx,
-                        hipStream_t s);
+                        hipStream_t s, bool stream_nt = false);
 float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const int* Ts, const int* row_starts, int M, int D,
                           float* ctx_out, int iters);
 int xattn_min_batch();

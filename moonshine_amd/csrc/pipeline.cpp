@@ -10,6 +10,7 @@ BatchPipeline::BatchPipeline(Engine& primary, int device, int lanes) : device_(d
   for (int i = 0; i < lanes; ++i) {
     std::unique_ptr<Engine> e(new Engine(device));
     e->share_weights_from(primary);
+    e->set_shared_gpu(lanes > 1);
     lanes_.push_back(std::move(e));
   }
   for (int i = 0; i < lanes; ++i) threads_.emplace_back([this, i] { worker(i); });
