@@ -24,7 +24,7 @@ GROUPS = {  # bench.py kernel group -> kernel-name pattern
     "dec_fc2_resid_gemm": r"gemm_dec_kernel<(52|36), \d+, false, .*EpiDecResidFm<true>", "dec_proj_resid_gemm": r"gemm_dec_kernel<(13|9), \d+, false, .*EpiDecResidFm<false>",
     "enc_attention": r"enc_attention_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
     "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiGnBiasGeluBf16", "enc_fc1_gelu_gemm": r"gemm_astat_kernel.*EpiBiasGeluBf16",
-    "enc_mlp_fused": r"mlp_fused_kernel", "enc_qkv_panel": r"panel_gemm_kernel", "cross_kv_gemm": r"EpiCrossKV",
+    "enc_oproj_mlp_fused": r"mlp_fused_kernel", "enc_qkv_panel": r"panel_gemm_kernel", "cross_kv_gemm": r"EpiCrossKV",
 }
 out = {}
 for name in ("fetch", "write"):
