@@ -51,6 +51,7 @@ struct EpiTanhBf16 {
   static constexpr bool kStagedBf16 = true;
   bf16_t* out;
   long ldc;
+  int nt = 0;   // 1: the output goes out with the non-temporal policy (staged_store_tile; MSH_STEM_STORE_NT)
   struct RowCtx {};
   struct ColCtx {};
   __device__ RowCtx row_ctx(int) const { return RowCtx{}; }
@@ -79,6 +80,7 @@ struct EpiGnBiasGeluBf16 {
   const float* table;   // [clips][N]: S2[n] + bias[n] - mean_b * rstd_b * S1[n]   (gn_fold_table, once per batch)
   const float2* stats;  // per clip {mean, rstd}
   const int* row_clip;  // per stream row
+  int nt = 0;           // 1: non-temporal output stores (see EpiTanhBf16)
   struct RowCtx {
     float rstd;
     const float* trow;
@@ -695,6 +697,13 @@ struct StagedRow {
   static constexpr int ROWP = TN * 4 + 2;  // uint2 per staged row: 16 * TN columns + 16 bytes of padding
 };
 // acc = the TN accumulators of one 16-row tile of this wave; stg = this wave's [16][ROWP] uint2 staging slab
+// epilogues that carry a run-time `nt` flag (non-temporal output stores)
+template <class E, class = void>
+struct has_nt_flag : std::false_type {};
+template <class E>
+struct has_nt_flag<E, std::void_t<decltype(std::declval<const E&>().nt)>> : std::true_type {};
+typedef unsigned int u32x4_native __attribute__((ext_vector_type(4)));
+
 template <int TN, class Epi>
 __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restrict__ stg, const f32x4 (&acc)[TN],
                                                   int mbase, int n0, int M, int N, int lane, float* rowtab = nullptr) {
@@ -730,9 +739,12 @@ __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restr
       const int m = mbase + r, n = n0 + c * 8;
       if (m < M) {
         bf16_t* dst = epi.out + (long)m * epi.ldc + n;
-        if (n + 8 <= N)
-          *reinterpret_cast<uint4*>(dst) = v;
-        else if (n + 4 <= N)
+        bool nt = false;
+        if constexpr (has_nt_flag<Epi>::value) nt = epi.nt != 0;
+        if (n + 8 <= N) {
+          if (nt) __builtin_nontemporal_store(u32x4_native{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_native*>(dst));
+          else *reinterpret_cast<uint4*>(dst) = v;
+        } else if (n + 4 <= N)
           *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
       }
     }

@@ -622,12 +622,21 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// developer probe MSH_STEM_STORE_NT=1: the conv1 / conv2 outputs (0.9 GB per 256 clips, written once, read by the next stem
+// kernel) with the non-temporal policy, so that one lane's stem does not flush the decoder weights the other lanes are reading
+static int stem_store_nt() {
+  static const int v = [] {
+    const char* e = getenv("MSH_STEM_STORE_NT");
+    return e != nullptr && e[0] == '1' ? 1 : 0;
+  }();
+  return v;
+}
 void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiTanhBf16{out, N}, s);
+  launch_tiled<true>(A, lda, W, M, N, K, EpiTanhBf16{out, N, stem_store_nt()}, s);
 }
 void gemm_gn_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* table, const float2* stats,
                             const int* row_clip, int M, int N, int K, bf16_t* out, hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiGnBiasGeluBf16{out, N, table, stats, row_clip}, s);
+  launch_tiled<true>(A, lda, W, M, N, K, EpiGnBiasGeluBf16{out, N, table, stats, row_clip, stem_store_nt()}, s);
 }
 void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
                          bf16_t* out, hipStream_t s) {
