@@ -1408,12 +1408,20 @@ void Engine::profile_decode_chain(int reps) {
         std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
         MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
         step_mask_ = mask;
-        for (int r = 0; r < reps; ++r) decode_step_enqueue(g);
+        try {
+          for (int r = 0; r < reps; ++r) decode_step_enqueue(g);
+        } catch (...) {   // never leave the stream in capture mode
+          step_mask_ = 0;
+          (void)hipStreamEndCapture(g.stream, &gr);
+          if (gr != nullptr) (void)hipGraphDestroy(gr);
+          throw;
+        }
         step_mask_ = 0;
         MSH_HIP(hipStreamEndCapture(g.stream, &gr));
         MSH_HIP(hipGraphGetNodes(gr, nullptr, &n_nodes));
-        MSH_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
-        MSH_HIP(hipGraphDestroy(gr));
+        const hipError_t inst = hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        MSH_HIP(inst);
       }
       if (n_nodes > 0) {
         MSH_HIP(hipGraphLaunch(ge, g.stream));
