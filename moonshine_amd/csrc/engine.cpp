@@ -56,6 +56,17 @@ bool xattn_stream_nt(bool shared_gpu) {
   }();
   return forced >= 0 ? forced != 0 : shared_gpu;
 }
+// the encoder block kernels' outputs (fused MLP, QKV panel) with non-temporal stores: measured SLOWER, in the kernels themselves
+// (0.62 / 0.33 against 0.57 / 0.30 ms) and in the overlapped bench (89.5 against 90.5 k audio-s/s; profiles/r5v_*), so it is off;
+// MSH_ENC_STORE_NT=1 forces it on (probe)
+constexpr bool kEncStoreNtInLanes = false;
+bool enc_store_nt(bool shared_gpu) {
+  static const int forced = [] {
+    const char* e = getenv("MSH_ENC_STORE_NT");
+    return e != nullptr ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  return forced >= 0 ? forced != 0 : (shared_gpu && kEncStoreNtInLanes);
+}
 // smallest batch that decodes with the absorbed cross-attention when the mode is automatic (Engine::set_cross_mode)
 int xattn_min_batch() {
   static const int v = [] {
@@ -1016,7 +1027,7 @@ void Engine::run_encoder() {
       // panel per CU the tiled GEMMs, whose tiles are smaller, fill the chip better
       ProfScope p(this, "enc_qkv_panel", 2.0 * sT * D * 3 * D, sT * D * (4 + 6));
       vt_ld = (long)((R + 127) / 128 * 128);
-      qkv_panel(H_.as<float>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s);
+      qkv_panel(H_.as<float>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s, enc_store_nt(shared_gpu_));
     } else {
       {
         ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
@@ -1044,7 +1055,7 @@ void Engine::run_encoder() {
       // o-proj + residual + LayerNorm + fc1 + GELU + fc2 + residual in ONE kernel: H is read once and written once per layer
       // for both blocks, the [R][F] intermediate never exists (k_mlp.hip)
       ProfScope p(this, "enc_oproj_mlp_fused", 2.0 * sT * D * D + 4.0 * sT * D * F, sT * D * (2 + 8));
-      mlp_fused_oproj(H_.as<float>(), AO_.as<bf16_t>(), W.mlp, W.b2, R, D, F, s);
+      mlp_fused_oproj(H_.as<float>(), AO_.as<bf16_t>(), W.mlp, W.b2, R, D, F, s, enc_store_nt(shared_gpu_));
       continue;
     }
     {

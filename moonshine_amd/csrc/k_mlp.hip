@@ -68,7 +68,8 @@ __device__ __forceinline__ void static_for(Body&& body) {
 // OP: the attention output projection of the layer rides in front: H' = H + AO Wo^T is formed in the fc2 accumulators
 // (NOP extra stages of two 32-column tiles each at the head of Wp, AO [R][D] bf16 as their B operand), LayerNorm is then
 // taken from those registers, and H is read ONCE and written once per layer for o-proj + MLP together.
-template <int D, int ABL = 0, bool OP = false>
+// NTS: the residual stream is written back with non-temporal stores (see mlp_fused_oproj)
+template <int D, int ABL = 0, bool OP = false, bool NTS = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H, const bf16_t* __restrict__ Wp,
                                                            const float* __restrict__ b2, int R, int NC,
                                                            const bf16_t* __restrict__ AO) {
@@ -418,7 +419,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
       for (int q = 0; q < 4; ++q) {
         const int c = t * 32 + q * 8;
         const float4 b = *reinterpret_cast<const float4*>(bp + c);
-        *reinterpret_cast<float4*>(op + c) = make_float4(oacc[t][4 * q] + b.x, oacc[t][4 * q + 1] + b.y, oacc[t][4 * q + 2] + b.z, oacc[t][4 * q + 3] + b.w);
+        typedef float f32x4_native __attribute__((ext_vector_type(4)));
+        const f32x4_native v = {oacc[t][4 * q] + b.x, oacc[t][4 * q + 1] + b.y, oacc[t][4 * q + 2] + b.z, oacc[t][4 * q + 3] + b.w};
+        if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_native*>(op + c));
+        else *reinterpret_cast<f32x4_native*>(op + c) = v;
       }
   }
 }
@@ -428,7 +432,13 @@ void launch_mlp(float* H, const bf16_t* Wp, const float* b2, int R, int F, hipSt
   MSH_LAUNCH((mlp_fused_kernel<D, ABL, false>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, (const bf16_t*)nullptr);
 }
 template <int D>
-void launch_mlp_o(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s) {
+void launch_mlp_o(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s, bool store_nt) {
+  if constexpr (D == 416) {
+    if (store_nt) {
+      MSH_LAUNCH((mlp_fused_kernel<D, 0, true, true>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, AO);
+      return;
+    }
+  }
   MSH_LAUNCH((mlp_fused_kernel<D, 0, true>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, AO);
 }
 
@@ -487,12 +497,12 @@ void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, cons
   }
 }
 
-void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s) {
+void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s, bool store_nt) {
   if (R <= 0) return;
   switch (D) {
-    case 416: return launch_mlp_o<416>(H, AO, Wp, b2, R, F, s);
-    case 288: return launch_mlp_o<288>(H, AO, Wp, b2, R, F, s);
-    case 64: return launch_mlp_o<64>(H, AO, Wp, b2, R, F, s);
+    case 416: return launch_mlp_o<416>(H, AO, Wp, b2, R, F, s, store_nt);
+    case 288: return launch_mlp_o<288>(H, AO, Wp, b2, R, F, s, false);
+    case 64: return launch_mlp_o<64>(H, AO, Wp, b2, R, F, s, false);
     default: throw std::runtime_error("mlp_fused_oproj: unsupported hidden size");
   }
 }

@@ -63,7 +63,8 @@ __device__ __forceinline__ float dpp_f(float v) {
 // (transposed: vt[c][row], the P.V operand of enc_attention).  A lane's row position is fixed for the whole panel: its
 // cos / sin factors (RP pairs) are loaded once into registers; which pair a value needs is a compile-time function of
 // (chunk in section, register) up to the lane half, which selects between two constants.
-template <int D, int DH, int RP>
+// NTS: q | k and V^T go out with non-temporal stores (see qkv_panel)
+template <int D, int DH, int RP, bool NTS = false>
 struct EpiQkvPanel {
   bf16_t* qk;         // [R][2D]
   bf16_t* vt;         // [D][vt_ld]
@@ -170,14 +171,22 @@ struct EpiQkvPanel {
       swap32(pk[4], pk[6]);
       swap32(pk[5], pk[7]);
       bf16_t* o = qk + (long)row * (2 * D) + sec * D + 32 * C + 8 * hh;
-      *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-      *reinterpret_cast<uint4*>(o + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      typedef unsigned int u32x4_nat __attribute__((ext_vector_type(4)));
+      if constexpr (NTS) {
+        __builtin_nontemporal_store(u32x4_nat{pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<u32x4_nat*>(o));
+        __builtin_nontemporal_store(u32x4_nat{pk[4], pk[5], pk[6], pk[7]}, reinterpret_cast<u32x4_nat*>(o + 16));
+      } else {
+        *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(o + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      }
     } else {
       const int r0 = row & ~3;   // the quad's first row
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = 32 * C + 8 * q + 4 * hh + (lane & 3);
-        *reinterpret_cast<uint2*>(vt + (long)c * vt_ld + r0) = make_uint2(pk[2 * q], pk[2 * q + 1]);
+        typedef unsigned int u32x2_nat __attribute__((ext_vector_type(2)));
+        if constexpr (NTS) __builtin_nontemporal_store(u32x2_nat{pk[2 * q], pk[2 * q + 1]}, reinterpret_cast<u32x2_nat*>(vt + (long)c * vt_ld + r0));
+        else *reinterpret_cast<uint2*>(vt + (long)c * vt_ld + r0) = make_uint2(pk[2 * q], pk[2 * q + 1]);
       }
     }
   }
@@ -477,8 +486,15 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
 
 template <int D, int DH, int RP>
 void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
-                      long vt_ld, hipStream_t s) {
+                      long vt_ld, hipStream_t s, bool store_nt) {
   if (rp.rot_pairs != RP || rp.head_dim != DH) throw std::runtime_error("qkv_panel: rotary layout not compiled");
+  if constexpr (D == 416) {
+    if (store_nt) {
+      EpiQkvPanel<D, DH, RP, true> e2{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
+      MSH_LAUNCH((panel_gemm_kernel<D, true, EpiQkvPanel<D, DH, RP, true>>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, e2, R, 2, 1);
+      return;
+    }
+  }
   EpiQkvPanel<D, DH, RP> epi{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
   static const int abl = [] {
     const char* e = getenv("MSH_PANEL_ABL");
@@ -548,12 +564,12 @@ void pack_panel_weights(const float* w, const float* gamma, int N, int D, bf16_t
 }
 
 void qkv_panel(const float* H, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
-               long vt_ld, hipStream_t s) {
+               long vt_ld, hipStream_t s, bool store_nt) {
   if (R <= 0) return;
   if ((R & 7) != 0) throw std::runtime_error("qkv_panel: the row count must be a multiple of 8");
   switch (D) {
-    case 416: return launch_qkv_panel<416, 52, 23>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s);
-    case 288: return launch_qkv_panel<288, 36, 16>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s);
+    case 416: return launch_qkv_panel<416, 52, 23>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s, store_nt);
+    case 288: return launch_qkv_panel<288, 36, 16>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s, false);
     default: throw std::runtime_error("qkv_panel: unsupported width");
   }
 }
