@@ -594,11 +594,14 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
       const int Hn = c.heads, dh = D / Hn;
       const std::vector<float> wqf = fold(fuse({p + "encoder_attn.q_proj.weight"}), p + "post_attention_layernorm.weight", D);
       const float scale = 1.4426950408889634f / sqrtf((float)dh);
-      std::vector<float> wqk((size_t)Hn * D * D, 0.f), wvo((size_t)D * Hn * D, 0.f);
+      // (the merged query weight is only formed when its GEMM is asked for: MSH_XATTN_QT, or a shape the two-stage kernel
+      // does not cover -- it is 8 D^3 multiply-adds per layer on the host)
+      const bool need_wqk = !crossq2_supported(D, Hn) || xattn_qt_mode() != 0;
+      std::vector<float> wqk(need_wqk ? (size_t)Hn * D * D : 0, 0.f), wvo((size_t)D * Hn * D, 0.f);
       const float* Wk = kv.data();
       const float* Wv = kv.data() + (size_t)D * D;
       msh_host::parallel_for((size_t)Hn, [&](size_t h) {
-        for (int j = 0; j < dh; ++j) {
+        for (int j = 0; need_wqk && j < dh; ++j) {
           const float* wkrow = Wk + (size_t)(h * dh + j) * D;
           const float* wqrow = wqf.data() + (size_t)(h * dh + j) * D;
           for (int d = 0; d < D; ++d) {
@@ -616,7 +619,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
           }
         }
       });
-      if (!crossq2_supported(D, Hn) || xattn_qt_mode() != 0) upload_bf16_fm(wqk, Hn * D, D, &L.wqk);
+      if (need_wqk) upload_bf16_fm(wqk, Hn * D, D, &L.wqk);
       upload_bf16_fm(wvo, D, Hn * D, &L.wvo);
       if (crossq2_supported(D, Hn)) {   // the factors of wqk, kept apart (k_crossq.hip)
         std::vector<float> w1((size_t)Hn * 64 * D, 0.f);
