@@ -335,7 +335,11 @@ constexpr int CROSS_MMAX = 4096;
 typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float s_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float s_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-template <int DH>
+// NT: the memory K / V rows of an auto-regressive step with the non-temporal policy -- the offline decoder's finding (DESIGN.md
+// 3c: keep what is read once per step out of the memory-side cache, so that it keeps the weights) on the streaming decoder,
+// whose weights (~240 MB at the medium dims) are what every step re-reads: config 5 931-934 -> 954-958 audio-s/s
+// (profiles/r5x_*).  Default for head_dim 80; MSH_STREAM_XATTN_NT=0 switches it off.
+template <int DH, bool NT = false>
 __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* __restrict__ q,
                                                                  const int* __restrict__ row_slot,
                                                                  const SlotDev* __restrict__ slots, int D, int heads,
@@ -372,10 +376,12 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
     su32x4 kr[DQ], vr[DQ];
 #pragma unroll
     for (int d = 0; d < DQ; ++d)
-      kr[d] = in ? *reinterpret_cast<const su32x4*>(kt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+      if constexpr (NT) kr[d] = in ? __builtin_nontemporal_load(reinterpret_cast<const su32x4*>(kt + (long)d * Mcap + key)) : su32x4{0u, 0u, 0u, 0u};
+      else kr[d] = in ? *reinterpret_cast<const su32x4*>(kt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int d = 0; d < DQ; ++d)
-      vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
+      if constexpr (NT) vr[d] = in ? __builtin_nontemporal_load(reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key)) : su32x4{0u, 0u, 0u, 0u};
+      else vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
     float sc[8];
 #pragma unroll
@@ -1031,6 +1037,15 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
   if (fm && (D & 31) != 0) throw std::runtime_error("stream_cross_attention: FM output needs D % 32 == 0");
   if (M <= 0) return;
   const int fmi = fm ? 1 : 0;
+  static const bool nt = [] {
+    const char* e = getenv("MSH_STREAM_XATTN_NT");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (nt && dh == 80) {
+    MSH_LAUNCH((cross_attention_kernel<80, true>), dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+               crossK, crossV, out, fmi, row_mem);
+    return;
+  }
 #define MSH_XATT(DHV)                                                                                                  \
   case DHV:                                                                                                            \
     MSH_LAUNCH(cross_attention_kernel<DHV>, dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads,     \
