@@ -221,7 +221,18 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
 // Arithmetic and summation order per output element are those of self_attention_kernel: scores as dot_row adds them, the
 // value sum in G interleaved partial sums (G = that kernel's key groups) added in group order.
 constexpr int SELF_AR_KEYS = 128;
-template <int DH>
+// NT (probe for the next round, MSH_STREAM_SELF_NT=1, head_dim 80 only): the cached K / V rows with the non-temporal policy
+typedef unsigned int su32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
+  if constexpr (NT) {
+    const su32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const su32x4_nt*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+template <int DH, bool NT = false>
 __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __restrict__ q, const int* __restrict__ row_slot,
                                                                const int* __restrict__ row_pos, int D, int heads, int layer,
                                                                int L, int Scap, const bf16_t* __restrict__ cacheK,
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __r
     const int j = lane + 64 * t;
     const bf16_t* kp = cacheK + base + (long)(j < nk ? j : 0) * D;
 #pragma unroll
-    for (int c = 0; c < C8; ++c) kr[t][c] = *reinterpret_cast<const uint4*>(kp + c * 8);
+    for (int c = 0; c < C8; ++c) kr[t][c] = ld16<NT>(kp + c * 8);
   }
   uint4 vr[NV];
   const int nchunks = nk * C8;
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __r
   for (int i = 0; i < NV; ++i) {
     const int idx = lane + 64 * i;
     const int j = idx / C8, c = idx - j * C8;
-    vr[i] = idx < nchunks ? *reinterpret_cast<const uint4*>(cacheV + base + (long)j * D + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+    vr[i] = idx < nchunks ? ld16<NT>(cacheV + base + (long)j * D + c * 8) : make_uint4(0u, 0u, 0u, 0u);
   }
   __builtin_amdgcn_sched_barrier(0);
   const float scale = rsqrtf((float)DH);
@@ -446,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
 struct RowRun {
   int row0, n;   // rows [row0, row0 + n) of the pass, all of one stream, 1 <= n <= RB
 };
-template <int DH, int RB>
+// NT (probe for the next round, MSH_STREAM_XRUNS_NT=1, head_dim 80 only): the memory rows of the wide pass non-temporal
+template <int DH, int RB, bool NT = false>
 __global__ __launch_bounds__(256, 2) void cross_attention_runs_kernel(const bf16_t* __restrict__ q,
                                                                       const int* __restrict__ row_slot,
                                                                       const RowRun* __restrict__ runs,
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void cross_attention_runs_kernel(const bf16
     const int key = k0 + lane * 8;
     su32x4 kv[DQ];
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Mcap * 2, 0);
+    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rk, key * 2, d * Mcap * 2, NT ? 2 : 0);
     float sc[RB][8];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void cross_attention_runs_kernel(const bf16
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Mcap * 2, 0);
+    for (int d = 0; d < DQ; ++d) kv[d] = __builtin_amdgcn_raw_buffer_load_b128(rv, key * 2, d * Mcap * 2, NT ? 2 : 0);
     if (k0 > 0) __syncthreads();
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -1012,6 +1024,15 @@ void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const in
     const char* e = getenv("MSH_STREAM_SELF_AR");
     return e != nullptr && e[0] == '0';
   }();
+  static const bool self_nt = [] {   // probe for the next round (default off: not measured yet)
+    const char* e = getenv("MSH_STREAM_SELF_NT");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (max_keys > 0 && max_keys <= SELF_AR_KEYS && !no_ar_kernel && dh == 80 && self_nt) {
+    MSH_LAUNCH((self_attention_ar_kernel<80, true>), dim3(M * heads), dim3(64), 0, s, q, row_slot, row_pos, D, heads, layer, L, Scap,
+               cacheK, cacheV, out, fm ? 1 : 0);
+    return;
+  }
   if (max_keys > 0 && max_keys <= SELF_AR_KEYS && !no_ar_kernel && (dh == 24 || dh == 40 || dh == 80)) {
 #define MSH_SELF_AR(DHV)                                                                                              \
   case DHV:                                                                                                           \
@@ -1071,6 +1092,15 @@ void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int
   if (n_runs <= 0) return;
   static_assert(sizeof(RowRun) == sizeof(int2), "RowRun is passed as int2");
   const RowRun* rr = reinterpret_cast<const RowRun*>(runs);
+  static const bool runs_nt = [] {   // probe for the next round (default off: not measured yet)
+    const char* e = getenv("MSH_STREAM_XRUNS_NT");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (runs_nt && D / heads == 80) {
+    MSH_LAUNCH((cross_attention_runs_kernel<80, kCrossRunRows, true>), dim3(n_runs, heads), dim3(256), 0, s, q, row_slot, rr, slots, D,
+               heads, layer, L, Mcap, crossK, crossV, out);
+    return;
+  }
 #define MSH_XRUN(DHV)                                                                                                   \
   case DHV:                                                                                                             \
     MSH_LAUNCH((cross_attention_runs_kernel<DHV, kCrossRunRows>), dim3(n_runs, heads), dim3(256), 0, s, q, row_slot, rr, \
