@@ -151,5 +151,10 @@ def build(force: bool = False, verbose: bool = False, check: bool = True) -> str
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
+    try:
+        path = build(force="--force" in sys.argv, verbose=True)
+    except Exception as e:  # the last line of the output says which it was (a `| tail -1` once hid a failed link for half an hour)
+        print(e, file=sys.stderr)
+        print("BUILD FAILED: the library was NOT relinked", file=sys.stderr)
+        sys.exit(1)
     print(path)
