@@ -57,6 +57,9 @@ def parse():
                     help="batches in flight per GPU (engine lanes with their own stream / workspace; 1 = strictly serial steps)")
     ap.add_argument("--decode-steps", type=int, default=65, help="forced decode steps (ceil(10 s * 6.5 tok/s))")
     ap.add_argument("--arch", default="base")
+    ap.add_argument("--cross-attention", default="auto", choices=["auto", "kv", "absorbed"],
+                    help="form of the decoder's cross-attention, ONE per engine (msh_set_cross_mode); auto = what the host "
+                         "layer's load-time rule picks for this sub-batch size: absorbed from 192 clips per batch, else kv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-streaming", action="store_true", help="skip the short config-5 (streaming) run inside the default bench")
@@ -334,6 +337,12 @@ def main():
         path = os.path.join(d, "model.safetensors")
         save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
         eng.load_weights_file(path)
+    # one cross-attention form per engine, fixed before the first batch (the host layer's `cross_attention=auto` rule,
+    # transcriber.cpp: absorbed when the configured sub-batch size is >= 192 clips)
+    xmode = args.cross_attention
+    if xmode == "auto":
+        xmode = "absorbed" if args.batch >= 192 and eng.cross_absorbed_supported() else "kv"
+    eng.set_cross_mode(xmode)
 
     # Utterance sharding: rank 0 owns the clip list and scatters it once (RCCL over xGMI); from then on
     # every rank's shard is resident in its own HBM, which is where the timed region starts.
@@ -567,16 +576,24 @@ def main():
     # ---- batch-1 latency (p50), encode / decode split ----
     latency = None
     if not args.no_latency:
+        # an engine of its own, configured the way a latency deployment is (one clip per call: the projected cross-attention
+        # form; the throughput engine above holds the form its 256-clip batches want, and an engine never mixes forms)
+        eng_l = Engine(local_rank)
+        with tempfile.TemporaryDirectory() as dl:
+            pl = os.path.join(dl, "model.safetensors")
+            save_safetensors(pl, w, {"arch": cfg.name, "heads": str(cfg.heads)})
+            eng_l.load_weights_file(pl)
+        eng_l.set_cross_mode("kv")
         one = [ptrs[0]]
         for _ in range(3):
-            eng.transcribe_tokens(device_ptrs=one, forced_steps=args.decode_steps)
+            eng_l.transcribe_tokens(device_ptrs=one, forced_steps=args.decode_steps)
         tot, enc_t, dec_t = [], [], []
         for _ in range(50):   # p50 over >= 50 repetitions after warm-up
             a = time.perf_counter()
-            eng.encode(device_ptrs=one)
-            eng.synchronize()
+            eng_l.encode(device_ptrs=one)
+            eng_l.synchronize()
             b = time.perf_counter()
-            eng.decode(forced_steps=args.decode_steps)
+            eng_l.decode(forced_steps=args.decode_steps)
             c = time.perf_counter()
             tot.append((c - a) * 1e3)
             enc_t.append((b - a) * 1e3)
@@ -585,6 +602,7 @@ def main():
                    "p50_decode": round(statistics.median(dec_t), 3), "decode_steps": args.decode_steps, "runs": 50,
                    # BASELINE.json configs[1] (batch = 1, one 10 s clip) as a rate
                    "audio_seconds_per_sec": round(CLIP_SECONDS / (statistics.median(tot) * 1e-3), 1)}
+        eng_l.close()
 
     # ---- CPU baseline on this box's host cores (rank 0, N = 1 only).  The reference's own CPU path (ONNX Runtime + int8
     # .ort graphs) is not buildable, so two stand-ins are timed on a bounded sample and the FASTER one
@@ -627,6 +645,10 @@ def main():
                 "clips": ns, "clips_with_ids_equal_to_gpu": sum(int(a == list(b)) for a, b in zip(toks_hs, ids_s)),
                 "what": "tied embedding x 4 (sharp_weights): >= 99 % of the decode positions clear the 0.1 margin; free-running "
                         f"{args.decode_steps}-step ids of the HF fp32 CPU run against the GPU's"}
+            # (the driver's record keeps `sample` but not nested keys: say it there too)
+            cands[-1]["sample"] += (f"; ids equal to the GPU's free run on {cands[-1]['clips_with_ids_equal_to_gpu']} of {nb} clips with the plain "
+                                    f"random weights (near-tie cascades) and on {cands[-1]['sharpened_checkpoint']['clips_with_ids_equal_to_gpu']} of {ns} "
+                                    "with the sharpened checkpoint (margins of a trained model)")
         except Exception as e:  # transformers missing / incompatible: keep the numpy port
             print(f"HF CPU baseline skipped: {e}", file=sys.stderr)
         n_clips = min(args.cpu_clips, 3)
@@ -662,6 +684,7 @@ def main():
     if world == 1 and not args.no_fp8:
         try:
             eng.set_batches_in_flight(0)
+            eng.set_cross_mode("kv")     # fp8 keys are projected keys: the absorbed form has none
             eng.set_kv_dtype("fp8")
             ids8 = eng.transcribe_tokens(device_ptrs=ptrs, forced_steps=args.decode_steps)   # allocates, captures its graph
             torch.cuda.synchronize()
@@ -706,6 +729,7 @@ def main():
             try:
                 eng.set_batches_in_flight(0)
                 eng.set_kv_dtype("bf16")
+                eng.set_cross_mode(xmode)
             except Exception:
                 pass
 
@@ -747,7 +771,7 @@ def main():
                    # steps are independent batches; up to this many are in flight per GPU (own stream + workspace each),
                    # the timed region still contains exactly `steps` complete passes
                    "batches_in_flight": F, "ids_match_serial_pass": ids_match,
-                   # form of the decoder's cross-attention on this run (msh_set_cross_mode, automatic by batch size):
+                   # form of the decoder's cross-attention on this run (msh_set_cross_mode; one form per engine, --cross-attention):
                    # "absorbed" = one pass over the encoder output for all heads (k_xattn.hip), "kv" = K^T / V^T stream
                    "cross_attention": "absorbed" if absorbed else "kv",
                    # the strict one-batch-at-a-time figure and the drop-in call under the reference's default options, here

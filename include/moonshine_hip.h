@@ -170,7 +170,8 @@ MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
 /* Test hook: copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
  * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]; "cross_k", "cross_v": K^T / V^T of the last
  * msh_encode, [layers][hidden * keys] at 2 bytes (bf16) or 1 byte (fp8) per key) to host memory; returns the buffer's
- * size in bytes, -1 on error.  No reference counterpart (ORT owns these tensors there). */
+ * size in bytes, -1 on error.  "graph_captures" (dst unused) returns the number of decode-step hipGraphs this engine has
+ * instantiated so far (captured steps are cached per batch shape).  No reference counterpart (ORT owns these tensors there). */
 MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
 /* Developer hook: self-test of the library's device allocator (odd sizes, pageable copies, interior slices); 0 = ok.
  * Meant for MSH_GUARD_ALLOC=1 (tools/gpu_guard.sh), where every buffer ends on an unmapped page. */
@@ -200,16 +201,22 @@ MSH_EXPORT int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_
 MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h,
                                     float* out_w, int32_t* out_pos);
 
-/* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  0 = automatic: from
- * MSH_XATTN_MIN_BATCH (default 192) clips per batch on, the "absorbed" form -- the key projection moved onto the query
- * (qt_h = Wk_h^T q_h) and the value projection onto the output projection (Wo_h Wv_h), so that a decode step reads the
- * encoder output ONCE per layer for all heads instead of K^T and V^T: half the bytes of the kernel that bounds batched
- * decode and no cross-K/V projection in the encoder (k_xattn.hip); below that the classic K^T / V^T stream.  1 = always
- * classic.  2 = absorbed whenever the architecture supports it (8 heads, hidden 288 / 416).  Word-timestamp capture and
- * kv_dtype = fp8 always use the classic form.  Applies to the next msh_encode; set it before msh_set_batches_in_flight. */
+/* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  ONE form per engine,
+ * whatever the batch size -- a clip's token ids never depend on how many clips share its batch:
+ *   1 (and 0, the default) = the projected K^T / V^T stream, the reference's form;
+ *   2 = the "absorbed" form -- the key projection moved onto the query (qt_h = Wk_h^T q_h) and the value projection onto the
+ *       output projection (Wo_h Wv_h), so that a decode step reads the encoder output ONCE per layer for all heads instead
+ *       of K^T and V^T: half the bytes of the kernel that bounds batched decode and no cross-K/V projection in the encoder
+ *       (k_xattn.hip).  It pays from ~192 clips per batch on (one workgroup per clip); the host layer's
+ *       `cross_attention=auto` picks it at LOAD when the configured sub-batch size (`batch_clips`) is >= 192.
+ * Mode 2 is an error (of this call, or of the next msh_encode) where it cannot be honoured: an architecture without the
+ * absorbed operands (msh_cross_absorbed_supported), the word-timestamp capture, kv_dtype = fp8.  Applies to the next
+ * msh_encode; set it before msh_set_batches_in_flight. */
 MSH_EXPORT int32_t msh_set_cross_mode(msh_engine* e, int32_t mode);
-/* 1 if the batch encoded last decodes with the absorbed form, else 0. */
+/* 1 if the batch encoded last decodes (with lanes: if the engine's batches decode) with the absorbed form, else 0. */
 MSH_EXPORT int32_t msh_cross_absorbed(const msh_engine* e);
+/* 1 if the loaded weights include the absorbed form's operands (8 heads, hidden 288 / 416), else 0. */
+MSH_EXPORT int32_t msh_cross_absorbed_supported(const msh_engine* e);
 /* Test / developer hook: the absorbed cross-attention kernel alone.  M clips, clip b = Ts[b] rows of `enc` [R][D] (fp32,
  * rounded to bf16 inside) from row row_starts[b]; qt [M][8 * D] fp32 (scores = qt_h . enc[t], already in the exp2 domain);
  * ctx_out [M][8 * D] fp32 receives the kernel's bf16 output (softmax_t(qt_h . enc[t]) weighted sum of the rows, per head).

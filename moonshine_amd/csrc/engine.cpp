@@ -67,13 +67,15 @@ bool enc_store_nt(bool shared_gpu) {
   }();
   return forced >= 0 ? forced != 0 : (shared_gpu && kEncStoreNtInLanes);
 }
-// smallest batch that decodes with the absorbed cross-attention when the mode is automatic (Engine::set_cross_mode)
+// Developer knob MSH_XATTN_MIN_BATCH=n (> 0): mode 0 switches to the absorbed form per batch from n clips on, as round 4 did
+// (A/B measurements only: a production engine has ONE form, Engine::set_cross_mode).  Where the absorbed form pays: one
+// workgroup per clip, so below ~200 clips most of the chip idles through the kernel and its two wider GEMMs cost more than
+// the halved stream saves (64 / 128 / 256 clips x 10 s: 8.7 / 12.0 / 17.8 us against 9 / 15 / 28.9) -- the host layer's
+// `auto` picks it when the configured sub-batch size is >= 192 (transcriber.cpp).
 int xattn_min_batch() {
   static const int v = [] {
     const char* e = getenv("MSH_XATTN_MIN_BATCH");
-    // one workgroup per clip: below ~200 clips most of the chip idles through the kernel and its two wider GEMMs cost more
-    // than the halved stream saves (measured at 64 / 128 / 256 clips x 10 s: 8.7 / 12.0 / 17.8 us against 9 / 15 / 28.9)
-    return e != nullptr ? atoi(e) : 192;
+    return e != nullptr ? atoi(e) : 0;
   }();
   return v;
 }
@@ -198,9 +200,12 @@ void device_free(void* p) {
   // unmapped addresses for the rest of the process.
 }
 
-std::mutex& device_structure_mutex() {
-  static std::mutex* m = new std::mutex();
-  return *m;
+std::mutex& device_structure_mutex(int device) {
+  // one per DEVICE: hipMalloc / hipFree synchronise their own device only, and a capture is a property of a stream of one
+  // device -- eight engines on eight GPUs of one process (options num_gpus / devices) warm up side by side, not in a queue
+  static std::mutex* m = new std::mutex[65];
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 64;
+  return m[device >= 0 && device < 64 ? device : 64];
 }
 
 void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -911,8 +916,15 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   // Cross-attention form of this batch (k_xattn.hip): absorbed = the decode steps attend over ENC_ itself and no K^T / V^T
   // is projected.  One workgroup per clip: it needs a batch that fills the chip, the classic form (8 workgroups per clip)
   // stays for small batches, for the word-timestamp capture (which reads K^T) and for fp8 keys.
-  absorbed_ = !dec_.empty() && dec_[0].wvo != nullptr && !capture_cross_ && !kv_fp8_ &&
-              (cross_mode_ == 2 || (cross_mode_ == 0 && (int)count >= xattn_min_batch()));
+  // The form is a property of the ENGINE (set_cross_mode), never of the batch: the same clip decodes to the same ids whatever
+  // shares its batch.  (MSH_XATTN_MIN_BATCH=n restores the round-4 per-batch switch of mode 0 for A/B measurements only.)
+  if (cross_mode_ == 2 && (!cross_absorbed_available() || capture_cross_ || kv_fp8_))
+    throw std::invalid_argument(std::string("cross_attention = absorbed cannot be honoured: ") +
+                                (!cross_absorbed_available() ? "this architecture has no absorbed operands"
+                                 : capture_cross_            ? "the word-timestamp capture reads the projected keys"
+                                                             : "kv_dtype = fp8 stores projected keys"));
+  absorbed_ = cross_mode_ == 2 || (cross_mode_ == 0 && xattn_min_batch() > 0 && cross_absorbed_available() && !capture_cross_ &&
+                                   !kv_fp8_ && (int)count >= xattn_min_batch());
   if (!absorbed_) {
     moved |= KT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
     moved |= VT_.reserve((size_t)L * D * kv_keys_ * kv_bytes());
@@ -1133,14 +1145,34 @@ struct Engine::DecodeGroup {
   bool fused_argmax = false;  // LM head writes per-tile (max, index) pairs instead of logits
   DecodeState state{};        // of the last decode() (profile_decode_chain replays its kernels)
   bool has_state = false;
-  hipGraphExec_t graph = nullptr;     // one decode step
-  hipGraphExec_t graph_n = nullptr;   // graph_steps() consecutive steps in one replay (the loop's steady state)
-  std::string key;
+  // Captured decode steps, a small LRU by shape key (everything baked into the kernel arguments): real batch calls are
+  // ragged -- clip count, frames and step budget change from call to call -- and a one-entry cache re-captured on almost
+  // every batch.  `g1` = one step, `gn` = graph_steps() consecutive steps in one replay (the loop's steady state); gn is
+  // ~9x the nodes, so only the first shape an engine sees (fixed-shape workloads) and shapes that come back get one.
+  struct GraphEntry {
+    std::string key;
+    hipGraphExec_t g1 = nullptr, gn = nullptr;
+    uint64_t last = 0;
+    uint32_t uses = 0;
+  };
+  static constexpr size_t kGraphCache = 8;
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0, graphs_ws_gen = 0, graphs_gen = 0;
+  uint64_t captures = 0;              // graphs instantiated so far (msh_debug counter: tests assert the cache works)
+  hipGraphExec_t graph = nullptr;     // of the current batch: one decode step (owned by `graphs`)
+  hipGraphExec_t graph_n = nullptr;   // of the current batch: graph_steps() steps, or null (owned by `graphs`)
   uint64_t gen = 0;
   int32_t n_active_h = 0;
+  void drop_graphs() {
+    for (GraphEntry& ge : graphs) {
+      if (ge.g1) (void)hipGraphExecDestroy(ge.g1);
+      if (ge.gn) (void)hipGraphExecDestroy(ge.gn);
+    }
+    graphs.clear();
+    graph = graph_n = nullptr;
+  }
   ~DecodeGroup() {
-    if (graph) (void)hipGraphExecDestroy(graph);
-    if (graph_n) (void)hipGraphExecDestroy(graph_n);
+    drop_graphs();
     DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher,
                       &pval, &pidx};
     for (DevBuf* b : bufs) b->release();
@@ -1195,6 +1227,11 @@ size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
     MSH_HIP(hipStreamSynchronize(stream_));
     if (dst != nullptr && bytes > 0) copy_blocking(dst, name == "cross_k" ? KT_.p : VT_.p, std::min(bytes, size), hipMemcpyDeviceToHost);
     return size;
+  }
+  if (name == "graph_captures") {   // decode-step graphs instantiated so far (the LRU of DecodeGroup::graphs at work)
+    size_t n = 0;
+    for (const auto& g : groups_) n += (size_t)g->captures;
+    return n;
   }
   if (groups_.empty()) throw std::runtime_error("debug_read: no decode() yet");
   DecodeGroup& g = *groups_[0];
@@ -1476,7 +1513,10 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     throw std::invalid_argument("decode: tokens_stride " + std::to_string(tokens_stride) + " < steps+1 = " +
                                 std::to_string(stride));
   if (teacher != nullptr && teacher_stride < 1) throw std::invalid_argument("decode: bad teacher stride");
-  Smax_ = round_up(steps, 8);
+  // K / V cache rows per (clip, head) and the device-side token stride: capacity BUCKETS (a stride, not a length -- the
+  // kernels read up to the current position), so that the captured graphs survive a changing step budget
+  Smax_ = steps <= 72 ? 72 : steps <= 144 ? 144 : steps <= 288 ? 288 : 512;
+  const int dstride = Smax_ + 8;   // >= steps + 1
   if (capture_cross_) {
     int tmax = 0;
     for (const ClipMeta& c : clips_h_) tmax = std::max(tmax, c.T);
@@ -1541,17 +1581,17 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     }
     moved |= g.cacheK.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
     moved |= g.cacheV.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
-    moved |= g.tokens.reserve((size_t)M * stride * sizeof(int32_t));
+    moved |= g.tokens.reserve((size_t)M * dstride * sizeof(int32_t));
     moved |= g.counts.reserve((size_t)M * sizeof(int32_t));
     moved |= g.finished.reserve((size_t)M * sizeof(int32_t));
     moved |= g.scalars.reserve(16 * sizeof(int32_t));
-    if (teacher) moved |= g.teacher.reserve((size_t)M * stride * sizeof(int32_t));
+    if (teacher) moved |= g.teacher.reserve((size_t)M * dstride * sizeof(int32_t));
     if (moved) ++g.gen;
     if (teacher) {
-      std::vector<int32_t> t((size_t)M * stride, 0);
+      std::vector<int32_t> t((size_t)M * dstride, 0);
       for (int b = 0; b < M; ++b)
         for (int i = 0; i < stride && i < teacher_stride; ++i)
-          t[(size_t)b * stride + i] = teacher[(size_t)(g.first + b) * teacher_stride + i];
+          t[(size_t)b * dstride + i] = teacher[(size_t)(g.first + b) * teacher_stride + i];
       copy_blocking(g.teacher.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     DecodeState& st = states[gi];
@@ -1561,7 +1601,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     st.pos = g.scalars.as<int32_t>();
     st.n_active = g.scalars.as<int32_t>() + 1;
     st.forced = teacher ? g.teacher.as<int32_t>() : nullptr;
-    st.stride = stride;
+    st.stride = dstride;
     st.eos = cfg_.eos;
     st.ignore_eos = forced ? 1 : 0;
     const ClipMeta* clips = clips_d_.as<ClipMeta>() + g.first;
@@ -1569,52 +1609,69 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     if (g.own_stream) MSH_HIP(hipStreamWaitEvent(g.stream, enc_done_, 0));
     decode_begin(M, st, cfg_.bos, embed_f32_, D, g.dH.as<float>(), g.stream);
     if (!eager) {
-      // everything baked into the captured kernel arguments
-      const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(ws_gen_) + ":" +
-                              std::to_string(g.gen) + ":" + std::to_string(Smax_) + ":" + std::to_string(stride) + ":" +
+      // everything baked into the captured kernel arguments (the step budget is not: it lives in the clips' metadata)
+      const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(Smax_) + ":" +
                               std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
-                              std::to_string(kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" + std::to_string(kv_fp8_) + ":" +
-                              std::to_string(absorbed_);
-      if (g.graph == nullptr || g.key != key) {
-        for (hipGraphExec_t* ge : {&g.graph, &g.graph_n})
-          if (*ge) {
-            MSH_HIP(hipGraphExecDestroy(*ge));
-            *ge = nullptr;
-          }
-        g.key.clear();
-        // nothing step-dependent is a kernel argument (position, counters and ids live in device memory), so n consecutive
-        // steps captured into ONE graph are n times the same nodes: the loop below replays that one wherever n whole steps
-        // are left -- one graph launch (its start / end packets and the gap between two replays) per n steps instead of per step
-        auto capture = [&](int n_steps, hipGraphExec_t* out) {
-          hipGraph_t gr = nullptr;
-          std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
-          MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-          try {
-            for (int r = 0; r < n_steps; ++r) {
-              decode_step_enqueue(g);
-              if (g.fused_argmax)
-                decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
-                                        g.dH.as<float>(), g.stream);
-              else
-                decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
-            }
-          } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
-            (void)hipStreamEndCapture(g.stream, &gr);
-            if (gr != nullptr) (void)hipGraphDestroy(gr);
-            throw;
-          }
-          MSH_HIP(hipStreamEndCapture(g.stream, &gr));
-          const hipError_t inst = hipGraphInstantiate(out, gr, nullptr, nullptr, 0);
-          (void)hipGraphDestroy(gr);
-          if (inst != hipSuccess) {
-            *out = nullptr;
-            MSH_HIP(inst);
-          }
-        };
-        capture(1, &g.graph);
-        if (graph_steps() > 1) capture(graph_steps(), &g.graph_n);
-        g.key = key;
+                              std::to_string(absorbed_ ? 0 : kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" +
+                              std::to_string(kv_fp8_) + ":" + std::to_string(absorbed_);
+      if (g.graphs_ws_gen != ws_gen_ || g.graphs_gen != g.gen) {   // a workspace moved: every captured pointer is stale
+        g.drop_graphs();
+        g.graphs_ws_gen = ws_gen_, g.graphs_gen = g.gen;
       }
+      // nothing step-dependent is a kernel argument (position, counters and ids live in device memory), so n consecutive
+      // steps captured into ONE graph are n times the same nodes: the loop below replays that one wherever n whole steps
+      // are left -- one graph launch (its start / end packets and the gap between two replays) per n steps instead of per step
+      auto capture = [&](int n_steps, hipGraphExec_t* out) {
+        hipGraph_t gr = nullptr;
+        std::lock_guard<std::mutex> structure_lock(device_structure_mutex(device_));
+        MSH_HIP(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        try {
+          for (int r = 0; r < n_steps; ++r) {
+            decode_step_enqueue(g);
+            if (g.fused_argmax)
+              decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
+                                      g.dH.as<float>(), g.stream);
+            else
+              decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
+          }
+        } catch (...) {   // never leave the stream in capture mode: end it, drop the partial graph, report the real error
+          (void)hipStreamEndCapture(g.stream, &gr);
+          if (gr != nullptr) (void)hipGraphDestroy(gr);
+          throw;
+        }
+        MSH_HIP(hipStreamEndCapture(g.stream, &gr));
+        const hipError_t inst = hipGraphInstantiate(out, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (inst != hipSuccess) {
+          *out = nullptr;
+          MSH_HIP(inst);
+        }
+        ++g.captures;
+      };
+      DecodeGroup::GraphEntry* ent = nullptr;
+      for (DecodeGroup::GraphEntry& ge : g.graphs)
+        if (ge.key == key) ent = &ge;
+      const bool first_shape = g.graphs.empty();
+      if (ent == nullptr) {
+        if (g.graphs.size() >= DecodeGroup::kGraphCache) {   // evict the least recently used shape
+          size_t lru = 0;
+          for (size_t k = 1; k < g.graphs.size(); ++k)
+            if (g.graphs[k].last < g.graphs[lru].last) lru = k;
+          if (g.graphs[lru].g1) MSH_HIP(hipGraphExecDestroy(g.graphs[lru].g1));
+          if (g.graphs[lru].gn) MSH_HIP(hipGraphExecDestroy(g.graphs[lru].gn));
+          g.graphs.erase(g.graphs.begin() + (long)lru);
+        }
+        g.graphs.emplace_back();
+        ent = &g.graphs.back();
+        ent->key = key;
+        capture(1, &ent->g1);
+      }
+      ++ent->uses;
+      ent->last = ++g.graph_clock;
+      if (ent->gn == nullptr && graph_steps() > 1 && steps >= graph_steps() && (first_shape || ent->uses >= 2))
+        capture(graph_steps(), &ent->gn);
+      g.graph = ent->g1;
+      g.graph_n = ent->gn;
     }
     g.n_active_h = M;
     g.state = st;
@@ -1622,11 +1679,13 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
   }
 
   int steps_run = 0;
+  bool have_n = true;   // every group holds the multi-step graph of this shape
+  for (int gi = 0; gi < ngroups; ++gi) have_n = have_n && groups_[gi]->graph_n != nullptr;
   const int gsteps = graph_steps();   // 8 = the interval at which the host looks at the active-clip counter anyway
   for (int i = 0; i < steps; ++i) {
     // a whole block of steps in one replay: from a block boundary, when that many steps are left (the reference loop stops
     // at EOS / budget per clip -- finished clips are masked on the device, the host only checks between blocks)
-    const bool block = !eager && gsteps > 1 && (i % gsteps) == 0 && i + gsteps <= steps;
+    const bool block = !eager && have_n && gsteps > 1 && (i % gsteps) == 0 && i + gsteps <= steps;
     for (int gi = 0; gi < ngroups; ++gi) {
       DecodeGroup& g = *groups_[gi];
       if (g.n_active_h <= 0) continue;
@@ -1673,7 +1732,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
   for (int gi = 0; gi < ngroups; ++gi) {
     DecodeGroup& g = *groups_[gi];
     if (tokens_out != nullptr || counts_out != nullptr) {
-      std::vector<int32_t> tk((size_t)g.M * stride), cn(g.M);
+      std::vector<int32_t> tk((size_t)g.M * dstride), cn(g.M);
       MSH_HIP(hipMemcpyAsync(tk.data(), g.tokens.p, tk.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
       MSH_HIP(hipMemcpyAsync(cn.data(), g.counts.p, cn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
       MSH_HIP(hipStreamSynchronize(g.stream));
@@ -1682,7 +1741,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
         if (counts_out) counts_out[gb] = cn[b];
         if (tokens_out)
           for (int i = 0; i < tokens_stride; ++i)
-            tokens_out[(size_t)gb * tokens_stride + i] = i < cn[b] ? tk[(size_t)b * stride + i] : -1;
+            tokens_out[(size_t)gb * tokens_stride + i] = i < cn[b] ? tk[(size_t)b * dstride + i] : -1;
       }
     } else {
       MSH_HIP(hipStreamSynchronize(g.stream));

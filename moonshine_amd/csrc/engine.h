@@ -96,17 +96,23 @@ class Engine {
     if (on && absorbed_) encoded_ = false;   // the capture reads K^T, which the absorbed form never writes: encode again
     capture_cross_ = on;
   }
-  // How the decoder's cross-attention runs (k_xattn.hip): 0 = automatic (the absorbed form -- one pass over the encoder
-  // output, no cross K/V -- from xattn_min_batch() = 192 clips on, the classic K^T / V^T stream below), 1 = always classic,
-  // 2 = absorbed whenever the shape supports it.  Applies to the next encode; lanes take it when they are created.
+  // How the decoder's cross-attention runs (k_xattn.hip): 1 (and 0, the default) = the projected K^T / V^T stream, the
+  // reference's form; 2 = the absorbed form -- one pass over the encoder output for all heads, no cross K/V.  ONE form per
+  // engine whatever the batch size: a clip's ids never depend on how many clips share its batch (until round 4 mode 0
+  // switched by batch size; the host layer now resolves its `auto` ONCE at load, from the configured sub-batch size).
+  // Mode 2 on an architecture without the absorbed operands, with the word-timestamp capture or with fp8 keys is an error
+  // of the next encode, not a silent change of form.  Applies to the next encode; lanes take it when they are created.
   void set_cross_mode(int mode) {
-    if (mode < 0 || mode > 2) throw std::invalid_argument("cross mode: 0 = auto, 1 = projected K/V, 2 = absorbed");
+    if (mode < 0 || mode > 2) throw std::invalid_argument("cross mode: 0 / 1 = projected K/V, 2 = absorbed");
+    if (mode == 2 && loaded_ && !cross_absorbed_available())
+      throw std::invalid_argument("cross mode 2 (absorbed): this architecture has no absorbed operands (8 heads, hidden 288 / 416 only)");
     if (mode != cross_mode_) {
       cross_mode_ = mode;
       encoded_ = false;
     }
   }
   int cross_mode() const { return cross_mode_; }
+  bool cross_absorbed_available() const { return !dec_.empty() && dec_[0].wvo != nullptr; }
   // this engine is one of several lanes that decode at the same time on one GPU (BatchPipeline): its once-per-launch streams
   // go with the non-temporal policy (kernels.h dec_cross_absorbed)
   void set_shared_gpu(bool on) { shared_gpu_ = on; }

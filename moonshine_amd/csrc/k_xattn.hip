@@ -27,6 +27,7 @@
 //                          (B: the S^T accumulator layout IS the 16x16x16 B-operand layout), MFMA 16x16x16, D/16 tiles.
 // At the end the four waves' (m, l, C) are merged through LDS (the ring is dead by then) and ctx is written as the bf16
 // fragment-major A operand of the residual GEMM (kernels.h fm16, K = heads * D).
+#include <atomic>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -472,12 +473,16 @@ template <int D, bool TR, int NWAVES, int NS, int ABL = 0, int XS = 0>
 void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s,
                          unsigned long long* dbg = nullptr) {
   using C = XaCfg<D, NWAVES, NS, XS>;
-  static const bool attr = [] {
+  // the attribute belongs to the (function, device) pair: engines on several GPUs of one process (options num_gpus / devices)
+  // each need it before their first launch
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  MSH_HIP(hipGetDevice(&dev));
+  if (dev >= 64 || ((attr_done.load(std::memory_order_acquire) >> dev) & 1ull) == 0) {
     MSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cross_absorbed_kernel<D, TR, NWAVES, NS, ABL, XS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-    return true;
-  }();
-  (void)attr;
+    if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
+  }
   // MSH_XATTN_XCD=0: plain block -> clip order (developer knob; see "Block -> clip" in the kernel)
   static const bool group = [] {
     const char* e = getenv("MSH_XATTN_XCD");

@@ -239,7 +239,13 @@ int32_t msh_set_cross_mode(msh_engine* e, int32_t mode) {
   });
 }
 
-int32_t msh_cross_absorbed(const msh_engine* e) { return e != nullptr && e->eng->cross_absorbed() ? 1 : 0; }
+int32_t msh_cross_absorbed(const msh_engine* e) {
+  if (e == nullptr) return 0;
+  // with lanes (msh_set_batches_in_flight) the batches are encoded by the lanes; the form is the engine's, all lanes share it
+  if (e->pipe) return e->eng->cross_mode() == 2 ? 1 : 0;
+  return e->eng->cross_absorbed() ? 1 : 0;
+}
+int32_t msh_cross_absorbed_supported(const msh_engine* e) { return e != nullptr && e->eng->cross_absorbed_available() ? 1 : 0; }
 
 int32_t msh_get_encoder_output(msh_engine* e, uint32_t clip, float* out) {
   return guarded(e, [&] {

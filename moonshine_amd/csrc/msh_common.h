@@ -85,8 +85,8 @@ inline void trace_launch_args(const char* kernel, dim3 grid, dim3 block, const A
 // Device allocation / release and graph capture never run at the same time in one process: hipMalloc / hipFree
 // synchronise the whole device behind the scenes, and doing that from one host thread while another is between
 // hipStreamBeginCapture and hipStreamEndCapture is where a (rare) crash of the multi-lane tests pointed.  Both sides
-// take this mutex; it is only ever contended while engines warm up.
-std::mutex& device_structure_mutex();
+// take this mutex (one per device since round 5); it is only ever contended while engines of ONE device warm up.
+std::mutex& device_structure_mutex(int device = -1);   // -1: the calling thread's current device
 // Every device allocation of the library (call with device_structure_mutex held).  Normally hipMalloc / hipFree.  With
 // MSH_GUARD_ALLOC=1 (diagnostic) each buffer gets its own virtual-memory mapping whose END is the end of the mapped range,
 // followed by an unmapped granule: a kernel that reads or writes 16 bytes or more past the end of ANY buffer takes a GPU

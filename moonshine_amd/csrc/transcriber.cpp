@@ -397,10 +397,6 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
   model_->batch_clips = opt_.batch_clips;
   model_->batches_in_flight = opt_.batches_in_flight;
   model_->word_timestamps = opt_.word_timestamps;
-  if (opt_.cross_attention != 0)
-    for (MoonshineModel::DeviceShard& d : model_->devices)
-      if (msh_set_cross_mode(d.engine, opt_.cross_attention) != MSH_OK)
-        throw std::runtime_error(std::string("cross_attention: ") + msh_last_error(d.engine));
   if (opt_.kv_dtype != 0) {
     if (opt_.word_timestamps) throw std::runtime_error("kv_dtype=fp8 cannot be combined with word_timestamps (the capture reads bf16 keys)");
     for (MoonshineModel::DeviceShard& d : model_->devices)
@@ -443,6 +439,21 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
     get(kTokenizerName, &o2, &t, &tn);
     if (model_->load_from_memory(w, wn, t, tn, (int32_t)opt_.model_arch) != 0)
       throw std::runtime_error("Failed to load model from memory: " + model_->error());
+  }
+  // Form of the decoder's cross-attention: ONE per transcriber, fixed here -- a clip's transcript never depends on how many
+  // clips shared its sub-batch.  `auto` = absorbed when this transcriber is configured for large sub-batches (batch_clips >=
+  // 192: where that form pays, k_xattn.hip) and nothing needs the projected keys, else the reference's projected form.
+  {
+    int mode = opt_.cross_attention;
+    const bool needs_keys = opt_.word_timestamps || opt_.kv_dtype != 0;
+    if (mode == 2 && needs_keys)
+      throw std::runtime_error("cross_attention=absorbed cannot be combined with word_timestamps or kv_dtype=fp8 (both read projected keys)");
+    for (MoonshineModel::DeviceShard& d : model_->devices) {
+      int m = mode;
+      if (m == 0) m = (opt_.batch_clips >= 192 && !needs_keys && msh_cross_absorbed_supported(d.engine) == 1) ? 2 : 1;
+      if (msh_set_cross_mode(d.engine, m) != MSH_OK)
+        throw std::runtime_error(std::string("cross_attention: ") + msh_last_error(d.engine));
+    }
   }
 }
 

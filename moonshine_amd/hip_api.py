@@ -69,6 +69,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_set_kv_dtype": (i32, [vp, i32]),
         "msh_set_cross_mode": (i32, [vp, i32]),
         "msh_cross_absorbed": (i32, [vp]),
+        "msh_cross_absorbed_supported": (i32, [vp]),
         "msh_test_cross_absorbed": (C.c_float, [vp, vp, C.c_int64, vp, vp, i32, i32, vp, i32]),
         "msh_test_crossq2": (C.c_float, [vp, vp, vp, i32, i32, vp, i32]),
         "msh_profile_enable": (i32, [vp, i32]),
@@ -139,7 +140,7 @@ DECLARED_SYMBOLS = [
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
     "msh_test_mlp_microbench", "msh_test_mlp_run", "msh_test_mlp_oproj_run", "msh_test_qkv_panel",
-    "msh_set_cross_mode", "msh_cross_absorbed", "msh_test_cross_absorbed", "msh_test_crossq2",
+    "msh_set_cross_mode", "msh_cross_absorbed", "msh_cross_absorbed_supported", "msh_test_cross_absorbed", "msh_test_crossq2",
     "msh_stream_get_features",
 ]
 
@@ -216,10 +217,18 @@ class Engine:
         """Cross K / V storage: "bf16" (default) or "fp8" (e4m3, per-row scales fixed at load); before set_batches_in_flight."""
         self._check(self.lib.msh_set_kv_dtype(self.h, {"bf16": 0, "fp8": 1}[dtype]))
 
-    def set_cross_mode(self, mode: str = "auto"):
-        """Form of the decoder's cross-attention: "auto", "kv" (projected K^T / V^T stream) or "absorbed" (one pass over the
-        encoder output for all heads, k_xattn.hip); before set_batches_in_flight."""
-        self._check(self.lib.msh_set_cross_mode(self.h, {"auto": 0, "kv": 1, "absorbed": 2}[mode]))
+    def set_cross_mode(self, mode: str = "kv"):
+        """Form of the decoder's cross-attention, ONE per engine whatever the batch size: "kv" (projected K^T / V^T stream,
+        the reference's form and the default) or "absorbed" (one pass over the encoder output for all heads, k_xattn.hip:
+        pays from ~192 clips per batch on); before set_batches_in_flight."""
+        self._check(self.lib.msh_set_cross_mode(self.h, {"default": 0, "kv": 1, "absorbed": 2}[mode]))
+
+    def cross_absorbed_supported(self) -> bool:
+        return bool(self.lib.msh_cross_absorbed_supported(self.h))
+
+    def graph_captures(self) -> int:
+        """Decode-step hipGraphs instantiated so far (captured steps are cached per batch shape)."""
+        return int(self.lib.msh_debug_read(self.h, b"graph_captures", None, 0))
 
     def cross_absorbed(self) -> bool:
         return bool(self.lib.msh_cross_absorbed(self.h))

@@ -67,3 +67,21 @@ def run(cfg, w, clips: list[np.ndarray], steps: int, batch: int, threads: int):
     for i in range(0, len(clips), batch):
         out += greedy(model, cfg, np.stack(clips[i:i + batch]), steps)
     return out, time.perf_counter() - t0
+
+
+def teacher_forced_logits(model, clips: np.ndarray, teacher: np.ndarray, sub_batch: int = 32) -> np.ndarray:
+    """clips [B, n] fp32, teacher [B, S + 1] ids (BOS first) -> logits [B, S, V] fp32: logits[b, i] is what the decoder
+    predicts after consuming teacher[b, :i + 1] -- the quantity step i of the reference loop takes its argmax of
+    (core/moonshine-model.cpp:380-517), computed for all positions in ONE causal decoder call per sub-batch (no cascade:
+    every position sees the teacher's ids, whatever the model itself would have picked)."""
+    import torch
+
+    out = []
+    with torch.no_grad():
+        for i in range(0, clips.shape[0], sub_batch):
+            x = torch.from_numpy(np.ascontiguousarray(clips[i:i + sub_batch]))
+            ids = torch.from_numpy(np.ascontiguousarray(teacher[i:i + sub_batch, :-1]).astype(np.int64))
+            enc_out = model.model.encoder(x)
+            res = model(decoder_input_ids=ids, encoder_outputs=enc_out, use_cache=False)
+            out.append(res.logits.float().numpy())
+    return np.concatenate(out, axis=0)

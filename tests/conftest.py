@@ -10,6 +10,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
 
 
 def pytest_configure(config):
@@ -23,3 +26,14 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the margins the parity tests measured (tests/margins.py) where the GPU run scripts pick them up."""
+    import margins
+
+    path = os.environ.get("MSH_PARITY_MARGINS", os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    try:
+        margins.dump(path)
+    except OSError:
+        pass

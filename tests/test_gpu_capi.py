@@ -395,25 +395,43 @@ def test_config1_beckett_wav_through_the_c_api(tiny, tiny_dir, engine):
 
 
 def test_cross_attention_option(tiny_dir, engine):
-    """Additive load option `cross_attention` (auto | kv | absorbed -> msh_set_cross_mode): a bad value fails the load; with
-    `absorbed` the batch call decodes over the encoder output itself (k_xattn.hip) and its token ids agree with the engine's
-    own absorbed decode of the same clips (the numerics of that form against the oracle: tests/test_gpu_xattn.py)."""
+    """Additive load option `cross_attention` (auto | kv | absorbed -> msh_set_cross_mode), ONE form per transcriber, fixed at
+    load: a bad value fails the load; `absorbed` together with word_timestamps or kv_dtype=fp8 fails the load (both read
+    projected keys) instead of silently changing form; with `absorbed` the batch call decodes over the encoder output itself
+    (k_xattn.hip) and its token ids agree with the engine's own absorbed decode of the same clips (the numerics of that form
+    against the oracle: tests/test_gpu_xattn.py); `auto` resolves from the configured sub-batch size -- absorbed for
+    batch_clips >= 192, the reference's projected form below -- whatever the size of the call at hand."""
     with pytest.raises(Exception):
         api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "sideways"})
+    with pytest.raises(Exception):
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "absorbed", "word_timestamps": "true"})
+    with pytest.raises(Exception):
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "absorbed", "kv_dtype": "fp8"})
     vocab = synthetic_vocab(ARCHS["tiny"].vocab)
-    clips = [make_audio(60 + i, n) for i, n in enumerate([16000, 48000, 30720, 80384])]
+    clips = [make_audio(60 + i, n) for i, n in enumerate([16000, 48000, 30720, 80384, 20480, 64000, 33280, 51200])]
     clips = [c[: (len(c) // 512) * 512] for c in clips]
-    t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "absorbed"})
-    try:
-        got = t.transcribe_batch_without_streaming(clips)
-    finally:
-        t.close()
-    engine.set_cross_mode("absorbed")
-    try:
-        want_ids = engine.transcribe_tokens(clips)
-        assert engine.cross_absorbed()
-    finally:
-        engine.set_cross_mode("auto")
-    for lines, ids in zip(got, want_ids):
-        assert len(lines) == 1
-        assert lines[0].text_bytes == host_ref.sanitize_text(host_ref.tokens_to_text(vocab, ids))
+
+    def texts(options):
+        t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, dict({"vad_threshold": "0"}, **options))
+        try:
+            got = t.transcribe_batch_without_streaming(clips)
+        finally:
+            t.close()
+        assert all(len(lines) == 1 for lines in got)
+        return [lines[0].text_bytes for lines in got]
+
+    want = {}
+    for form in ("absorbed", "kv"):
+        engine.set_cross_mode(form)
+        try:
+            ids = engine.transcribe_tokens(clips)
+            assert engine.cross_absorbed() == (form == "absorbed")
+        finally:
+            engine.set_cross_mode("kv")
+        want[form] = [host_ref.sanitize_text(host_ref.tokens_to_text(vocab, t)) for t in ids]
+    assert texts({"cross_attention": "absorbed"}) == want["absorbed"]
+    assert texts({"cross_attention": "kv", "batch_clips": "256"}) == want["kv"]
+    # auto: by the CONFIGURED sub-batch size, not by the 8 clips of this call
+    assert texts({"batch_clips": "256"}) == want["absorbed"]
+    assert texts({"batch_clips": "64"}) == want["kv"]
+    assert texts({"batch_clips": "256", "word_timestamps": "true"}) == want["kv"]

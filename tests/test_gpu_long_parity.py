@@ -18,6 +18,7 @@ import os
 import numpy as np
 import pytest
 
+from margins import record as record_margin
 from oracle import moonshine_ref as ref
 from oracle.host_ref import max_decode_len
 from oracle.weights import ARCHS, make_audio, make_weights, save_safetensors
@@ -106,6 +107,8 @@ def _ids_and_logits_vs_oracle(e, w, cfg, clips, picked, steps, logit_steps):
                     worst_1frame = max(worst_1frame, d)
                 else:
                     worst_logit = max(worst_logit, d)
+    record_margin(logits_max_abs=worst_logit, logits_max_abs_one_frame_clip=worst_1frame, encoder_rel_rms=worst_enc, ids_checked=checked,
+                   near_tie_flips=flips, clips_checked=len(picked), steps=steps)
     assert worst_logit <= LOGIT_MAXABS, worst_logit
     assert worst_1frame <= LOGIT_MAXABS_1FRAME, worst_1frame
     assert checked >= len(picked) * steps // 2, (checked, flips)
@@ -158,6 +161,7 @@ def test_tiny_capacity_clip_full_budget_vs_oracle(tiny):
             if float(top2[1] - top2[0]) > MARGIN:
                 assert toks[b][i + 1] == o_toks[i + 1], (b, i)
                 checked += 1
+    record_margin(ids_checked=checked, ids_total=1008, steps=504)
     assert checked >= 504
     print(f"capacity clip: {checked} of 1008 ids checked against the oracle over 504 steps")
 
@@ -239,6 +243,7 @@ def test_sharpened_checkpoint_free_running_ids(tmp_path_factory):
         else:
             k = next(i for i in range(steps) if got[b][i + 1] != o_toks[i + 1])
             assert margins[k] <= MARGIN, (b, k, margins[k])      # a flip may only start at a near-tie
+    record_margin(clips=n, clips_with_ids_equal_to_oracle_free_run=equal, positions_clear_of_margin=clear / total)
     print(f"sharpened checkpoint: {equal} of {n} clips with ids equal to the oracle's free run; {clear / total:.3f} of the positions clear {MARGIN}")
     assert clear / total >= 0.95
     assert equal >= (9 * n + 9) // 10, equal

@@ -12,6 +12,7 @@ import os
 import numpy as np
 import pytest
 
+import margins
 from oracle import moonshine_ref as ref
 from oracle.host_ref import max_decode_len
 from oracle.weights import ARCHS, make_audio, make_weights, save_safetensors
@@ -52,6 +53,9 @@ def _enc_check(got, want):
     err = got - want
     relrms = float(np.sqrt((err**2).mean()) / np.sqrt((want**2).mean()))
     maxabs = float(np.abs(err).max())
+    prev = margins.RECORDS.get(os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" (")[0], {})
+    margins.record(encoder_rel_rms=max(relrms, prev.get("encoder_rel_rms", 0.0)), encoder_max_abs=max(maxabs, prev.get("encoder_max_abs", 0.0)),
+                   encoder_checks=prev.get("encoder_checks", 0) + 1)
     assert relrms <= ENC_RELRMS, (relrms, maxabs)
     assert maxabs <= ENC_MAXABS, (relrms, maxabs)
     return relrms, maxabs
@@ -118,6 +122,7 @@ def _teacher_logit_check(e, w, cfg, clips, steps):
                 assert toks[b][i + 1] == gold[b][i + 1], (b, i, margin)
             elif toks[b][i + 1] != gold[b][i + 1]:
                 flips += 1
+    margins.record(logits_max_abs=worst, near_tie_flips=flips, clips=len(clips), steps=steps)
     assert worst <= LOGIT_MAXABS, worst
     return worst, flips
 
@@ -396,18 +401,21 @@ def test_base_batch256_benchmark_path_vs_oracle(base):
                 flips += 1
             if i < logit_steps:
                 worst = max(worst, float(np.abs(logits[i, b] - o_logits[i]).max()))
+    margins.record(logits_max_abs=worst, ids_checked=checked, near_tie_flips=flips, clips_checked=len(picked), cross_absorbed=bool(e.cross_absorbed()))
     assert worst <= LOGIT_MAXABS, worst
     assert checked >= len(picked) * steps // 2, (checked, flips)   # the check must not be vacuous
     print(f"batch-256 parity: {checked} ids checked against the oracle, {flips} near-tie flips, logits max-abs {worst:.3e}")
 
 
-def test_batches_in_flight_soak_base_256(base):
-    """Soak test of the overlapped mode bench.py quotes: 56 base batches of 256 x 10 s on 4 lanes (encoder GEMMs of one
-    batch next to the decode kernels of three others), every one bit-equal to the ids of the serial pass.  The device
-    code is built without packed-FP32 instructions (build.py checks the disassembly): with them a few
-    clips per batch used to differ."""
+@pytest.mark.parametrize("form", ["absorbed", "kv"])
+def test_batches_in_flight_soak_base_256(base, form):
+    """Soak test of the overlapped mode bench.py quotes (its cross-attention form, absorbed, and the projected one): 56 base
+    batches of 256 x 10 s on 4 lanes (encoder GEMMs of one batch next to the decode kernels of three others), every one
+    bit-equal to the ids of the serial pass.  The device code is built without packed-FP32 instructions (build.py checks
+    the disassembly): with them a few clips per batch used to differ."""
     e, _, cfg = base
     steps = 65
+    e.set_cross_mode(form)
     batches = [[make_audio(5000 + 300 * b + i, 160000) for i in range(256)] for b in range(4)]
     want = [e.transcribe_tokens(c, forced_steps=steps) for c in batches]
     assert want[0] != want[1]
@@ -423,3 +431,4 @@ def test_batches_in_flight_soak_base_256(base):
         assert not bad, f"(round, submission, differing clips): {bad}"
     finally:
         e.set_batches_in_flight(0)
+        e.set_cross_mode("kv")

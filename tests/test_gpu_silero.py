@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+import margins
 from moonshine_amd.hip_api import load_library
 from moonshine_amd.synth import make_audio, make_silero_weights, save_safetensors
 from oracle.silero_ref import SileroRef
@@ -88,6 +89,7 @@ def test_device_probabilities_match_the_oracle_and_the_host_network(blob):
             assert np.isfinite(d).all()
             worst = max(worst, float(np.abs(d - want).max()))
             worst_host = max(worst_host, float(np.abs(d - host).max()))
+    margins.record(device_vs_oracle_max_abs=worst, device_vs_host_max_abs=worst_host, tolerance=TOL)
     assert worst < TOL, worst
     assert worst_host < TOL, worst_host
     # the probabilities move (a constant output would pass a lazy tolerance on a saturated network)

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+import margins
 from oracle import streaming_ref as sr
 from oracle.weights import STREAMING_ARCHS, make_audio, make_streaming_weights, write_streaming_model_dir
 
@@ -81,6 +82,9 @@ def test_stream_matches_reference_graphs(tmp_path, name):
     assert mem_lens == g["mem_lens"].tolist()
     feats, mem = eng.features(s), eng.memory(s)
     assert feats.shape == g["features"].shape and mem.shape == g["memory"].shape
+    margins.record(features_rel_rms=float(relrms(feats, g["features"])), features_max_abs=float(np.abs(feats - g["features"]).max()),
+                   memory_rel_rms=float(relrms(mem, g["memory"])), memory_max_abs=float(np.abs(mem - g["memory"]).max()),
+                   tolerances="features rel-RMS 1e-2 / max-abs 8e-2, memory twice that, logits max-abs 6e-2")
     assert relrms(feats, g["features"]) < RELRMS and np.abs(feats - g["features"]).max() < MAXABS
     assert relrms(mem, g["memory"]) < 2 * RELRMS and np.abs(mem - g["memory"]).max() < 2 * MAXABS
     # wide (teacher-forced) pass over the golden tokens
@@ -90,6 +94,8 @@ def test_stream_matches_reference_graphs(tmp_path, name):
     assert eng.cache_len(s) == len(toks) - 1
     ti = g["wide_top8_idx"].astype(np.int64)
     got = np.take_along_axis(logits, ti, axis=-1)
+    margins.record(logits_max_abs_top8=float(np.abs(got - g["wide_top8_val"]).max()),
+                   logits_max_abs_first64=float(np.abs(logits[:, :64] - g["wide_logits_sel"]).max()))
     assert np.abs(got - g["wide_top8_val"]).max() < LOGIT_MAXABS
     assert np.abs(logits[:, :64] - g["wide_logits_sel"]).max() < LOGIT_MAXABS
     margin = g["wide_top8_val"][:, 0] - g["wide_top8_val"][:, 1]
@@ -99,6 +105,7 @@ def test_stream_matches_reference_graphs(tmp_path, name):
     # one token per call reproduces the wide pass (cache growth path)
     eng.decoder_reset([s])
     step = np.stack([eng.decode_tokens([s], [[t]])[0][0] for t in toks[:-1]])
+    margins.record(step_vs_wide_max_abs=float(np.abs(step - logits).max()))
     assert np.abs(step - logits).max() < 2e-2
     eng.close()
 

@@ -238,34 +238,73 @@ def test_base_batch256_benchmark_path_vs_oracle_absorbed(base_x):
     assert base_x[0].cross_absorbed()
 
 
-def test_automatic_mode_picks_the_form_by_batch_size(tmp_path_factory):
-    """Mode 0: absorbed from MSH_XATTN_MIN_BATCH (192) clips on, the classic stream below; the word-timestamp capture and
-    fp8 keys always use the classic form; a batch's ids do not depend on which clips share it within one form."""
+def test_one_form_per_engine_whatever_the_batch_size(tmp_path_factory):
+    """An engine holds ONE cross-attention form (msh_set_cross_mode), never one per batch: the default is the reference's
+    projected form at any batch size (until round 4 mode 0 switched to the absorbed form at 192 clips, so a clip's ids
+    depended on how many neighbours it had); within a form a batch's ids do not depend on which clips share it; the
+    absorbed form refuses the word-timestamp capture and fp8 keys instead of silently changing form."""
+    from moonshine_amd.hip_api import MshError
+
     e, w, cfg = tp._engine(tmp_path_factory, "tiny", 3)
+    assert e.cross_absorbed_supported()
     clips = [make_audio(300 + i, 16000 + 37 * i) for i in range(200)]
     e.encode(clips[:8])
     assert not e.cross_absorbed()
     small = e.decode(forced_steps=6)[0]
     e.encode(clips)
-    assert e.cross_absorbed()
+    assert not e.cross_absorbed()            # 200 clips: still the projected form
     big = e.decode(forced_steps=6)[0]
-    agree = sum(a == b for a, b in zip(small, big[:8]))
-    assert agree >= 6, (small, big[:8])   # two roundings of the same function: near-ties may flip, nothing else
+    assert big[:8] == small                  # a clip alone == the same clip among 200
     e.set_cross_mode("absorbed")
-    forced = e.transcribe_tokens(clips[:8], forced_steps=6)
-    assert forced == big[:8]              # absorbed at batch 8 == absorbed inside the batch of 200
+    big_x = e.transcribe_tokens(clips, forced_steps=6)
+    assert e.cross_absorbed()
+    assert e.transcribe_tokens(clips[:8], forced_steps=6) == big_x[:8]
+    assert e.cross_absorbed()                # 8 clips: still the absorbed form
+    agree = sum(a == b for a, b in zip(small, big_x[:8]))
+    assert agree >= 6, (small, big_x[:8])    # two roundings of the same function: near-ties may flip, nothing else
+    tp.margins.record(clips_with_equal_ids_across_forms=agree, clips=8, steps=6)
+    # the word-timestamp capture reads K^T, fp8 keys are projected keys: neither is available in the absorbed form
+    e.lib.msh_set_capture_cross_attention(e.h, 1)
+    with pytest.raises(MshError):
+        e.encode(clips[:4])
+    e.lib.msh_set_capture_cross_attention(e.h, 0)
+    e.set_kv_dtype("fp8")
+    with pytest.raises(MshError):
+        e.encode(clips[:4])
+    e.set_kv_dtype("bf16")
+    assert e.transcribe_tokens(clips[:8], forced_steps=6) == big_x[:8]
     e.set_cross_mode("kv")
     assert e.transcribe_tokens(clips[:8], forced_steps=6) == small
-    e.encode(clips)
-    assert not e.cross_absorbed()
-    # the word-timestamp capture reads K^T: it always gets the classic form, and switching it on re-encodes
-    e.set_cross_mode("absorbed")
-    e.encode(clips[:4])
-    assert e.cross_absorbed()
-    e.lib.msh_set_capture_cross_attention(e.h, 1)
-    e.encode(clips[:4])
-    assert not e.cross_absorbed()
-    e.lib.msh_set_capture_cross_attention(e.h, 0)
+    # an architecture without the absorbed operands says so
+    m, _, _ = tp._engine(tmp_path_factory, "micro", 0)
+    if not m.cross_absorbed_supported():
+        with pytest.raises(MshError):
+            m.set_cross_mode("absorbed")
+
+
+def test_decode_graphs_are_cached_per_shape(tmp_path_factory):
+    """Captured decode steps are kept per batch shape in a small LRU (engine.cpp DecodeGroup::graphs): alternating between
+    shapes the engine has seen costs no further capture, a changing step budget inside one capacity bucket is the SAME
+    shape, and the multi-step graph of a new shape is only built when the shape comes back."""
+    e, w, cfg = tp._engine(tmp_path_factory, "tiny", 4)
+    a = [make_audio(500 + i, 32000) for i in range(6)]
+    b = [make_audio(520 + i, 36000 + 640 * i) for i in range(9)]
+    tb = e.transcribe_tokens(b, forced_steps=20)      # the larger shape first: the workspaces settle (a grown workspace
+    c0 = e.graph_captures()                           # invalidates every captured pointer, and with it the cache)
+    assert c0 in (1, 2)                               # first shape: one-step graph (+ the 8-step one unless MSH_DEC_GRAPH_STEPS=1)
+    multi = c0 - 1
+    ta = e.transcribe_tokens(a, forced_steps=20)
+    assert e.graph_captures() == c0 + 1               # new shape: its one-step graph only
+    assert e.transcribe_tokens(b, forced_steps=20) == tb
+    assert e.graph_captures() == c0 + 1               # back to a cached shape: nothing captured
+    ta33 = e.transcribe_tokens(a, forced_steps=33)    # another budget, same capacity bucket: the SAME shape, which has now
+    assert [t[:21] for t in ta33] == ta               # come back -> it gets its 8-step graph, once
+    c1 = e.graph_captures()
+    assert c1 == c0 + 1 + multi
+    for _ in range(3):
+        assert e.transcribe_tokens(a, forced_steps=20) == ta
+        assert e.transcribe_tokens(b, forced_steps=20) == tb
+    assert e.graph_captures() == c1
 
 
 def test_decode_gemm_tile_order_and_graph_blocking_do_not_change_ids(tmp_path_factory):

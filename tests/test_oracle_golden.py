@@ -66,3 +66,25 @@ def test_max_len_and_lengths():
     assert max_decode_len(160000) == 65                        # ceil(10 * 6.5)
     assert max_decode_len(159744) == 65
     assert max_decode_len(16000) == 7
+
+
+def test_hf_teacher_forced_helper_matches_the_oracle_and_hf_step_by_step():
+    """`oracle/hf_baseline.teacher_forced_logits` (one causal decoder call for all positions: what the full-batch GPU parity
+    test compares 256 x 65 x 32768 logits with) against (a) HF's own step-by-step KV-cache loop on the same ids and (b) the
+    numpy oracle, teacher-forced: same argmax everywhere, logits within fp32 noise."""
+    pytest.importorskip("transformers")
+    from oracle import hf_baseline as hb
+
+    cfg = ARCHS["micro"]
+    w = make_weights(cfg, 0)
+    model = hb.build_hf(cfg, w)
+    clips = np.stack([make_audio(40 + i, 16000) for i in range(3)])
+    steps = 9
+    toks = np.asarray(hb.greedy(model, cfg, clips, steps), np.int32)
+    lg = hb.teacher_forced_logits(model, clips, toks, sub_batch=2)
+    assert lg.shape == (3, steps, cfg.vocab)
+    assert (lg.argmax(-1) == toks[:, 1:]).all()
+    for b in range(3):
+        enc = ref.encoder_forward(w, cfg, clips[b])
+        o_toks, o_lg = ref.greedy_decode(w, cfg, enc, steps, ignore_eos=True, return_logits=True, teacher=toks[b].tolist())
+        assert float(np.abs(np.stack(o_lg) - lg[b]).max()) < 2e-4
