@@ -208,7 +208,7 @@ MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_
  *       output projection (Wo_h Wv_h), so that a decode step reads the encoder output ONCE per layer for all heads instead
  *       of K^T and V^T: half the bytes of the kernel that bounds batched decode and no cross-K/V projection in the encoder
  *       (k_xattn.hip).  It pays from ~192 clips per batch on (one workgroup per clip); the host layer's
- *       `cross_attention=auto` picks it at LOAD when the configured sub-batch size (`batch_clips`) is >= 192.
+ *       `cross_attention=auto` picks it at LOAD when the caller passed `batch_clips` / `max_batch_size` >= 192.
  * Mode 2 is an error (of this call, or of the next msh_encode) where it cannot be honoured: an architecture without the
  * absorbed operands (msh_cross_absorbed_supported), the word-timestamp capture, kv_dtype = fp8.  Applies to the next
  * msh_encode; set it before msh_set_batches_in_flight. */

@@ -99,7 +99,10 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
       else if (t == "absorbed") o->cross_attention = 2;
       else throw std::runtime_error("cross_attention must be auto, kv or absorbed, got '" + v + "'");
     }
-    else if (k == "batch_clips" || k == "max_batch_size") o->batch_clips = parse_int32(v);  // additive (batch calls; SURVEY 8b names it max_batch_size)
+    else if (k == "batch_clips" || k == "max_batch_size") {   // additive (batch calls; SURVEY 8b names it max_batch_size)
+      o->batch_clips = parse_int32(v);
+      o->batch_clips_given = true;   // asking for large sub-batches is what switches cross_attention=auto to the absorbed form
+    }
     else if (k == "num_gpus") o->num_gpus = parse_int32(v);                         // additive: shard batch calls over GPUs device .. device+n-1 (-1 = all)
     else if (k == "devices") {                                                      // additive: explicit GPU list, e.g. "0,1,2,3"
       o->device_ids.clear();

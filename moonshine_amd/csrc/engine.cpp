@@ -1141,8 +1141,13 @@ struct Engine::DecodeGroup {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int first = 0, M = 0;
-  DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher, pval, pidx;
+  DevBuf dH, dq, dao, dz, dy, logits, cacheK, cacheV, tokens, counts, finished, scalars, teacher, pval, pidx, xpart;
+  bool self_fused = false;    // single-clip latency path: self-attention inside the output projection's launch (<= 2 clips)
+  bool loop_cross = false;    // 5 .. 63 clips: the same cross-attention with one workgroup per (clip, head) walking the slices
+  bool split_cross = false;   // single-clip latency path: cross-attention split over key slices (k_dec_small.hip)
+  int xs_max = 0;             // slices of the longest clip of the group
   bool fused_argmax = false;  // LM head writes per-tile (max, index) pairs instead of logits
+  int argmax_tiles = 0;       // pairs per row: gemm_argmax_tiles(V)
   DecodeState state{};        // of the last decode() (profile_decode_chain replays its kernels)
   bool has_state = false;
   // Captured decode steps, a small LRU by shape key (everything baked into the kernel arguments): real batch calls are
@@ -1174,7 +1179,7 @@ struct Engine::DecodeGroup {
   ~DecodeGroup() {
     drop_graphs();
     DevBuf* bufs[] = {&dH, &dq, &dao, &dz, &dy, &logits, &cacheK, &cacheV, &tokens, &counts, &finished, &scalars, &teacher,
-                      &pval, &pidx};
+                      &pval, &pidx, &xpart};
     for (DevBuf* b : bufs) b->release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -1284,14 +1289,22 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       ProfScope p(this, "dec_qkv_gemm", 2.0 * M * D * 3 * D, 3 * w_dd + M * D * 4.0 * 2);
       dec_gemm_qkv(dH, W.wqkv, M, D, pos, rp, dq, cK, cV, Smax_, s);
     }
-    if (on(1)) {
-      // q (fp32) + the cached K / V rows of every (clip, head) up to the current position + the bf16 output
-      ProfScope p(this, "dec_self_attention", 0, M * D * 6.0 + 2.0 * M * D * 2.0 * 33);
-      dec_self_attention(dq, cK, cV, pos, M, D, Hh, Smax_, dao, s);
-    }
-    if (on(2)) {
-      ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
-      dec_gemm_resid(dao, W.wo, nullptr, M, D, D, dH, s);
+    if (g.self_fused) {
+      // single-clip latency path (k_dec_small.hip): self-attention + output projection + residual in one launch
+      if (on(1)) {
+        ProfScope p(this, "dec_self_attention", 2.0 * M * D * D, w_dd + M * D * 14.0 + 2.0 * M * D * 2.0 * 33);
+        dec_self_oproj(dq, cK, cV, pos, W.wo, M, D, Hh, Smax_, dH, s);
+      }
+    } else {
+      if (on(1)) {
+        // q (fp32) + the cached K / V rows of every (clip, head) up to the current position + the bf16 output
+        ProfScope p(this, "dec_self_attention", 0, M * D * 6.0 + 2.0 * M * D * 2.0 * 33);
+        dec_self_attention(dq, cK, cV, pos, M, D, Hh, Smax_, dao, s);
+      }
+      if (on(2)) {
+        ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
+        dec_gemm_resid(dao, W.wo, nullptr, M, D, D, dH, s);
+      }
     }
     static const bool fuse_q = [] {
       const char* e = getenv("MSH_NO_FUSED_CROSSQ");
@@ -1319,6 +1332,23 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         ProfScope p(this, "dec_ctx_resid_gemm", 2.0 * M * D * D * Hh, w_dd * Hh + M * D * (2.0 * Hh + 8.0));
         dec_gemm_resid(dao, W.wvo, nullptr, M, D, Hh * D, dH, s);
       }
+    } else if (g.split_cross) {
+      // single-clip latency path (k_dec_small.hip): one wave per (64-key slice, head, clip) with LayerNorm + query projection
+      // inside, then the output projection with the merge of the slices as its prologue
+      if (on(4)) {
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
+        dec_cross_split(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, g.xs_max, g.xpart.as<float>(), s);
+      }
+      if (on(5)) {
+        ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
+        dec_merge_resid(g.xpart.as<float>(), W.wo_c, M, D, Hh, g.xs_max, dH, s);
+      }
+    } else if (g.loop_cross) {
+      // the same arithmetic, one workgroup per (clip, head) looping over the slices; the standard projection follows below
+      if (on(4)) {
+        ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
+        dec_cross_looped(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, dao, s);
+      }
     } else if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
       if (on(4)) {
@@ -1338,7 +1368,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         dec_cross_attention(dq, KTl, VTl, clips, M, D, Hh, dao, s, kdq(l), vdq(l));
       }
     }
-    if (on(5) && !absorbed_) {
+    if (on(5) && !absorbed_ && !g.split_cross) {
       ProfScope p(this, "dec_proj_resid_gemm", 2.0 * M * D * D, w_dd + M * D * 10.0);
       dec_gemm_resid(dao, W.wo_c, nullptr, M, D, D, dH, s);
     }
@@ -1404,7 +1434,7 @@ void Engine::profile_decode_chain(int reps) {
           step_only_ = -1;
         } else if (id == 10) {
           if (g.fused_argmax)
-            decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), g.M,
+            decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), g.argmax_tiles, g.M,
                                     clips_d_.as<ClipMeta>() + g.first, g.state, embed_f32_, D, g.dH.as<float>(), g.stream);
           else
             decode_advance(g.logits.as<float>(), g.M, V, clips_d_.as<ClipMeta>() + g.first, g.state, embed_f32_, D,
@@ -1570,14 +1600,36 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     moved |= g.dz.reserve(M16 * F * sizeof(bf16_t));
     moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
     moved |= g.logits.reserve((size_t)M * V * sizeof(float));
-    moved |= g.pval.reserve((size_t)M * gemm_argmax_tiles(V) * sizeof(float));
-    moved |= g.pidx.reserve((size_t)M * gemm_argmax_tiles(V) * sizeof(int));
     {
-      static const bool off = [] {
-        const char* e = getenv("MSH_NO_FUSED_ARGMAX");
-        return e != nullptr && e[0] == '1';
-      }();
+      const char* fe = getenv("MSH_NO_FUSED_ARGMAX");   // (read per call: the tests switch it)
+      const bool off = fe != nullptr && fe[0] == '1';
+      // nobody reads the logits: the tiled LM head (from 128 clips on) reduces every 128 x 208 tile to (max, first index).
+      // (The same on the split-K decode GEMM's 16 x 16 tiles was built and measured at one clip: head 6.5 against 6.4 us,
+      // bookkeeping 4.85 against 4.25 -- that kernel's time is its chain of dependent accesses, not the scan; removed.)
       g.fused_argmax = !off && logits_out == nullptr && M >= 128;
+      g.argmax_tiles = gemm_argmax_tiles(V);
+    }
+    moved |= g.pval.reserve((size_t)M * g.argmax_tiles * sizeof(float));
+    moved |= g.pidx.reserve((size_t)M * g.argmax_tiles * sizeof(int));
+    {
+      // single-clip latency path: split cross-attention (MSH_XSPLIT_M = largest batch that takes it, 0 = off)
+      const char* xe = getenv("MSH_XSPLIT_M");   // (read per call: the tests switch it)
+      const int xsplit_m = xe != nullptr ? atoi(xe) : 4;
+      const char* sfe = getenv("MSH_SELF_FUSED_M");   // largest batch whose self-attention runs inside the o-proj launch (0 = off)
+      const int self_m = sfe != nullptr ? atoi(sfe) : 2;
+      g.self_fused = M <= std::min(self_m, 2) && dec_self_oproj_supported(D, Hh, M);
+      int tmax = 1;
+      for (int b = 0; b < M; ++b) tmax = std::max(tmax, (int)clips_h_[g.first + b].T);
+      const int xs = dec_cross_split_slices(tmax);
+      const bool small_ok = !absorbed_ && !capture_cross_ && !kv_fp8_ && M < 64 && dec_cross_split_supported(D, Hh);
+      g.split_cross = small_ok && M <= xsplit_m;
+      const char* xl = getenv("MSH_XLOOP");   // 0: batches above MSH_XSPLIT_M keep k_attn.hip's one-pass kernel (A/B measurements)
+      g.loop_cross = small_ok && !g.split_cross && xs <= dec_cross_looped_max_slices() && !(xl != nullptr && xl[0] == '0');
+      if (g.split_cross) {
+        if (xs != g.xs_max) ++g.gen;   // baked into the captured launches
+        g.xs_max = xs;
+        moved |= g.xpart.reserve(dec_cross_split_part_floats(M, Hh, xs) * sizeof(float));
+      }
     }
     moved |= g.cacheK.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
     moved |= g.cacheV.reserve((size_t)cfg_.dec_layers * M * Hh * Smax_ * dh * sizeof(bf16_t));
@@ -1613,7 +1665,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const std::string key = std::to_string(M) + ":" + std::to_string(g.first) + ":" + std::to_string(Smax_) + ":" +
                               std::to_string(st.ignore_eos) + ":" + std::to_string(teacher != nullptr) + ":" +
                               std::to_string(absorbed_ ? 0 : kv_keys_) + ":" + std::to_string(g.fused_argmax) + ":" +
-                              std::to_string(kv_fp8_) + ":" + std::to_string(absorbed_);
+                              std::to_string(kv_fp8_) + ":" + std::to_string(absorbed_) + ":" + std::to_string(g.split_cross ? g.xs_max : 0) + ":" + std::to_string(g.self_fused) + ":" + std::to_string(g.loop_cross);
       if (g.graphs_ws_gen != ws_gen_ || g.graphs_gen != g.gen) {   // a workspace moved: every captured pointer is stale
         g.drop_graphs();
         g.graphs_ws_gen = ws_gen_, g.graphs_gen = g.gen;
@@ -1629,7 +1681,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
           for (int r = 0; r < n_steps; ++r) {
             decode_step_enqueue(g);
             if (g.fused_argmax)
-              decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), M, clips, st, embed_f32_, D,
+              decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), g.argmax_tiles, M, clips, st, embed_f32_, D,
                                       g.dH.as<float>(), g.stream);
             else
               decode_advance(g.logits.as<float>(), M, V, clips, st, embed_f32_, D, g.dH.as<float>(), g.stream);
@@ -1699,8 +1751,8 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
           MSH_HIP(hipMemcpyAsync(logits_out + (size_t)i * Mtot * V, g.logits.p, (size_t)Mtot * V * sizeof(float),
                                  hipMemcpyDeviceToHost, g.stream));
         if (g.fused_argmax) {
-          ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * gemm_argmax_tiles(V) * 8);
-          decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), gemm_argmax_tiles(V), g.M,
+          ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * g.argmax_tiles * 8);
+          decode_advance_partials(g.pval.as<float>(), g.pidx.as<int>(), g.argmax_tiles, g.M,
                                   clips_d_.as<ClipMeta>() + g.first, states[gi], embed_f32_, D, g.dH.as<float>(), g.stream);
         } else {
           ProfScope p(this, "dec_argmax_advance", 0, (double)g.M * V * 4);

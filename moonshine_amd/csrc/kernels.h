@@ -181,6 +181,27 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
 void dec_cross_attention(const float* q, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                          int heads, bf16_t* out, hipStream_t s, const float* kdq = nullptr, const float* vdq = nullptr);
 
+// ---------------- single-clip latency path (k_dec_small.hip; M <= 16) ----------------
+// Cross-attention of the projected form split over 64-key slices, one workgroup per (slice, head, clip): LayerNorm + the head's
+// query projection + the slice's (max, sum, unnormalised output) -> part [M][heads][ns_max][64] fp32 (slices beyond a clip's
+// frames: empty records); Wq_rm = cross-q weight, row-major, LayerNorm scale folded in.  dec_merge_resid: H (FM fp32) += merge(part) Wo^T with the merge as the GEMM's prologue.
+bool dec_cross_split_supported(int D, int heads);
+int dec_cross_split_slices(int T);
+size_t dec_cross_split_part_floats(int M, int heads, int ns_max);
+void dec_cross_split(const float* H, const bf16_t* Wq_rm, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
+                     int heads, int ns_max, float* part, hipStream_t s);
+void dec_merge_resid(const float* part, const bf16_t* Wo_fm, int M, int D, int heads, int ns_max, float* H, hipStream_t s);
+// the same attention with one workgroup per (clip, head) walking the slices itself (batches of 5 .. 63 clips, clips of at most
+// dec_cross_looped_max_slices() slices): writes the attention output as FM bf16 [M16][D], the A operand of dec_gemm_resid;
+// bit-identical to dec_cross_split + dec_merge_resid
+int dec_cross_looped_max_slices();
+void dec_cross_looped(const float* H, const bf16_t* Wq_rm, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
+                      int heads, bf16_t* out_fm, hipStream_t s);
+// self-attention over the cache + output projection + residual in one launch (M <= 2): H += selfattn(q, cacheK, cacheV) Wo^T
+bool dec_self_oproj_supported(int D, int heads, int M);
+void dec_self_oproj(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, const bf16_t* Wo_fm, int M, int D,
+                    int heads, int Smax, float* H, hipStream_t s);
+
 // Absorbed form (k_xattn.hip): the attention of all heads of a clip in ONE pass over the encoder output `enc` [R][D] bf16
 // (clip b's T frames start at row clips[b].row_start).  qf = the keys-side queries of the heads, LN(h) Wqk^T with the merged
 // weight Wqk (softmax scale and log2(e) folded in), as dec_gemm_ln_qt writes them: [M][D / 32][16][32] bf16, value and rounding

@@ -441,8 +441,10 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
       throw std::runtime_error("Failed to load model from memory: " + model_->error());
   }
   // Form of the decoder's cross-attention: ONE per transcriber, fixed here -- a clip's transcript never depends on how many
-  // clips shared its sub-batch.  `auto` = absorbed when this transcriber is configured for large sub-batches (batch_clips >=
-  // 192: where that form pays, k_xattn.hip) and nothing needs the projected keys, else the reference's projected form.
+  // clips shared its sub-batch.  `auto` = absorbed when the caller configured this transcriber for large sub-batches (the
+  // batch_clips / max_batch_size option PASSED and >= 192: where that form pays, k_xattn.hip) and nothing needs the projected
+  // keys; else the reference's projected form -- a transcriber loaded without options serves single clips through the
+  // latency path (k_dec_small.hip), which exists for the projected form only.
   {
     int mode = opt_.cross_attention;
     const bool needs_keys = opt_.word_timestamps || opt_.kv_dtype != 0;
@@ -450,7 +452,7 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
       throw std::runtime_error("cross_attention=absorbed cannot be combined with word_timestamps or kv_dtype=fp8 (both read projected keys)");
     for (MoonshineModel::DeviceShard& d : model_->devices) {
       int m = mode;
-      if (m == 0) m = (opt_.batch_clips >= 192 && !needs_keys && msh_cross_absorbed_supported(d.engine) == 1) ? 2 : 1;
+      if (m == 0) m = (opt_.batch_clips_given && opt_.batch_clips >= 192 && !needs_keys && msh_cross_absorbed_supported(d.engine) == 1) ? 2 : 1;
       if (msh_set_cross_mode(d.engine, m) != MSH_OK)
         throw std::runtime_error(std::string("cross_attention: ") + msh_last_error(d.engine));
     }

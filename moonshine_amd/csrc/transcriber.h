@@ -99,8 +99,9 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   float max_stream_seconds = 40.0f;      // additive: longest streaming line the device state is sized for
   bool word_timestamps = false;          // reference core/transcriber.h (word_timestamps): offline architectures here
   int kv_dtype = 0;                      // additive: storage of the decoder's cross K / V on the device: 0 = bf16, 1 = fp8 e4m3 (msh_set_kv_dtype)
-  int cross_attention = 0;               // additive: form of the decoder's cross-attention (msh_set_cross_mode), ONE per transcriber, fixed at load: 0 = auto (absorbed when batch_clips >= 192 and neither word_timestamps nor kv_dtype=fp8 is on, else projected K / V), 1 = projected K / V, 2 = absorbed (an error where it cannot be honoured)
+  int cross_attention = 0;               // additive: form of the decoder's cross-attention (msh_set_cross_mode), ONE per transcriber, fixed at load: 0 = auto (absorbed when the caller ASKED for sub-batches of >= 192 clips -- batch_clips / max_batch_size passed -- and neither word_timestamps nor kv_dtype=fp8 is on; else projected K / V, the reference's order of operations and the form with the single-clip latency path), 1 = projected K / V, 2 = absorbed (an error where it cannot be honoured)
   int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call
+  bool batch_clips_given = false;        // the option was passed (the cross_attention=auto rule reads it)
   int batches_in_flight = 2;             // additive: sub-batches on the GPU at once (1 = strictly one after the other)
   bool return_audio_data = true;
   bool log_output_text = false;

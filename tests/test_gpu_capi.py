@@ -24,8 +24,8 @@ def tiny_dir(tmp_path_factory):
 
 @pytest.fixture(scope="module")
 def tiny(tiny_dir):
-    # the form is pinned: `auto` resolves from batch_clips at load (256 -> absorbed), and the tests below compare this
-    # transcriber with raw engines and with transcribers configured for small sub-batches, which run the projected form
+    # the form is pinned: `auto` resolves at load (absorbed when batch_clips >= 192 is ASKED for), and the tests below compare
+    # this transcriber with raw engines and with transcribers configured for other sub-batch sizes
     t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "kv"})
     yield t
     t.close()
@@ -440,7 +440,8 @@ def test_cross_attention_option(tiny_dir, engine):
         want[form] = [host_ref.sanitize_text(host_ref.tokens_to_text(vocab, t)) for t in ids]
     assert texts({"cross_attention": "absorbed"}) == want["absorbed"]
     assert texts({"cross_attention": "kv", "batch_clips": "256"}) == want["kv"]
-    # auto: by the CONFIGURED sub-batch size, not by the 8 clips of this call
+    # auto: by the sub-batch size the caller ASKED for, not by the 8 clips of this call; no option = the projected form
+    assert texts({}) == want["kv"]
     assert texts({"batch_clips": "256"}) == want["absorbed"]
     assert texts({"batch_clips": "64"}) == want["kv"]
     assert texts({"batch_clips": "256", "word_timestamps": "true"}) == want["kv"]

@@ -1,0 +1,111 @@
+"""Single-clip latency path of the offline decoder (moonshine_amd/csrc/k_dec_small.hip): the cross-attention split over
+64-key slices (one wave per slice, head and clip, LayerNorm + query projection inside) and the output projection that
+merges the slices in its prologue.  Up to 4 clips take that shape (MSH_XSPLIT_M, read per call); 5 .. 63 clips
+run the same arithmetic with one workgroup per (clip, head) walking the slices (bit-identical: a clip's ids do not depend on its
+batch); one or two clips also run the self-attention inside the output projection's launch (MSH_SELF_FUSED_M).
+
+What is checked, on the GPU through the C ABI:
+  * against the path it replaces (MSH_XSPLIT_M=0: one workgroup per (clip, head), k_attn.hip) on the same teacher-forced
+    ids: logits within 2.5e-2 of each other (measured 1.3e-2: the two differ in summation order, which now and then moves a
+    bf16 rounding of an attention output; each is held to the oracle separately) -- for 1, 3 and 8 ragged clips, among them a clip of
+    more than 8 slices (the merge's second round) and one shorter than a slice;
+  * against the numpy oracle (the reference's greedy loop, core/moonshine-model.cpp:380-517) with the suite's tolerances:
+    logits max-abs <= 5e-2, ids identical wherever the oracle's margin exceeds 0.1;
+  * a clip decoded alone and inside a batch of 8 gives the same ids (the kernels are per-clip: bit-identical logits).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import margins
+from oracle import moonshine_ref as ref
+from oracle.weights import ARCHS, make_audio, make_weights, save_safetensors
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_MAXABS = 5e-2
+MARGIN = 0.1
+
+
+@pytest.fixture(scope="module", params=["base", "tiny"])
+def model(request, tmp_path_factory):
+    from moonshine_amd.hip_api import Engine
+
+    cfg = ARCHS[request.param]
+    w = make_weights(cfg, 3)
+    d = tmp_path_factory.mktemp(f"w_small_{request.param}")
+    path = os.path.join(d, "model.safetensors")
+    save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
+    e = Engine(0)
+    e.load_weights_file(path)
+    os.remove(path)
+    yield e, w, cfg
+    e.close()
+
+
+def _decode(e, clips, teacher, steps, form, monkeypatch):
+    """form: "split" = one workgroup per slice + merging projection at any batch size, "loop" = one workgroup per (clip, head)
+    walking the slices, "onepass" = the kernel of k_attn.hip both replace below 64 clips."""
+    monkeypatch.setenv("MSH_XSPLIT_M", "63" if form == "split" else "0")
+    monkeypatch.setenv("MSH_XLOOP", "0" if form == "onepass" else "1")
+    monkeypatch.setenv("MSH_SELF_FUSED_M", "0" if form == "onepass" else "2")
+    e.encode(clips)
+    return e.decode(forced_steps=steps, teacher=teacher, want_logits=steps)
+
+
+# 1 clip; 3 clips (one shorter than a slice: 0.5 s = 20 frames, one of 10 slices: 14.5 s); 8 ragged clips
+CASES = {
+    "one_10s": [160000],
+    "three_ragged": [8000, 232000, 52345],
+    "eight_ragged": [160000, 16000, 100000, 31111, 200000, 64000, 12800, 140000],
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_split_path_vs_workgroup_path_and_oracle(model, case, monkeypatch):
+    e, w, cfg = model
+    if cfg.name != "base" and case != "three_ragged":
+        pytest.skip("the other head widths run the ragged case only (oracle time)")
+    steps = 10
+    clips = [make_audio(700 + i, n) for i, n in enumerate(CASES[case])]
+    gold, gold_logits = [], []
+    for c in clips:
+        toks, lg = ref.greedy_decode(w, cfg, ref.encoder_forward(w, cfg, c), steps, ignore_eos=True, return_logits=True)
+        gold.append(toks)
+        gold_logits.append(lg)
+    teacher = np.asarray(gold, np.int32)
+    toks_s, lg_s = _decode(e, clips, teacher, steps, "split", monkeypatch)
+    toks_l, lg_l = _decode(e, clips, teacher, steps, "loop", monkeypatch)
+    assert np.array_equal(lg_s, lg_l), "the looped form must give the split form's bits"
+    toks_w, lg_w = _decode(e, clips, teacher, steps, "onepass", monkeypatch)
+    d_paths = float(np.abs(lg_s - lg_w).max())
+    assert d_paths <= 2.5e-2, d_paths
+    worst, worst_w, flips = 0.0, 0.0, 0
+    for b in range(len(clips)):
+        for i in range(steps):
+            g = gold_logits[b][i]
+            worst = max(worst, float(np.abs(lg_s[i, b] - g).max()))
+            worst_w = max(worst_w, float(np.abs(lg_w[i, b] - g).max()))
+            top2 = np.partition(g, -2)[-2:]
+            if float(top2[1] - top2[0]) > MARGIN:
+                assert toks_s[b][i + 1] == gold[b][i + 1], (b, i)
+            elif toks_s[b][i + 1] != gold[b][i + 1]:
+                flips += 1
+    margins.record(logits_max_abs=worst, workgroup_path_logits_max_abs=worst_w, split_vs_workgroup_logits_max_abs=d_paths, near_tie_flips=flips, clips=len(clips), steps=steps)
+    print(f"\n[{cfg.name} {case}] split vs workgroup path: logits max-abs {d_paths:.2e}; vs oracle {worst:.3e} (workgroup path {worst_w:.3e}), {flips} near-tie flips")
+    assert worst <= LOGIT_MAXABS, worst
+
+
+def test_a_clip_alone_equals_the_clip_in_a_batch(model):
+    """One clip (self-attention inside the o-proj launch: the GEMM body keeps gemm_dec_kernel's k-step assignment and summation
+    order), two clips, and the clip inside batches of 8 and 40 (separate kernels; split cross-attention, more than one row tile in
+    the merging projection): bit-identical logits, hence the same ids over 30 free-running steps."""
+    e, w, cfg = model
+    clips = [make_audio(740 + i, CASES["eight_ragged"][i % 8] + 977 * (i // 8)) for i in range(40)]
+    b40 = e.transcribe_tokens(clips, forced_steps=30)
+    b8 = e.transcribe_tokens(clips[:8], forced_steps=30)
+    assert b8 == b40[:8]
+    assert e.transcribe_tokens(clips[:2], forced_steps=30) == b40[:2]
+    for i in (0, 3, 6, 17):
+        assert e.transcribe_tokens([clips[i]], forced_steps=30)[0] == b40[i], i

@@ -491,6 +491,7 @@ def test_cross_attention_runs_kernel_is_bit_identical_to_the_per_row_kernel(tmp_
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
+sys.path.insert(0, "./tests")
 from tests.test_gpu_streaming import make_engine, feed
 from moonshine_amd.synth import make_audio
 import pathlib, tempfile

@@ -1,9 +1,15 @@
 #!/bin/bash
-# round 4: single-clip path -- the fused-q cross-attention requests its first K rows before it forms the query and reduces by DPP
+# Round 5, GPU call 7: latency path with the split cross-attention for every batch below 64 and the bit-identical fused
+# self-attention: tests (clip alone == clip in a batch), chain costs at 1 / 8 / 16 / 32 / 48 / 63 clips split on and off
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out
+TAG=${1:-r5g}
+timeout 900 python -m pytest tests/test_gpu_dec_small.py tests/test_gpu_capi.py -m gpu -q -s --durations=5 > gpurun_out/${TAG}_pytest.log 2>&1
+tail -6 gpurun_out/${TAG}_pytest.log
 {
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_capi.py tests/test_gpu_kv_fp8.py -q -x 2>&1 | tail -2
-timeout 300 python tools/chain_probe.py 1 16 32 2>&1 | grep -v amdgpu.ids
-timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-streaming --no-pcie --no-typical --no-c-api --no-fp8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['latency_ms'])"
-} 2>&1 | tee gpurun_out/r5g_single_clip.txt
+for m in 4 0; do
+  echo "== MSH_XSPLIT_M=$m"
+  MSH_XLOOP=$([ $m = 0 ] && echo 0 || echo 1) MSH_XSPLIT_M=$m timeout 300 python tools/chain_probe.py 1 4 8 16 32 63 2>&1 | grep "^B="
+done
+echo "== latency, defaults"; timeout 300 python tools/latency_probe.py 2>&1 | tail -2
+} 2>&1 | tee gpurun_out/${TAG}_chain.txt
