@@ -173,34 +173,6 @@ MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
  * size in bytes, -1 on error.  "graph_captures" (dst unused) returns the number of decode-step hipGraphs this engine has
  * instantiated so far (captured steps are cached per batch shape).  No reference counterpart (ORT owns these tensors there). */
 MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
-/* Developer hook: self-test of the library's device allocator (odd sizes, pageable copies, interior slices); 0 = ok.
- * Meant for MSH_GUARD_ALLOC=1 (tools/gpu_guard.sh), where every buffer ends on an unmapped page. */
-MSH_EXPORT int32_t msh_test_device_alloc(void);
-/* Developer hook: ms per launch of one tiled-GEMM configuration on synthetic operands (tools/gemm_microbench.py). */
-MSH_EXPORT float msh_test_gemm_microbench(int32_t M, int32_t N, int32_t K, int64_t lda, int32_t cfg, int32_t abl,
-                                          int32_t iters);
-
-/* Developer hook: ms per launch of the fused encoder MLP kernel (LayerNorm + fc1 + GELU + fc2 + residual, k_mlp.hip) on R
- * rows of uniform random data (tools/mlp_microbench.py); abl = 0, or an ablation of k_mlp.hip (garbage results). */
-MSH_EXPORT float msh_test_mlp_microbench(int32_t R, int32_t D, int32_t F, int32_t iters, int32_t abl);
-
-/* Test hook: the fused encoder MLP kernel alone -- h [R][D] (host, in place) += fc2(gelu(fc1(LayerNorm(h) * gamma) + b1)) + b2
- * with w1 [F][D], w2 [D][F] fp32 (rounded to bf16 inside, as at load).  D in {64, 288, 416}, F % 32 == 0. */
-MSH_EXPORT int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
-                                    const float* b1, const float* w2, const float* b2);
-
-/* Test hook: the same kernel with the attention output projection in front (h += ao wo^T first, ao [R][D], wo [D][D] fp32,
- * both rounded to bf16 inside), as the encoder runs it from 16 k rows on. */
-MSH_EXPORT int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
-                                          const float* b1, const float* w2, const float* b2, const float* ao, const float* wo);
-
-/* Developer / test hook: the encoder QKV panel kernel (LayerNorm + q | k with RoPE + V transposed, k_panel.hip) on R rows
- * (R % 8 == 0) of synthetic data at width D (416 or 288); returns ms per launch (< 0 on error).  Non-null outputs receive the
- * last launch's results as bf16 bit patterns (qk [R][2D], vt [D][R]) and the inputs used (h [R][D], w [3D][D] fp32, pos [R],
- * pos < 0 = padding row) so that a test can recompute them (tests/test_gpu_panel.py). */
-MSH_EXPORT float msh_test_qkv_panel(int32_t R, int32_t D, int32_t iters, uint16_t* out_qk, uint16_t* out_vt, float* out_h,
-                                    float* out_w, int32_t* out_pos);
-
 /* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  ONE form per engine,
  * whatever the batch size -- a clip's token ids never depend on how many clips share its batch:
  *   1 (and 0, the default) = the projected K^T / V^T stream, the reference's form;
@@ -217,20 +189,6 @@ MSH_EXPORT int32_t msh_set_cross_mode(msh_engine* e, int32_t mode);
 MSH_EXPORT int32_t msh_cross_absorbed(const msh_engine* e);
 /* 1 if the loaded weights include the absorbed form's operands (8 heads, hidden 288 / 416), else 0. */
 MSH_EXPORT int32_t msh_cross_absorbed_supported(const msh_engine* e);
-/* Test / developer hook: the absorbed cross-attention kernel alone.  M clips, clip b = Ts[b] rows of `enc` [R][D] (fp32,
- * rounded to bf16 inside) from row row_starts[b]; qt [M][8 * D] fp32 (scores = qt_h . enc[t], already in the exp2 domain);
- * ctx_out [M][8 * D] fp32 receives the kernel's bf16 output (softmax_t(qt_h . enc[t]) weighted sum of the rows, per head).
- * D = 416 or 288.  Returns ms per launch over `iters` launches (0 = a single untimed launch), < 0 on error. */
-MSH_EXPORT float msh_test_cross_absorbed(const float* qt, const float* enc, int64_t R, const int32_t* Ts,
-                                         const int32_t* row_starts, int32_t M, int32_t D, float* ctx_out, int32_t iters);
-
-/* Test / developer hook: the two-stage query kernel of the absorbed form alone (k_crossq.hip).  x [M][D] fp32 (residual
- * stream rows), wq [D][D] = the scaled, LayerNorm-folded query projection with rows (head, j), wk [D][D] the key projection
- * with rows (head, j); qt_out [M][8 * D] fp32 receives qt_h = Wk_h^T (wq_h LN(x)) per head (value + rounding residual of the
- * kernel's split-bf16 output).  D = 416 or 288.  Returns ms per launch over `iters` launches (0 = one untimed launch), < 0 on error. */
-MSH_EXPORT float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out,
-                                  int32_t iters);
-
 /* ---- host-side byte / sample helpers of the transcription path, exported so that parity tests (and
  * bindings that want them) can call exactly the code the Transcriber runs.  No GPU involved. ----
  * msh_host_tokens_to_text : tokenizer.bin blob + ids -> text (reference core/bin-tokenizer/bin-tokenizer.cpp:406-426).

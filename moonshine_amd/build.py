@@ -4,7 +4,9 @@
     python -m moonshine_amd.build --force
 
 hipcc cross-compiles gfx950 without a GPU.  Objects go to moonshine_amd/_build/, the library to
-moonshine_amd/lib/libmoonshine.so (git-ignored, but shipped to the GPU box with the tree).
+moonshine_amd/lib/libmoonshine.so (git-ignored, but shipped to the GPU box with the tree); beside it
+libmoonshine_dev.so = the same objects + csrc/dev_hooks.cpp (msh_test_*: kernel-alone tests and microbenchmarks),
+which the product library does not export.
 """
 from __future__ import annotations
 
@@ -19,6 +21,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmoonshine.so")
+LIB_DEV = os.path.join(LIBDIR, "libmoonshine_dev.so")   # the same objects + the development hooks (include/moonshine_hip_dev.h)
+DEV_ONLY = {"dev_hooks.cpp"}                            # sources that never go into the product library
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
@@ -142,11 +146,13 @@ def build(force: bool = False, verbose: bool = False, check: bool = True) -> str
             f.write("\n".join(f"{k} {v}" for k, v in sorted(seen.items())) + "\n")
         if verbose:
             print("no packed-FP32 instructions in", ", ".join(f"{k} ({v} instr.)" for k, v in sorted(seen.items())), file=sys.stderr)
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    product = [o for o in objs if os.path.basename(o)[:-2] not in DEV_ONLY]
+    for lib, members in ((LIB, product), (LIB_DEV, objs)):
+        if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in members):
+            cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *members, "-lpthread"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

@@ -1034,9 +1034,51 @@ void Engine::run_encoder() {
     ProfScope p(this, "conv3_gelu_gemm", 2.0 * sT * D * 6 * D, sL2 * 2 * D * 2 + sT * D * 4);
     gemm_bias_gelu_f32(x2_.as<bf16_t>(), 4L * D, conv3_w_, conv3_b_, R, D, 6 * D, H_.as<float>(), s);
   }
+  // A few clips (the latency case; one 10 s clip = 424 rows): the tiled kernel's 128 x 208 tiles give a layer's GEMMs 8 .. 32
+  // workgroups on 256 CUs, each walking K alone (fc2: 52 slices, 35 us at one clip).  The split-K decode GEMM (16 x 32 tiles,
+  // four waves over K, operands straight from global memory) puts 350 .. 1400 workgroups on the same shapes: MSH_ENC_SMALL_ROWS
+  // = largest row count that takes it (default 1024; 0 = off).  Same epilogue arithmetic, a different summation order over K.
+  const char* small_env = getenv("MSH_ENC_SMALL_ROWS");
+  const long small_rows = small_env != nullptr ? atol(small_env) : 1024;
+  const bool small_gemms = R <= small_rows && (R & 3) == 0 && qkv_env == nullptr && mlp_env == nullptr;   // (a developer switch that names a kernel gets that kernel)
   for (int l = 0; l < cfg_.enc_layers; ++l) {
     const EncLayerW& W = enc_[l];
     long vt_ld = (long)R;
+    if (small_gemms) {
+      bool ok = true;
+      {
+        ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+        layernorm_bf16(H_.as<float>(), W.ln1, R, D, Y_.as<bf16_t>(), nullptr, s);
+      }
+      {
+        ProfScope p(this, "enc_qkv_rope_gemm", 2.0 * sT * D * 3 * D, sT * D * 2 * 5);
+        ok = ok && small_gemm_qkv_rope_bf16(Y_.as<bf16_t>(), D, W.wqkv, R, 2 * D, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), s);
+        // V^T [D][R] = Wv x Y^T: the weight is the row operand, the stream rows are the output columns
+        ok = ok && small_gemm_act(W.wqkv + (size_t)2 * D * D, D, Y_.as<bf16_t>(), nullptr, 0, D, (int)R, D, VTe_.as<bf16_t>(), nullptr, s);
+      }
+      {
+        ProfScope p(this, "enc_attention", 4.0 * sT2 * D, sT * D * 2 * 4);
+        enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, AO_.as<bf16_t>(), clips, (int)n_clips_, max_rows_, D, Hh, s);
+      }
+      {
+        ProfScope p(this, "enc_oproj_gemm", 2.0 * sT * D * D, sT * D * (2 + 8));
+        ok = ok && small_gemm_resid_f32(AO_.as<bf16_t>(), D, W.wo, nullptr, R, D, D, H_.as<float>(), s);
+      }
+      {
+        ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
+        layernorm_bf16(H_.as<float>(), W.ln2, R, D, Y_.as<bf16_t>(), nullptr, s);
+      }
+      {
+        ProfScope p(this, "enc_fc1_gelu_gemm", 2.0 * sT * D * F, sT * (D + F) * 2);
+        ok = ok && small_gemm_act(Y_.as<bf16_t>(), D, W.fc1, W.b1, 2, R, F, D, Z_.as<bf16_t>(), nullptr, s);
+      }
+      {
+        ProfScope p(this, "enc_fc2_gemm", 2.0 * sT * D * F, sT * (F * 2 + D * 8));
+        ok = ok && small_gemm_resid_f32(Z_.as<bf16_t>(), F, W.fc2, W.b2, R, D, F, H_.as<float>(), s);
+      }
+      if (!ok) throw std::logic_error("run_encoder: a width of this architecture is not compiled into the split-K GEMM");
+      continue;
+    }
     if (qkv_panel_on && W.qkv_panel != nullptr && R >= qkv_panel_min_rows && (R & 7) == 0) {
       // LayerNorm + q | k with RoPE + V transposed in one A-stationary panel kernel (k_panel.hip); below about half a
       // panel per CU the tiled GEMMs, whose tiles are smaller, fill the chip better

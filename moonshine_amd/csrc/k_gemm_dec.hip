@@ -503,11 +503,14 @@ void dec_gemm_resid(const bf16_t* A, const bf16_t* W, const float* bias, int M, 
 }
 // ---- bf16-input small-batch GEMMs of the streaming decoder (row-based passes with M <= 256) ----
 // Same split-K kernel, LayerNorm done by the caller; K covers the streaming widths (320 / 640 tiny / assumed-medium,
-// 1280 / 2560 their ffn, 96 / 192 the test model) next to the offline ones.
+// 1280 / 2560 their ffn, 96 / 192 the test model) next to the offline ones (incl. 64 / 256, the offline test model: the
+// offline ENCODER runs its layers' GEMMs here when a call holds few rows, Engine::run_encoder).
 template <int TN, class Epi>
 bool launch_dec_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((N & 3) != 0) return false;
   switch (K) {
+    case 64: launch_dec_cfg<2, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
+    case 256: launch_dec_cfg<8, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
     case 96: launch_dec_cfg<3, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
     case 192: launch_dec_cfg<6, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;
     case 288: launch_dec_cfg<9, TN, false, Epi>(A, lda, nullptr, W, M, N, epi, s); return true;

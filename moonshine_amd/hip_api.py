@@ -70,8 +70,6 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_set_cross_mode": (i32, [vp, i32]),
         "msh_cross_absorbed": (i32, [vp]),
         "msh_cross_absorbed_supported": (i32, [vp]),
-        "msh_test_cross_absorbed": (C.c_float, [vp, vp, C.c_int64, vp, vp, i32, i32, vp, i32]),
-        "msh_test_crossq2": (C.c_float, [vp, vp, vp, i32, i32, vp, i32]),
         "msh_profile_enable": (i32, [vp, i32]),
         "msh_profile_reset": (i32, [vp]),
         "msh_profile_count": (i32, [vp]),
@@ -106,7 +104,6 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_stream_profile_reset": (i32, [vp]),
         "msh_stream_profile_count": (i32, [vp]),
         "msh_stream_profile_get": (i32, [vp, i32, P(ProfileEntry)]),
-        "msh_test_mlp_microbench": (C.c_float, [i32, i32, i32, i32, i32]),
         "msh_stream_get_memory": (i32, [vp, i32, vp]),
         "msh_stream_get_features": (i32, [vp, i32, vp]),
         "msh_host_tokens_to_text": (C.c_int64, [vp, u64, vp, u64, vp, u64]),
@@ -127,6 +124,42 @@ def load_library(path: str | None = None) -> C.CDLL:
     return lib
 
 
+_dev_lib = None
+
+
+def load_dev_library() -> C.CDLL:
+    """libmoonshine_dev.so: the product library's objects + the development hooks of include/moonshine_hip_dev.h (msh_test_*:
+    kernel-alone test entry points, microbenchmarks).  A second, independent copy of the library in the process: the hooks
+    allocate and free their own device buffers and share nothing with engines created through load_library()."""
+    global _dev_lib
+    if _dev_lib is not None:
+        return _dev_lib
+    p = os.path.join(os.path.dirname(LIB_PATH), "libmoonshine_dev.so")
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not found: run `python -m moonshine_amd.build`")
+    lib = C.CDLL(p)
+    vp, i32 = C.c_void_p, C.c_int32
+    protos = {
+        "msh_test_device_alloc": (i32, []),
+        "msh_test_gemm_microbench": (C.c_float, [i32, i32, i32, C.c_int64, i32, i32, i32]),
+        "msh_test_mlp_microbench": (C.c_float, [i32, i32, i32, i32, i32]),
+        "msh_test_mlp_run": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "msh_test_mlp_oproj_run": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "msh_test_qkv_panel": (C.c_float, [i32, i32, i32, vp, vp, vp, vp, vp]),
+        "msh_test_cross_absorbed": (C.c_float, [vp, vp, C.c_int64, vp, vp, i32, i32, vp, i32]),
+        "msh_test_crossq2": (C.c_float, [vp, vp, vp, i32, i32, vp, i32]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _dev_lib = lib
+    return lib
+
+
+DEV_SYMBOLS = ["msh_test_device_alloc", "msh_test_gemm_microbench", "msh_test_mlp_microbench", "msh_test_mlp_run",
+               "msh_test_mlp_oproj_run", "msh_test_qkv_panel", "msh_test_cross_absorbed", "msh_test_crossq2"]
+
 DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
@@ -139,8 +172,7 @@ DECLARED_SYMBOLS = [
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens", "msh_stream_cross_attention",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
-    "msh_test_mlp_microbench", "msh_test_mlp_run", "msh_test_mlp_oproj_run", "msh_test_qkv_panel",
-    "msh_set_cross_mode", "msh_cross_absorbed", "msh_cross_absorbed_supported", "msh_test_cross_absorbed", "msh_test_crossq2",
+    "msh_set_cross_mode", "msh_cross_absorbed", "msh_cross_absorbed_supported",
     "msh_stream_get_features",
 ]
 

@@ -32,19 +32,19 @@ def _fake_engine(audio: torch.Tensor, lens: list[int], sub_batch: int = 3) -> li
     return out
 
 
-def _clips(n):
+def _clips(n, max_len=160000):
     rng = np.random.default_rng(5)
-    lens = rng.integers(900, 160000, n)
+    lens = rng.integers(900, max_len, n)
     lens[1] = lens[4]            # a tie: the stable sort keeps the caller's order
     return [rng.standard_normal(int(k)).astype(np.float32) for k in lens]
 
 
-def _worker(rank, world, port, n_clips, q):
+def _worker(rank, world, port, n_clips, q, max_len=160000):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cpu")
     r, w = msd.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    clips = _clips(n_clips) if rank == 0 else None
+    clips = _clips(n_clips, max_len) if rank == 0 else None
     audio, lens, plan = msd.scatter_clips(clips, world, rank, dev)
     assert audio.shape[0] == len(plan[rank]) == len(lens)
     assert lens == sorted(lens, reverse=True)        # a rank's shard arrives longest first
@@ -112,6 +112,31 @@ def test_two_rank_ids_equal_single_process():
         assert tmax == 2.0
     audio = sorted(r[3] for r in results)
     assert audio[1] - audio[0] <= 160000              # the shards hold the same amount of audio within one clip
+
+
+def test_eight_ranks_2048_clips_ids_equal_single_process():
+    """BASELINE.json configs[3] in shape -- 2048 ragged clips over 8 ranks (256 per GPU) -- on CPU over gloo: the plan deals
+    every rank 256 clips holding the same amount of audio within one clip, every rank reconstructs ids(1 process) in the
+    caller's order, and the timing reduction is the maximum over the eight ranks.  (Clips are kept short: the plumbing, not
+    the audio, is what eight CPU processes can exercise.)"""
+    n_clips, world, max_len = 2048, 8, 6000
+    want = [_fake_tokens(c) for c in _clips(n_clips, max_len)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q, max_len)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, allt, tmax, _ in results:
+        assert allt == want, f"rank {rank} reconstructed a different transcript list"
+        assert tmax == 8.0
+    audio = sorted(r[3] for r in results)
+    assert audio[-1] - audio[0] <= max_len            # balanced within one clip
+    assert sorted(r[0] for r in results) == list(range(world))
 
 
 def test_shard_plan_properties():

@@ -85,12 +85,14 @@ def test_batch_call_equals_single_calls(tiny):
 
 
 @pytest.mark.parametrize("form", ["kv", "absorbed"])
-def test_batch_call_in_sub_batches_with_two_in_flight(tiny_dir, form):
+def test_batch_call_in_sub_batches_with_two_in_flight(tiny_dir, form, monkeypatch):
     """Additive options batch_clips / batches_in_flight: a 23-clip call cut into sub-batches of 4 with two of them on the
     GPU at once returns exactly the transcripts of the uncut call, and so does the strictly serial cut (in flight = 1).
     The cross-attention form is pinned on both sides: `auto` is a load-time rule on batch_clips (>= 192 -> absorbed), so a
     transcriber configured for sub-batches of 4 and one configured for 256 are different engines by design (INTEGRATION.md);
-    with the form fixed, how a call is cut must not change a single byte."""
+    with the form fixed, how a call is cut must not change a single byte.  (The encoder's GEMM kernels are chosen by the rows
+    of a sub-batch -- below 1024 the split-K form, a different summation order over K -- and are pinned to one set here.)"""
+    monkeypatch.setenv("MSH_ENC_SMALL_ROWS", "0")
     clips = [make_audio(200 + i, 12000 + 3517 * ((5 * i) % 17)) for i in range(23)]
     base = {"vad_threshold": "0", "cross_attention": form}
     t0 = api.Transcriber(tiny_dir[0], api.ARCH_TINY, base)
@@ -339,16 +341,18 @@ def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_pat
           f"{tdev * 1e3:.0f} ms with the network on the GPU")
 
 
-def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir):
+def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir, monkeypatch):
     """Additive load options `devices` / `num_gpus` / `max_batch_size`: the batch call shards its
     clips over one engine per listed GPU inside the C++ host layer (length-sorted snake deal, one host thread per device,
     replicated weights, no collective) and must return ids(N devices) == ids(1 device), in the caller's order.  The box has
     one GPU, so the device list names it twice -- two engines, two shards, the same code path as two GPUs."""
+    monkeypatch.setenv("MSH_ENC_SMALL_ROWS", "0")   # (shards and sub-batches of different row counts: one set of encoder GEMMs)
     lens = [16000 + 3111 * ((5 * i + 3) % 17) for i in range(23)] + [900, 160000]
     clips = [make_audio(500 + i, n) for i, n in enumerate(lens)]
     want = [[l.text_bytes for l in t] for t in tiny.transcribe_batch_without_streaming(clips)]
     for opts in ({"devices": "0,0"}, {"devices": "0, 0,0", "max_batch_size": "4", "batches_in_flight": "2"},
-                 {"devices": "0,0", "batch_clips": "5", "batches_in_flight": "1"}):
+                 {"devices": "0,0", "batch_clips": "5", "batches_in_flight": "1"},
+                 {"devices": "0,0,0,0,0,0,0,0", "batch_clips": "2"}):   # the 8-GPU shape on the box's one GPU
         t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "kv", **opts})
         for _ in range(2):   # second call: warmed lanes on every shard
             got = [[l.text_bytes for l in r] for r in t.transcribe_batch_without_streaming(clips)]

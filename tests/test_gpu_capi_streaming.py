@@ -340,6 +340,11 @@ def test_streams_sharded_over_devices_equal_one_device(model_dir):
 
     two4 = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "devices": "0,0", "max_streams": "2"})
     assert live(two4, 4) == live(one, 4)        # 4 live streams = 2 per device
+    # the shape of BASELINE.json's 8-GPU configuration on the one GPU of the box: eight entries = eight engines, eight slot
+    # pools, eight host threads per update (per-device structure locks: their warm-up does not serialise)
+    eight = api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "devices": "0,0,0,0,0,0,0,0", "max_streams": "1"})
+    assert [[l.text_bytes for l in r] for r in eight.transcribe_batch_without_streaming(clips)] == want
+    eight.close()
     with pytest.raises(api.MoonshineError):     # more GPUs than the box has: the load says so
         api.Transcriber(model_dir, api.ARCH_TINY_STREAMING, {"vad_threshold": "0", "num_gpus": "2"})
     for t in (one, two, two4):

@@ -97,11 +97,13 @@ def test_split_path_vs_workgroup_path_and_oracle(model, case, monkeypatch):
     assert worst <= LOGIT_MAXABS, worst
 
 
-def test_a_clip_alone_equals_the_clip_in_a_batch(model):
-    """One clip (self-attention inside the o-proj launch: the GEMM body keeps gemm_dec_kernel's k-step assignment and summation
+def test_a_clip_alone_equals_the_clip_in_a_batch(model, monkeypatch):
+    """The DECODER's kernels are chosen by batch size; the encoder is pinned to one set here (MSH_ENC_SMALL_ROWS=0: its own
+    choice, by rows per call, changes the summation order over K).  One clip (self-attention inside the o-proj launch: the GEMM body keeps gemm_dec_kernel's k-step assignment and summation
     order), two clips, and the clip inside batches of 8 and 40 (separate kernels; split cross-attention, more than one row tile in
     the merging projection): bit-identical logits, hence the same ids over 30 free-running steps."""
     e, w, cfg = model
+    monkeypatch.setenv("MSH_ENC_SMALL_ROWS", "0")
     clips = [make_audio(740 + i, CASES["eight_ragged"][i % 8] + 977 * (i // 8)) for i in range(40)]
     b40 = e.transcribe_tokens(clips, forced_steps=30)
     b8 = e.transcribe_tokens(clips[:8], forced_steps=30)

@@ -30,8 +30,8 @@ def test_suite_slice_under_guard_allocator():
 
 @pytest.mark.gpu
 def test_device_allocator_self_test():
-    code = ("import sys; sys.path.insert(0, '.'); from moonshine_amd.hip_api import load_library; "
-            "sys.exit(0 if load_library().msh_test_device_alloc() == 0 else 3)")
+    code = ("import sys; sys.path.insert(0, '.'); from moonshine_amd.hip_api import load_dev_library; "
+            "sys.exit(0 if load_dev_library().msh_test_device_alloc() == 0 else 3)")
     for extra in ({}, {"MSH_GUARD_ALLOC": "1"}, {"MSH_GUARD_ALLOC": "1", "MSH_GUARD_ALIGN": "16"}):
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=300)

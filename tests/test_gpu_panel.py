@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from moonshine_amd.hip_api import load_library
+from moonshine_amd.hip_api import load_dev_library as load_library   # msh_test_*: the development library
 
 pytestmark = pytest.mark.gpu
 

@@ -26,7 +26,7 @@ def _bf16_round(x):
 
 
 def _run_kernel(qt, enc, Ts, starts, D, iters=0):
-    from moonshine_amd.hip_api import load_library
+    from moonshine_amd.hip_api import load_dev_library as load_library   # msh_test_*: the development library
 
     lib = load_library()
     M = len(Ts)
@@ -125,7 +125,7 @@ def test_two_stage_query_kernel_vs_numpy(D, M):
     Rows with a large common offset and an outlier feature exercise the LayerNorm; M = 37 / 1 leave a ragged last row tile.
     The kernel rounds LN(x) to bf16 (like every decode GEMM) and keeps q and its output as two bf16 halves: the bound is
     that of one bf16 operand rounding over K = D."""
-    from moonshine_amd.hip_api import load_library
+    from moonshine_amd.hip_api import load_dev_library as load_library   # msh_test_*: the development library
 
     lib = load_library()
     rng = np.random.default_rng(D + M)
@@ -154,7 +154,7 @@ def test_two_stage_query_kernel_vs_numpy(D, M):
 
 def test_two_stage_query_kernel_rate():
     """Informational: per-launch time of the query kernel at the benchmark shape (256 rows), back-to-back launches."""
-    from moonshine_amd.hip_api import load_library
+    from moonshine_amd.hip_api import load_dev_library as load_library   # msh_test_*: the development library
 
     lib = load_library()
     D, M = 416, 256

@@ -19,16 +19,29 @@ INCLUDE = os.path.join(ROOT, "include")
 
 
 def test_library_exports_every_declared_symbol():
+    """The product library exports every symbol of include/moonshine-c-api.h and include/moonshine_hip.h and NONE of the
+    development hooks; those (include/moonshine_hip_dev.h, msh_test_*) live in libmoonshine_dev.so, built from the same
+    objects + csrc/dev_hooks.cpp."""
     lib = C.CDLL(LIB_PATH)
-    declared = []
-    for h in sorted(os.listdir(INCLUDE)):
+    dev = C.CDLL(os.path.join(os.path.dirname(LIB_PATH), "libmoonshine_dev.so"))
+
+    def declared_in(h):
         txt = open(os.path.join(INCLUDE, h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         txt = re.sub(r"#define[^\n]*", "", txt)
-        declared += re.findall(r"(?:MSH_EXPORT|MOONSHINE_EXPORT)[^;(]*?\b(\w+)\s*\(", txt)
-    assert len(declared) >= 40
+        return re.findall(r"(?:MSH_EXPORT|MOONSHINE_EXPORT)[^;(]*?\b(\w+)\s*\(", txt)
+
+    declared, hooks = [], []
+    for h in sorted(os.listdir(INCLUDE)):
+        (hooks if h == "moonshine_hip_dev.h" else declared).extend(declared_in(h))
+    assert len(declared) >= 40 and len(hooks) >= 8
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert hasattr(dev, name), f"{name} missing from the development library"
+    for name in hooks:
+        assert name.startswith("msh_test_")
+        assert hasattr(dev, name), f"{name} declared in moonshine_hip_dev.h but not exported by libmoonshine_dev.so"
+        assert not hasattr(lib, name), f"development hook {name} is exported by the product library"
     assert set(api.C_API_SYMBOLS) <= set(declared)
 
 

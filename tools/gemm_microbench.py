@@ -3,7 +3,7 @@ import ctypes as C
 import sys
 
 sys.path.insert(0, ".")
-from moonshine_amd.hip_api import load_library
+from moonshine_amd.hip_api import load_dev_library as load_library
 
 lib = load_library()
 lib.msh_test_gemm_microbench.restype = C.c_float

@@ -39,3 +39,13 @@ for p in eng.profile():
         per_step[k] = p["ms"] / REPS * 1e3                 # us per decode step (all launches of the group)
 tot_us = sum(v for k, v in per_step.items() if k != "empty_step")
 print(f"B=1 chain: step {tot_us:.1f} us  " + "  ".join(f"{k[4:] if k.startswith('dec_') else k}={rows[k]:.2f}x{round(per_step[k] / rows[k])}" for k in sorted(rows)), flush=True)
+
+# the encoder of the single clip, kernel by kernel (HIP-event scopes: ~4.8 us of overhead inside each figure)
+eng.profile_reset()
+eng.profile_enable(True)
+for _ in range(5):
+    eng.encode(device_ptrs=one)
+    eng.synchronize()
+eng.profile_enable(False)
+rows = [(p["name"], p["ms"] / 5 * 1e3, p["launches"] // 5) for p in eng.profile() if not p["name"].startswith("chain_") and p["launches"] > 0]
+print("B=1 encoder (us per encode, launches): " + "  ".join(f"{n}={u:.0f}/{l}" for n, u, l in rows) + f"  sum={sum(u for _, u, _ in rows):.0f}", flush=True)

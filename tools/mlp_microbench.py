@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from moonshine_amd.hip_api import load_library  # noqa: E402
+from moonshine_amd.hip_api import load_dev_library as load_library  # noqa: E402
 
 lib = load_library()
 lib.msh_test_mlp_microbench.restype = C.c_float

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
-    from moonshine_amd.hip_api import load_library
+    from moonshine_amd.hip_api import load_dev_library as load_library
     lib = load_library()
     lib.msh_test_qkv_panel.restype = C.c_float
     lib.msh_test_qkv_panel.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from moonshine_amd.hip_api import load_library
+from moonshine_amd.hip_api import load_dev_library as load_library
 
 D, T, M = 416, int(os.environ.get("XA_T", "415")), int(os.environ.get("XA_M", "256"))
 rng = np.random.default_rng(1)
