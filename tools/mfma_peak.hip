@@ -14,8 +14,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // CHAINS independent accumulators, each fed ITERS times in turn: CHAINS = 1 is one dependent chain (the next MFMA reads the
 // accumulator the previous one writes), larger values leave CHAINS - 1 independent MFMAs between two dependent ones.
 template <int CHAINS, bool BIG>
-__global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ seed, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ seed, float* __restrict__ out, int iters,
+                                                 unsigned long long* __restrict__ cyc) {
   const int lane = threadIdx.x & 63;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();   // shader-clock ticks (MI355X_MICROARCH.md: tick = shader cycle)
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) {
     a[e] = (__bf16)(seed[(lane * 8 + e) & 1023] * 0.01f);
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ seed,
       for (int i = 0; i < 4; ++i) keep += acc[c][i];
   }
   if (keep == 12345.678f) out[threadIdx.x] = keep;   // never true in practice: keeps the accumulators alive
+  if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
 }
 
 template <int CHAINS, bool BIG>
@@ -51,17 +54,29 @@ int run(const char* what, const float* seed, float* out, int wgs, int threads, i
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((mfma_loop<CHAINS, BIG>), dim3(wgs), dim3(threads), 0, 0, seed, out, iters / 8);   // warm
+  static unsigned long long* cyc = nullptr;
+  if (cyc == nullptr) CK(hipMalloc(&cyc, 1024 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL((mfma_loop<CHAINS, BIG>), dim3(wgs), dim3(threads), 0, 0, seed, out, iters / 8, cyc);   // warm
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL((mfma_loop<CHAINS, BIG>), dim3(wgs), dim3(threads), 0, 0, seed, out, iters);
+  hipLaunchKernelGGL((mfma_loop<CHAINS, BIG>), dim3(wgs), dim3(threads), 0, 0, seed, out, iters, cyc);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> hc(wgs);
+  CK(hipMemcpy(hc.data(), cyc, wgs * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double csum = 0;
+  for (int i = 0; i < wgs; ++i) csum += (double)hc[i];
+  const double cycles = csum / wgs;   // shader cycles a wave spent in the kernel
   const double flops = (double)wgs * (threads / 64) * (double)iters * CHAINS * (BIG ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32);
-  printf("%-58s %4d wg x %d waves  %8.3f ms  %7.1f TFLOP/s  = %.3f of 2.5 PFLOP/s\n", what, wgs, threads / 64, ms, flops / (ms * 1e-3) / 1e12,
-         flops / (ms * 1e-3) / 2.5e15);
+  // effective shader clock = cycles / wall (the event pair also holds the launch, ~10 us of a >= 10 ms kernel); cycles per MFMA
+  // per SIMD = cycles / MFMAs issued on that SIMD; what the same cycle count would give at the 2.4 GHz the 2.5 PFLOP/s assume
+  const double ghz = cycles / (ms * 1e6), waves_per_simd = (double)wgs * (threads / 64) / 1024.0;
+  const double cyc_per_mfma = cycles / ((double)iters * CHAINS * (waves_per_simd < 1 ? 1 : waves_per_simd));
+  printf("%-62s %4d wg x %d  %8.3f ms  %7.1f TFLOP/s = %.3f of 2.5 PF | clock %.2f GHz, %.1f cycles per MFMA per SIMD (floor %d) -> %.3f at 2.4 GHz\n",
+         what, wgs, threads / 64, ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15, ghz, cyc_per_mfma, BIG ? 32 : 16,
+         flops / (ms * 1e-3) / 2.5e15 * 2.4 / ghz);
   return 0;
 }
 
@@ -72,7 +87,13 @@ int main() {
   CK(hipMalloc(&seed, 4096));
   CK(hipMalloc(&out, 4096));
   CK(hipMemcpy(seed, h.data(), 4096, hipMemcpyHostToDevice));
+  float* zeros = nullptr;   // the same loops on all-zero operands: the guide's 2,495 TFLOP/s figure is a zero / trivial-data number,
+  CK(hipMalloc(&zeros, 4096));   // and the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS give-back)
+  CK(hipMemset(zeros, 0, 4096));
   const int IT = 40000;
+  run<13, true>("ZERO DATA 32x32x16, 1 wave/SIMD, 13 chains", zeros, out, 256, 256, IT / 13);
+  run<4, true>("ZERO DATA 32x32x16, 2 waves/SIMD, 4 chains each", zeros, out, 512, 256, IT / 4);
+  run<8, false>("ZERO DATA 16x16x32, 2 waves/SIMD, 8 chains each", zeros, out, 512, 256, IT / 8);
   // one wave per SIMD (the fused MLP kernel's occupancy): 256 workgroups of 4 waves
   run<1, true>("32x32x16, 1 wave/SIMD, one dependent chain", seed, out, 256, 256, IT);
   run<2, true>("32x32x16, 1 wave/SIMD, 2 chains", seed, out, 256, 256, IT / 2);
