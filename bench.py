@@ -185,6 +185,7 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
         step()
     for k in stats:
         stats[k] = 0
+    eng.query(0, 14)   # reset the engine's decode_full statistics (passes run, GPU time in AR loops / verify passes)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,6 +198,18 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
     torch.cuda.synchronize()
     elapsed = msd.max_over_ranks(time.perf_counter() - t0, world, dev)
     timed = dict(stats)   # the timed steps only (the profiled step below keeps counting into `stats`)
+    # what a decoder pass costs, whatever share of the draft the workload accepts (noise + random weights: ~45 %; a trained model
+    # on speech accepts most of it and takes few AR passes): GPU time between HIP events inside decode_full
+    ar_passes, ver_passes = eng.query(0, 10), eng.query(0, 11)
+    ar_us, ver_us = eng.query(0, 12), eng.query(0, 13)
+    # bytes an AR pass must move: the decoder's weights once (bf16) + every stream's cross K / V memory once per layer
+    dec_w = cfg.depth * (4 * cfg.dec_dim * cfg.dec_dim * 2 + 2 * cfg.dec_dim * cfg.dec_dim + 3 * cfg.dec_dim * cfg.dec_ffn) * 2 + cfg.vocab * cfg.dec_dim * 2
+    passes = {"ar_passes_per_step": round(ar_passes / max(steps, 1), 1), "verify_passes_per_step": round(ver_passes / max(steps, 1), 1),
+              "us_per_ar_pass": round(ar_us / max(ar_passes, 1), 1), "us_per_verify_pass": round(ver_us / max(ver_passes, 1), 1),
+              "ar_pass_weight_bytes": dec_w,
+              "ar_pass_hbm_frac_weights_only": round(dec_w / max(ar_us / max(ar_passes, 1), 1e-9) * 1e6 / 8e12, 4),
+              "note": "GPU time between HIP events inside decode_full (the AR loop's host round trips every 8 steps included); "
+                      "independent of the draft acceptance of the workload"}
     # ---- per-kernel-group HIP-event times over one more step (the AR steps run eagerly while profiling) ----
     skernels, sroof = [], None
     if rank == 0 and not args.no_stream_profile:
@@ -237,6 +250,7 @@ def run_streaming(args, steps, warmup, local_rank, rank, world, dev, dist):
                       "decode_ms_per_step": round(timed["decode_ms"] / k, 2),
                       "draft_acceptance": round(timed["accepted"] / max(timed["draft"], 1), 4),
                       "tokens_per_final_line": round(sum(len(t) for t in final_tokens) / S, 2),
+                      "decoder_passes": passes,
                       "kernels": skernels, "roofline": sroof},
     }
     return line

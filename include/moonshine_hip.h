@@ -347,7 +347,10 @@ MSH_EXPORT int32_t msh_stream_profile_enable(msh_stream_engine* e, int32_t on);
 MSH_EXPORT int32_t msh_stream_profile_reset(msh_stream_engine* e);
 MSH_EXPORT int32_t msh_stream_profile_count(msh_stream_engine* e);
 MSH_EXPORT int32_t msh_stream_profile_get(msh_stream_engine* e, int32_t index, msh_profile_entry* out);
-/* state queries: 0 memory_len, 1 feature_count, 2 cache_len, 3 frames_emitted, 4 max_tokens for the memory */
+/* state queries: 0 memory_len, 1 feature_count, 2 cache_len, 3 frames_emitted, 4 max_tokens for the memory;
+ * engine-wide decode_full statistics since the last reset (slot ignored): 10 auto-regressive passes run, 11 wide (verify)
+ * passes run, 12 / 13 microseconds of GPU time in AR loops / verify passes (HIP events, no extra synchronisation), 14 resets --
+ * what a pass costs does not depend on the draft acceptance of the workload */
 MSH_EXPORT int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what);
 MSH_EXPORT int32_t msh_stream_get_memory(msh_stream_engine* e, int32_t slot, float* out);   /* [memory_len][Dd] */
 MSH_EXPORT int32_t msh_stream_get_features(msh_stream_engine* e, int32_t slot, float* out); /* [features][De] */

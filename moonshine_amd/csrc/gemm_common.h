@@ -774,6 +774,30 @@ __device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_base) { 
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+// Up to four consecutive KiB from gsrc (per lane: + 16 * lane) to LDS at lds_base (wave-uniform) + 16 * lane in ONE setting of
+// M0 and of the address register: the instruction's offset field moves both the global and the LDS address, so pieces that lie
+// 1 KiB apart on both sides need nothing between them -- 8 instructions for 4 KiB where four dma16 calls (M0 saved / set /
+// restored and a 64-bit address add each) are 28.
+template <int N>
+__device__ __forceinline__ void dma16_run(const void* gsrc, unsigned lds_base) {
+  static_assert(N >= 1 && N <= 4, "the offset field reaches 4095");
+  unsigned keep;
+  if constexpr (N == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

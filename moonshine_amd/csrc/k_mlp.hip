@@ -40,7 +40,8 @@ struct MlpGeom {
   static constexpr int WP = KS + 2 * CT;    // weight fragments (1 KiB each) per stage
   static constexpr int PIECES = WP + 1;     // + the bias piece (first 32 floats = b1 of the chunk)
   static constexpr int NST = 3;             // ring stages: being read, published, being filled (159 KiB at D = 416)
-  static constexpr int PMAX = (PIECES + 3) / 4;             // pieces per wave per stage
+  static constexpr int PMAX = (PIECES + 3) / 4;             // pieces per wave per stage: a contiguous run of the stage
+  static constexpr int NG = (PMAX + 3) / 4;                 // DMA groups of up to four pieces (one M0 / address setting each)
   static_assert(D % 32 == 0 && KS == 2 * CT, "hidden size must be a multiple of 32");
   static_assert(NST * PIECES <= 160, "ring does not fit the LDS");
 };
@@ -64,7 +65,8 @@ __device__ __forceinline__ void static_for(Body&& body) {
 // the prologue (compute side alone), bit 1 = no GELU arithmetic, bit 2 = fc1 alternating between TWO accumulators instead
 // of one chain (correct), bit 3 = ring of 2 fragment registers instead of 4 (correct), bit 4 = a stage's DMAs issued
 // together behind the barrier instead of spread over the MFMAs that follow it (correct), bit 5 = no stages at all
-// (LayerNorm prologue + residual epilogue only), bit 6 = no fragment reads, bit 7 = no workgroup barrier.
+// (LayerNorm prologue + residual epilogue only), bit 6 = no fragment reads, bit 7 = no workgroup barrier, bit 8 = no MFMAs
+// (with bits 1 and 6: the weight stream alone -- DMA issue, the waits and the barrier: what the CU INGESTS per stage).
 // OP: the attention output projection of the layer rides in front: H' = H + AO Wo^T is formed in the fc2 accumulators
 // (NOP extra stages of two 32-column tiles each at the head of Wp, AO [R][D] bf16 as their B operand), LayerNorm is then
 // taken from those registers, and H is read ONCE and written once per layer for o-proj + MLP together.
@@ -74,30 +76,36 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
                                                            const float* __restrict__ b2, int R, int NC,
                                                            const bf16_t* __restrict__ AO) {
   using G = MlpGeom<D>;
-  constexpr int KS = G::KS, CT = G::CT, WP = G::WP, PIECES = G::PIECES, NST = G::NST, PMAX = G::PMAX;
+  constexpr int KS = G::KS, CT = G::CT, WP = G::WP, PIECES = G::PIECES, NST = G::NST, PMAX = G::PMAX, NG = G::NG;
   constexpr int NOP = OP ? (CT + 1) / 2 : 0;   // o-proj stages
   __shared__ __attribute__((aligned(16))) uint4 lds[NST * PIECES * 64];
 
   const int tid = threadIdx.x, lane = tid & 63, mrow = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int my_pieces = (PIECES - wave + 3) / 4;   // wave-uniform: pieces wave, wave + 4, ...; PMAX or PMAX - 1
+  // wave w moves PMAX consecutive pieces of a stage from piece min(w PMAX, PIECES - PMAX) on (the last wave's run overlaps its
+  // neighbour's by 4 PMAX - PIECES pieces: the same bytes to the same place, harmless, and every wave issues the same static
+  // pattern): consecutive KiB on both sides, so four of them go out behind ONE setting of M0 and of the address register
+  // (dma16_run).  The first version dealt the pieces round-robin (piece q of wave w = 4 q + w, 4 KiB apart: beyond the offset
+  // field) and paid 7 instructions per piece, ~98 of a stage's 472.
+  const int my_first = wave * PMAX < PIECES - PMAX ? wave * PMAX : PIECES - PMAX;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(&lds[0]));
   const int nstages = NOP + NC + 1;
 
-  // piece q of this wave for stage `st` into ring buffer `buf` (a stage past the end re-fetches the last one into a
+  // group g of this wave for stage `st` into ring buffer `buf` (a stage past the end re-fetches the last one into a
   // buffer nobody reads any more: the issue / wait pattern is the same for every stage)
-  const bf16_t* wsrc = Wp + (long)wave * 512 + lane * 8;
+  const bf16_t* wsrc = Wp + (long)my_first * 512 + lane * 8;
   auto stage_src = [&](int st) { return wsrc + (long)(st < nstages ? st : nstages - 1) * (PIECES * 512); };
-  auto stage_dst = [&](int buf) { return lds_base + (unsigned)(buf * PIECES + wave) * 1024u; };
-  auto issue_piece = [&](const bf16_t* src, unsigned dst, int q) {
-    if (q < PMAX - 1 || my_pieces == PMAX) dma16(src + (long)q * 2048, dst + (unsigned)q * 4096u);
+  auto stage_dst = [&](int buf) { return lds_base + (unsigned)(buf * PIECES + my_first) * 1024u; };
+  auto issue_group = [&](const bf16_t* src, unsigned dst, auto gc) {
+    constexpr int g = decltype(gc)::value, n = PMAX - 4 * g >= 4 ? 4 : PMAX - 4 * g;
+    static_assert(n >= 1, "group beyond the wave's run");
+    dma16_run<n>(src + (long)g * 2048, dst + (unsigned)g * 4096u);
   };
 #pragma unroll
   for (int s = 0; s < 2; ++s) {   // stages 0 and 1 up front
     const bf16_t* src = stage_src(s);
     const unsigned dst = stage_dst(s);
-#pragma unroll
-    for (int q = 0; q < PMAX; ++q) issue_piece(src, dst, q);
+    static_for<NG>([&](auto gc) { issue_group(src, dst, gc); });
   }
 
   // ---- LayerNorm of this lane's row straight from the residual stream, kept as the fc1 B-operand ----
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
     static_assert((2 * KS) % PF == 0, "a steady stage must leave the ring's phase unchanged");
     // GELU values [16 (i - G0) / GN, 16 (i + 1 - G0) / GN) (rounded up) are computed behind fc2 step i
     constexpr int G0 = KS > 2 ? 1 : 0, GN = KS - G0 - (KS > 3 ? 1 : 0);
-    // DMA piece q of this wave goes behind step MID + 1 + q * DS (all behind MID with ABL bit 4)
-    constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / PMAX > 0 ? (NF - MID - 2) / PMAX : 1);
+    // DMA group g of this wave goes behind step MID + 1 + g * DS (all behind MID with ABL bit 4)
+    constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / NG > 0 ? (NF - MID - 2) / NG : 1);
     const int nbuf = buf + 1 == NST ? 0 : buf + 1;           // stage j + 1
     const bf16_t* nsrc = stage_src(NOP + j + 2);
     const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);   // stage j + 2 goes where stage j - 1 was
@@ -249,13 +257,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
     static_for<NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value, piece = F0 + f;
       if constexpr (piece < KS) {
-        if constexpr (!TWO_ACC || (piece & 1) == 0)
+        if constexpr ((ABL & 256) != 0) {
+        } else if constexpr (!TWO_ACC || (piece & 1) == 0)
           za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), yf[piece], za, 0, 0, 0);
         else
           zc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), yf[piece], zc, 0, 0, 0);
       } else {
         constexpr int i = piece - KS, u = i / CT, t = i % CT;
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), u ? zb1 : zb0, oacc[t], 0, 0, 0);
+        if constexpr ((ABL & 256) == 0)
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fr[(RO + f) % PF]), u ? zb1 : zb0, oacc[t], 0, 0, 0);
         if constexpr (DO1) {
           // (the empty asm pins each value HERE: the IR-level passes otherwise sink the whole GELU below the last MFMA,
           // where nothing overlaps it -- sched_barrier only binds the machine scheduler)
@@ -279,9 +289,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
         if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();   // stage j + 1 complete for everyone; stage j - 1 read by everyone
       }
       if constexpr ((ABL & 1) == 0 && f > MID) {
-        static_for<PMAX>([&](auto qc) {
+        static_for<NG>([&](auto qc) {
           constexpr int q = decltype(qc)::value, at = (MID + 1 + q * DS) < NF ? (MID + 1 + q * DS) : NF - 1;
-          if constexpr (at == f) issue_piece(nsrc, ndst, q);
+          if constexpr (at == f) issue_group(nsrc, ndst, qc);
         });
       }
       if constexpr ((ABL & 64) == 0) {
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
         constexpr int I = decltype(ic)::value, T0 = 2 * I, T1 = 2 * I + 1 < CT ? 2 * I + 1 : CT - 1;   // (a missing last tile: zero weights)
         constexpr int NF = 2 * KS, MID = NF / 2;
         static_assert(NF % PF == 0, "an o-proj stage must leave the fragment ring's phase unchanged");
-        constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / PMAX > 0 ? (NF - MID - 2) / PMAX : 1);
+        constexpr int DS = (ABL & 16) ? 0 : ((NF - MID - 2) / NG > 0 ? (NF - MID - 2) / NG : 1);
         const int nbuf = buf + 1 == NST ? 0 : buf + 1;
         const bf16_t* nsrc = stage_src(I + 2);
         const unsigned ndst = stage_dst(buf == 0 ? NST - 1 : buf - 1);
@@ -345,9 +355,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
             if constexpr ((ABL & 128) == 0) __builtin_amdgcn_s_barrier();
           }
           if constexpr ((ABL & 1) == 0 && f > MID) {
-            static_for<PMAX>([&](auto qc) {
+            static_for<NG>([&](auto qc) {
               constexpr int q = decltype(qc)::value, at = (MID + 1 + q * DS) < NF ? (MID + 1 + q * DS) : NF - 1;
-              if constexpr (at == f) issue_piece(nsrc, ndst, q);
+              if constexpr (at == f) issue_group(nsrc, ndst, qc);
             });
           }
           if constexpr (f + PF < NF) fr[f % PF] = st[(f + PF) * 64];
@@ -586,6 +596,7 @@ float mlp_microbench(int R, int D, int F, int iters, int abl) {
       case 67: return launch_mlp<416, 67>(H, Wp, B2, R, F, 0);
       case 195: return launch_mlp<416, 195>(H, Wp, B2, R, F, 0);
       case 199: return launch_mlp<416, 199>(H, Wp, B2, R, F, 0);
+      case 322: return launch_mlp<416, 322>(H, Wp, B2, R, F, 0);   // 256 + 64 + 2: the weight stream alone
       default: throw std::runtime_error("mlp_microbench: bad ablation");
     }
   };

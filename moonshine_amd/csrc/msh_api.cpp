@@ -585,6 +585,10 @@ int32_t msh_stream_query(const msh_stream_engine* e, int32_t slot, int32_t what)
       case 2: return e->eng->cache_len(slot);
       case 3: return e->eng->frames_emitted(slot);
       case 4: return e->eng->max_tokens_for(slot);
+      case 10: case 11: case 12: case 13: case 14: {   // decode_full statistics of the ENGINE (slot ignored), clamped to int32
+        const long v = const_cast<msh::StreamingEngine*>(e->eng)->decode_stat(what - 10);
+        return (int32_t)std::min<long>(v, 0x7fffffffL);
+      }
       default: return MSH_ERR_INVALID_ARGUMENT;
     }
   } catch (const std::exception&) {

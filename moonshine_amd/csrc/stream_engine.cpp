@@ -82,6 +82,10 @@ StreamingEngine::~StreamingEngine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (ar_graph_ != nullptr) (void)hipGraphExecDestroy(ar_graph_);
+  for (hipEvent_t ev : stat_ev_)
+    if (ev != nullptr) (void)hipEventDestroy(ev);
+  if (pin_ != nullptr) (void)hipHostFree(pin_);
+  if (rb_ != nullptr) (void)hipHostFree(rb_);
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
     for (void* p : allocs_) device_free(p);
@@ -146,11 +150,48 @@ void StreamingEngine::upload_bf16_fm(const std::vector<float>& src, int rows, in
 template <class T>
 T* StreamingEngine::stage(DevBuf& buf, const std::vector<T>& host) {
   buf.reserve(std::max<size_t>(host.size(), 1) * sizeof(T));
-  if (!host.empty()) {
-    MSH_HIP(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
-    MSH_HIP(hipStreamSynchronize(stream_));
+  if (!host.empty()) {   // through the pinned ring: a truly asynchronous copy, and the host vector may die at once
+    const size_t bytes = host.size() * sizeof(T);
+    void* h = pin_take(bytes);
+    memcpy(h, host.data(), bytes);
+    MSH_HIP(hipMemcpyAsync(buf.p, h, bytes, hipMemcpyHostToDevice, stream_));
   }
   return buf.as<T>();
+}
+
+void* StreamingEngine::pin_take(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > pin_cap_ / 2) {   // (first use, or a transfer the ring was not sized for: the PCM of a long update)
+    MSH_HIP(hipStreamSynchronize(stream_));
+    if (pin_ != nullptr) (void)hipHostFree(pin_);
+    pin_ = nullptr;
+    pin_cap_ = std::max<size_t>((size_t)8 << 20, 4 * bytes);
+    MSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_), pin_cap_, hipHostMallocDefault));
+    pin_off_ = pin_live_ = 0;
+  }
+  if (pin_off_ + bytes > pin_cap_) {   // wrap: the skipped tail counts as handed out
+    pin_live_ += pin_cap_ - pin_off_;
+    pin_off_ = 0;
+  }
+  if (pin_live_ + bytes > pin_cap_) {   // the slice would overlap one a queued copy may still read: drain first
+    MSH_HIP(hipStreamSynchronize(stream_));
+    pin_live_ = 0;
+  }
+  void* p = pin_ + pin_off_;
+  pin_off_ += bytes;
+  pin_live_ += bytes;
+  return p;
+}
+
+void* StreamingEngine::rb_area(size_t bytes) {
+  if (bytes > rb_cap_) {
+    MSH_HIP(hipStreamSynchronize(stream_));
+    if (rb_ != nullptr) (void)hipHostFree(rb_);
+    rb_ = nullptr;
+    rb_cap_ = (bytes + 4095) & ~(size_t)4095;
+    MSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&rb_), rb_cap_, hipHostMallocDefault));
+  }
+  return rb_;
 }
 
 const StreamingEngine::SlotHost& StreamingEngine::st(int slot) const {
@@ -829,6 +870,20 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     gemm_logits_f32(Y, Dd, head_w_, M, V, Dd, logits, stream_);
 }
 
+long StreamingEngine::decode_stat(int what) {
+  switch (what) {
+    case 0: return stat_ar_passes_;
+    case 1: return stat_verify_passes_;
+    case 2: return (long)stat_ar_us_;
+    case 3: return (long)stat_verify_us_;
+    case 4:
+      stat_ar_passes_ = stat_verify_passes_ = 0;
+      stat_ar_us_ = stat_verify_us_ = 0.0;
+      return 0;
+    default: throw std::invalid_argument("decode_stat: unknown statistic");
+  }
+}
+
 void StreamingEngine::decode_tokens(int n, const int* slots, const int32_t* const* tokens, const int* lens,
                                     float* logits_out) {
   if (!loaded_) throw std::runtime_error("weights not loaded");
@@ -1004,6 +1059,9 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   for (size_t j = 0; j < job_slot.size(); ++j) job_mem[j] = st(job_slot[j]).mem_len;
   const int* jmem_d = stage(jobmem_, job_mem);   // the AR rows' memory lengths (fixed for the whole decode_full)
   MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
+  for (hipEvent_t& ev : stat_ev_)
+    if (ev == nullptr) MSH_HIP(hipEventCreate(&ev));
+  MSH_HIP(hipEventRecord(stat_ev_[0], stream_));
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
   const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
   int n_runs = 0;
@@ -1105,38 +1163,55 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
     fprintf(stderr, "[moonshine] decode_full: %d streams, %d rows: staging + verify pass %.0f us\n", J, M, us_since(t_call));
   }
   const auto t_ar = now();
-  int32_t active = 1;
+  MSH_HIP(hipEventRecord(stat_ev_[1], stream_));
+  // read-back area (pinned): [0, 64) the active-stream counter, then every slot's record, then the token table
+  const size_t rb_slots = 64, rb_tokens = rb_slots + (((size_t)max_slots_ * sizeof(SlotDev) + 63) & ~(size_t)63);
+  unsigned char* rb = static_cast<unsigned char*>(rb_area(rb_tokens + (size_t)max_slots_ * Scap_ * sizeof(int32_t)));
+  volatile int32_t* active_h = reinterpret_cast<volatile int32_t*>(rb);
+  *active_h = 1;
   int steps_run = 0;
   for (int step = 0; step < max_budget; ++step) {
     if (step % 8 == 0) {
-      MSH_HIP(hipMemcpyAsync(&active, n_active_d_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+      MSH_HIP(hipMemcpyAsync(rb, n_active_d_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
       MSH_HIP(hipStreamSynchronize(stream_));
-      if (active <= 0) break;
+      if (*active_h <= 0) break;
     }
     if (graph_now) MSH_HIP(hipGraphLaunch(ar_graph_, stream_));
     else ar_step();
     ++steps_run;
   }
+  MSH_HIP(hipEventRecord(stat_ev_[2], stream_));
   if (timing) {
     MSH_HIP(hipStreamSynchronize(stream_));
     const double us = us_since(t_ar);
     fprintf(stderr, "[moonshine] decode_full: %d AR steps in %.0f us = %.1f us per step (%s)\n", steps_run, us, us / std::max(steps_run, 1),
              graph_now ? "graph" : "eager");
   }
-  std::vector<SlotDev> sd(J);
-  for (int j = 0; j < J; ++j)
-    MSH_HIP(hipMemcpyAsync(&sd[j], slots_d_ + jobs[j].slot, sizeof(SlotDev), hipMemcpyDeviceToHost, stream_));
+  // results: every slot's record and the whole token table in TWO copies into pinned memory (they were two pageable copies
+  // per stream, each of which blocks the caller for tens of microseconds)
+  const SlotDev* sd = reinterpret_cast<const SlotDev*>(rb + rb_slots);
+  const int32_t* tok_h = reinterpret_cast<const int32_t*>(rb + rb_tokens);
+  MSH_HIP(hipMemcpyAsync(rb + rb_slots, slots_d_, (size_t)max_slots_ * sizeof(SlotDev), hipMemcpyDeviceToHost, stream_));
+  MSH_HIP(hipMemcpyAsync(rb + rb_tokens, result_, (size_t)max_slots_ * Scap_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
   MSH_HIP(hipStreamSynchronize(stream_));
+  {
+    float v_ms = 0.f, a_ms = 0.f;
+    if (hipEventElapsedTime(&v_ms, stat_ev_[0], stat_ev_[1]) == hipSuccess && hipEventElapsedTime(&a_ms, stat_ev_[1], stat_ev_[2]) == hipSuccess) {
+      stat_verify_us_ += (double)v_ms * 1e3;
+      stat_ar_us_ += (double)a_ms * 1e3;
+      stat_verify_passes_ += 1;
+      stat_ar_passes_ += steps_run;
+    }
+  }
   for (int j = 0; j < J; ++j) {
     const int i = job_index[j];
-    counts_out[i] = sd[j].count;
-    if (accepted_out) accepted_out[i] = sd[j].accepted;
-    st(jobs[j].slot).cache_len = sd[j].cache_len;
-    if (sd[j].count > 0)
-      MSH_HIP(hipMemcpyAsync(tokens_out + (size_t)i * tokens_stride, result_ + (size_t)jobs[j].slot * Scap_,
-                             (size_t)sd[j].count * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    const SlotDev& r = sd[jobs[j].slot];
+    counts_out[i] = r.count;
+    if (accepted_out) accepted_out[i] = r.accepted;
+    st(jobs[j].slot).cache_len = r.cache_len;
+    if (r.count > 0)
+      memcpy(tokens_out + (size_t)i * tokens_stride, tok_h + (size_t)jobs[j].slot * Scap_, (size_t)r.count * sizeof(int32_t));
   }
-  MSH_HIP(hipStreamSynchronize(stream_));
 }
 
 }  // namespace msh

@@ -76,6 +76,10 @@ class StreamingEngine {
   void get_memory(int slot, float* out);    // [memory_len][Dd]
   void get_features(int slot, float* out);  // [feature_count][De]
   int max_tokens_for(int slot) const;       // streaming-model.cpp:1217-1219
+  // decode_full statistics since the last reset (GPU time between HIP events on the engine's stream, no extra synchronisation):
+  // 0 = auto-regressive passes run, 1 = wide (verify) passes run, 2 = microseconds in AR loops, 3 = microseconds in verify passes
+  // (embedding + pass + bias + argmax + verify); 4 resets.  What a pass costs does not depend on the draft's acceptance rate.
+  long decode_stat(int what);
   void synchronize();
   void profile_enable(bool on) { prof_.enable(on, stream_); }
   void profile_reset() { prof_.reset(stream_); }
@@ -129,6 +133,20 @@ class StreamingEngine {
   ScopeProfiler prof_;
   double pass_cross_bytes_ = 0.0;
   hipGraphExec_t ar_graph_ = nullptr;  // one autoregressive decode step (decode_full), replayed
+  hipEvent_t stat_ev_[3] = {nullptr, nullptr, nullptr};
+  // Pinned host memory for the engine's small transfers.  A copy between PAGEABLE host memory and the device goes through the
+  // runtime's bounce buffers and blocks the caller (~30-50 us each): decode_full read its results back with two such copies per
+  // stream (128 per call at 64 streams: 6 of the 8.5 ms of host time a call cost beside its GPU work) and staged nine descriptor
+  // arrays with a copy + stream drain each.  pin_: a ring for host -> device staging (slices stay untouched until the stream has
+  // been drained since they were handed out); rb_: the read-back area (slot records + token table + the active counter).
+  unsigned char* pin_ = nullptr;
+  size_t pin_cap_ = 0, pin_off_ = 0, pin_live_ = 0;
+  void* pin_take(size_t bytes);
+  unsigned char* rb_ = nullptr;
+  size_t rb_cap_ = 0;
+  void* rb_area(size_t bytes);
+  long stat_ar_passes_ = 0, stat_verify_passes_ = 0;
+  double stat_ar_us_ = 0.0, stat_verify_us_ = 0.0;
   std::string ar_key_;
   float* capture_probs_ = nullptr;  // set while cross_attention() runs its pass
   int capture_ecap_ = 0;

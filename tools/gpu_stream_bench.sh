@@ -1,13 +1,15 @@
 #!/bin/bash
-# streaming workload bench + kernel-level profile
-tag=${1:-sb}
-mkdir -p gpurun_out
-timeout 900 python bench.py --workload streaming --steps 2 --warmup 1 > gpurun_out/${tag}_stream_bench.json 2> gpurun_out/${tag}_stream_bench.err
-tail -3 gpurun_out/${tag}_stream_bench.err
-cat gpurun_out/${tag}_stream_bench.json
-cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -- python $GRAFT_REPO_ROOT/bench.py --workload streaming --steps 1 --warmup 1 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
-f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp $f gpurun_out/${tag}_stream_kernel_stats.csv && head -30 $f | cut -c1-200
-rm -rf gpurun_out/${tag}_prof
+# Streaming engine: its GPU tests, then BASELINE config 5 (64 streams x 10 s, 0.5 s updates, speculative) as its own bench line.
+set -u
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out
+TAG=${1:-stream}
+timeout 900 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_capi_streaming.py -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1
+tail -4 gpurun_out/${TAG}_pytest.log
+timeout 600 python bench.py --workload streaming --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_streaming.json 2> gpurun_out/${TAG}_bench_streaming.err
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_bench_streaming.json").read().strip().splitlines()[-1])
+s = d["streaming"]
+print(d["value"], d["ms_per_step"], {k: s[k] for k in ("ms_per_update", "frontend_ms_per_step", "encode_ms_per_step", "decode_ms_per_step", "draft_acceptance")})
+print(s["decoder_passes"])
+PY

@@ -27,7 +27,7 @@ for R in (32768, 65536, 98304, 108544):   # whole rounds of 256 panels, then the
     ms = min(lib.msh_test_mlp_microbench(R, D, F, 10, 0) for _ in range(3))
     print(f"R = {R:6d} ({R / 128 / 256:.2f} rounds of 256 panels) {ms:.3f} ms = {4.0 * R * D * F / ms / 1e9:.0f} TFLOP/s", flush=True)
 R = 32768
-names = {1: "no DMA", 2: "no GELU", 3: "no DMA, no GELU", 4: "fc1 on two accumulators", 8: "6-deep fragment ring", 16: "DMAs issued together", 32: "prologue + epilogue only", 67: "MFMAs + barrier only", 195: "MFMAs only", 199: "MFMAs only, fc1 on two accumulators"}
+names = {1: "no DMA", 2: "no GELU", 3: "no DMA, no GELU", 4: "fc1 on two accumulators", 8: "6-deep fragment ring", 16: "DMAs issued together", 32: "prologue + epilogue only", 67: "MFMAs + barrier only", 195: "MFMAs only", 199: "MFMAs only, fc1 on two accumulators", 322: "weight stream only (DMA + waits + barrier)"}
 for abl, nm in names.items():
     ms = min(lib.msh_test_mlp_microbench(R, D, F, 10, abl) for _ in range(2))
     print(f"ablation {abl:2d} ({nm:24s}) {ms:.3f} ms = {4.0 * R * D * F / ms / 1e9:.0f} TFLOP/s", flush=True)
