@@ -16,15 +16,34 @@
 namespace msh {
 namespace {
 
+// Full-wave reductions on the VALU: four DPP row rotations inside the 16-lane rows, then the gfx950 row swaps (permlane16 /
+// permlane32) across them -- no trip through the LDS crossbar (__shfl_xor is ds_bpermute + a wait on lgkmcnt, six times per
+// reduction, on the critical path of every attention kernel here).  Fixed order, every lane gets the result; all callers reduce
+// at wave-uniform points.  (The same forms as k_attn.hip's wave_sum_dpp / wave_max_dpp.)
+#define MSH_S_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, true))
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += MSH_S_ROR(v, 8);
+  v += MSH_S_ROR(v, 4);
+  v += MSH_S_ROR(v, 2);
+  v += MSH_S_ROR(v, 1);
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned w = __float_as_uint(v);
+  auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 __device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, MSH_S_ROR(v, 8));
+  v = fmaxf(v, MSH_S_ROR(v, 4));
+  v = fmaxf(v, MSH_S_ROR(v, 2));
+  v = fmaxf(v, MSH_S_ROR(v, 1));
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const unsigned w = __float_as_uint(v);
+  auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 __device__ __forceinline__ float bf(bf16_t h) { return bf16_to_f32(h); }
 
@@ -264,8 +283,13 @@ __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __r
   for (int t = 0; t < 2; ++t) {
     const int j = lane + 64 * t;
     const bf16_t* kp = cacheK + base + (long)(j < nk ? j : 0) * D;
+    if (t == 0 || nk > 64) {   // (wave-uniform: a row of at most 64 keys has no second key per lane)
 #pragma unroll
-    for (int c = 0; c < C8; ++c) kr[t][c] = ld16<NT>(kp + c * 8);
+      for (int c = 0; c < C8; ++c) kr[t][c] = ld16<NT>(kp + c * 8);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C8; ++c) kr[t][c] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   uint4 vr[NV];
   const int nchunks = nk * C8;
@@ -290,6 +314,10 @@ __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __r
   float sc[2], mx = -INFINITY;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
+    if (t == 1 && nk <= 64) {   // wave-uniform
+      sc[t] = -INFINITY;
+      continue;
+    }
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < C8; ++c) {
@@ -315,21 +343,33 @@ __global__ __launch_bounds__(64) void self_attention_ar_kernel(const bf16_t* __r
   }
   const float inv = 1.0f / wsum(sum);
   __syncthreads();
+  // P.V with lane = (key group g, 4-dim piece c), as self_attention_kernel has it: group g walks keys g, g + G, ... with 8-byte
+  // LDS reads, the G partial sums of a dim are added in group order -- the same sums in the same order as the first version of
+  // this kernel (one lane per dim walking ALL keys with 2-byte reads, a second pass for dims 64..79), a third of the iterations
+  __shared__ __attribute__((aligned(16))) float pt[G][DH];
+  {
+    const int g = lane / TPK, c = lane - g * TPK;
+    if (g < G) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int jk = g; jk < nk; jk += G) {
+        const uint2 u = *reinterpret_cast<const uint2*>(&sv[jk * VROW + c * 4]);
+        const float pw = sp[jk];
+        acc.x += pw * __uint_as_float(u.x << 16);
+        acc.y += pw * __uint_as_float(u.x & 0xffff0000u);
+        acc.z += pw * __uint_as_float(u.y << 16);
+        acc.w += pw * __uint_as_float(u.y & 0xffff0000u);
+      }
+      *reinterpret_cast<float4*>(&pt[g][c * 4]) = acc;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     const int d = lane + 64 * i;
     if (d < DH) {
-      float part[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) part[g] = 0.f;
-      for (int j0 = 0; j0 < nk; j0 += G) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-          if (j0 + g < nk) part[g] += sp[j0 + g] * bf(sv[(j0 + g) * VROW + d]);
-      }
       float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < G; ++g) t += part[g];
+      for (int g = 0; g < G; ++g) t += pt[g][d];
       const int col = head * DH + d;
       out[fm ? fm16(row, col, D >> 5) : (long)row * D + col] = f32_to_bf16(t * inv);
     }

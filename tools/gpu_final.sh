@@ -118,3 +118,9 @@ f=$(find /tmp/sprof_${TAG} -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_rocprofv3_kernel_stats_streaming.csv && head -6 "$f" | cut -c1-160
 timeout 300 python tools/mlp_microbench.py > gpurun_out/${TAG}_mlp_fused_ablations.txt 2>&1; tail -3 gpurun_out/${TAG}_mlp_fused_ablations.txt
 timeout 300 python tools/panel_microbench.py > gpurun_out/${TAG}_qkv_panel_ablations.txt 2>&1; head -3 gpurun_out/${TAG}_qkv_panel_ablations.txt
+# round 5: the single-clip latency path (p50 + chain costs + the clip's encoder kernel by kernel), chain costs at small batches,
+# the fused-kernel probes with the shader clock, the parity margins recorded by the suite above
+timeout 300 python tools/latency_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_latency_batch1.txt; head -1 gpurun_out/${TAG}_latency_batch1.txt | cut -c1-200
+timeout 300 python tools/chain_probe.py 1 2 4 8 16 32 63 2>&1 | grep "^B=" > gpurun_out/${TAG}_small_batch_chain_costs.txt
+[ -x tools/build/mfma_peak ] && timeout 120 tools/build/mfma_peak > gpurun_out/${TAG}_mfma_issue_ceiling_with_clock.txt 2>&1
+cp gpurun_out/parity_margins.json gpurun_out/${TAG}_parity_margins.json 2>/dev/null
