@@ -1658,7 +1658,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const char* xe = getenv("MSH_XSPLIT_M");   // (read per call: the tests switch it)
       const int xsplit_m = xe != nullptr ? atoi(xe) : 4;
       const char* sfe = getenv("MSH_SELF_FUSED_M");   // largest batch whose self-attention runs inside the o-proj launch (0 = off)
-      const int self_m = sfe != nullptr ? atoi(sfe) : 2;
+      const int self_m = sfe != nullptr ? atoi(sfe) : 1;   // (two clips: 7.7 us fused against 4.9 + 2.1 -- the waves take the clips in turn)
       g.self_fused = M <= std::min(self_m, 2) && dec_self_oproj_supported(D, Hh, M);
       int tmax = 1;
       for (int b = 0; b < M; ++b) tmax = std::max(tmax, (int)clips_h_[g.first + b].T);

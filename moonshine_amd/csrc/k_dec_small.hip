@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void dec_merge_resid_kernel(const float* __res
 
 
 // ------------------------------------------------------------------------------------------------
-// Self-attention + output projection in ONE launch (one or two clips): H += selfattn(q, cache) Wo^T.
+// Self-attention + output projection in ONE launch (one clip by default; the kernel takes two): H += selfattn(q, cache) Wo^T.
 // grid = D / 16 column tiles, 512 threads.  Wave h of EVERY workgroup computes head h of the clip(s) -- at one clip that is 26 x
 // the work of the separate kernel, all of it out of the L2 (a layer's cache at 66 keys is 110 KB), and it removes a launch and a
 // round trip through HBM from a chain whose every link costs >= 2 us.  The wave-level attention is that of k_attn.hip's

@@ -197,7 +197,7 @@ void dec_merge_resid(const float* part, const bf16_t* Wo_fm, int M, int D, int h
 int dec_cross_looped_max_slices();
 void dec_cross_looped(const float* H, const bf16_t* Wq_rm, const bf16_t* KT, const bf16_t* VT, const ClipMeta* clips, int M, int D,
                       int heads, bf16_t* out_fm, hipStream_t s);
-// self-attention over the cache + output projection + residual in one launch (M <= 2): H += selfattn(q, cacheK, cacheV) Wo^T
+// self-attention over the cache + output projection + residual in one launch (M <= 2; the engine uses it for one clip): H += selfattn(q, cacheK, cacheV) Wo^T
 bool dec_self_oproj_supported(int D, int heads, int M);
 void dec_self_oproj(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, const bf16_t* Wo_fm, int M, int D,
                     int heads, int Smax, float* H, hipStream_t s);

@@ -2,7 +2,7 @@
 
 Every parity test that computes a worst-case error calls ``record(...)`` with the numbers it asserted on; at the end of the
 pytest session ``tests/conftest.py`` writes them all to ``gpurun_out/parity_margins.json`` (``MSH_PARITY_MARGINS`` overrides
-the path), which ``tools/gpu_final5.sh`` copies to ``profiles/`` -- so the distance to each tolerance is tracked from round to
+the path), which ``tools/gpu_final.sh`` copies to ``profiles/`` -- so the distance to each tolerance is tracked from round to
 round instead of living in a log nobody keeps.  Test infrastructure only.
 """
 import os

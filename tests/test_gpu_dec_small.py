@@ -2,7 +2,7 @@
 64-key slices (one wave per slice, head and clip, LayerNorm + query projection inside) and the output projection that
 merges the slices in its prologue.  Up to 4 clips take that shape (MSH_XSPLIT_M, read per call); 5 .. 63 clips
 run the same arithmetic with one workgroup per (clip, head) walking the slices (bit-identical: a clip's ids do not depend on its
-batch); one or two clips also run the self-attention inside the output projection's launch (MSH_SELF_FUSED_M).
+batch); a single clip also runs the self-attention inside the output projection's launch (MSH_SELF_FUSED_M; the kernel takes two).
 
 What is checked, on the GPU through the C ABI:
   * against the path it replaces (MSH_XSPLIT_M=0: one workgroup per (clip, head), k_attn.hip) on the same teacher-forced
