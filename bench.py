@@ -807,6 +807,10 @@ def main():
             # steps (8 layers each, the real step's arguments), GPU otherwise idle; with batches in flight the same
             # launches stretch (profiles/*_inflight.csv).  rocprofv3's kernel duration of the same launches is in profiles/.
             "measured_in": dominant.get("timed_in", "HIP-event scope around every launch"),
+            # PMC counters need their own rocprofv3 --pmc passes: `traffic` is NOT collected in this run
+            "traffic_source": ("profiles/pmc_traffic.json: FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch from the --pmc passes of "
+                               "tools/gpu_final.sh on this tree and workload; read from the committed file, not measured in this run")
+                              if dominant.get("traffic") is not None else None,
             "ms_per_launch_back_to_back_sweep": sweep_ms,
             "ms_per_launch_with_event_scope": per_scope_ms,
             # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s is the spec figure, a float4 copy measures 6.29 TB/s (79 %)

@@ -41,7 +41,7 @@ UtilStreams& util_streams() {
 // merged weight Wqk (one wide decode GEMM) instead of the two-stage kernel (k_crossq.hip)
 int xattn_qt_mode() {   // 0 = two-stage kernel, 1 = merged weight, 2 = two-stage kernel with the merged weight uploaded as well (probe)
   static const int v = [] {
-    const char* e = getenv("MSH_XATTN_QT");
+    const char* e = dev_getenv("MSH_XATTN_QT");
     return e != nullptr ? atoi(e) : 0;
   }();
   return v;
@@ -51,7 +51,7 @@ bool xattn_merged_qt() { return xattn_qt_mode() == 1; }
 // on the GPU; MSH_XATTN_NT=0 / 1 forces it off / on (developer knob)
 bool xattn_stream_nt(bool shared_gpu) {
   static const int forced = [] {
-    const char* e = getenv("MSH_XATTN_NT");
+    const char* e = dev_getenv("MSH_XATTN_NT");
     return e != nullptr ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   return forced >= 0 ? forced != 0 : shared_gpu;
@@ -62,7 +62,7 @@ bool xattn_stream_nt(bool shared_gpu) {
 constexpr bool kEncStoreNtInLanes = false;
 bool enc_store_nt(bool shared_gpu) {
   static const int forced = [] {
-    const char* e = getenv("MSH_ENC_STORE_NT");
+    const char* e = dev_getenv("MSH_ENC_STORE_NT");
     return e != nullptr ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   return forced >= 0 ? forced != 0 : (shared_gpu && kEncStoreNtInLanes);
@@ -74,7 +74,7 @@ bool enc_store_nt(bool shared_gpu) {
 // `auto` picks it when the configured sub-batch size is >= 192 (transcriber.cpp).
 int xattn_min_batch() {
   static const int v = [] {
-    const char* e = getenv("MSH_XATTN_MIN_BATCH");
+    const char* e = dev_getenv("MSH_XATTN_MIN_BATCH");
     return e != nullptr ? atoi(e) : 0;
   }();
   return v;
@@ -83,7 +83,7 @@ int xattn_min_batch() {
 // decode steps per graph replay in the steady state of the decode loop (MSH_DEC_GRAPH_STEPS; 1 = one replay per step)
 int graph_steps() {
   static const int v = [] {
-    const char* e = getenv("MSH_DEC_GRAPH_STEPS");
+    const char* e = dev_getenv("MSH_DEC_GRAPH_STEPS");
     const int n = e != nullptr ? atoi(e) : 8;
     return n == 1 || n == 2 || n == 4 || n == 8 ? n : 8;
   }();
@@ -233,7 +233,7 @@ void zero_blocking(void* p, size_t bytes) {
 // the encoder panel kernels, DESIGN.md 3b / 3c, is that.)
 static size_t buf_skew_bytes() {
   static const size_t kb = [] {
-    const char* e = getenv("MSH_BUF_SKEW_KB");
+    const char* e = dev_getenv("MSH_BUF_SKEW_KB");
     const long v = e != nullptr ? atol(e) : 0;
     return (size_t)(v > 0 && !guard_alloc_enabled() ? v : 0);
   }();
@@ -294,16 +294,16 @@ Engine::Engine(int device) : device_(device) {
     MSH_HIP(hipMemsetAsync(stream_probe_, 0, 256, stream_));
     MSH_HIP(hipStreamSynchronize(stream_));
   }
-  if (const char* sk = getenv("MSH_ALLOC_SKEW_KB")) {   // developer probe: shift every later allocation of this engine (placement sensitivity)
+  if (const char* sk = dev_getenv("MSH_ALLOC_SKEW_KB")) {   // developer probe: shift every later allocation of this engine (placement sensitivity)
     const long kb = atol(sk);
     if (kb > 0) {
       std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
       weight_allocs_.push_back(device_alloc((size_t)kb << 10));
     }
   }
-  const char* ng = getenv("MSH_NO_GRAPH");
+  const char* ng = dev_getenv("MSH_NO_GRAPH");
   if (ng != nullptr && ng[0] == '1') use_graph_ = false;
-  const char* dg = getenv("MSH_DEC_GROUPS");
+  const char* dg = dev_getenv("MSH_DEC_GROUPS");
   if (dg != nullptr) dec_groups_ = atoi(dg);
 }
 
@@ -343,7 +343,7 @@ void Engine::synchronize() {
 // or the guard allocator (every buffer its own mapping, that is its point): one allocation per tensor as before.
 void* Engine::weight_alloc(size_t bytes) {
   static const bool arena = [] {
-    const char* e = getenv("MSH_WEIGHT_ARENA");
+    const char* e = dev_getenv("MSH_WEIGHT_ARENA");
     return !(e != nullptr && e[0] == '0') && !guard_alloc_enabled();
   }();
   constexpr size_t kSlab = (size_t)64 << 20;
@@ -658,7 +658,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     upload(vec(p + "final_layernorm.weight", D), &L.ln3);
   }
   upload_bf16(cross, &cross_kv_w_);
-  if (const char* gap = getenv("MSH_ALLOC_GAP_KB")) {   // developer probe: a dummy block between the weights and the workspaces
+  if (const char* gap = dev_getenv("MSH_ALLOC_GAP_KB")) {   // developer probe: a dummy block between the weights and the workspaces
     const long kb = atol(gap);
     if (kb > 0 && !dry_run_) {
       std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
@@ -667,7 +667,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
   }
   // the same weight packed for the panel kernel (k_panel.hip): only when that instance is asked for (it is off by default,
   // see run_encoder)
-  const char* ckv_load_env = getenv("MSH_ENC_CROSS_KV_PANEL");
+  const char* ckv_load_env = dev_getenv("MSH_ENC_CROSS_KV_PANEL");
   if (cross_kv_panel_supported(D) && !dry_run_ && ckv_load_env != nullptr && ckv_load_env[0] == '2') {
     const int Lc = c.dec_layers;
     std::vector<bf16_t> packed(panel_packed_elems(Lc * 2 * D, D));
@@ -1002,12 +1002,12 @@ void Engine::run_encoder() {
   // MSH_ENC_MLP=0: the MLP block as LayerNorm + two tiled GEMMs (A/B switch; the fused kernel is the default)
   // developer switch (read per call, so that one test process can compare both paths): 0 = the tiled GEMMs, 2 = the panel
   // kernel at any batch size
-  const char* qkv_env = getenv("MSH_ENC_QKV_PANEL");
+  const char* qkv_env = dev_getenv("MSH_ENC_QKV_PANEL");
   const bool qkv_panel_on = !(qkv_env != nullptr && qkv_env[0] == '0');
   const long qkv_panel_min_rows = (qkv_env != nullptr && qkv_env[0] == '2') ? 8 : 128 * 128;
   // developer switch (per call): 0 = tiled GEMMs, 2 = the MLP block alone in the fused kernel behind a tiled o-proj,
   // 3 = o-proj + MLP fused at any batch size; default 1 = o-proj + MLP fused from 32 k rows on
-  const char* mlp_env = getenv("MSH_ENC_MLP");
+  const char* mlp_env = dev_getenv("MSH_ENC_MLP");
   const int fused_mlp = mlp_env == nullptr ? 1 : (mlp_env[0] == '0' ? 0 : mlp_env[0] == '2' ? 2 : 1);
   const long mlp_min_rows = (mlp_env != nullptr && mlp_env[0] == '3') ? 1 : 128 * 256;
 
@@ -1038,7 +1038,7 @@ void Engine::run_encoder() {
   // workgroups on 256 CUs, each walking K alone (fc2: 52 slices, 35 us at one clip).  The split-K decode GEMM (16 x 32 tiles,
   // four waves over K, operands straight from global memory) puts 350 .. 1400 workgroups on the same shapes: MSH_ENC_SMALL_ROWS
   // = largest row count that takes it (default 1024; 0 = off).  Same epilogue arithmetic, a different summation order over K.
-  const char* small_env = getenv("MSH_ENC_SMALL_ROWS");
+  const char* small_env = dev_getenv("MSH_ENC_SMALL_ROWS");
   const long small_rows = small_env != nullptr ? atol(small_env) : 1024;
   const bool small_gemms = R <= small_rows && (R & 3) == 0 && qkv_env == nullptr && mlp_env == nullptr;   // (a developer switch that names a kernel gets that kernel)
   for (int l = 0; l < cfg_.enc_layers; ++l) {
@@ -1145,7 +1145,7 @@ void Engine::run_encoder() {
     // The panel kernel's cross-KV instance is OFF unless asked for (MSH_ENC_CROSS_KV_PANEL=2): at 256 x 10 s it measured
     // 1.01 ms against 0.93 ms for the A-stationary tiled kernel -- this GEMM writes 1.42 GB of K^T / V^T per batch and is
     // bound by that, not by its operand traffic.  Its parity test keeps the instance honest.
-    const char* ckv_env = getenv("MSH_ENC_CROSS_KV_PANEL");
+    const char* ckv_env = dev_getenv("MSH_ENC_CROSS_KV_PANEL");
     const bool ckv_panel = cross_kv_panel_w_ != nullptr && ckv_env != nullptr && ckv_env[0] == '2';
     ProfScope p(this, ckv_panel ? "cross_kv_panel" : "cross_kv_gemm", 2.0 * sT * D * 2 * D * L, sT * D * 2 + sT * D * 2.0 * L * 2);
     if (ckv_panel)
@@ -1349,7 +1349,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       }
     }
     static const bool fuse_q = [] {
-      const char* e = getenv("MSH_NO_FUSED_CROSSQ");
+      const char* e = dev_getenv("MSH_NO_FUSED_CROSSQ");
       return !(e != nullptr && e[0] == '1');
     }();
     const bf16_t* KTl = kv_layer(KT_, l);
@@ -1515,7 +1515,7 @@ void Engine::profile_decode_chain(int reps) {
   // Developer: MSH_CHAIN_MASKS = comma-separated bit masks of kernel groups (bit i = group i of `names`, per layer): each
   // mask is timed as its own replayed chain ("chainmask_<mask>", ms per decode STEP in `ms / launches * groups-in-mask * 8`
   // terms: launches counts the graph's nodes) -- what a SEQUENCE of different kernels costs, against the sum of its members.
-  if (const char* masks = getenv("MSH_CHAIN_MASKS")) {
+  if (const char* masks = dev_getenv("MSH_CHAIN_MASKS")) {
     std::string list(masks);
     size_t pos = 0;
     while (pos < list.size()) {
@@ -1643,7 +1643,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     moved |= g.dy.reserve((size_t)M * D * sizeof(bf16_t));
     moved |= g.logits.reserve((size_t)M * V * sizeof(float));
     {
-      const char* fe = getenv("MSH_NO_FUSED_ARGMAX");   // (read per call: the tests switch it)
+      const char* fe = dev_getenv("MSH_NO_FUSED_ARGMAX");   // (read per call: the tests switch it)
       const bool off = fe != nullptr && fe[0] == '1';
       // nobody reads the logits: the tiled LM head (from 128 clips on) reduces every 128 x 208 tile to (max, first index).
       // (The same on the split-K decode GEMM's 16 x 16 tiles was built and measured at one clip: head 6.5 against 6.4 us,
@@ -1655,9 +1655,9 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
     moved |= g.pidx.reserve((size_t)M * g.argmax_tiles * sizeof(int));
     {
       // single-clip latency path: split cross-attention (MSH_XSPLIT_M = largest batch that takes it, 0 = off)
-      const char* xe = getenv("MSH_XSPLIT_M");   // (read per call: the tests switch it)
+      const char* xe = dev_getenv("MSH_XSPLIT_M");   // (read per call: the tests switch it)
       const int xsplit_m = xe != nullptr ? atoi(xe) : 4;
-      const char* sfe = getenv("MSH_SELF_FUSED_M");   // largest batch whose self-attention runs inside the o-proj launch (0 = off)
+      const char* sfe = dev_getenv("MSH_SELF_FUSED_M");   // largest batch whose self-attention runs inside the o-proj launch (0 = off)
       const int self_m = sfe != nullptr ? atoi(sfe) : 1;   // (two clips: 7.7 us fused against 4.9 + 2.1 -- the waves take the clips in turn)
       g.self_fused = M <= std::min(self_m, 2) && dec_self_oproj_supported(D, Hh, M);
       int tmax = 1;
@@ -1665,7 +1665,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       const int xs = dec_cross_split_slices(tmax);
       const bool small_ok = !absorbed_ && !capture_cross_ && !kv_fp8_ && M < 64 && dec_cross_split_supported(D, Hh);
       g.split_cross = small_ok && M <= xsplit_m;
-      const char* xl = getenv("MSH_XLOOP");   // 0: batches above MSH_XSPLIT_M keep k_attn.hip's one-pass kernel (A/B measurements)
+      const char* xl = dev_getenv("MSH_XLOOP");   // 0: batches above MSH_XSPLIT_M keep k_attn.hip's one-pass kernel (A/B measurements)
       g.loop_cross = small_ok && !g.split_cross && xs <= dec_cross_looped_max_slices() && !(xl != nullptr && xl[0] == '0');
       if (g.split_cross) {
         if (xs != g.xs_max) ++g.gen;   // baked into the captured launches

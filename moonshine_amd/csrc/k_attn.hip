@@ -807,11 +807,11 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
   // per (clip, head), 13 tiles each -- two of them share a CU (232 VGPRs), so one's barriers and prologue are covered by
   // the other; MSH_ENC_ATT_WIDE=1 selects the earlier shape, one workgroup of 7 waves (28 tile slots) alone on its CU.
   static const bool wide_wg = [] {
-    const char* e = getenv("MSH_ENC_ATT_WIDE");
+    const char* e = dev_getenv("MSH_ENC_ATT_WIDE");
     return e != nullptr && e[0] == '1';
   }();
   static const bool two_tiles = [] {
-    const char* e = getenv("MSH_ENC_ATT_EQT");
+    const char* e = dev_getenv("MSH_ENC_ATT_EQT");
     return e != nullptr && e[0] == '2';
   }();
   const int ntiles = (max_rows + 15) / 16;
@@ -848,7 +848,7 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
   // caches are the part nobody reads again before the next step -- keeping them from displacing the weights makes a layer's
   // kernels IN SEQUENCE 57 instead of 62 us (tools/chain_masks.py), the serial batch 5 % faster
   static const bool nt = [] {
-    const char* e = getenv("MSH_SELF_NT");
+    const char* e = dev_getenv("MSH_SELF_NT");
     return !(e != nullptr && e[0] == '0');
   }();
 #define MSH_SELF(DHV)                                                                                                              \

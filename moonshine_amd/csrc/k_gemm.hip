@@ -572,7 +572,7 @@ void launch_astat_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, 
 // 3 = LDS-DMA, 256x208 tile, 8 waves (two per SIMD), 4 stages.
 inline int gemm_mode() {
   static int mode = [] {
-    const char* e = getenv("MSH_GEMM_MODE");
+    const char* e = dev_getenv("MSH_GEMM_MODE");
     return e ? atoi(e) : 2;
   }();
   return mode;
@@ -626,7 +626,7 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
 // kernel) with the non-temporal policy, so that one lane's stem does not flush the decoder weights the other lanes are reading
 static int stem_store_nt() {
   static const int v = [] {
-    const char* e = getenv("MSH_STEM_STORE_NT");
+    const char* e = dev_getenv("MSH_STEM_STORE_NT");
     return e != nullptr && e[0] == '1' ? 1 : 0;
   }();
   return v;
@@ -682,7 +682,7 @@ void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int
                           hipStream_t s) {
   if ((K & 31) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_argmax_partials: unsupported shape");
   static const bool w_nt = [] {   // developer probe: the 27 MB embedding with the non-temporal policy
-    const char* e = getenv("MSH_LMHEAD_NT");
+    const char* e = dev_getenv("MSH_LMHEAD_NT");
     return e != nullptr && e[0] == '1';
   }();
   if (w_nt)

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dec_kernel(const void* __restric
 
 static bool dec_xcd_order() {
   static const bool on = [] {
-    const char* e = getenv("MSH_DEC_XCD");
+    const char* e = dev_getenv("MSH_DEC_XCD");
     return !(e != nullptr && e[0] == '0');
   }();
   return on;
@@ -310,7 +310,7 @@ void launch_dec_cfg(const void* A, long lda, const float* gamma, const bf16_t* W
 }
 static int dec_tm2_threshold() {
   static int thr = [] {
-    const char* e = getenv("MSH_DEC_TM2_M");
+    const char* e = dev_getenv("MSH_DEC_TM2_M");
     return e ? atoi(e) : 128;
   }();
   return thr;
@@ -391,7 +391,7 @@ bool launch_sfm(const void* A, const bf16_t* W, int M, int N, int K, Epi epi, hi
 // The per-element summation order does not depend on the tile width, so results are bit-identical.
 static bool few_tiles(int M, int N) {
   static const int thr = [] {
-    const char* e = getenv("MSH_DEC_NARROW_TILES");
+    const char* e = dev_getenv("MSH_DEC_NARROW_TILES");
     return e ? atoi(e) : 192;
   }();
   return ((M + 15) / 16) * ((N + 31) / 32) < thr;
@@ -400,7 +400,7 @@ static bool few_tiles(int M, int N) {
 // stream (o-proj 13 -> 26, qkv 39 -> 78, fc1 104 -> 208); measured p50 of a 10 s clip 20.8 -> 19.0 ms (decode 19.4 -> 17.6).
 static bool narrow_small_batch(int M) {
   static const int thr = [] {
-    const char* e = getenv("MSH_DEC_NARROW_M");
+    const char* e = dev_getenv("MSH_DEC_NARROW_M");
     return e ? atoi(e) : 16;
   }();
   return M <= thr;
@@ -477,7 +477,7 @@ static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int
 }
 static int wide_k_tn() {   // developer knob: column tiles per workgroup of the wide-K residual GEMM (1 or 2)
   static const int v = [] {
-    const char* e = getenv("MSH_XATTN_G2_TN");
+    const char* e = dev_getenv("MSH_XATTN_G2_TN");
     return e != nullptr && e[0] == '2' ? 2 : 1;   // measured at M = 256: 6.6 us (416 workgroups) against 7.4 (208)
   }();
   return v;
@@ -581,7 +581,7 @@ bool small_gemm_logits_f32(const bf16_t* A, long lda, const bf16_t* W, int M, in
 // ---- streaming decoder, AR steps: FM operands (weights packed at load, H / attention outputs / z in FM between the
 // kernels).  Per element the k-split and the MFMA order are those of the row-major forms above: bit-identical results. ----
 static int sfm_cfg(int digit, int dflt) {   // developer knob: MSH_SFM_CFG = digits (qkv, cross-q, fc1, resid), 0 = default
-  static const char* e = getenv("MSH_SFM_CFG");
+  static const char* e = dev_getenv("MSH_SFM_CFG");
   if (e == nullptr || (int)strlen(e) <= digit || e[digit] == '0') return dflt;
   return e[digit] - '0';
 }

@@ -497,7 +497,7 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
   }
   EpiQkvPanel<D, DH, RP> epi{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
   static const int abl = [] {
-    const char* e = getenv("MSH_PANEL_ABL");
+    const char* e = dev_getenv("MSH_PANEL_ABL");
     return e ? atoi(e) : 0;
   }();
   using E = EpiQkvPanel<D, DH, RP>;

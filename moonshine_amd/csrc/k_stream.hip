@@ -1061,11 +1061,11 @@ void stream_self_attention_cached(const bf16_t* q, const int* row_slot, const in
   if (M <= 0) return;
   if (fm && (D & 31) != 0) throw std::runtime_error("stream_self_attention: FM output needs D % 32 == 0");
   static const bool no_ar_kernel = [] {
-    const char* e = getenv("MSH_STREAM_SELF_AR");
+    const char* e = dev_getenv("MSH_STREAM_SELF_AR");
     return e != nullptr && e[0] == '0';
   }();
   static const bool self_nt = [] {   // probe for the next round (default off: not measured yet)
-    const char* e = getenv("MSH_STREAM_SELF_NT");
+    const char* e = dev_getenv("MSH_STREAM_SELF_NT");
     return e != nullptr && e[0] == '1';
   }();
   if (max_keys > 0 && max_keys <= SELF_AR_KEYS && !no_ar_kernel && dh == 80 && self_nt) {
@@ -1099,7 +1099,7 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
   if (M <= 0) return;
   const int fmi = fm ? 1 : 0;
   static const bool nt = [] {
-    const char* e = getenv("MSH_STREAM_XATTN_NT");
+    const char* e = dev_getenv("MSH_STREAM_XATTN_NT");
     return !(e != nullptr && e[0] == '0');
   }();
   if (nt && dh == 80) {
@@ -1133,7 +1133,7 @@ void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int
   static_assert(sizeof(RowRun) == sizeof(int2), "RowRun is passed as int2");
   const RowRun* rr = reinterpret_cast<const RowRun*>(runs);
   static const bool runs_nt = [] {   // probe for the next round (default off: not measured yet)
-    const char* e = getenv("MSH_STREAM_XRUNS_NT");
+    const char* e = dev_getenv("MSH_STREAM_XRUNS_NT");
     return e != nullptr && e[0] == '1';
   }();
   if (runs_nt && D / heads == 80) {

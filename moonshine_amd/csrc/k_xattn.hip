@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void dec_cross_absorbed_kernel(cons
 // fragments gathered by 2-byte reads instead of ds_read_b64_tr_b16 (the check of that read).
 int xattn_cfg() {
   static const int v = [] {
-    const char* e = getenv("MSH_XATTN_CFG");
+    const char* e = dev_getenv("MSH_XATTN_CFG");
     const int c = e != nullptr ? atoi(e) : 84;
     return c == 81 || c == 43 || c == 42 || c == 40 ? c : 84;
   }();
@@ -485,7 +485,7 @@ void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* cl
   }
   // MSH_XATTN_XCD=0: plain block -> clip order (developer knob; see "Block -> clip" in the kernel)
   static const bool group = [] {
-    const char* e = getenv("MSH_XATTN_XCD");
+    const char* e = dev_getenv("MSH_XATTN_XCD");
     return !(e != nullptr && e[0] == '0');
   }();
   const unsigned grid = group ? 128u * (unsigned)(((M + 15) / 16 + 7) / 8) : (unsigned)M;
@@ -495,7 +495,7 @@ void launch_absorbed_cfg(const bf16_t* qt, const bf16_t* enc, const ClipMeta* cl
 template <int D>
 void launch_absorbed(const bf16_t* qt, const bf16_t* enc, const ClipMeta* clips, int M, bf16_t* ctx, hipStream_t s, bool stream_nt) {
   static const int abl = [] {
-    const char* e = getenv("MSH_XATTN_ABL");
+    const char* e = dev_getenv("MSH_XATTN_ABL");
     return e != nullptr ? atoi(e) : 0;
   }();
   if constexpr (D == 416) {
@@ -586,7 +586,7 @@ float cross_absorbed_host(const float* qt, const float* enc_f32, long R, const i
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b2);
   }
-  if (const char* tl = getenv("MSH_XATTN_TIMELINE"); tl != nullptr && tl[0] == '1' && D == 416) {
+  if (const char* tl = dev_getenv("MSH_XATTN_TIMELINE"); tl != nullptr && tl[0] == '1' && D == 416) {
     // developer: per-wave s_memtime stamps of the default shape (tools/xattn_microbench.py prints nothing else for it)
     const size_t nb = 128u * (size_t)(((M + 15) / 16 + 7) / 8) + (size_t)M;   // blocks of either block -> clip order
     const size_t n = nb * 8 * 16;

@@ -2,6 +2,8 @@
 // gfx950 only: 64-wide wavefronts, bf16 MFMA 16x16x32, fp32 accumulate.
 #pragma once
 
+#include <stdlib.h>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -73,6 +75,17 @@ inline void trace_launch_args(const char* kernel, dim3 grid, dim3 block, const A
     MSH_HIP(hipGetLastError());                                               \
     ::msh::trace_launch(#kernel, __FILE__, __LINE__, stream);                 \
   } while (0)
+
+// Developer switches (kernel variants, ablations, A/B thresholds) are read through dev_getenv, which answers
+// only when MSH_DEV_KNOBS=1 is set as well: a production process cannot pick up an unmeasured path from a stray MSH_* variable.
+// The tests and the tools set it.  Diagnostics (MSH_GUARD_*, MSH_TRACE_LAUNCH, MSH_*_TIMING) are read with plain getenv.
+inline const char* dev_getenv(const char* name) {
+  static const bool on = [] {
+    const char* e = getenv("MSH_DEV_KNOBS");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on ? getenv(name) : nullptr;
+}
 
 // Blocking copies / zero-fills that stay OFF the legacy (null) stream: hipMemcpy / hipMemset / hipDeviceSynchronize
 // touch it, and the legacy stream may not be used while ANOTHER host thread captures a decode-step graph on its own

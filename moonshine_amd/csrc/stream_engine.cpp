@@ -357,7 +357,7 @@ void StreamingEngine::load(const SafeTensors& st, const std::string& json) {
   }
   dec_.resize(L);
   {
-    const char* e = getenv("MSH_STREAM_FM");   // developer switch: 0 = AR steps on the row-major operands
+    const char* e = dev_getenv("MSH_STREAM_FM");   // developer switch: 0 = AR steps on the row-major operands
     fm_ok_ = !(e != nullptr && e[0] == '0') && stream_fm_supported(Dd, Fd);
   }
   std::vector<float> cross;
@@ -746,7 +746,7 @@ void StreamingEngine::decoder_reset(int n, const int* slots) {
 const int2* StreamingEngine::stage_runs(const std::vector<int>& rs, int* n_runs) {
   *n_runs = 0;
   static const bool off = [] {   // A/B switch: MSH_NO_CROSS_RUNS=1 keeps the one-row-per-workgroup kernel for every pass
-    const char* e = getenv("MSH_NO_CROSS_RUNS");
+    const char* e = dev_getenv("MSH_NO_CROSS_RUNS");
     return e != nullptr && e[0] == '1';
   }();
   if (off || !stream_cross_attention_runs_supported(cfg_.decoder_dim, cfg_.nheads, Mcap_)) return nullptr;
@@ -1085,7 +1085,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   // per-tile argmax epilogue (W read once instead of once per 16-row tile: 40 -> 14 us at 64 streams) and the advance kernel
   // picks the token from the tile maxima; no logits, no argmax launch.  Same first-max rule.
   static const bool no_fused_head = [] {
-    const char* e = getenv("MSH_NO_FUSED_ARGMAX");
+    const char* e = dev_getenv("MSH_NO_FUSED_ARGMAX");
     return e != nullptr && e[0] == '1';
   }();
   const bool fused_head = !no_fused_head && bias_.n_nodes == 0 && J >= 32 && (Dd & 31) == 0;
@@ -1118,7 +1118,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
                    steppos_.as<int>(), n_active_d_, stream_, fm);
   };
   static const bool use_graph = [] {
-    const char* e = getenv("MSH_NO_GRAPH");
+    const char* e = dev_getenv("MSH_NO_GRAPH");
     return !(e != nullptr && e[0] == '1');
   }();
   const bool graph_now = use_graph && !prof_.on();   // event scopes cannot sit inside a replayed graph

@@ -6,6 +6,9 @@ import pytest
 # lanes ("batches in flight") overlap only on separate HIP hardware queues; the pool size is read from the environment when
 # the HIP runtime initialises, and the library leaves the environment to its host (include/moonshine_hip.h msh_set_hw_queues)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the library honours its developer switches (MSH_ENC_MLP, MSH_XSPLIT_M, ...: kernel variants the tests compare) only when
+# this is set too -- a production process cannot pick one up from a stray variable (csrc/msh_common.h dev_getenv)
+os.environ.setdefault("MSH_DEV_KNOBS", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -3,6 +3,7 @@ sum of their members timed alone: a kernel that is cheap back to back with itsel
 another (cold operands, the next kernel's start).  Groups per layer: bit 0 qkv, 1 self-attention, 2 o-proj, 3 cross-q,
 4 cross-attention, 5 context / cross o-proj, 6 fc1, 7 fc2.   python tools/chain_masks.py [batch]"""
 import os, sys, tempfile
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import numpy as np
 sys.path.insert(0, ".")
 MASKS = ["0x08", "0x10", "0x20", "0x18", "0x0c", "0x30", "0x38", "0x3c", "0x03", "0xc0", "0xff"]

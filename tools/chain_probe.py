@@ -1,5 +1,6 @@
 """Per-kernel cost inside a replayed decode graph (msh_profile_decode_chain) at small batch sizes."""
 import os, sys, tempfile
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import numpy as np
 sys.path.insert(0, ".")
 import torch

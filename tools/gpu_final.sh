@@ -2,6 +2,7 @@
 # Round-end evidence run: GPU tests, smoke, default bench, rocprofv3 kernel stats of the same command, and HBM-byte
 # counters (separate --pmc passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) for the decode kernels.
 set -u
+export MSH_DEV_KNOBS=1   # the library reads its developer switches only with this set
 TAG=${1:-final}
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"

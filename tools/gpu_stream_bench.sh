@@ -1,6 +1,7 @@
 #!/bin/bash
 # Streaming engine: its GPU tests, then BASELINE config 5 (64 streams x 10 s, 0.5 s updates, speculative) as its own bench line.
 set -u
+export MSH_DEV_KNOBS=1   # the library reads its developer switches only with this set
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; mkdir -p gpurun_out
 TAG=${1:-stream}
 timeout 900 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_capi_streaming.py -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1

@@ -1,6 +1,7 @@
 """Batch-1 latency of one 10 s clip (the bench's latency_ms leg alone: p50 of 50 runs, encode / decode split) + the per-kernel
 chain costs at batch 1.  Knobs are read from the environment (MSH_XSPLIT_M, ...)."""
 import os, statistics, sys, tempfile, time
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import numpy as np
 sys.path.insert(0, ".")
 import torch

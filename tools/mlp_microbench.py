@@ -2,6 +2,7 @@
 (fc1 + GELU, fc2 + residual; LayerNorm not included on that side), same box, uniform random data."""
 import ctypes as C
 import os
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@
 (each ablation runs in its own process: MSH_PANEL_ABL is read once)."""
 import ctypes as C
 import os
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import subprocess
 import sys
 

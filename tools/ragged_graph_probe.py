@@ -4,6 +4,7 @@ from call to call, drawn from 6 distinct shapes: wall time per call with the gra
 with one step per replay (MSH_DEC_GRAPH_STEPS=1: the cheapest capture), and the number of graphs instantiated.
 Run on the GPU box: python tools/ragged_graph_probe.py"""
 import os
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import subprocess
 import sys
 import json

@@ -1,6 +1,7 @@
 """Where a config-5 update's decode time goes on the HOST side: wall time of decoder_reset and decode_full per update against the
 GPU time between the engine's own events (msh_stream_query 12 / 13), with the engine's phase prints (MSH_STREAM_TIMING=1)."""
 import os, sys, time, tempfile
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import numpy as np
 sys.path.insert(0, ".")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

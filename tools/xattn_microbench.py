@@ -1,6 +1,7 @@
 """Rate of the absorbed cross-attention kernel alone (k_xattn.hip) at the benchmark shape; MSH_XATTN_ABL / _SLOTS / _TR select
 the variant (developer tool, see tools/gpu_r4c.sh)."""
 import os
+os.environ.setdefault("MSH_DEV_KNOBS", "1")   # developer switches are honoured only with this set
 import sys
 
 import numpy as np
