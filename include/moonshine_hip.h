@@ -239,12 +239,33 @@ MSH_EXPORT int64_t msh_host_align_words(const uint8_t* tokenizer_bin, uint64_t t
  * at a time on the host).  msh_silero_probabilities takes 16 kHz clips in HOST memory and writes, concatenated, the
  * probability of every whole 512-sample hop of every clip (clip i at offset sum_{j<i} n[j] / 512), each clip from a fresh
  * state -- what msh_host_silero_probabilities returns clip by clip, up to fp32 summation order.  Returns the number of
- * probabilities, or a negative msh error (cap too small: MSH_ERR_INVALID_ARGUMENT). */
+ * probabilities, or a negative msh error (cap too small: MSH_ERR_INVALID_ARGUMENT).
+ * msh_silero_probabilities_keep_audio does the same and leaves the uploaded audio on the device: device_audio_out[i]
+ * receives a DEVICE pointer to clip i's whole hops (n_samples[i] / 512 * 512 floats, the caller's samples verbatim; NULL for
+ * a clip with no whole hop, or once the handle keeps 8 GiB), valid until msh_silero_release_audio / msh_silero_destroy.  It is
+ * what msh_encode / msh_submit_transcribe_tokens take with on_device = 1: the batch call under the reference's default
+ * vad_threshold (core/transcriber.cpp:656-696,997 segments every clip, then transcribes the segments) hands the engine
+ * slices of it instead of sending the same PCM over PCIe a second time.  Calls on one handle are not thread-safe. */
 typedef struct msh_silero msh_silero;
 MSH_EXPORT int32_t msh_silero_create(int32_t device, const uint8_t* weights, uint64_t weights_size, msh_silero** out);
 MSH_EXPORT void msh_silero_destroy(msh_silero* s);
 MSH_EXPORT int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count,
                                             float* probs_out, uint64_t cap);
+MSH_EXPORT int64_t msh_silero_probabilities_keep_audio(msh_silero* s, const float* const* pcm, const uint64_t* n_samples,
+                                                       uint64_t count, float* probs_out, uint64_t cap,
+                                                       const float** device_audio_out);
+/* The same in two halves, for a caller that has work of its own per chunk of clips (the batch call: the detectors' state
+ * machines, the submission of the segments): msh_silero_submit stages one chunk -- at most 65536 whole hops unless it is a
+ * single clip -- and enqueues its upload and network, returning a ticket (>= 0) or a negative msh error; msh_silero_collect
+ * waits for it and writes the probabilities of its clips back to back (return value = their number) and, when
+ * device_audio_out is given (`count` entries, the submission's clip count; only meaningful after keep_audio != 0), the
+ * device pointers described above.  Two submissions may be outstanding -- chunk k + 1 is gathered and uploaded while the
+ * network of chunk k runs --; tickets are collected in the order they were given. */
+MSH_EXPORT int64_t msh_silero_submit(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count,
+                                     int32_t keep_audio);
+MSH_EXPORT int64_t msh_silero_collect(msh_silero* s, int64_t ticket, float* probs_out, uint64_t cap,
+                                      const float** device_audio_out, uint64_t count);
+MSH_EXPORT int32_t msh_silero_release_audio(msh_silero* s);
 MSH_EXPORT const char* msh_silero_last_error(msh_silero* s);
 
 /* Voice activity detection (reference core/silero-vad.cpp:78-173, core/voice-activity-detector.cpp:125-199), as the

@@ -509,9 +509,19 @@ int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, flo
       vad.process_audio(audio + off, (size_t)(n_samples - off < chunk ? n_samples - off : chunk), sample_rate);
     vad.stop();
     const std::vector<VadSegment>& segs = vad.segments();
+    // the invariant the batch call's device-audio slices rest on (VadSegment::src_offset): a segment's audio is the verbatim
+    // slice of the 16 kHz input, however the input was cut into calls (look-behind across call boundaries included)
+    if (sample_rate == kSampleRate)
+      for (const VadSegment& sg : segs)
+        if (sg.src_offset + sg.audio.size() > n_samples ||
+            memcmp(sg.audio.data(), audio + sg.src_offset, sg.audio.size() * sizeof(float)) != 0) {
+          MSH_LOGF("vad_segments: a segment's audio is not the input slice at its src_offset %zu (+%zu)", sg.src_offset, sg.audio.size());
+          return MSH_ERR_UNKNOWN;
+        }
     for (size_t i = 0; i < segs.size() && i < max_segments; ++i) {
-      // start / end in samples of the 16 kHz stream (times are sample counts / 16000 in the detector), + completeness
-      bounds[3 * i] = (int64_t)llroundf(segs[i].start_time * kSampleRate);
+      // start (the detector's own sample count: VadSegment::src_offset, which the batch call slices the device VAD's audio
+      // by) / length in samples of the 16 kHz stream + completeness
+      bounds[3 * i] = (int64_t)segs[i].src_offset;
       bounds[3 * i + 1] = (int64_t)segs[i].audio.size();
       bounds[3 * i + 2] = segs[i].is_complete ? 1 : 0;
     }
@@ -538,7 +548,7 @@ int64_t msh_host_vad_segments_from_probs(const uint8_t* weights, uint64_t weight
     vad.stop();
     const std::vector<VadSegment>& segs = vad.segments();
     for (size_t i = 0; i < segs.size() && i < max_segments; ++i) {
-      bounds[3 * i] = (int64_t)llroundf(segs[i].start_time * kSampleRate);
+      bounds[3 * i] = (int64_t)segs[i].src_offset;
       bounds[3 * i + 1] = (int64_t)segs[i].audio.size();
       bounds[3 * i + 2] = segs[i].is_complete ? 1 : 0;
     }

@@ -221,7 +221,10 @@ void VoiceActivityDetector::process_audio(const float* audio, size_t count, int3
     src = resampled.data();
     n = resampled.size();
   }
-  // whole hops only; the sub-hop tail waits in remainder_ for the next call.  Hops are read in place (no staging copy).
+  // whole hops only; the sub-hop tail waits in remainder_ for the next call.  Hops are read in place (no staging copy), and
+  // so is the look-behind: `region_` is the run of consecutive samples of THIS call that ends with the hop being
+  // processed; look_buf_ holds what came before it and is brought up to date once per run (sliding it on every hop was a
+  // 32 KB memmove per 2 KB hop: most of the detector's time with the network on the GPU).
   size_t off = 0;
   if (!remainder_.empty()) {
     const size_t take = std::min((size_t)hop_ - remainder_.size(), n);
@@ -229,7 +232,10 @@ void VoiceActivityDetector::process_audio(const float* audio, size_t count, int3
     off = take;
     if (remainder_.size() < (size_t)hop_) return;
     call_remaining_ = n - off;
+    region_ = remainder_.data(), region_len_ = (size_t)hop_;
     process_hop(remainder_.data());
+    append_history(remainder_.data(), (size_t)hop_);
+    region_ = nullptr, region_len_ = 0;
     remainder_.clear();
   }
   // Silero probabilities of all the whole hops of this call in one go (the network's state-independent part runs for
@@ -243,13 +249,29 @@ void VoiceActivityDetector::process_audio(const float* audio, size_t count, int3
       silero_->predict_many(src + off, whole, hop_probs_.data());
     }
   }
+  const size_t run0 = off;
   for (size_t i = 0; i < whole; ++i) {
     call_remaining_ = n - off - hop_;
+    region_ = src + run0, region_len_ = off - run0 + (size_t)hop_;
     process_hop(src + off, silero_ ? &hop_probs_[i] : nullptr);
     off += hop_;
   }
+  if (off > run0) append_history(src + run0, off - run0);
+  region_ = nullptr, region_len_ = 0;
   call_remaining_ = 0;
   remainder_.assign(src + off, src + n);
+}
+
+// look_buf_ := the last look_behind_ samples of (look_buf_ | p[0 .. count))
+void VoiceActivityDetector::append_history(const float* p, size_t count) {
+  const size_t cap = look_buf_.size();
+  if (cap == 0) return;
+  if (count >= cap) {
+    std::copy(p + count - cap, p + count, look_buf_.begin());
+  } else {
+    std::move(look_buf_.begin() + (long)count, look_buf_.end(), look_buf_.begin());
+    std::copy(p, p + count, look_buf_.end() - (long)count);
+  }
 }
 
 void VoiceActivityDetector::clear_completed_audio() {
@@ -259,13 +281,6 @@ void VoiceActivityDetector::clear_completed_audio() {
 
 void VoiceActivityDetector::process_hop(const float* hop, const float* silero_prob) {
   processed_ += hop_;
-  // slide the look-behind window
-  if ((size_t)hop_ >= look_buf_.size()) {
-    std::copy(hop + hop_ - look_buf_.size(), hop + hop_, look_buf_.begin());
-  } else {
-    std::move(look_buf_.begin() + hop_, look_buf_.end(), look_buf_.begin());
-    std::copy(hop, hop + hop_, look_buf_.end() - hop_);
-  }
   // threshold 0: probability 1; otherwise Silero's probability averaged over the last `window` hops (a ring that
   // starts at zero, reference :139-151).  Either is scaled by the max-length fade once the segment passes 2/3 of the cap.
   float p = 1.0f;
@@ -292,7 +307,14 @@ void VoiceActivityDetector::process_hop(const float* hop, const float* silero_pr
     if (max_segment_) want = std::min(want, max_segment_ + (size_t)hop_);
     if (hard_cap_) want = std::min(want, hard_cap_);
     s.audio.reserve(std::max(want, lb));
-    s.audio.assign(look_buf_.end() - lb, look_buf_.end());
+    // the last lb samples up to the end of this hop: from the run this hop ends, and what it lacks from the history before it
+    if (lb <= region_len_) {
+      s.audio.assign(region_ + region_len_ - lb, region_ + region_len_);
+    } else {
+      s.audio.assign(look_buf_.end() - (long)(lb - region_len_), look_buf_.end());
+      s.audio.insert(s.audio.end(), region_, region_ + region_len_);
+    }
+    s.src_offset = processed_ - lb;
     s.start_time = now - (float)s.audio.size() / kSampleRate;
     s.end_time = now;
     s.just_updated = true;

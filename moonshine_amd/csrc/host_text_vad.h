@@ -49,6 +49,10 @@ struct VadSegment {
   std::vector<float> audio;  // 16 kHz samples of the segment so far
   float start_time = 0.f, end_time = 0.f;
   bool is_complete = false, just_updated = false;
+  // first sample of the segment in the detector's 16 kHz input, counted from start(): the audio is always the verbatim
+  // slice [src_offset, src_offset + audio.size()) of it (the max-length fade scales the probability, never the samples),
+  // which lets a batch call hand the engine a slice of the PCM the device VAD already uploaded
+  size_t src_offset = 0;
 };
 
 // Segmenter with the reference's state machine (reference core/voice-activity-detector.cpp:69-199):
@@ -82,6 +86,7 @@ class VoiceActivityDetector {
 
  private:
   void process_hop(const float* hop, const float* silero_prob = nullptr);   // silero_prob: precomputed for this hop
+  void append_history(const float* p, size_t count);
   float threshold_;
   int32_t hop_;
   size_t look_behind_, max_segment_, hard_cap_;
@@ -93,7 +98,9 @@ class VoiceActivityDetector {
   // the open segment's samples live in segments_.back().audio only (the reference re-copies its growing buffer into the
   // segment on every hop -- quadratic in the segment length: ~100 MB of memcpy for one 10 s clip)
   size_t open_size() const { return prev_voice_ && !segments_.empty() ? segments_.back().audio.size() : 0; }
-  std::vector<float> look_buf_, remainder_, hop_probs_;
+  std::vector<float> look_buf_, remainder_, hop_probs_;   // look_buf_: the look_behind_ samples in front of region_
+  const float* region_ = nullptr;   // consecutive samples of the current call, ending with the hop being processed
+  size_t region_len_ = 0;
   size_t call_remaining_ = 0;  // samples of the current process_audio call not yet consumed (a reserve() hint)
   std::vector<VadSegment> segments_;
 };

@@ -373,8 +373,9 @@ void msh_silero_destroy(msh_silero* s) {
   delete s->dev;
   delete s;
 }
-int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count, float* probs_out,
-                                 uint64_t cap) {
+namespace {
+int64_t silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count, float* probs_out,
+                             uint64_t cap, const float** device_audio_out) {
   if (s == nullptr || s->dev == nullptr || (count > 0 && (pcm == nullptr || n_samples == nullptr))) return MSH_ERR_INVALID_ARGUMENT;
   try {
     uint64_t total = 0;
@@ -384,11 +385,13 @@ int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const u
       return MSH_ERR_INVALID_ARGUMENT;
     }
     std::vector<std::vector<float>> probs;
-    s->dev->probabilities(pcm, n_samples, (size_t)count, &probs);
+    std::vector<const float*> resident;
+    s->dev->probabilities(pcm, n_samples, (size_t)count, &probs, device_audio_out != nullptr ? &resident : nullptr);
     uint64_t off = 0;
     for (uint64_t i = 0; i < count; ++i) {
       if (!probs[i].empty()) memcpy(probs_out + off, probs[i].data(), probs[i].size() * sizeof(float));
       off += probs[i].size();
+      if (device_audio_out != nullptr) device_audio_out[i] = resident[i];
     }
     return (int64_t)off;
   } catch (const msh::HipError& ex) {
@@ -398,6 +401,55 @@ int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const u
     s->last_error = ex.what();
     return MSH_ERR_INVALID_ARGUMENT;
   }
+}
+}  // namespace
+int64_t msh_silero_probabilities(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count, float* probs_out,
+                                 uint64_t cap) {
+  return silero_probabilities(s, pcm, n_samples, count, probs_out, cap, nullptr);
+}
+int64_t msh_silero_probabilities_keep_audio(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count,
+                                            float* probs_out, uint64_t cap, const float** device_audio_out) {
+  if (device_audio_out == nullptr && count > 0) return MSH_ERR_INVALID_ARGUMENT;
+  return silero_probabilities(s, pcm, n_samples, count, probs_out, cap, device_audio_out);
+}
+int64_t msh_silero_submit(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count, int32_t keep_audio) {
+  if (s == nullptr || s->dev == nullptr || (count > 0 && (pcm == nullptr || n_samples == nullptr))) return MSH_ERR_INVALID_ARGUMENT;
+  try {
+    return s->dev->submit(pcm, n_samples, (size_t)count, keep_audio != 0);
+  } catch (const msh::HipError& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+int64_t msh_silero_collect(msh_silero* s, int64_t ticket, float* probs_out, uint64_t cap, const float** device_audio_out,
+                           uint64_t count) {
+  if (s == nullptr || s->dev == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  try {
+    std::vector<float> probs;
+    std::vector<const float*> resident;
+    s->dev->collect(ticket, &probs, device_audio_out != nullptr ? &resident : nullptr);
+    if (probs.size() > cap || (!probs.empty() && probs_out == nullptr) || (device_audio_out != nullptr && resident.size() != count)) {
+      s->last_error = "msh_silero_collect: output arrays do not match the submission";
+      return MSH_ERR_INVALID_ARGUMENT;
+    }
+    if (!probs.empty()) memcpy(probs_out, probs.data(), probs.size() * sizeof(float));
+    for (size_t i = 0; i < resident.size(); ++i) device_audio_out[i] = resident[i];
+    return (int64_t)probs.size();
+  } catch (const msh::HipError& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+int32_t msh_silero_release_audio(msh_silero* s) {
+  if (s == nullptr || s->dev == nullptr) return MSH_ERR_INVALID_ARGUMENT;
+  s->dev->release_audio();
+  return MSH_OK;
 }
 const char* msh_silero_last_error(msh_silero* s) { return s != nullptr ? s->last_error.c_str() : ""; }
 

@@ -1,5 +1,9 @@
 #include "pipeline.h"
 
+#include "host_utils.h"
+
+#include <algorithm>
+#include <chrono>
 #include <stdexcept>
 
 namespace msh {
@@ -44,6 +48,7 @@ int64_t BatchPipeline::submit(const float* const* pcm, const uint64_t* n_samples
   j->tokens_out = tokens_out;
   j->counts_out = counts_out;
   j->tokens_stride = tokens_stride;
+  j->submitted = std::chrono::steady_clock::now();
   {
     std::lock_guard<std::mutex> lock(mu_);
     j->ticket = next_ticket_++;
@@ -79,8 +84,23 @@ void BatchPipeline::worker(int lane) {
       queue_.pop_front();
     }
     try {
+      static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;   // one line per sub-batch, to the log
+      const auto t0 = std::chrono::steady_clock::now();
       eng.encode(j->pcm.data(), j->n_samples.data(), (uint32_t)j->pcm.size(), j->on_device, j->mtps);
+      const auto t1 = std::chrono::steady_clock::now();
       eng.decode(j->forced_steps, nullptr, 0, nullptr, 0, j->tokens_out, j->counts_out, j->tokens_stride);
+      if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        uint64_t sum = 0, longest = 0, shortest = ~0ull;
+        for (uint64_t n : j->n_samples) sum += n, longest = std::max(longest, n), shortest = std::min(shortest, n);
+        const uint64_t captures = eng.debug_read("graph_captures", nullptr, 0);
+        MSH_LOGF("lane %d: sub-batch %lld of %zu clips (%.0f s of audio, %.2f .. %.2f s, %s) encode %.1f ms, decode %.1f ms, started %.1f ms "
+                 "after its submission; %llu decode graphs captured by this lane so far",
+                 lane, (long long)j->ticket, j->pcm.size(), (double)sum / 16000.0, (double)shortest / 16000.0, (double)longest / 16000.0,
+                 j->on_device ? "device audio" : "host audio", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                 std::chrono::duration<double, std::milli>(t0 - j->submitted).count(), (unsigned long long)captures);
+      }
     } catch (...) {
       j->error = std::current_exception();
     }

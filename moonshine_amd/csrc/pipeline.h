@@ -7,6 +7,7 @@
 // (core/moonshine-model.cpp:229).
 #pragma once
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -45,6 +46,7 @@ class BatchPipeline {
     int forced_steps = -1;
     int32_t *tokens_out = nullptr, *counts_out = nullptr;
     int tokens_stride = 0;
+    std::chrono::steady_clock::time_point submitted;
     bool done = false;
     std::exception_ptr error;
   };

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <stdexcept>
 
 #include "host_utils.h"
@@ -16,7 +17,6 @@ const int kConvIn[4] = {129, 128, 64, 64}, kConvOut[4] = {128, 64, 64, 128}, kCo
 // ~2.3 KB = ~23 KB (plus DevBuf's 12.5 % growth slack), so 64 Ki hops = ~1.5 GB per chunk, 209 clips of 10 s.  (200000
 // hops, the first value, was 4.6 GB per chunk on top of the engines' workspaces: the out-of-memory fallback to the host
 // network would have come far earlier than intended.)
-constexpr long kMaxHopsPerChunk = 65536;
 }  // namespace
 
 SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : device_(device) {
@@ -25,6 +25,11 @@ SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : devic
   if (device < 0 || device >= n_dev) throw HipError("invalid device index " + std::to_string(device));
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  MSH_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  for (Slot& sl : slots_) {
+    MSH_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+    MSH_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
   try {
     upload_weights(w);
   } catch (...) {   // a constructor that throws runs no destructor: hand back what was taken so far
@@ -32,6 +37,8 @@ SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : devic
       std::lock_guard<std::mutex> lock(device_structure_mutex());
       for (void* p : weights_) device_free(p);
     }
+    for (Slot& sl : slots_) (void)hipEventDestroy(sl.uploaded), (void)hipEventDestroy(sl.done);
+    (void)hipStreamDestroy(copy_stream_);
     (void)hipStreamDestroy(stream_);
     throw;
   }
@@ -70,84 +77,181 @@ void SileroDevice::upload_weights(const msh_host::SileroWeights& w) {
 
 SileroDevice::~SileroDevice() {
   (void)hipSetDevice(device_);
+  if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   {
     std::lock_guard<std::mutex> lock(device_structure_mutex());
     for (void* p : weights_) device_free(p);
   }
-  DevBuf* bufs[] = {&audio_, &hop_base_, &clip_hop0_, &frames_, &stft_, &act_[0], &act_[1], &cols_, &gin_, &probs_};
+  DevBuf* bufs[] = {&frames_, &stft_, &act_[0], &act_[1], &cols_, &gin_, &probs_};
   for (DevBuf* b : bufs) b->release();
-  if (pinned_) (void)hipHostFree(pinned_);
+  for (auto& b : arena_) b->release();
+  for (Slot& sl : slots_) {
+    sl.audio.release(), sl.hop_base.release(), sl.clip_hop0_d.release();
+    if (sl.pinned) (void)hipHostFree(sl.pinned);
+    if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void SileroDevice::probabilities(const float* const* pcm, const uint64_t* n, size_t count, std::vector<std::vector<float>>* probs) {
+void SileroDevice::probabilities(const float* const* pcm, const uint64_t* n, size_t count, std::vector<std::vector<float>>* probs,
+                                 std::vector<const float*>* resident) {
   probs->assign(count, std::vector<float>());
-  size_t c0 = 0;
-  while (c0 < count) {
+  if (resident != nullptr) resident->assign(count, nullptr);
+  // chunks of at most kMaxHopsPerSubmit hops; chunk k + 1 is staged and uploaded while chunk k's network runs
+  std::vector<std::pair<size_t, size_t>> chunks;
+  for (size_t c0 = 0; c0 < count;) {
     long hops = 0;
     size_t c1 = c0;
     while (c1 < count) {
       const long h = (long)(n[c1] / kHop);
-      if (c1 > c0 && hops + h > kMaxHopsPerChunk) break;
+      if (c1 > c0 && hops + h > kMaxHopsPerSubmit) break;
       hops += h;
       ++c1;
     }
-    run_chunk(pcm, n, c0, c1, probs);
+    chunks.push_back({c0, c1});
     c0 = c1;
+  }
+  std::vector<int64_t> tickets(chunks.size(), -1);
+  auto collect_into = [&](size_t k) {
+    const size_t c0 = chunks[k].first, nc = chunks[k].second - c0;
+    std::vector<float> flat;
+    std::vector<const float*> res;
+    collect(tickets[k], &flat, resident != nullptr ? &res : nullptr);
+    size_t off = 0;
+    for (size_t i = 0; i < nc; ++i) {
+      const size_t h = (size_t)(n[c0 + i] / kHop);
+      (*probs)[c0 + i].assign(flat.begin() + (long)off, flat.begin() + (long)(off + h));
+      off += h;
+      if (resident != nullptr) (*resident)[c0 + i] = res[i];
+    }
+  };
+  try {
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      tickets[k] = submit(pcm + chunks[k].first, n + chunks[k].first, chunks[k].second - chunks[k].first, resident != nullptr);
+      if (k > 0) collect_into(k - 1);
+    }
+    if (!chunks.empty()) collect_into(chunks.size() - 1);
+  } catch (...) {
+    abandon();
+    throw;
   }
 }
 
-void SileroDevice::run_chunk(const float* const* pcm, const uint64_t* n, size_t c0, size_t c1,
-                             std::vector<std::vector<float>>* probs) {
+void SileroDevice::release_audio() {
+  bool busy = false;
+  for (const Slot& sl : slots_) busy |= sl.busy;
+  if (busy || next_collect_ != next_ticket_) abandon();
+  arena_used_ = 0, arena_live_bytes_ = 0;
+}
+
+void SileroDevice::abandon() {
+  (void)hipStreamSynchronize(copy_stream_);
+  (void)hipStreamSynchronize(stream_);
+  (void)hipGetLastError();
+  for (Slot& sl : slots_) sl.busy = false;
+  next_collect_ = next_ticket_;
+}
+
+void SileroDevice::sync_streams() {
+  MSH_HIP(hipStreamSynchronize(copy_stream_));
+  MSH_HIP(hipStreamSynchronize(stream_));
+}
+
+int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t nc, bool keep_audio) {
   MSH_HIP(hipSetDevice(device_));
-  const size_t nc = c1 - c0;
+  Slot& sl = slots_[next_ticket_ % kSlots];
+  if (sl.busy) throw std::invalid_argument("device VAD: two submissions are outstanding, collect one first");
   // flat audio: per clip 64 zeros of context, then its whole hops
-  std::vector<long> clip_off(nc), clip_hop0(nc + 1, 0);
+  sl.clip_off.assign(nc, 0);
+  sl.clip_hop0.assign(nc + 1, 0);
   long samples = 0, hops = 0;
   for (size_t i = 0; i < nc; ++i) {
-    const long h = (long)(n[c0 + i] / kHop);
-    if (h > 0 && pcm[c0 + i] == nullptr) throw std::invalid_argument("null audio pointer");
-    clip_off[i] = samples;
-    clip_hop0[i] = hops;
+    const long h = (long)(n[i] / kHop);
+    if (h > 0 && pcm[i] == nullptr) throw std::invalid_argument("null audio pointer");
+    sl.clip_off[i] = samples;
+    sl.clip_hop0[i] = hops;
     samples += kContext + h * kHop;
     hops += h;
   }
-  clip_hop0[nc] = hops;
-  if (hops == 0) return;
-  std::vector<long> hop_base((size_t)hops);
-  for (size_t i = 0; i < nc; ++i)
-    for (long j = clip_hop0[i]; j < clip_hop0[i + 1]; ++j) hop_base[(size_t)j] = clip_off[i] + (j - clip_hop0[i]) * kHop;
-  // gather into pinned memory on a few host threads, one DMA
-  const size_t bytes = (size_t)samples * sizeof(float);
-  if (bytes > pinned_cap_) {
-    if (pinned_) MSH_HIP(hipHostFree(pinned_));
-    pinned_ = nullptr;
-    pinned_cap_ = 0;
-    MSH_HIP(hipHostMalloc(&pinned_, bytes + bytes / 8, hipHostMallocDefault));
-    pinned_cap_ = bytes + bytes / 8;
+  sl.clip_hop0[nc] = hops;
+  if (hops > kMaxHopsPerSubmit && nc > 1)
+    throw std::invalid_argument("device VAD: more than " + std::to_string(kMaxHopsPerSubmit) + " hops in one submission");
+  sl.nc = nc;
+  sl.hops = hops;
+  sl.abuf = nullptr;
+  sl.ticket = next_ticket_;
+  if (hops == 0) {   // nothing to compute: the ticket is collected without touching the GPU
+    sl.busy = true;
+    return next_ticket_++;
   }
-  float* stage = static_cast<float*>(pinned_);
+  // One pinned block per slot: the audio, the hop table, the clips' first hops -- and the place the probabilities come back to
+  // (a copy to or from pageable memory blocks the host until it is done, which would serialise the two slots)
+  const size_t bytes = (size_t)samples * sizeof(float);
+  const size_t off_hops = (bytes + 255) & ~(size_t)255, off_clips = off_hops + (size_t)hops * sizeof(long);
+  const size_t off_probs = (off_clips + (nc + 1) * sizeof(long) + 255) & ~(size_t)255, pinned_need = off_probs + (size_t)hops * sizeof(float);
+  if (pinned_need > sl.pinned_cap) {
+    if (sl.pinned) MSH_HIP(hipHostFree(sl.pinned));
+    sl.pinned = nullptr;
+    sl.pinned_cap = 0;
+    MSH_HIP(hipHostMalloc(&sl.pinned, pinned_need + pinned_need / 8, hipHostMallocDefault));
+    sl.pinned_cap = pinned_need + pinned_need / 8;
+  }
+  static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;
+  static const unsigned gather_threads = [] {   // MSH_SILERO_GATHER_THREADS: host threads of the pageable -> pinned gather
+    const char* e = dev_getenv("MSH_SILERO_GATHER_THREADS");
+    return e != nullptr && atoi(e) > 0 ? (unsigned)atoi(e) : std::min(8u, msh_host::effective_cpus());
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  char* pin = static_cast<char*>(sl.pinned);
+  float* stage = reinterpret_cast<float*>(pin);
   msh_host::parallel_for(nc, [&](size_t i) {
-    float* dst = stage + clip_off[i];
+    float* dst = stage + sl.clip_off[i];
     memset(dst, 0, kContext * sizeof(float));
-    const size_t cnt = (size_t)(clip_hop0[i + 1] - clip_hop0[i]) * kHop;
-    if (cnt > 0) memcpy(dst + kContext, pcm[c0 + i], cnt * sizeof(float));
-  }, std::min(8u, msh_host::effective_cpus()));
-  audio_.reserve(bytes + 4096);   // (the last hop's reflect padding reads inside its own 576 samples: no over-read)
-  hop_base_.reserve((size_t)hops * sizeof(long));
-  clip_hop0_.reserve((nc + 1) * sizeof(long));
-  frames_.reserve((size_t)hops * 4 * 256 * sizeof(float));
-  stft_.reserve((size_t)hops * 4 * 258 * sizeof(float));
-  act_[0].reserve((size_t)hops * 129 * 4 * sizeof(float));
-  act_[1].reserve((size_t)hops * 128 * 4 * sizeof(float));
-  cols_.reserve((size_t)hops * 4 * kpad_[0] * sizeof(float));
-  gin_.reserve((size_t)hops * 512 * sizeof(float));
-  probs_.reserve((size_t)hops * sizeof(float));
-  MSH_HIP(hipMemcpyAsync(audio_.p, stage, bytes, hipMemcpyHostToDevice, stream_));
-  MSH_HIP(hipMemcpyAsync(hop_base_.p, hop_base.data(), (size_t)hops * sizeof(long), hipMemcpyHostToDevice, stream_));
-  MSH_HIP(hipMemcpyAsync(clip_hop0_.p, clip_hop0.data(), (nc + 1) * sizeof(long), hipMemcpyHostToDevice, stream_));
-  silero_frames(audio_.as<float>(), hop_base_.as<long>(), hops, frames_.as<float>(), stream_);
+    const size_t cnt = (size_t)(sl.clip_hop0[i + 1] - sl.clip_hop0[i]) * kHop;
+    if (cnt > 0) memcpy(dst + kContext, pcm[i], cnt * sizeof(float));
+  }, gather_threads);
+  long* hop_base = reinterpret_cast<long*>(pin + off_hops);
+  for (size_t i = 0; i < nc; ++i)
+    for (long j = sl.clip_hop0[i]; j < sl.clip_hop0[i + 1]; ++j) hop_base[j] = sl.clip_off[i] + (j - sl.clip_hop0[i]) * kHop;
+  memcpy(pin + off_clips, sl.clip_hop0.data(), (nc + 1) * sizeof(long));
+  sl.probs_host = reinterpret_cast<float*>(pin + off_probs);
+  sl.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  sl.t_enqueued = std::chrono::steady_clock::now();
+  // the chunk's audio: the slot's scratch buffer, or -- residency asked for and room left -- a buffer of its own that outlives
+  // the call
+  DevBuf* abuf = &sl.audio;
+  if (keep_audio && arena_live_bytes_ + bytes <= kArenaBudget) {
+    if (arena_used_ == arena_.size()) arena_.emplace_back(new DevBuf());
+    abuf = arena_[arena_used_++].get();
+    arena_live_bytes_ += bytes;
+  }
+  // buffers only this slot's work touches (it was collected: nothing of it is in flight)
+  abuf->reserve(bytes + 4096);   // (the last hop's reflect padding reads inside its own 576 samples: no over-read)
+  sl.hop_base.reserve((size_t)hops * sizeof(long));
+  sl.clip_hop0_d.reserve((nc + 1) * sizeof(long));
+  // the network's workspaces are shared by both slots (their kernels run in order on one stream): growing one means the
+  // other slot's kernels must be done with it first
+  struct Need {
+    DevBuf* b;
+    size_t bytes;
+  } needs[] = {{&frames_, (size_t)hops * 4 * 256 * sizeof(float)}, {&stft_, (size_t)hops * 4 * 258 * sizeof(float)},
+               {&act_[0], (size_t)hops * 129 * 4 * sizeof(float)}, {&act_[1], (size_t)hops * 128 * 4 * sizeof(float)},
+               {&cols_, (size_t)hops * 4 * kpad_[0] * sizeof(float)}, {&gin_, (size_t)hops * 512 * sizeof(float)},
+               {&probs_, (size_t)hops * sizeof(float)}};
+  bool grow = false;
+  for (const Need& nd : needs) grow |= nd.b->cap < nd.bytes;
+  if (grow) sync_streams();
+  for (const Need& nd : needs) nd.b->reserve(nd.bytes);
+  // upload on the copy stream (it overlaps the other slot's network), network + read-back on the compute stream
+  MSH_HIP(hipMemcpyAsync(abuf->p, stage, bytes, hipMemcpyHostToDevice, copy_stream_));
+  MSH_HIP(hipMemcpyAsync(sl.hop_base.p, hop_base, (size_t)hops * sizeof(long), hipMemcpyHostToDevice, copy_stream_));
+  MSH_HIP(hipMemcpyAsync(sl.clip_hop0_d.p, pin + off_clips, (nc + 1) * sizeof(long), hipMemcpyHostToDevice, copy_stream_));
+  MSH_HIP(hipEventRecord(sl.uploaded, copy_stream_));
+  MSH_HIP(hipStreamWaitEvent(stream_, sl.uploaded, 0));
+  silero_frames(abuf->as<float>(), sl.hop_base.as<long>(), hops, frames_.as<float>(), stream_);
   silero_stft_mag(frames_.as<float>(), basis_, hops, stft_.as<float>(), act_[0].as<float>(), stream_);
   // conv stack: [129][4] -> [128][4] -> [64][2] -> [64][1] -> [128][1]
   int tin = 4, src = 0;
@@ -158,12 +262,37 @@ void SileroDevice::run_chunk(const float* const* pcm, const uint64_t* n, size_t 
     src ^= 1;
   }
   silero_gate_inputs(act_[src].as<float>(), w_ih_, bias_sum_, hops, gin_.as<float>(), stream_);
-  silero_lstm(gin_.as<float>(), w_hh_, out_w_, out_b_, clip_hop0_.as<long>(), (int)nc, probs_.as<float>(), stream_);
-  std::vector<float> all((size_t)hops);
-  MSH_HIP(hipMemcpyAsync(all.data(), probs_.p, (size_t)hops * sizeof(float), hipMemcpyDeviceToHost, stream_));
-  MSH_HIP(hipStreamSynchronize(stream_));   // also: hop_base / clip_hop0 / the pinned buffer may be reused from here on
-  for (size_t i = 0; i < nc; ++i)
-    (*probs)[c0 + i].assign(all.begin() + clip_hop0[i], all.begin() + clip_hop0[i + 1]);
+  silero_lstm(gin_.as<float>(), w_hh_, out_w_, out_b_, sl.clip_hop0_d.as<long>(), (int)nc, probs_.as<float>(), stream_);
+  MSH_HIP(hipMemcpyAsync(sl.probs_host, probs_.p, (size_t)hops * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  MSH_HIP(hipEventRecord(sl.done, stream_));
+  sl.abuf = abuf;
+  sl.kept = abuf != &sl.audio;
+  sl.busy = true;
+  if (timing) sl.bytes = bytes;
+  return next_ticket_++;
+}
+
+void SileroDevice::collect(int64_t ticket, std::vector<float>* probs, std::vector<const float*>* resident) {
+  MSH_HIP(hipSetDevice(device_));
+  if (ticket < 0) throw std::invalid_argument("device VAD: unknown ticket " + std::to_string(ticket));
+  Slot& sl = slots_[ticket % kSlots];
+  if (!sl.busy || sl.ticket != ticket) throw std::invalid_argument("device VAD: unknown ticket " + std::to_string(ticket));
+  if (ticket != next_collect_) throw std::invalid_argument("device VAD: tickets are collected in the order they were given");
+  ++next_collect_;
+  sl.busy = false;
+  probs->clear();
+  if (resident != nullptr) resident->assign(sl.nc, nullptr);
+  if (sl.hops == 0) return;
+  MSH_HIP(hipEventSynchronize(sl.done));
+  static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;
+  if (timing)
+    MSH_LOGF("device VAD: %zu clips, %.0f MB gathered into pinned memory in %.2f ms, upload + network + read-back done %.2f ms after "
+             "they were enqueued", sl.nc, (double)sl.bytes / 1e6, sl.gather_ms,
+             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sl.t_enqueued).count());
+  probs->assign(sl.probs_host, sl.probs_host + sl.hops);
+  if (resident != nullptr && sl.kept)
+    for (size_t i = 0; i < sl.nc; ++i)
+      if (sl.clip_hop0[i + 1] > sl.clip_hop0[i]) (*resident)[i] = sl.abuf->as<float>() + sl.clip_off[i] + kContext;
 }
 
 }  // namespace msh

@@ -9,6 +9,7 @@
 // probabilities (process_audio_with_probs).
 #pragma once
 
+#include <chrono>
 #include <memory>
 #include <vector>
 
@@ -25,11 +26,47 @@ class SileroDevice {
   SileroDevice& operator=(const SileroDevice&) = delete;
   // pcm[i]: n[i] samples of 16 kHz audio in HOST memory.  probs[i] gets n[i] / 512 values: what SileroVad::predict returns
   // hop after hop from a fresh state (up to fp32 summation order).  Clips are processed in chunks that bound the workspace.
-  void probabilities(const float* const* pcm, const uint64_t* n, size_t count, std::vector<std::vector<float>>* probs);
+  // resident (optional): the uploaded audio stays on the device -- (*resident)[i] = DEVICE pointer to the whole hops of clip i
+  // (n[i] / 512 * 512 floats, the caller's samples verbatim), or nullptr once this object holds kArenaBudget bytes of kept
+  // audio; valid until release_audio().  A batch call hands segments to the engine as slices of it (Engine::encode,
+  // on_device) instead of sending the same PCM over PCIe a second time.
+  void probabilities(const float* const* pcm, const uint64_t* n, size_t count, std::vector<std::vector<float>>* probs,
+                     std::vector<const float*>* resident = nullptr);
+  // The same in two halves: submit() stages one chunk of clips (at most kMaxHopsPerSubmit whole hops, unless it is a single
+  // clip) and enqueues its upload and network; collect() waits for it and returns the probabilities of its clips back to
+  // back (+ the device pointers, as above).  Two submissions may be outstanding: chunk k + 1 is gathered and uploaded while
+  // chunk k's network runs and the caller consumes chunk k - 1.  Tickets are collected in order.
+  static constexpr long kMaxHopsPerSubmit = 65536;
+  int64_t submit(const float* const* pcm, const uint64_t* n, size_t count, bool keep_audio);
+  void collect(int64_t ticket, std::vector<float>* probs, std::vector<const float*>* resident);
+  void abandon();   // after a failure: waits for the streams and forgets the outstanding tickets
+  // the kept audio may be overwritten by later calls (the buffers themselves stay allocated for them)
+  // (submissions never collected -- a caller that gave up half-way -- are waited for and forgotten)
+  void release_audio();
+  static constexpr size_t kArenaBudget = (size_t)8 << 30;
 
  private:
   void upload_weights(const msh_host::SileroWeights& w);
-  void run_chunk(const float* const* pcm, const uint64_t* n, size_t c0, size_t c1, std::vector<std::vector<float>>* probs);
+  void sync_streams();
+  static constexpr int kSlots = 2;
+  struct Slot {   // one submission in flight
+    bool busy = false, kept = false;
+    int64_t ticket = -1;
+    size_t nc = 0, bytes = 0;
+    long hops = 0;
+    std::vector<long> clip_off, clip_hop0;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    float* probs_host = nullptr;   // inside `pinned`
+    DevBuf audio, hop_base, clip_hop0_d;
+    DevBuf* abuf = nullptr;
+    hipEvent_t uploaded = nullptr, done = nullptr;
+    double gather_ms = 0.0;
+    std::chrono::steady_clock::time_point t_enqueued;
+  };
+  Slot slots_[kSlots];
+  int64_t next_ticket_ = 0, next_collect_ = 0;
+  hipStream_t copy_stream_ = nullptr;
   int device_;
   hipStream_t stream_ = nullptr;
   std::vector<void*> weights_;
@@ -37,9 +74,9 @@ class SileroDevice {
   float *w_ih_ = nullptr, *w_hh_ = nullptr, *bias_sum_ = nullptr, *out_w_ = nullptr;
   float out_b_ = 0.f;
   int kpad_[4] = {0, 0, 0, 0};
-  DevBuf audio_, hop_base_, clip_hop0_, frames_, stft_, act_[2], cols_, gin_, probs_;
-  void* pinned_ = nullptr;
-  size_t pinned_cap_ = 0;
+  DevBuf frames_, stft_, act_[2], cols_, gin_, probs_;   // the network's workspaces, shared by the slots
+  std::vector<std::unique_ptr<DevBuf>> arena_;   // audio of chunks whose caller asked for residency, one buffer per chunk
+  size_t arena_used_ = 0, arena_live_bytes_ = 0;
 };
 
 }  // namespace msh

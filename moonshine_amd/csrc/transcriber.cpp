@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "host_utils.h"
+#include "msh_common.h"
 
 namespace msh_host {
 
@@ -150,6 +151,131 @@ int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx_i
   }
   for (uint32_t i = 0; i < count; ++i)
     (*ids)[idx[i]].assign(tokens.begin() + (size_t)i * stride, tokens.begin() + (size_t)i * stride + counts[i]);
+  return 0;
+}
+
+// ---- the batch in pieces (transcriber.h: rolling_begin / rolling_add / rolling_finish) ----
+int MoonshineModel::rolling_begin() {
+  std::unique_ptr<Rolling> r(new Rolling());
+  r->lock = std::unique_lock<std::mutex>(processing_mutex);
+  if (msh_set_capture_cross_attention(engine, 0) != MSH_OK) return 1;
+  for (DeviceShard& d : devices)
+    if (!d.lanes_ready) {
+      if (msh_set_batches_in_flight(d.engine, std::max(1, batches_in_flight)) != MSH_OK) {
+        MSH_LOGF("batches in flight on device %d: %s", d.device, msh_last_error(d.engine));
+        return 1;
+      }
+      d.lanes_ready = true;
+    }
+  rolling_ = std::move(r);
+  return 0;
+}
+
+int MoonshineModel::rolling_submit(const RollingClip* c, uint32_t m) {
+  Rolling& r = *rolling_;
+  r.subs.emplace_back();
+  RollingSub& sb = r.subs.back();
+  sb.dev = r.next_dev;
+  r.next_dev = (r.next_dev + 1) % devices.size();
+  DeviceShard& d = devices[sb.dev];
+  bool on_device = d.device == r.device_audio_gpu;
+  for (uint32_t i = 0; i < m && on_device; ++i) on_device = c[i].dev != nullptr;
+  sb.idx.resize(m), sb.pcm.resize(m), sb.n.resize(m);
+  uint64_t longest = 0;
+  for (uint32_t i = 0; i < m; ++i) {
+    sb.idx[i] = c[i].idx;
+    sb.pcm[i] = on_device ? c[i].dev : c[i].host;
+    sb.n[i] = c[i].n;
+    longest = std::max(longest, c[i].n);
+  }
+  // rows wide enough for the step budget of the longest clip (the engine's rule: ceil(seconds * tokens/s)) + BOS
+  sb.stride = (int32_t)ceilf((float)longest / 16000.0f * max_tokens_per_second) + 2;
+  sb.tokens.assign((size_t)m * sb.stride, 0);
+  sb.counts.assign(m, 0);
+  sb.ticket = msh_submit_transcribe_tokens(d.engine, sb.pcm.data(), sb.n.data(), m, on_device ? 1 : 0, max_tokens_per_second, -1,
+                                           sb.tokens.data(), sb.counts.data(), sb.stride);
+  if (sb.ticket < 0) {
+    MSH_LOGF("submit failed on device %d: %s", d.device, msh_last_error(d.engine));
+    r.subs.pop_back();
+    r.failed = true;
+    return 1;
+  }
+  return 0;
+}
+
+int MoonshineModel::rolling_add(const float* const* host_audio, const float* const* device_audio, int device_audio_gpu,
+                                const size_t* n_samples, size_t count, bool last) {
+  if (!rolling_) return 1;
+  Rolling& r = *rolling_;
+  if (r.failed) return 1;
+  if (device_audio != nullptr) r.device_audio_gpu = device_audio_gpu;
+  for (size_t i = 0; i < count; ++i)
+    r.pool.push_back({r.next_idx++, host_audio[i], device_audio != nullptr ? device_audio[i] : nullptr, (uint64_t)n_samples[i]});
+  // A sub-batch decodes until its LAST clip is done and a decode step costs about the same for 16 rows as for 1024, so the
+  // cost of a call is the sum over its sub-batches of their longest clip: clips of similar length belong together (run_shard
+  // sorts a whole batch, longest first).  Here the batch arrives in pieces, and every piece brings clips of every length.
+  // Submitting "the longest 2560 s waiting" after every piece measured WORSE than waiting for everything (every sub-batch
+  // then holds a 10 s clip: 60 % more decode steps than the sorted cut) -- so while pieces keep coming only the SHORT clips
+  // go out (cheap sub-batches: few steps, and they keep the GPU busy beside the segmentation), in full sub-batches, and the
+  // long ones wait for the last add, where they are cut sorted like a whole batch.  "Short" = the shortest clips that hold
+  // 15 % of the first piece's audio: about the share of the call's work the GPU can do while the segmentation runs (~55 of
+  // ~340 ms for 2048 clips; measured on one box: 0.02 / 0.15 / 0.25 / 0.4 -> 347 / 342 / 383 / 374 ms per call).
+  std::stable_sort(r.pool.begin(), r.pool.end(), [](const RollingClip& a, const RollingClip& b) { return a.n > b.n; });
+  const uint32_t bc = (uint32_t)std::max(1, batch_clips);
+  const uint32_t clip_cap = (uint32_t)std::min<long>(4L * bc, 1024);
+  const uint64_t audio_cap = (uint64_t)bc * 160000ull;
+  if (r.short_len == 0 && !r.pool.empty()) {
+    const char* e = msh::dev_getenv("MSH_ROLLING_SHORT_FRAC");
+    const double frac = e != nullptr ? atof(e) : 0.15;
+    uint64_t total = 0, acc = 0;
+    for (const RollingClip& c : r.pool) total += c.n;
+    r.short_len = r.pool.back().n;
+    for (size_t k = r.pool.size(); k-- > 0;) {   // ascending
+      if ((double)(acc + r.pool[k].n) > frac * (double)total) break;
+      acc += r.pool[k].n;
+      r.short_len = r.pool[k].n;
+    }
+  }
+  size_t lo = 0;   // first candidate: everything on the last add, else the first short clip
+  if (!last)
+    while (lo < r.pool.size() && r.pool[lo].n > r.short_len) ++lo;
+  uint64_t waiting = 0;
+  for (size_t k = lo; k < r.pool.size(); ++k) waiting += r.pool[k].n;
+  while (lo < r.pool.size()) {
+    // full sub-batches; everything on the last add; and whatever short clips there are while the GPU has nothing yet
+    if (!last && waiting < audio_cap && !r.subs.empty()) break;
+    uint64_t sum = 0;
+    uint32_t m = 0;
+    while (lo + m < r.pool.size() && m < clip_cap) {
+      if (m >= bc && sum + r.pool[lo + m].n > audio_cap) break;
+      sum += r.pool[lo + m].n;
+      ++m;
+    }
+    if (rolling_submit(r.pool.data() + lo, m) != 0) return 1;
+    r.pool.erase(r.pool.begin() + (long)lo, r.pool.begin() + (long)(lo + m));
+    waiting -= sum;
+  }
+  return 0;
+}
+
+int MoonshineModel::rolling_finish(std::vector<std::string>* out_texts) {
+  std::unique_ptr<Rolling> r = std::move(rolling_);   // released (and the model unlocked) on every way out
+  if (!r) return 1;
+  bool failed = r->failed;
+  for (RollingSub& sb : r->subs)   // every submitted sub-batch is waited for, also after a failure: the lanes write into it
+    if (msh_wait(devices[sb.dev].engine, sb.ticket) != MSH_OK) {
+      MSH_LOGF("sub-batch failed on device %d: %s", devices[sb.dev].device, msh_last_error(devices[sb.dev].engine));
+      failed = true;
+    }
+  if (failed || out_texts == nullptr) return failed ? 1 : 0;
+  if (!r->pool.empty()) {
+    MSH_LOGF("internal: %zu clips were never submitted (rolling_add without last)", r->pool.size());
+    return 1;
+  }
+  out_texts->assign(r->next_idx, std::string());
+  for (const RollingSub& sb : r->subs)
+    for (size_t i = 0; i < sb.idx.size(); ++i)
+      (*out_texts)[sb.idx[i]] = tokenizer->tokens_to_text(sb.tokens.data() + i * (size_t)sb.stride, (size_t)sb.counts[i]);
   return 0;
 }
 
@@ -814,7 +940,8 @@ void Transcriber::save_input(TranscriberStream* s, const float* audio, uint64_t 
 // The per-segment loop of reference core/transcriber.cpp:989-1148, with every model call of the pass
 // gathered into one GPU batch.
 void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& streams,
-                                       std::vector<std::vector<VadSegment>>& segments, transcript_t** outs) {
+                                       std::vector<std::vector<VadSegment>>& segments, transcript_t** outs,
+                                       const std::vector<std::string>* given_texts, uint32_t given_latency_ms) {
   struct Job {
     size_t stream, segment;
   };
@@ -834,9 +961,8 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
         // the line id doubles as the streaming segment id (reference core/transcriber.cpp:1024-1027)
         std::lock_guard<std::mutex> lock(streams[si]->out.mutex);
         while (gi >= streams[si]->out.order.size()) streams[si]->out.order.push_back(next_line_id_.fetch_add(1));
-      } else {
-        if (!seg.is_complete && !opt_.decode_incomplete_lines) continue;
-        if (seg.audio.size() < 895) continue;  // shorter than the conv stem's receptive field: empty text
+      } else if (!is_offline_job(seg)) {
+        continue;
       }
       jobs.push_back({si, gi});
       ptrs.push_back(seg.audio.data());
@@ -873,6 +999,11 @@ void Transcriber::update_from_segments(const std::vector<TranscriberStream*>& st
       remaining -= idx.size();
     }
     latency_ms = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  } else if (!jobs.empty() && given_texts != nullptr) {
+    if (given_texts->size() != jobs.size())
+      throw std::runtime_error("internal: " + std::to_string(given_texts->size()) + " texts for " + std::to_string(jobs.size()) + " segments");
+    texts = *given_texts;
+    latency_ms = given_latency_ms;
   } else if (!jobs.empty()) {
     std::lock_guard<std::mutex> lock(model_mutex_);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1017,35 +1148,52 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // THIS call's decision: a device VAD left over from an earlier 16 kHz call must not see the un-resampled audio of a
   // call at another rate (process_audio would refuse the probabilities and the whole batch would fail)
   bool use_device_vad = device_vad && silero_device_ != nullptr;
-  auto segment = [&](uint64_t c0, uint64_t c1) {
-    std::vector<float> probs;
-    std::vector<size_t> poff;
-    bool have_probs = false;
-    if (use_device_vad) {
-      poff.resize((size_t)(c1 - c0) + 1, 0);
-      for (uint64_t i = c0; i < c1; ++i) poff[i - c0 + 1] = poff[i - c0] + (size_t)(n[i] / (uint64_t)opt_.vad_hop_size);
-      probs.resize(std::max<size_t>(poff.back(), 1));
-      const int64_t got = msh_silero_probabilities(silero_device_, audio + c0, n + c0, c1 - c0, probs.data(), poff.back());
-      have_probs = got == (int64_t)poff.back();
-      if (!have_probs) {   // e.g. out of device memory: the host network does this wave and every later one
-        MSH_LOGF("device VAD failed (%s): falling back to the host network", msh_silero_last_error(silero_device_));
-        msh_silero_destroy(silero_device_);
-        silero_device_ = nullptr;
-        silero_device_failed_ = true;
-        use_device_vad = false;
-      }
-    }
+  double detectors_ms = 0.0;   // of the segmentation time: the detectors' state machines (incl. the copy of every segment's audio)
+  if (use_device_vad) msh_silero_release_audio(silero_device_);   // the previous call's audio
+  // the detectors' state machines of clips [c0, c1), one clip per host thread; probs (nullable): the device network's
+  // probabilities of their whole hops, clip k at poff[k]
+  auto run_detectors = [&](uint64_t c0, uint64_t c1, const float* probs, const std::vector<size_t>& poff) {
+    const auto t_det = now();
     parallel_for((size_t)(c1 - c0), [&](size_t k) {
       const size_t i = (size_t)c0 + k;
       TranscriberStream* s = streams[i];
       s->vad->start();
-      if (have_probs)
-        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate, probs.data() + poff[k], poff[k + 1] - poff[k]);
+      if (probs != nullptr)
+        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate, probs + poff[k], poff[k + 1] - poff[k]);
       else
         s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
       s->vad->stop();
       segs[i] = s->vad->take_segments();
     }, vad_threads);
+    detectors_ms += ms_since(t_det);
+  };
+  auto hop_offsets = [&](uint64_t c0, uint64_t c1) {
+    std::vector<size_t> poff((size_t)(c1 - c0) + 1, 0);
+    for (uint64_t i = c0; i < c1; ++i) poff[i - c0 + 1] = poff[i - c0] + (size_t)(n[i] / (uint64_t)opt_.vad_hop_size);
+    return poff;
+  };
+  // e.g. out of device memory: the host network does this chunk and every later one.  keep_device: the rolling call's
+  // sub-batches may still read the audio the device VAD kept -- the handle is destroyed when they are done.
+  auto device_vad_failed = [&](bool keep_device) {
+    MSH_LOGF("device VAD failed (%s): falling back to the host network", msh_silero_last_error(silero_device_));
+    if (!keep_device) {
+      msh_silero_destroy(silero_device_);
+      silero_device_ = nullptr;
+    }
+    silero_device_failed_ = true;
+    use_device_vad = false;
+  };
+  auto segment = [&](uint64_t c0, uint64_t c1) {
+    if (use_device_vad) {
+      const std::vector<size_t> poff = hop_offsets(c0, c1);
+      std::vector<float> probs(std::max<size_t>(poff.back(), 1));
+      if (msh_silero_probabilities(silero_device_, audio + c0, n + c0, c1 - c0, probs.data(), poff.back()) == (int64_t)poff.back()) {
+        run_detectors(c0, c1, probs.data(), poff);
+        return;
+      }
+      device_vad_failed(false);
+    }
+    run_detectors(c0, c1, nullptr, {});
   };
   std::vector<transcript_t*> outs(count, nullptr);
   auto transcribe = [&](uint64_t w0, uint64_t w1) {
@@ -1068,6 +1216,12 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // sub-batches after a first wave of one: the device VAD + the detectors' state machines of wave k + 1 run beside the
   // transcription of wave k, and there are few wave boundaries (each one is a tail of half-empty sub-batches on the GPU).
   const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
+  // the rolling form of the pipeline (below); word timestamps and the per-kernel log read one sub-batch at a time from the
+  // first engine and keep the waves (MSH_BATCH_ROLLING=0: the waves for everything, for A/B runs)
+  const bool rolling = pipelined && model_ != nullptr && !opt_.word_timestamps && !opt_.log_ort_run && [] {
+    const char* e = msh::dev_getenv("MSH_BATCH_ROLLING");
+    return e == nullptr || atoi(e) != 0;
+  }();
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 8 : 2)
                                          : std::max<uint64_t>(count, 1);
@@ -1079,6 +1233,112 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     t_phase = now();
     for (uint64_t w0 = 0; w0 < count; w0 += wave) transcribe(w0, std::min(count, w0 + wave));
     if (timing) MSH_LOGF("batch call: transcription + transcript assembly in %.1f ms", ms_since(t_phase));
+  } else if (rolling) {
+    // Clips are segmented chunk by chunk and the segments of every chunk join the model's rolling batch: the GPU starts on
+    // the first chunk's segments and never waits for a wave to end.  A chunk = what one pass of the device VAD takes (64 Ki
+    // hops, ~200 clips of 10 s; silero_device.cpp), or a few clips per host thread for the host network.
+    const auto t_call = now();
+    const bool keep_audio = [] {
+      const char* e = msh::dev_getenv("MSH_VAD_KEEP_AUDIO");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    std::vector<std::string> texts;
+    size_t n_jobs = 0, n_resident = 0;
+    bool begun = false;
+    try {
+      {
+        std::lock_guard<std::mutex> lock(model_mutex_);
+        if (model_->rolling_begin() != 0) throw std::runtime_error("Failed to transcribe: " + model_->error());
+      }
+      begun = true;
+      const uint64_t chunk_clips = [] {   // MSH_BATCH_CHUNK_CLIPS: clips per chunk (the tests force many small chunks)
+        const char* e = msh::dev_getenv("MSH_BATCH_CHUNK_CLIPS");
+        return e != nullptr && atoi(e) > 0 ? (uint64_t)atoi(e) : 0ull;
+      }();
+      std::vector<std::pair<uint64_t, uint64_t>> chunks;
+      for (uint64_t c0 = 0, c1 = 0; c0 < count; c0 = c1) {
+        if (chunk_clips > 0) {
+          c1 = std::min<uint64_t>(count, c0 + chunk_clips);
+        } else if (use_device_vad) {
+          uint64_t hops = 0;
+          for (c1 = c0; c1 < count; ++c1) {
+            const uint64_t h = n[c1] / (uint64_t)opt_.vad_hop_size;
+            if (c1 > c0 && hops + h > 65536) break;
+            hops += h;
+          }
+        } else {
+          c1 = std::min<uint64_t>(count, c0 + std::max(64u, 2u * vad_threads));
+        }
+        chunks.push_back({c0, c1});
+      }
+      // The device network runs one chunk ahead (msh_silero_submit / _collect): chunk k + 1 is gathered and uploaded, and its
+      // network runs, while this thread feeds chunk k's probabilities to the detectors and submits its segments.
+      std::vector<int64_t> tickets(chunks.size(), -1);
+      auto vad_submit = [&](size_t k) {
+        if (!use_device_vad || k >= chunks.size()) return;
+        const uint64_t c0 = chunks[k].first, c1 = chunks[k].second;
+        tickets[k] = msh_silero_submit(silero_device_, audio + c0, n + c0, c1 - c0, keep_audio ? 1 : 0);
+        if (tickets[k] < 0) device_vad_failed(true);
+      };
+      const auto ts0 = now();
+      vad_submit(0);
+      seg_ms += ms_since(ts0);
+      for (size_t k = 0; k < chunks.size(); ++k) {
+        const uint64_t c0 = chunks[k].first, c1 = chunks[k].second;
+        const auto ts = now();
+        vad_submit(k + 1);
+        std::vector<const float*> resident;
+        bool have_probs = false;
+        if (use_device_vad && tickets[k] >= 0) {
+          const std::vector<size_t> poff = hop_offsets(c0, c1);
+          std::vector<float> probs(std::max<size_t>(poff.back(), 1));
+          if (keep_audio) resident.assign((size_t)(c1 - c0), nullptr);
+          have_probs = msh_silero_collect(silero_device_, tickets[k], probs.data(), poff.back(), keep_audio ? resident.data() : nullptr,
+                                          c1 - c0) == (int64_t)poff.back();
+          if (have_probs) {
+            run_detectors(c0, c1, probs.data(), poff);
+          } else {
+            device_vad_failed(true);
+            resident.clear();
+          }
+        }
+        if (!have_probs) run_detectors(c0, c1, nullptr, {});
+        seg_ms += ms_since(ts);
+        std::vector<const float*> host, dev;
+        std::vector<size_t> lens;
+        for (uint64_t i = c0; i < c1; ++i) {
+          const uint64_t whole = n[i] / (uint64_t)opt_.vad_hop_size * (uint64_t)opt_.vad_hop_size;
+          for (const VadSegment& seg : segs[i]) {
+            if (!is_offline_job(seg)) continue;
+            host.push_back(seg.audio.data());
+            lens.push_back(seg.audio.size());
+            const float* base = resident.empty() ? nullptr : resident[i - c0];
+            const bool slice = base != nullptr && seg.src_offset + seg.audio.size() <= whole;
+            dev.push_back(slice ? base + seg.src_offset : nullptr);
+            n_resident += slice ? 1 : 0;
+          }
+        }
+        n_jobs += host.size();
+        if (model_->rolling_add(host.data(), resident.empty() ? nullptr : dev.data(), opt_.device, lens.data(), host.size(),
+                                k + 1 == chunks.size()) != 0)
+          throw std::runtime_error("Failed to transcribe: " + model_->error());
+      }
+      begun = false;
+      if (model_->rolling_finish(&texts) != 0) throw std::runtime_error("Failed to transcribe: " + model_->error());
+    } catch (...) {
+      if (begun) model_->rolling_finish(nullptr);   // waits for what was submitted: the lanes write into the batch's arrays
+      if (silero_device_failed_ && silero_device_ != nullptr) msh_silero_destroy(silero_device_), silero_device_ = nullptr;
+      throw;
+    }
+    if (silero_device_failed_ && silero_device_ != nullptr) msh_silero_destroy(silero_device_), silero_device_ = nullptr;
+    const double call_ms = ms_since(t_call);
+    if (timing)
+      MSH_LOGF("batch call: %zu segments (%zu read from the device VAD's audio) transcribed in %.1f ms, of which segmentation %.1f ms "
+               "(%.1f ms of that in the detectors' state machines on %u threads) beside the transcription", n_jobs, n_resident, call_ms, seg_ms,
+               detectors_ms, vad_threads);
+    t_phase = now();
+    update_from_segments(streams, segs, outs.data(), &texts, (uint32_t)call_ms);
+    if (timing) MSH_LOGF("batch call: transcript assembly in %.1f ms", ms_since(t_phase));
   } else {
     std::future<void> pending;   // the previous wave on the GPU
     try {

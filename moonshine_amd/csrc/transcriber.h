@@ -11,6 +11,7 @@
 #pragma once
 
 #include <atomic>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -66,7 +67,46 @@ struct MoonshineModel {
                        std::vector<std::string>* out_texts, std::vector<std::vector<TranscriberWord>>* out_words = nullptr);
   std::string error() const;
 
+  // The same batch, handed over in pieces while earlier pieces are already on the GPU (the batch call under the
+  // reference's default VAD: segments keep arriving from the segmentation of later clips).  rolling_begin takes the
+  // model; every rolling_add appends clips -- their indices continue from the previous add -- and submits sub-batches to
+  // the devices' lanes as soon as a full one (batch_clips x 10 s of audio, longest clips of what is waiting first) can be
+  // cut, `last` submits what is left; rolling_finish waits for everything and returns the texts in index order.
+  // device_audio (nullable, entries nullable): the same samples already in the memory of `device_audio_gpu` -- a sub-batch
+  // whose clips all have one and that runs on that GPU reads them there instead of uploading host_audio.
+  // All three return 0 on success; after a failure rolling_finish still has to be called (it waits and releases).
+  int rolling_begin();
+  int rolling_add(const float* const* host_audio, const float* const* device_audio, int device_audio_gpu, const size_t* n_samples,
+                  size_t count, bool last);
+  int rolling_finish(std::vector<std::string>* out_texts);
+
  private:
+  struct RollingSub {
+    std::vector<uint32_t> idx;
+    std::vector<const float*> pcm;
+    std::vector<uint64_t> n;
+    std::vector<int32_t> tokens, counts;
+    int32_t stride = 0;
+    int64_t ticket = -1;
+    size_t dev = 0;
+  };
+  struct RollingClip {
+    uint32_t idx;
+    const float *host, *dev;
+    uint64_t n;
+  };
+  struct Rolling {
+    std::unique_lock<std::mutex> lock;
+    std::vector<RollingClip> pool;   // waiting clips
+    std::deque<RollingSub> subs;     // submitted sub-batches (their arrays are written by the lanes: addresses must not move)
+    uint32_t next_idx = 0;
+    size_t next_dev = 0;
+    int device_audio_gpu = -1;
+    uint64_t short_len = 0;          // clips up to this length go out before the last add (rolling_add)
+    bool failed = false;
+  };
+  std::unique_ptr<Rolling> rolling_;
+  int rolling_submit(const RollingClip* clips, uint32_t m);
   // clips `idx` (indices into audio / lens) on one device: sub-batches of batch_clips, batches_in_flight of them at once;
   // ids[i] receives the token ids of clip i.  Returns 0 on success (the reference's status convention).
   int run_shard(DeviceShard& d, const std::vector<uint32_t>& idx, const std::vector<const float*>& audio,
@@ -186,8 +226,16 @@ class Transcriber {
   std::shared_ptr<TranscriberStream> find_stream(int32_t id);  // the caller's copy keeps the stream alive against free_stream
   // transcribe every just-updated segment of `streams[i]` (all in one GPU batch), then rebuild outputs.  `segments` is the
   // caller's snapshot and is consumed: the audio of a segment moves into its transcript line (no copy per line)
+  // given_texts (offline models; nullable): the texts of the pass's jobs, in job order -- stream by stream, segment by
+  // segment, every segment is_offline_job() accepts --, already computed (the rolling batch call); the model is not called
   void update_from_segments(const std::vector<TranscriberStream*>& streams, std::vector<std::vector<VadSegment>>& segments,
-                            transcript_t** outs);
+                            transcript_t** outs, const std::vector<std::string>* given_texts = nullptr,
+                            uint32_t given_latency_ms = 0);
+  // a segment an offline model transcribes in this pass (reference core/transcriber.cpp:1075-1100)
+  bool is_offline_job(const VadSegment& seg) const {
+    return seg.just_updated && model_ != nullptr && (seg.is_complete || opt_.decode_incomplete_lines) &&
+           seg.audio.size() >= 895;  // shorter than the conv stem's receptive field: empty text
+  }
   void save_input(TranscriberStream* s, const float* audio, uint64_t n, int32_t rate, bool flush);
   struct StreamingJob {
     TranscriberStream* stream;

@@ -341,6 +341,56 @@ def test_batch_call_with_silero_segments_clips_on_host_threads(tiny_dir, tmp_pat
           f"{tdev * 1e3:.0f} ms with the network on the GPU")
 
 
+def test_default_options_batch_call_rolls_segments_into_sub_batches(tiny_dir, tmp_path, monkeypatch):
+    """The batch call under the reference's default options (vad_threshold 0.5): clips are segmented chunk by chunk, the segments
+    join a rolling batch whose sub-batches go to the lanes while later chunks are still being segmented, and they read the
+    audio the device VAD uploaded instead of a second upload (transcriber.cpp, MoonshineModel::rolling_*).  Forced into many
+    chunks and sub-batches here (5 clips per chunk, 40 s of audio per sub-batch):
+      * reading the device VAD's audio vs uploading the segments from the host: the same samples in the same sub-batches, so
+        identical transcripts;
+      * against the wave pipeline it replaces (other sub-batch compositions): identical cuts, texts equal except near-ties;
+      * on two engines of one GPU (sub-batches dealt round-robin) and with the host network: identical cuts."""
+    import shutil
+
+    from moonshine_amd.synth import save_safetensors
+    from oracle import silero_ref as sr
+
+    d = str(tmp_path / "with_vad_rolling")
+    shutil.copytree(tiny_dir[0], d)
+    save_safetensors(os.path.join(d, "silero_vad.safetensors"), sr.make_weights(2))
+    clips = []
+    for i in range(37):
+        n = int((3.0 + 0.29 * i) * 16000) + 17 * i
+        env = (np.sin(np.arange(n) / 16000 * 2 * np.pi * (0.5 + 0.05 * i)) > 0).astype(np.float32)
+        clips.append((make_audio(950 + i, n) * (0.05 + 3.0 * env)).astype(np.float32))
+    opts = {"batch_clips": "4", "batches_in_flight": "2", "cross_attention": "kv"}
+
+    def run(env, more=None):
+        for k in ("MSH_BATCH_ROLLING", "MSH_VAD_KEEP_AUDIO", "MSH_BATCH_CHUNK_CLIPS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t = api.Transcriber(d, api.ARCH_TINY, dict(opts, **(more or {})))
+        t.transcribe_batch_without_streaming(clips[:3])   # warm; also: a second call on the handle releases the kept audio
+        r = [[(l.text_bytes, l.start_time, l.duration) for l in c] for c in t.transcribe_batch_without_streaming(clips)]
+        t.close()
+        return r
+
+    rolling = run({"MSH_BATCH_CHUNK_CLIPS": "5"})
+    assert sum(len(c) for c in rolling) > len(clips)
+    assert run({"MSH_BATCH_CHUNK_CLIPS": "5", "MSH_VAD_KEEP_AUDIO": "0"}) == rolling
+    spans = lambda r: [[(a, b) for _, a, b in c] for c in r]
+    waves = run({"MSH_BATCH_ROLLING": "0"})
+    assert spans(waves) == spans(rolling)
+    texts_r = [t for c in rolling for t, _, _ in c]
+    texts_w = [t for c in waves for t, _, _ in c]
+    same = sum(a == b for a, b in zip(texts_r, texts_w))
+    assert same >= 0.8 * len(texts_r), (same, len(texts_r))
+    assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"devices": "0,0"})) == spans(rolling)
+    assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"vad_device": "0"})) == spans(rolling)
+    assert spans(run({})) == spans(rolling)     # the default chunking (one chunk here)
+
+
 def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir, monkeypatch):
     """Additive load options `devices` / `num_gpus` / `max_batch_size`: the batch call shards its
     clips over one engine per listed GPU inside the C++ host layer (length-sorted snake deal, one host thread per device,

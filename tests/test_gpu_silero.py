@@ -101,6 +101,91 @@ def test_device_probabilities_match_the_oracle_and_the_host_network(blob):
     lib.msh_silero_destroy(h)
 
 
+def test_keep_audio_leaves_the_clips_whole_hops_on_the_device(blob):
+    """msh_silero_probabilities_keep_audio: the same probabilities, and device pointers to every clip's whole hops -- the
+    caller's samples verbatim (read back with hipMemcpy) --, over more than one chunk of the network (64 Ki hops), NULL for a clip
+    without a whole hop; after msh_silero_release_audio the next call may reuse the buffers and still returns its own audio."""
+    lib = _lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.msh_silero_probabilities_keep_audio.restype = C.c_int64
+    lib.msh_silero_probabilities_keep_audio.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64), C.c_uint64,
+                                                        C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.msh_silero_release_audio.restype = C.c_int32
+    lib.msh_silero_release_audio.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    assert lib.msh_silero_create(0, blob, len(blob), C.byref(h)) == 0
+
+    def run(clips):
+        n = len(clips)
+        ptrs = (C.POINTER(C.c_float) * n)(*[c.ctypes.data_as(C.POINTER(C.c_float)) for c in clips])
+        lens = (C.c_uint64 * n)(*[c.shape[0] for c in clips])
+        total = sum(c.shape[0] // 512 for c in clips)
+        out = np.zeros(max(total, 1), np.float32)
+        dev = (C.c_void_p * n)()
+        got = lib.msh_silero_probabilities_keep_audio(h, ptrs, lens, n, out.ctypes.data_as(C.POINTER(C.c_float)), total, dev)
+        assert got == total, lib.msh_silero_last_error(h)
+        for c, d in zip(clips, dev):
+            whole = c.shape[0] // 512 * 512
+            if whole == 0:
+                assert not d
+                continue
+            assert d and d % 4 == 0
+            back = np.empty(whole, np.float32)
+            assert hip.hipMemcpy(back.ctypes.data, d, whole * 4, 2) == 0
+            assert np.array_equal(back, c[:whole])
+        return out[:total], [int(d or 0) for d in dev]
+
+    # 230 clips of 10 s = 71.9 Ki hops: two chunks; ragged ones in front
+    lens = [160000, 512, 300, 0, 1023, 16000 * 3 + 77] + [160000] * 224
+    clips = [np.ascontiguousarray(make_audio(430 + (i % 24), max(n, 1))[:n], dtype=np.float32) for i, n in enumerate(lens)]
+    probs, where = run(clips)
+    plain = np.concatenate(_device_probs(lib, h, clips))
+    assert np.array_equal(probs, plain)
+    assert lib.msh_silero_release_audio(h) == 0
+    probs2, where2 = run(clips[:40][::-1])
+    assert where2[-1] != 0 and set(where2) & set(where)            # buffers are reused after the release
+    assert np.array_equal(probs2, np.concatenate(_device_probs(lib, h, clips[:40][::-1])))
+    # the two halves (msh_silero_submit / _collect), two submissions outstanding: the same probabilities and the same audio
+    lib.msh_silero_submit.restype = C.c_int64
+    lib.msh_silero_submit.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64), C.c_uint64, C.c_int32]
+    lib.msh_silero_collect.restype = C.c_int64
+    lib.msh_silero_collect.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_void_p), C.c_uint64]
+    assert lib.msh_silero_release_audio(h) == 0
+    groups = [clips[:6], clips[6:100], clips[100:206]]
+    keep = []
+
+    def submit(g):
+        ptrs = (C.POINTER(C.c_float) * len(g))(*[c.ctypes.data_as(C.POINTER(C.c_float)) for c in g])
+        lens = (C.c_uint64 * len(g))(*[c.shape[0] for c in g])
+        keep.append((ptrs, lens))
+        t = lib.msh_silero_submit(h, ptrs, lens, len(g), 1)
+        assert t >= 0, lib.msh_silero_last_error(h)
+        return t
+
+    def collect(t, g):
+        total = sum(c.shape[0] // 512 for c in g)
+        out = np.zeros(max(total, 1), np.float32)
+        dev = (C.c_void_p * len(g))()
+        assert lib.msh_silero_collect(h, t, out.ctypes.data_as(C.POINTER(C.c_float)), total, dev, len(g)) == total, lib.msh_silero_last_error(h)
+        for c, d in zip(g, dev):
+            whole = c.shape[0] // 512 * 512
+            if whole:
+                back = np.empty(whole, np.float32)
+                assert hip.hipMemcpy(back.ctypes.data, d, whole * 4, 2) == 0
+                assert np.array_equal(back, c[:whole])
+        return out[:total]
+
+    t0, t1 = submit(groups[0]), submit(groups[1])
+    assert lib.msh_silero_submit(h, keep[0][0], keep[0][1], 6, 1) < 0          # a third one is refused
+    assert lib.msh_silero_collect(h, t1, None, 0, None, 0) < 0                  # out of order
+    got = [collect(t0, groups[0])]
+    t2 = submit(groups[2])
+    got += [collect(t1, groups[1]), collect(t2, groups[2])]
+    assert np.array_equal(np.concatenate(got), probs[:sum(len(g) for g in got)])
+    lib.msh_silero_destroy(h)
+
+
 def test_device_silero_throughput_report(blob, capsys):
     import time
 
