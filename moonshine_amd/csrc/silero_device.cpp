@@ -25,11 +25,7 @@ SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : devic
   if (device < 0 || device >= n_dev) throw HipError("invalid device index " + std::to_string(device));
   MSH_HIP(hipSetDevice(device_));
   MSH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  MSH_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (Slot& sl : slots_) {
-    MSH_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
-    MSH_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-  }
+  for (Slot& sl : slots_) MSH_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   try {
     upload_weights(w);
   } catch (...) {   // a constructor that throws runs no destructor: hand back what was taken so far
@@ -37,8 +33,7 @@ SileroDevice::SileroDevice(int device, const msh_host::SileroWeights& w) : devic
       std::lock_guard<std::mutex> lock(device_structure_mutex());
       for (void* p : weights_) device_free(p);
     }
-    for (Slot& sl : slots_) (void)hipEventDestroy(sl.uploaded), (void)hipEventDestroy(sl.done);
-    (void)hipStreamDestroy(copy_stream_);
+    for (Slot& sl : slots_) (void)hipEventDestroy(sl.done);
     (void)hipStreamDestroy(stream_);
     throw;
   }
@@ -77,7 +72,6 @@ void SileroDevice::upload_weights(const msh_host::SileroWeights& w) {
 
 SileroDevice::~SileroDevice() {
   (void)hipSetDevice(device_);
-  if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   {
     std::lock_guard<std::mutex> lock(device_structure_mutex());
@@ -89,10 +83,8 @@ SileroDevice::~SileroDevice() {
   for (Slot& sl : slots_) {
     sl.audio.release(), sl.hop_base.release(), sl.clip_hop0_d.release();
     if (sl.pinned) (void)hipHostFree(sl.pinned);
-    if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
-  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -148,7 +140,6 @@ void SileroDevice::release_audio() {
 }
 
 void SileroDevice::abandon() {
-  (void)hipStreamSynchronize(copy_stream_);
   (void)hipStreamSynchronize(stream_);
   (void)hipGetLastError();
   for (Slot& sl : slots_) sl.busy = false;
@@ -156,7 +147,6 @@ void SileroDevice::abandon() {
 }
 
 void SileroDevice::sync_streams() {
-  MSH_HIP(hipStreamSynchronize(copy_stream_));
   MSH_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -245,12 +235,13 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   for (const Need& nd : needs) grow |= nd.b->cap < nd.bytes;
   if (grow) sync_streams();
   for (const Need& nd : needs) nd.b->reserve(nd.bytes);
-  // upload on the copy stream (it overlaps the other slot's network), network + read-back on the compute stream
-  MSH_HIP(hipMemcpyAsync(abuf->p, stage, bytes, hipMemcpyHostToDevice, copy_stream_));
-  MSH_HIP(hipMemcpyAsync(sl.hop_base.p, hop_base, (size_t)hops * sizeof(long), hipMemcpyHostToDevice, copy_stream_));
-  MSH_HIP(hipMemcpyAsync(sl.clip_hop0_d.p, pin + off_clips, (nc + 1) * sizeof(long), hipMemcpyHostToDevice, copy_stream_));
-  MSH_HIP(hipEventRecord(sl.uploaded, copy_stream_));
-  MSH_HIP(hipStreamWaitEvent(stream_, sl.uploaded, 0));
+  // Upload, network and read-back in order on the ONE stream this object owns.  (A copy stream of its own for the upload --
+  // chunk k + 1's DMA beside chunk k's network, also in four pieces on four streams -- measured no faster: the network is ~1 ms
+  // of a chunk's ~6; and every extra stream competes with the engine's lanes for the process's hardware queues -- with 8
+  // queues and 4 lanes the wave pipeline went from 381 to 450 ms per call when this object took five of them.)
+  MSH_HIP(hipMemcpyAsync(abuf->p, stage, bytes, hipMemcpyHostToDevice, stream_));
+  MSH_HIP(hipMemcpyAsync(sl.hop_base.p, hop_base, (size_t)hops * sizeof(long), hipMemcpyHostToDevice, stream_));
+  MSH_HIP(hipMemcpyAsync(sl.clip_hop0_d.p, pin + off_clips, (nc + 1) * sizeof(long), hipMemcpyHostToDevice, stream_));
   silero_frames(abuf->as<float>(), sl.hop_base.as<long>(), hops, frames_.as<float>(), stream_);
   silero_stft_mag(frames_.as<float>(), basis_, hops, stft_.as<float>(), act_[0].as<float>(), stream_);
   // conv stack: [129][4] -> [128][4] -> [64][2] -> [64][1] -> [128][1]

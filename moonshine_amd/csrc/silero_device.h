@@ -34,8 +34,8 @@ class SileroDevice {
                      std::vector<const float*>* resident = nullptr);
   // The same in two halves: submit() stages one chunk of clips (at most kMaxHopsPerSubmit whole hops, unless it is a single
   // clip) and enqueues its upload and network; collect() waits for it and returns the probabilities of its clips back to
-  // back (+ the device pointers, as above).  Two submissions may be outstanding: chunk k + 1 is gathered and uploaded while
-  // chunk k's network runs and the caller consumes chunk k - 1.  Tickets are collected in order.
+  // back (+ the device pointers, as above).  Two submissions may be outstanding: chunk k + 1 is gathered, and its upload queued
+  // behind chunk k's network, while the caller consumes chunk k - 1.  Tickets are collected in order.
   static constexpr long kMaxHopsPerSubmit = 65536;
   int64_t submit(const float* const* pcm, const uint64_t* n, size_t count, bool keep_audio);
   void collect(int64_t ticket, std::vector<float>* probs, std::vector<const float*>* resident);
@@ -60,13 +60,12 @@ class SileroDevice {
     float* probs_host = nullptr;   // inside `pinned`
     DevBuf audio, hop_base, clip_hop0_d;
     DevBuf* abuf = nullptr;
-    hipEvent_t uploaded = nullptr, done = nullptr;
+    hipEvent_t done = nullptr;
     double gather_ms = 0.0;
     std::chrono::steady_clock::time_point t_enqueued;
   };
   Slot slots_[kSlots];
   int64_t next_ticket_ = 0, next_collect_ = 0;
-  hipStream_t copy_stream_ = nullptr;
   int device_;
   hipStream_t stream_ = nullptr;
   std::vector<void*> weights_;

@@ -236,7 +236,37 @@ int MoonshineModel::rolling_add(const float* const* host_audio, const float* con
       r.short_len = r.pool[k].n;
     }
   }
-  size_t lo = 0;   // first candidate: everything on the last add, else the first short clip
+  // the cut run_shard makes at position lo of the sorted pool: m clips, their audio in *sum
+  auto cut_at = [&](size_t lo, uint64_t* sum) {
+    uint32_t m = 0;
+    *sum = 0;
+    while (lo + m < r.pool.size() && m < clip_cap) {
+      if (m >= bc && *sum + r.pool[lo + m].n > audio_cap) break;
+      *sum += r.pool[lo + m].n;
+      ++m;
+    }
+    return m;
+  };
+  if (!last) {
+    // (1) anywhere in the sorted pool: a FULL sub-batch of clips of nearly one length (the shortest within 10 % of the
+    // longest) is what the sorted cut of the whole call would make of them anyway -- it goes out now.  (Real batches have
+    // such classes: clips the detector did not split are all as long as the caller's clips.)
+    static const bool narrow_runs = [] {
+      const char* e = msh::dev_getenv("MSH_ROLLING_NARROW_RUNS");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    for (size_t i = 0; narrow_runs && i < r.pool.size();) {
+      uint64_t sum = 0;
+      const uint32_t m = cut_at(i, &sum);
+      if (sum * 10 >= audio_cap * 9 && r.pool[i + m - 1].n * 10 >= r.pool[i].n * 9) {
+        if (rolling_submit(r.pool.data() + i, m) != 0) return 1;
+        r.pool.erase(r.pool.begin() + (long)i, r.pool.begin() + (long)(i + m));
+      } else {
+        ++i;
+      }
+    }
+  }
+  size_t lo = 0;   // (2) first candidate: everything on the last add, else the first short clip
   if (!last)
     while (lo < r.pool.size() && r.pool[lo].n > r.short_len) ++lo;
   uint64_t waiting = 0;
@@ -245,12 +275,7 @@ int MoonshineModel::rolling_add(const float* const* host_audio, const float* con
     // full sub-batches; everything on the last add; and whatever short clips there are while the GPU has nothing yet
     if (!last && waiting < audio_cap && !r.subs.empty()) break;
     uint64_t sum = 0;
-    uint32_t m = 0;
-    while (lo + m < r.pool.size() && m < clip_cap) {
-      if (m >= bc && sum + r.pool[lo + m].n > audio_cap) break;
-      sum += r.pool[lo + m].n;
-      ++m;
-    }
+    const uint32_t m = cut_at(lo, &sum);
     if (rolling_submit(r.pool.data() + lo, m) != 0) return 1;
     r.pool.erase(r.pool.begin() + (long)lo, r.pool.begin() + (long)(lo + m));
     waiting -= sum;
