@@ -208,6 +208,14 @@ std::mutex& device_structure_mutex(int device) {
   return m[device >= 0 && device < 64 ? device : 64];
 }
 
+// One large host -> device upload per device at a time (Engine::encode): four lanes that start their sub-batches together
+// otherwise share the link, all four uploads end together (4 x 164 MB: ~26 ms) and no lane computes before that; in turn, the
+// first lane starts after a quarter of it and the others upload beside its kernels.
+std::mutex& device_upload_mutex(int device) {
+  static std::mutex* m = new std::mutex[65];
+  return m[device >= 0 && device < 64 ? device : 64];
+}
+
 void copy_blocking(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return;
   UtilStreams& u = util_streams();
@@ -933,12 +941,18 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
 
   // clip pointers: stage host PCM into one device buffer, or use the caller's device pointers
   std::vector<const float*> ptrs(count);
+  std::unique_lock<std::mutex> upload_turn;
   if (on_device) {
     for (uint32_t i = 0; i < count; ++i) ptrs[i] = pcm[i];
   } else {
     size_t total = 0;
     for (uint32_t i = 0; i < count; ++i) total += (n_samples[i] + 3) & ~size_t(3);
     pcm_stage_.reserve(total * sizeof(float));
+    static const bool in_turn = [] {   // MSH_UPLOAD_IN_TURN=0: lanes upload side by side (A/B)
+      const char* e = dev_getenv("MSH_UPLOAD_IN_TURN");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    if (in_turn && total * sizeof(float) >= ((size_t)8 << 20)) upload_turn = std::unique_lock<std::mutex>(device_upload_mutex(device_));
     std::vector<size_t> offs(count);
     size_t off = 0;
     for (uint32_t i = 0; i < count; ++i) {
@@ -979,6 +993,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   MSH_HIP(hipMemcpyAsync(clips_d_.p, clips_h_.data(), count * sizeof(ClipMeta), hipMemcpyHostToDevice, stream_));
   MSH_HIP(hipMemcpyAsync(clip_ptrs_d_.p, ptrs.data(), count * sizeof(float*), hipMemcpyHostToDevice, stream_));
   MSH_HIP(hipStreamSynchronize(stream_));  // `ptrs` / `clips_h_` staging is on the host stack
+  if (upload_turn.owns_lock()) upload_turn.unlock();
   run_encoder();
   prof_flush();
   encoded_ = true;

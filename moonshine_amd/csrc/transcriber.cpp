@@ -1240,13 +1240,17 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
   // ... and with the network on the GPU (tens of milliseconds per thousand clips) the same pipeline, in waves of eight
   // sub-batches after a first wave of one: the device VAD + the detectors' state machines of wave k + 1 run beside the
   // transcription of wave k, and there are few wave boundaries (each one is a tail of half-empty sub-batches on the GPU).
-  const bool pipelined = !streaming_model_ && opt_.vad_threshold > 0.0f;
-  // the rolling form of the pipeline (below); word timestamps and the per-kernel log read one sub-batch at a time from the
-  // first engine and keep the waves (MSH_BATCH_ROLLING=0: the waves for everything, for A/B runs)
-  const bool rolling = pipelined && model_ != nullptr && !opt_.word_timestamps && !opt_.log_ort_run && [] {
+  const bool vad_on = !streaming_model_ && opt_.vad_threshold > 0.0f;
+  // The rolling form of the pipeline (below): with Silero on, and without it for calls of more than one sub-batch (their
+  // "segmentation" is the copy of every clip into its line, 12 ms for 2048 clips, which then runs beside the first sub-batches).
+  // Word timestamps and the per-kernel log read one sub-batch at a time from the first engine and keep the waves
+  // (MSH_BATCH_ROLLING=0: the waves / the single wave for everything, for A/B runs).
+  const bool rolling = !streaming_model_ && model_ != nullptr && (vad_on || count > (uint64_t)std::max(1, opt_.batch_clips)) &&
+                       !opt_.word_timestamps && !opt_.log_ort_run && [] {
     const char* e = msh::dev_getenv("MSH_BATCH_ROLLING");
     return e == nullptr || atoi(e) != 0;
   }();
+  const bool pipelined = vad_on || rolling;
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 8 : 2)
                                          : std::max<uint64_t>(count, 1);
@@ -1292,7 +1296,8 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
             hops += h;
           }
         } else {
-          c1 = std::min<uint64_t>(count, c0 + std::max(64u, 2u * vad_threads));
+          // the host network: a few clips per thread; no network (vad_threshold 0, a clip is one segment): a sub-batch of clips
+          c1 = std::min<uint64_t>(count, c0 + (vad_on ? (uint64_t)std::max(64u, 2u * vad_threads) : (uint64_t)std::max(64, opt_.batch_clips)));
         }
         chunks.push_back({c0, c1});
       }
