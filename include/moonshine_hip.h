@@ -288,6 +288,15 @@ MSH_EXPORT int64_t msh_host_vad_segments_from_probs(const uint8_t* weights, uint
                                                     int32_t hop, uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap,
                                                     const float* audio, uint64_t n_samples, const float* probs, uint64_t n_probs,
                                                     int64_t* bounds, uint64_t max_segments);
+/* The plan of the batch call's rolling batch (no reference counterpart; csrc/rolling_plan.h): clips of lens[] (16 kHz samples)
+ * arrive in pieces of piece_sizes[] clips; which sub-batch each clip goes out in and after which piece -- before the last
+ * piece only full sub-batches of nearly one length or of the short class (the shortest clips holding short_frac of the first
+ * piece's audio), the rest sorted like a whole batch.  sub_of_clip[i] = sub-batch of clip i; piece_of_sub[s] / first_of_sub[s]
+ * (max_subs entries) = the piece after which sub-batch s was submitted / its first, longest clip.  Returns the number of
+ * sub-batches.  Host code, no GPU. */
+MSH_EXPORT int64_t msh_host_rolling_plan(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces, int32_t batch_clips,
+                                         float short_frac, int32_t narrow_runs, int32_t* sub_of_clip, int32_t* piece_of_sub,
+                                         int32_t* first_of_sub, uint64_t max_subs);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

@@ -491,6 +491,36 @@ int64_t msh_host_silero_probabilities(const uint8_t* weights, uint64_t weights_s
   }
 }
 
+// The rolling batch's plan on the host alone (rolling_plan.h): clips of lens[] arrive in pieces of piece_sizes[]; sub_of_clip[i]
+// receives the sub-batch clip i went out in, piece_of_sub[s] the piece after which sub-batch s was submitted, first_of_sub[s]
+// its first (= longest) clip.  Returns the number of sub-batches (more than max_subs: only the first max_subs are described).
+int64_t msh_host_rolling_plan(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces, int32_t batch_clips,
+                              float short_frac, int32_t narrow_runs, int32_t* sub_of_clip, int32_t* piece_of_sub,
+                              int32_t* first_of_sub, uint64_t max_subs) {
+  try {
+    if ((lens == nullptr || piece_sizes == nullptr) && n_pieces > 0) return MSH_ERR_INVALID_ARGUMENT;
+    RollingPlanner plan(batch_clips, short_frac, narrow_runs != 0);
+    uint64_t off = 0, subs = 0;
+    for (uint64_t p = 0; p < n_pieces; ++p) {
+      for (const std::vector<uint32_t>& ids : plan.add(lens + off, (size_t)piece_sizes[p], p + 1 == n_pieces)) {
+        if (sub_of_clip != nullptr)
+          for (uint32_t id : ids) sub_of_clip[id] = (int32_t)subs;
+        if (subs < max_subs) {
+          if (piece_of_sub != nullptr) piece_of_sub[subs] = (int32_t)p;
+          if (first_of_sub != nullptr) first_of_sub[subs] = ids.empty() ? -1 : (int32_t)ids[0];
+        }
+        ++subs;
+      }
+      off += piece_sizes[p];
+    }
+    if (plan.waiting() != 0) return MSH_ERR_UNKNOWN;
+    return (int64_t)subs;
+  } catch (const std::exception& e) {
+    MSH_LOGF("rolling_plan failed: %s", e.what());
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
+
 int32_t msh_host_effective_cpus(void) { return (int32_t)msh_host::effective_cpus(); }
 
 int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window, int32_t hop,

@@ -158,6 +158,11 @@ int MoonshineModel::run_shard(DeviceShard& d, const std::vector<uint32_t>& idx_i
 int MoonshineModel::rolling_begin() {
   std::unique_ptr<Rolling> r(new Rolling());
   r->lock = std::unique_lock<std::mutex>(processing_mutex);
+  {
+    const char* f = msh::dev_getenv("MSH_ROLLING_SHORT_FRAC");
+    const char* nr = msh::dev_getenv("MSH_ROLLING_NARROW_RUNS");
+    r->plan.reset(new RollingPlanner(batch_clips, f != nullptr ? atof(f) : 0.15, nr == nullptr || atoi(nr) != 0));
+  }
   if (msh_set_capture_cross_attention(engine, 0) != MSH_OK) return 1;
   for (DeviceShard& d : devices)
     if (!d.lanes_ready) {
@@ -209,76 +214,17 @@ int MoonshineModel::rolling_add(const float* const* host_audio, const float* con
   Rolling& r = *rolling_;
   if (r.failed) return 1;
   if (device_audio != nullptr) r.device_audio_gpu = device_audio_gpu;
-  for (size_t i = 0; i < count; ++i)
-    r.pool.push_back({r.next_idx++, host_audio[i], device_audio != nullptr ? device_audio[i] : nullptr, (uint64_t)n_samples[i]});
-  // A sub-batch decodes until its LAST clip is done and a decode step costs about the same for 16 rows as for 1024, so the
-  // cost of a call is the sum over its sub-batches of their longest clip: clips of similar length belong together (run_shard
-  // sorts a whole batch, longest first).  Here the batch arrives in pieces, and every piece brings clips of every length.
-  // Submitting "the longest 2560 s waiting" after every piece measured WORSE than waiting for everything (every sub-batch
-  // then holds a 10 s clip: 60 % more decode steps than the sorted cut) -- so while pieces keep coming only the SHORT clips
-  // go out (cheap sub-batches: few steps, and they keep the GPU busy beside the segmentation), in full sub-batches, and the
-  // long ones wait for the last add, where they are cut sorted like a whole batch.  "Short" = the shortest clips that hold
-  // 15 % of the first piece's audio: about the share of the call's work the GPU can do while the segmentation runs (~55 of
-  // ~340 ms for 2048 clips; measured on one box: 0.02 / 0.15 / 0.25 / 0.4 -> 347 / 342 / 383 / 374 ms per call).
-  std::stable_sort(r.pool.begin(), r.pool.end(), [](const RollingClip& a, const RollingClip& b) { return a.n > b.n; });
-  const uint32_t bc = (uint32_t)std::max(1, batch_clips);
-  const uint32_t clip_cap = (uint32_t)std::min<long>(4L * bc, 1024);
-  const uint64_t audio_cap = (uint64_t)bc * 160000ull;
-  if (r.short_len == 0 && !r.pool.empty()) {
-    const char* e = msh::dev_getenv("MSH_ROLLING_SHORT_FRAC");
-    const double frac = e != nullptr ? atof(e) : 0.15;
-    uint64_t total = 0, acc = 0;
-    for (const RollingClip& c : r.pool) total += c.n;
-    r.short_len = r.pool.back().n;
-    for (size_t k = r.pool.size(); k-- > 0;) {   // ascending
-      if ((double)(acc + r.pool[k].n) > frac * (double)total) break;
-      acc += r.pool[k].n;
-      r.short_len = r.pool[k].n;
-    }
+  std::vector<uint64_t> lens(count);
+  for (size_t i = 0; i < count; ++i) {
+    lens[i] = (uint64_t)n_samples[i];
+    r.clips.push_back({(uint32_t)r.clips.size(), host_audio[i], device_audio != nullptr ? device_audio[i] : nullptr, lens[i]});
   }
-  // the cut run_shard makes at position lo of the sorted pool: m clips, their audio in *sum
-  auto cut_at = [&](size_t lo, uint64_t* sum) {
-    uint32_t m = 0;
-    *sum = 0;
-    while (lo + m < r.pool.size() && m < clip_cap) {
-      if (m >= bc && *sum + r.pool[lo + m].n > audio_cap) break;
-      *sum += r.pool[lo + m].n;
-      ++m;
-    }
-    return m;
-  };
-  if (!last) {
-    // (1) anywhere in the sorted pool: a FULL sub-batch of clips of nearly one length (the shortest within 10 % of the
-    // longest) is what the sorted cut of the whole call would make of them anyway -- it goes out now.  (Real batches have
-    // such classes: clips the detector did not split are all as long as the caller's clips.)
-    static const bool narrow_runs = [] {
-      const char* e = msh::dev_getenv("MSH_ROLLING_NARROW_RUNS");
-      return e == nullptr || atoi(e) != 0;
-    }();
-    for (size_t i = 0; narrow_runs && i < r.pool.size();) {
-      uint64_t sum = 0;
-      const uint32_t m = cut_at(i, &sum);
-      if (sum * 10 >= audio_cap * 9 && r.pool[i + m - 1].n * 10 >= r.pool[i].n * 9) {
-        if (rolling_submit(r.pool.data() + i, m) != 0) return 1;
-        r.pool.erase(r.pool.begin() + (long)i, r.pool.begin() + (long)(i + m));
-      } else {
-        ++i;
-      }
-    }
-  }
-  size_t lo = 0;   // (2) first candidate: everything on the last add, else the first short clip
-  if (!last)
-    while (lo < r.pool.size() && r.pool[lo].n > r.short_len) ++lo;
-  uint64_t waiting = 0;
-  for (size_t k = lo; k < r.pool.size(); ++k) waiting += r.pool[k].n;
-  while (lo < r.pool.size()) {
-    // full sub-batches; everything on the last add; and whatever short clips there are while the GPU has nothing yet
-    if (!last && waiting < audio_cap && !r.subs.empty()) break;
-    uint64_t sum = 0;
-    const uint32_t m = cut_at(lo, &sum);
-    if (rolling_submit(r.pool.data() + lo, m) != 0) return 1;
-    r.pool.erase(r.pool.begin() + (long)lo, r.pool.begin() + (long)(lo + m));
-    waiting -= sum;
+  // which of the waiting clips go out now: rolling_plan.h
+  std::vector<RollingClip> sub;
+  for (const std::vector<uint32_t>& ids : r.plan->add(lens.data(), count, last)) {
+    sub.clear();
+    for (uint32_t id : ids) sub.push_back(r.clips[id]);
+    if (rolling_submit(sub.data(), (uint32_t)sub.size()) != 0) return 1;
   }
   return 0;
 }
@@ -293,11 +239,11 @@ int MoonshineModel::rolling_finish(std::vector<std::string>* out_texts) {
       failed = true;
     }
   if (failed || out_texts == nullptr) return failed ? 1 : 0;
-  if (!r->pool.empty()) {
-    MSH_LOGF("internal: %zu clips were never submitted (rolling_add without last)", r->pool.size());
+  if (r->plan->waiting() != 0) {
+    MSH_LOGF("internal: %zu clips were never submitted (rolling_add without last)", r->plan->waiting());
     return 1;
   }
-  out_texts->assign(r->next_idx, std::string());
+  out_texts->assign(r->clips.size(), std::string());
   for (const RollingSub& sb : r->subs)
     for (size_t i = 0; i < sb.idx.size(); ++i)
       (*out_texts)[sb.idx[i]] = tokenizer->tokens_to_text(sb.tokens.data() + i * (size_t)sb.stride, (size_t)sb.counts[i]);

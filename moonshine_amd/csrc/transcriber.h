@@ -23,6 +23,7 @@
 #include "../../include/moonshine_hip.h"
 #include "context_extractor.h"
 #include "host_text_vad.h"
+#include "rolling_plan.h"
 #include "streaming_model.h"
 #include "word_alignment.h"
 
@@ -70,8 +71,8 @@ struct MoonshineModel {
   // The same batch, handed over in pieces while earlier pieces are already on the GPU (the batch call under the
   // reference's default VAD: segments keep arriving from the segmentation of later clips).  rolling_begin takes the
   // model; every rolling_add appends clips -- their indices continue from the previous add -- and submits sub-batches to
-  // the devices' lanes as soon as a full one (batch_clips x 10 s of audio, longest clips of what is waiting first) can be
-  // cut, `last` submits what is left; rolling_finish waits for everything and returns the texts in index order.
+  // the devices' lanes as the plan of rolling_plan.h releases them (full sub-batches of one length or of the short clips
+  // while pieces keep coming, the sorted rest on the `last` one); rolling_finish waits for everything and returns the texts in index order.
   // device_audio (nullable, entries nullable): the same samples already in the memory of `device_audio_gpu` -- a sub-batch
   // whose clips all have one and that runs on that GPU reads them there instead of uploading host_audio.
   // All three return 0 on success; after a failure rolling_finish still has to be called (it waits and releases).
@@ -97,12 +98,11 @@ struct MoonshineModel {
   };
   struct Rolling {
     std::unique_lock<std::mutex> lock;
-    std::vector<RollingClip> pool;   // waiting clips
-    std::deque<RollingSub> subs;     // submitted sub-batches (their arrays are written by the lanes: addresses must not move)
-    uint32_t next_idx = 0;
+    std::unique_ptr<RollingPlanner> plan;   // which waiting clips go out when (rolling_plan.h)
+    std::vector<RollingClip> clips;         // every clip handed over so far, by index
+    std::deque<RollingSub> subs;            // submitted sub-batches (their arrays are written by the lanes: addresses must not move)
     size_t next_dev = 0;
     int device_audio_gpu = -1;
-    uint64_t short_len = 0;          // clips up to this length go out before the last add (rolling_add)
     bool failed = false;
   };
   std::unique_ptr<Rolling> rolling_;
