@@ -151,6 +151,15 @@ MOONSHINE_EXPORT int32_t moonshine_transcribe_stream(int32_t transcriber_handle,
 MOONSHINE_EXPORT int32_t moonshine_transcribe_batch_without_streaming(
     int32_t transcriber_handle, const float *const *audio_data, const uint64_t *audio_lengths, uint64_t count,
     int32_t sample_rate, uint32_t flags, struct transcript_t **out_transcripts);
+/* The same for 16-bit PCM, the format most recordings are stored in: sample value / 32768 is what the float entry point
+ * would be handed, so the transcripts (and the lines' float audio_data) are identical to a call with those floats.  Why it
+ * exists: a batch call moves every sample from host memory to the GPU once -- 64 KB per audio second as fp32, 32 KB as
+ * 16-bit -- and at 60-85 k audio seconds per second and GPU that is 4-5 GB/s per GPU of host reads and PCIe traffic (eight
+ * GPUs of one host: 40 GB/s).  With the default options on 16 kHz audio the clips cross PCIe at two bytes per sample and are
+ * widened on the GPU; on every other path they are widened on the host first. */
+MOONSHINE_EXPORT int32_t moonshine_transcribe_batch_without_streaming_pcm16(
+    int32_t transcriber_handle, const int16_t *const *audio_data, const uint64_t *audio_lengths, uint64_t count,
+    int32_t sample_rate, uint32_t flags, struct transcript_t **out_transcripts);
 
 /* ---- out of scope for this engine, exported as stubs (reference core/moonshine-c-api.h:758-1258) ----
  * Sentence embeddings, text to speech, grapheme-to-phoneme, model catalogs and download manifests are not part of the

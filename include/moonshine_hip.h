@@ -263,6 +263,11 @@ MSH_EXPORT int64_t msh_silero_probabilities_keep_audio(msh_silero* s, const floa
  * network of chunk k runs --; tickets are collected in the order they were given. */
 MSH_EXPORT int64_t msh_silero_submit(msh_silero* s, const float* const* pcm, const uint64_t* n_samples, uint64_t count,
                                      int32_t keep_audio);
+/* msh_silero_submit for 16-bit PCM: the clips cross PCIe at two bytes per sample and become fp32 on the device (x / 32768,
+ * exact -- the value the fp32 entry points would be given for the same recording); everything else as msh_silero_submit, the
+ * kept audio (keep_audio != 0) is fp32. */
+MSH_EXPORT int64_t msh_silero_submit_pcm16(msh_silero* s, const int16_t* const* pcm16, const uint64_t* n_samples, uint64_t count,
+                                           int32_t keep_audio);
 MSH_EXPORT int64_t msh_silero_collect(msh_silero* s, int64_t ticket, float* probs_out, uint64_t cap,
                                       const float** device_audio_out, uint64_t count);
 MSH_EXPORT int32_t msh_silero_release_audio(msh_silero* s);

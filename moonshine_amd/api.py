@@ -57,7 +57,7 @@ C_API_SYMBOLS = [
     "moonshine_load_transcriber_from_memory", "moonshine_load_transcriber_from_memory_files", "moonshine_free_transcriber",
     "moonshine_transcribe_without_streaming", "moonshine_create_stream", "moonshine_free_stream", "moonshine_start_stream",
     "moonshine_stop_stream", "moonshine_transcribe_add_audio_to_stream", "moonshine_transcribe_stream",
-    "moonshine_transcribe_batch_without_streaming",
+    "moonshine_transcribe_batch_without_streaming", "moonshine_transcribe_batch_without_streaming_pcm16",
 ]
 
 _lib = None
@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
     l.moonshine_transcribe_without_streaming.argtypes = [i32, P(C.c_float), u64, i32, u32, P(P(TranscriptC))]
     l.moonshine_transcribe_batch_without_streaming.restype = i32
     l.moonshine_transcribe_batch_without_streaming.argtypes = [i32, P(P(C.c_float)), P(u64), u64, i32, u32, P(P(TranscriptC))]
+    l.moonshine_transcribe_batch_without_streaming_pcm16.restype = i32
+    l.moonshine_transcribe_batch_without_streaming_pcm16.argtypes = [i32, P(P(C.c_int16)), P(u64), u64, i32, u32, P(P(TranscriptC))]
     for name in ("moonshine_create_stream",):
         getattr(l, name).restype = i32
         getattr(l, name).argtypes = [i32, u32]
@@ -201,6 +203,16 @@ class Transcriber:
         return _parse(out)
 
     def transcribe_batch_without_streaming(self, clips, sample_rate: int = 16000, flags: int = 0) -> list[list[TranscriptLine]]:
+        if len(clips) > 0 and all(np.asarray(c).dtype == np.int16 for c in clips):   # 16-bit PCM: the additive _pcm16 entry point
+            arrs = [np.ascontiguousarray(c, dtype=np.int16) for c in clips]
+            n = len(arrs)
+            ptrs = (C.POINTER(C.c_int16) * n)(*[a.ctypes.data_as(C.POINTER(C.c_int16)) for a in arrs])
+            lens = (C.c_uint64 * n)(*[a.shape[0] for a in arrs])
+            outs = (C.POINTER(TranscriptC) * n)()
+            rc = lib().moonshine_transcribe_batch_without_streaming_pcm16(self.handle, ptrs, lens, n, sample_rate, flags, outs)
+            if rc != 0:
+                raise MoonshineError(rc)
+            return [_parse(outs[i]) for i in range(n)]
         arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
         n = len(arrs)
         ptrs = (C.POINTER(C.c_float) * n)(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])

@@ -303,6 +303,19 @@ int32_t moonshine_transcribe_batch_without_streaming(int32_t handle, const float
   });
 }
 
+int32_t moonshine_transcribe_batch_without_streaming_pcm16(int32_t handle, const int16_t* const* audio_data,
+                                                           const uint64_t* audio_lengths, uint64_t count, int32_t sample_rate,
+                                                           uint32_t flags, struct transcript_t** out_transcripts) {
+  return with_transcriber(handle, "transcribe batch (16-bit PCM)", [&](Transcriber* t) -> int32_t {
+    if (count > 0 && (audio_data == nullptr || audio_lengths == nullptr || out_transcripts == nullptr))
+      return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < count; ++i)
+      if (audio_data[i] == nullptr && audio_lengths[i] > 0) return MOONSHINE_ERROR_INVALID_ARGUMENT;
+    t->transcribe_batch_without_streaming_pcm16(audio_data, audio_lengths, count, sample_rate, flags, out_transcripts);
+    return MOONSHINE_ERROR_NONE;
+  });
+}
+
 int32_t moonshine_create_stream(int32_t handle, uint32_t /*flags*/) {
   return with_transcriber(handle, "create stream", [&](Transcriber* t) -> int32_t { return t->create_stream(); });
 }

@@ -13,6 +13,8 @@
 
 #include "silero_kernels.h"
 
+#include <algorithm>
+
 namespace msh {
 namespace {
 
@@ -198,7 +200,24 @@ __global__ __launch_bounds__(512) void silero_lstm_kernel(const float* __restric
   }
 }
 
+// 16-bit PCM -> fp32 in [-1, 1): x / 32768, exact (the host detectors convert the same way)
+__global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const short* __restrict__ src, float* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const short4 v = reinterpret_cast<const short4*>(src)[i];
+    reinterpret_cast<float4*>(dst)[i] = make_float4((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f),
+                                                    (float)v.z * (1.0f / 32768.0f), (float)v.w * (1.0f / 32768.0f));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = (float)src[n4 * 4 + threadIdx.x] * (1.0f / 32768.0f);
+}
+
 }  // namespace
+
+void silero_pcm16_to_f32(const int16_t* src, float* dst, long n, hipStream_t s) {
+  if (n <= 0) return;
+  const long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 4096);
+  MSH_LAUNCH(pcm16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const short*>(src), dst, n);
+}
 
 void silero_frames(const float* audio, const long* hop_base, long n_hops, float* frames, hipStream_t s) {
   if (n_hops <= 0) return;

@@ -424,6 +424,18 @@ int64_t msh_silero_submit(msh_silero* s, const float* const* pcm, const uint64_t
     return MSH_ERR_INVALID_ARGUMENT;
   }
 }
+int64_t msh_silero_submit_pcm16(msh_silero* s, const int16_t* const* pcm16, const uint64_t* n_samples, uint64_t count, int32_t keep_audio) {
+  if (s == nullptr || s->dev == nullptr || (count > 0 && (pcm16 == nullptr || n_samples == nullptr))) return MSH_ERR_INVALID_ARGUMENT;
+  try {
+    return s->dev->submit_pcm16(pcm16, n_samples, (size_t)count, keep_audio != 0);
+  } catch (const msh::HipError& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_HIP;
+  } catch (const std::exception& ex) {
+    s->last_error = ex.what();
+    return MSH_ERR_INVALID_ARGUMENT;
+  }
+}
 int64_t msh_silero_collect(msh_silero* s, int64_t ticket, float* probs_out, uint64_t cap, const float** device_audio_out,
                            uint64_t count) {
   if (s == nullptr || s->dev == nullptr) return MSH_ERR_INVALID_ARGUMENT;

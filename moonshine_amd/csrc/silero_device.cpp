@@ -81,7 +81,7 @@ SileroDevice::~SileroDevice() {
   for (DevBuf* b : bufs) b->release();
   for (auto& b : arena_) b->release();
   for (Slot& sl : slots_) {
-    sl.audio.release(), sl.hop_base.release(), sl.clip_hop0_d.release();
+    sl.audio.release(), sl.audio16.release(), sl.hop_base.release(), sl.clip_hop0_d.release();
     if (sl.pinned) (void)hipHostFree(sl.pinned);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
@@ -151,6 +151,15 @@ void SileroDevice::sync_streams() {
 }
 
 int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t nc, bool keep_audio) {
+  return submit_any(pcm, nullptr, n, nc, keep_audio);
+}
+int64_t SileroDevice::submit_pcm16(const int16_t* const* pcm16, const uint64_t* n, size_t nc, bool keep_audio) {
+  return submit_any(nullptr, pcm16, n, nc, keep_audio);
+}
+
+// exactly one of pcm / pcm16 is given.  16-bit clips cross PCIe as they are (half the bytes) and become fp32 (x / 32768, exact)
+// on the device, in the buffer the network -- and, kept, the engine -- reads.
+int64_t SileroDevice::submit_any(const float* const* pcm, const int16_t* const* pcm16, const uint64_t* n, size_t nc, bool keep_audio) {
   MSH_HIP(hipSetDevice(device_));
   Slot& sl = slots_[next_ticket_ % kSlots];
   if (sl.busy) throw std::invalid_argument("device VAD: two submissions are outstanding, collect one first");
@@ -160,7 +169,7 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   long samples = 0, hops = 0;
   for (size_t i = 0; i < nc; ++i) {
     const long h = (long)(n[i] / kHop);
-    if (h > 0 && pcm[i] == nullptr) throw std::invalid_argument("null audio pointer");
+    if (h > 0 && (pcm16 != nullptr ? (const void*)pcm16[i] : (const void*)pcm[i]) == nullptr) throw std::invalid_argument("null audio pointer");
     sl.clip_off[i] = samples;
     sl.clip_hop0[i] = hops;
     samples += kContext + h * kHop;
@@ -179,8 +188,9 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   }
   // One pinned block per slot: the audio, the hop table, the clips' first hops -- and the place the probabilities come back to
   // (a copy to or from pageable memory blocks the host until it is done, which would serialise the two slots)
-  const size_t bytes = (size_t)samples * sizeof(float);
-  const size_t off_hops = (bytes + 255) & ~(size_t)255, off_clips = off_hops + (size_t)hops * sizeof(long);
+  const size_t bytes = (size_t)samples * sizeof(float);                                   // on the device, fp32
+  const size_t stage_bytes = pcm16 != nullptr ? (size_t)samples * sizeof(int16_t) : bytes;   // what crosses PCIe
+  const size_t off_hops = (stage_bytes + 255) & ~(size_t)255, off_clips = off_hops + (size_t)hops * sizeof(long);
   const size_t off_probs = (off_clips + (nc + 1) * sizeof(long) + 255) & ~(size_t)255, pinned_need = off_probs + (size_t)hops * sizeof(float);
   if (pinned_need > sl.pinned_cap) {
     if (sl.pinned) MSH_HIP(hipHostFree(sl.pinned));
@@ -197,11 +207,18 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   const auto t0 = std::chrono::steady_clock::now();
   char* pin = static_cast<char*>(sl.pinned);
   float* stage = reinterpret_cast<float*>(pin);
+  int16_t* stage16 = reinterpret_cast<int16_t*>(pin);
   msh_host::parallel_for(nc, [&](size_t i) {
-    float* dst = stage + sl.clip_off[i];
-    memset(dst, 0, kContext * sizeof(float));
     const size_t cnt = (size_t)(sl.clip_hop0[i + 1] - sl.clip_hop0[i]) * kHop;
-    if (cnt > 0) memcpy(dst + kContext, pcm[i], cnt * sizeof(float));
+    if (pcm16 != nullptr) {
+      int16_t* dst = stage16 + sl.clip_off[i];
+      memset(dst, 0, kContext * sizeof(int16_t));
+      if (cnt > 0) memcpy(dst + kContext, pcm16[i], cnt * sizeof(int16_t));
+    } else {
+      float* dst = stage + sl.clip_off[i];
+      memset(dst, 0, kContext * sizeof(float));
+      if (cnt > 0) memcpy(dst + kContext, pcm[i], cnt * sizeof(float));
+    }
   }, gather_threads);
   long* hop_base = reinterpret_cast<long*>(pin + off_hops);
   for (size_t i = 0; i < nc; ++i)
@@ -239,7 +256,13 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   // chunk k + 1's DMA beside chunk k's network, also in four pieces on four streams -- measured no faster: the network is ~1 ms
   // of a chunk's ~6; and every extra stream competes with the engine's lanes for the process's hardware queues -- with 8
   // queues and 4 lanes the wave pipeline went from 381 to 450 ms per call when this object took five of them.)
-  MSH_HIP(hipMemcpyAsync(abuf->p, stage, bytes, hipMemcpyHostToDevice, stream_));
+  if (pcm16 != nullptr) {
+    sl.audio16.reserve(stage_bytes + 64);
+    MSH_HIP(hipMemcpyAsync(sl.audio16.p, stage16, stage_bytes, hipMemcpyHostToDevice, stream_));
+    silero_pcm16_to_f32(sl.audio16.as<int16_t>(), abuf->as<float>(), samples, stream_);
+  } else {
+    MSH_HIP(hipMemcpyAsync(abuf->p, stage, bytes, hipMemcpyHostToDevice, stream_));
+  }
   MSH_HIP(hipMemcpyAsync(sl.hop_base.p, hop_base, (size_t)hops * sizeof(long), hipMemcpyHostToDevice, stream_));
   MSH_HIP(hipMemcpyAsync(sl.clip_hop0_d.p, pin + off_clips, (nc + 1) * sizeof(long), hipMemcpyHostToDevice, stream_));
   silero_frames(abuf->as<float>(), sl.hop_base.as<long>(), hops, frames_.as<float>(), stream_);
@@ -259,7 +282,7 @@ int64_t SileroDevice::submit(const float* const* pcm, const uint64_t* n, size_t 
   sl.abuf = abuf;
   sl.kept = abuf != &sl.audio;
   sl.busy = true;
-  if (timing) sl.bytes = bytes;
+  if (timing) sl.bytes = stage_bytes;
   return next_ticket_++;
 }
 

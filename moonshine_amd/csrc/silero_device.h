@@ -38,6 +38,8 @@ class SileroDevice {
   // behind chunk k's network, while the caller consumes chunk k - 1.  Tickets are collected in order.
   static constexpr long kMaxHopsPerSubmit = 65536;
   int64_t submit(const float* const* pcm, const uint64_t* n, size_t count, bool keep_audio);
+  // the same for 16-bit PCM: the clips cross PCIe at two bytes per sample and become fp32 (x / 32768) on the device
+  int64_t submit_pcm16(const int16_t* const* pcm16, const uint64_t* n, size_t count, bool keep_audio);
   void collect(int64_t ticket, std::vector<float>* probs, std::vector<const float*>* resident);
   void abandon();   // after a failure: waits for the streams and forgets the outstanding tickets
   // the kept audio may be overwritten by later calls (the buffers themselves stay allocated for them)
@@ -48,6 +50,7 @@ class SileroDevice {
  private:
   void upload_weights(const msh_host::SileroWeights& w);
   void sync_streams();
+  int64_t submit_any(const float* const* pcm, const int16_t* const* pcm16, const uint64_t* n, size_t nc, bool keep_audio);
   static constexpr int kSlots = 2;
   struct Slot {   // one submission in flight
     bool busy = false, kept = false;
@@ -58,7 +61,7 @@ class SileroDevice {
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     float* probs_host = nullptr;   // inside `pinned`
-    DevBuf audio, hop_base, clip_hop0_d;
+    DevBuf audio, audio16, hop_base, clip_hop0_d;   // audio16: the 16-bit upload of submit_pcm16, converted into audio / the arena
     DevBuf* abuf = nullptr;
     hipEvent_t done = nullptr;
     double gather_ms = 0.0;

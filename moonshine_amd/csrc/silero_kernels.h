@@ -5,6 +5,8 @@
 
 namespace msh {
 
+// 16-bit PCM -> fp32 (x / 32768), n samples; src 8-byte, dst 16-byte aligned
+void silero_pcm16_to_f32(const int16_t* src, float* dst, long n, hipStream_t s);
 // frames [(hop * 4 + t)][256] from the flat audio buffer; hop_base[h] = index of the 64 context samples in front of hop h
 void silero_frames(const float* audio, const long* hop_base, long n_hops, float* frames, hipStream_t s);
 // |STFT|: frames x basis[258][256]^T -> stft_tmp [hops * 4][258] -> mag [hop][129][4]

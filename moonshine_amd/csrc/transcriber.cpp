@@ -1052,7 +1052,19 @@ void Transcriber::transcribe_without_streaming(const float* audio, uint64_t n, i
 }
 
 void Transcriber::transcribe_batch_without_streaming(const float* const* audio, const uint64_t* n, uint64_t count,
-                                                     int32_t sample_rate, uint32_t /*flags*/, transcript_t** out) {
+                                                     int32_t sample_rate, uint32_t flags, transcript_t** out) {
+  transcribe_batch_any(audio, nullptr, n, count, sample_rate, flags, out);
+}
+void Transcriber::transcribe_batch_without_streaming_pcm16(const int16_t* const* audio16, const uint64_t* n, uint64_t count,
+                                                           int32_t sample_rate, uint32_t flags, transcript_t** out) {
+  transcribe_batch_any(nullptr, audio16, n, count, sample_rate, flags, out);
+}
+
+// Exactly one of audio / audio16 is given.  16-bit PCM means x / 32768 (exact in fp32): on the pipeline that keeps the device
+// VAD's audio the clips cross PCIe at two bytes per sample and are converted on the GPU (msh_silero_submit_pcm16), the
+// detectors convert a clip at a time on their host threads; every other path converts the whole call up front.
+void Transcriber::transcribe_batch_any(const float* const* audio, const int16_t* const* audio16, const uint64_t* n, uint64_t count,
+                                       int32_t sample_rate, uint32_t /*flags*/, transcript_t** out) {
   std::lock_guard<std::mutex> lock(batch_mutex_);
   static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;   // phase times of the host layer, to the log
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1128,11 +1140,20 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     parallel_for((size_t)(c1 - c0), [&](size_t k) {
       const size_t i = (size_t)c0 + k;
       TranscriberStream* s = streams[i];
+      std::vector<float> from16;
+      const float* a = nullptr;
+      if (audio16 != nullptr) {
+        from16.resize((size_t)n[i]);
+        for (size_t j = 0; j < from16.size(); ++j) from16[j] = (float)audio16[i][j] * (1.0f / 32768.0f);
+        a = from16.data();
+      } else {
+        a = audio[i];
+      }
       s->vad->start();
       if (probs != nullptr)
-        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate, probs + poff[k], poff[k + 1] - poff[k]);
+        s->vad->process_audio(a, (size_t)n[i], sample_rate, probs + poff[k], poff[k + 1] - poff[k]);
       else
-        s->vad->process_audio(audio[i], (size_t)n[i], sample_rate);
+        s->vad->process_audio(a, (size_t)n[i], sample_rate);
       s->vad->stop();
       segs[i] = s->vad->take_segments();
     }, vad_threads);
@@ -1197,6 +1218,24 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     return e == nullptr || atoi(e) != 0;
   }();
   const bool pipelined = vad_on || rolling;
+  const bool keep_audio = [] {   // MSH_VAD_KEEP_AUDIO=0: segments are uploaded from the host (A/B)
+    const char* e = msh::dev_getenv("MSH_VAD_KEEP_AUDIO");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  // 16-bit input anywhere but on the device-audio pipeline: fp32 copies of the clips for the rest of the call
+  std::vector<std::vector<float>> from16;
+  std::vector<const float*> from16_ptrs;
+  if (audio16 != nullptr && !(rolling && use_device_vad && keep_audio)) {
+    from16.resize((size_t)count);
+    from16_ptrs.resize((size_t)count);
+    parallel_for((size_t)count, [&](size_t i) {
+      from16[i].resize((size_t)n[i]);
+      for (size_t j = 0; j < from16[i].size(); ++j) from16[i][j] = (float)audio16[i][j] * (1.0f / 32768.0f);
+      from16_ptrs[i] = from16[i].data();
+    }, vad_threads);
+    audio = from16_ptrs.data();
+    audio16 = nullptr;
+  }
   const uint64_t wave = streaming_model_ ? (uint64_t)std::max(1, opt_.max_streams) * (1 + streaming_more_.size())
                         : pipelined      ? (uint64_t)std::max(1, opt_.batch_clips) * (use_device_vad ? 8 : 2)
                                          : std::max<uint64_t>(count, 1);
@@ -1213,10 +1252,6 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
     // the first chunk's segments and never waits for a wave to end.  A chunk = what one pass of the device VAD takes (64 Ki
     // hops, ~200 clips of 10 s; silero_device.cpp), or a few clips per host thread for the host network.
     const auto t_call = now();
-    const bool keep_audio = [] {
-      const char* e = msh::dev_getenv("MSH_VAD_KEEP_AUDIO");
-      return e == nullptr || atoi(e) != 0;
-    }();
     std::vector<std::string> texts;
     size_t n_jobs = 0, n_resident = 0;
     bool begun = false;
@@ -1253,7 +1288,8 @@ void Transcriber::transcribe_batch_without_streaming(const float* const* audio, 
       auto vad_submit = [&](size_t k) {
         if (!use_device_vad || k >= chunks.size()) return;
         const uint64_t c0 = chunks[k].first, c1 = chunks[k].second;
-        tickets[k] = msh_silero_submit(silero_device_, audio + c0, n + c0, c1 - c0, keep_audio ? 1 : 0);
+        tickets[k] = audio16 != nullptr ? msh_silero_submit_pcm16(silero_device_, audio16 + c0, n + c0, c1 - c0, keep_audio ? 1 : 0)
+                                        : msh_silero_submit(silero_device_, audio + c0, n + c0, c1 - c0, keep_audio ? 1 : 0);
         if (tickets[k] < 0) device_vad_failed(true);
       };
       const auto ts0 = now();

@@ -205,6 +205,9 @@ class Transcriber {
                                     transcript_t** out);
   void transcribe_batch_without_streaming(const float* const* audio, const uint64_t* n, uint64_t count,
                                           int32_t sample_rate, uint32_t flags, transcript_t** out);
+  // additive: the same for 16-bit PCM (sample value / 32768); with the device VAD the clips cross PCIe at two bytes per sample
+  void transcribe_batch_without_streaming_pcm16(const int16_t* const* audio16, const uint64_t* n, uint64_t count, int32_t sample_rate,
+                                                uint32_t flags, transcript_t** out);
   int32_t create_stream();
   void free_stream(int32_t id);
   void start_stream(int32_t id);
@@ -221,6 +224,8 @@ class Transcriber {
   void set_context(const std::string& context, int32_t max_terms);
 
  private:
+  void transcribe_batch_any(const float* const* audio, const int16_t* const* audio16, const uint64_t* n, uint64_t count,
+                            int32_t sample_rate, uint32_t flags, transcript_t** out);
   TranscriberStream* new_stream(int32_t id);
   void load_streaming_model();
   std::shared_ptr<TranscriberStream> find_stream(int32_t id);  // the caller's copy keeps the stream alive against free_stream

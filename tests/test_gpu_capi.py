@@ -389,6 +389,20 @@ def test_default_options_batch_call_rolls_segments_into_sub_batches(tiny_dir, tm
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"devices": "0,0"})) == spans(rolling)
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"vad_device": "0"})) == spans(rolling)
     assert spans(run({})) == spans(rolling)     # the default chunking (one chunk here)
+    # 16-bit PCM (moonshine_transcribe_batch_without_streaming_pcm16): a call with the int16 clips == a call with their values
+    # / 32768 as floats -- on the device-audio pipeline (two bytes per sample over PCIe, widened on the GPU), with the segments
+    # uploaded from the host and without VAD (widened on the host)
+    clips16 = [np.clip(np.round(c * 4000.0), -32768, 32767).astype(np.int16) for c in clips]
+    clips = [(c.astype(np.float32) / np.float32(32768.0)).astype(np.float32) for c in clips16]
+    want = run({"MSH_BATCH_CHUNK_CLIPS": "5"})
+    assert sum(len(c) for c in want) > 0
+    clips = clips16
+    assert run({"MSH_BATCH_CHUNK_CLIPS": "5"}) == want
+    assert run({"MSH_BATCH_CHUNK_CLIPS": "5", "MSH_VAD_KEEP_AUDIO": "0"}) == want
+    clips = [(c.astype(np.float32) / np.float32(32768.0)).astype(np.float32) for c in clips16]
+    want0 = run({}, {"vad_threshold": "0"})
+    clips = clips16
+    assert run({}, {"vad_threshold": "0"}) == want0
 
 
 def test_batch_call_sharded_over_devices_equals_one_device(tiny, tiny_dir, monkeypatch):

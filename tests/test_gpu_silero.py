@@ -176,6 +176,20 @@ def test_keep_audio_leaves_the_clips_whole_hops_on_the_device(blob):
                 assert np.array_equal(back, c[:whole])
         return out[:total]
 
+    # 16-bit PCM (msh_silero_submit_pcm16): two bytes per sample over PCIe, x / 32768 on the device -- the probabilities and the
+    # kept fp32 audio of the float submission of those values, bit for bit
+    lib.msh_silero_submit_pcm16.restype = C.c_int64
+    lib.msh_silero_submit_pcm16.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.c_uint64), C.c_uint64, C.c_int32]
+    g16 = [np.clip(np.round(c * 6000.0), -32768, 32767).astype(np.int16) for c in clips[:40]]
+    gf = [(c.astype(np.float32) / np.float32(32768.0)).astype(np.float32) for c in g16]
+    p16 = (C.POINTER(C.c_int16) * len(g16))(*[c.ctypes.data_as(C.POINTER(C.c_int16)) for c in g16])
+    l16 = (C.c_uint64 * len(g16))(*[c.shape[0] for c in g16])
+    t16 = lib.msh_silero_submit_pcm16(h, p16, l16, len(g16), 1)
+    assert t16 >= 0, lib.msh_silero_last_error(h)
+    probs16 = collect(t16, gf)                  # (checks the kept audio against the float values)
+    probs_f = collect(submit(gf), gf)
+    assert np.array_equal(probs16, probs_f) and float(np.std(probs16)) > 1e-4
+
     t0, t1 = submit(groups[0]), submit(groups[1])
     assert lib.msh_silero_submit(h, keep[0][0], keep[0][1], 6, 1) < 0          # a third one is refused
     assert lib.msh_silero_collect(h, t1, None, 0, None, 0) < 0                  # out of order
