@@ -519,6 +519,29 @@ def main():
                                     "options": {"vad_threshold": 0.5, "vad_device": 1,
                                                 "vad": "Silero network on the GPU for the whole batch (k_silero.hip), the detectors' "
                                                        "state machines on host threads"}}
+            # ---- the additive 16-bit entry point on the same options: the clips quantised to int16 (two bytes per sample over
+            # PCIe, widened on the GPU) against the SAME values handed over as fp32 (x / 32768), one call each ----
+            import numpy as _np
+            a16 = [_np.clip(_np.round(host[i] * 8000.0), -32768, 32767).astype(_np.int16) for i in range(B)]
+            af = [(a.astype(_np.float32) / _np.float32(32768.0)) for a in a16]
+            p16 = (C.POINTER(C.c_int16) * n)(*[a16[i % B].ctypes.data_as(C.POINTER(C.c_int16)) for i in range(n)])
+            pf = (C.POINTER(C.c_float) * n)(*[af[i % B].ctypes.data_as(C.POINTER(C.c_float)) for i in range(n)])
+            call16 = lambda: mapi.lib().moonshine_transcribe_batch_without_streaming_pcm16(trv.handle, p16, clens, n, 16000, 0, outs)
+            callf = lambda: mapi.lib().moonshine_transcribe_batch_without_streaming(trv.handle, pf, clens, n, 16000, 0, outs)
+            assert callf() == 0
+            t0 = time.perf_counter()
+            assert callf() == 0
+            dtf = time.perf_counter() - t0
+            lines_f = sum(int(outs[i].contents.line_count) for i in range(n))
+            assert call16() == 0
+            t0 = time.perf_counter()
+            assert call16() == 0
+            dt16 = time.perf_counter() - t0
+            c_api["default_vad"]["pcm16"] = {
+                "value": round(n * CLIP_SECONDS / dt16, 1), "ms_per_call": round(dt16 * 1e3, 1),
+                "lines": sum(int(outs[i].contents.line_count) for i in range(n)),
+                "entry_point": "moonshine_transcribe_batch_without_streaming_pcm16",
+                "same_values_as_fp32": {"value": round(n * CLIP_SECONDS / dtf, 1), "ms_per_call": round(dtf * 1e3, 1), "lines": lines_f}}
             trv.close()
         except Exception as e:  # the headline does not depend on this sub-run
             print(f"default-VAD sub-run failed: {e}", file=sys.stderr)
