@@ -449,13 +449,27 @@ def test_config1_beckett_wav_through_the_c_api(tiny, tiny_dir, engine):
     audio = np.zeros(n, np.float32)
     assert lib.msh_host_load_wav(path, audio.ctypes.data, n, C.addressof(rate)) == n
     assert 0.05 < float(np.abs(audio).max()) <= 1.0
+    # the vocabulary is the reference's own shipped tiny-en tokenizer.bin (tests/golden/tiny_en_tokenizer.bin, 32,768 entries):
+    # a model directory with the suite's synthetic weights next to the REAL tokenizer file
+    import shutil
+    import tempfile
+
+    real_dir = tempfile.mkdtemp(prefix="tiny_real_tok_")
+    shutil.copy(os.path.join(tiny_dir[0], "model.safetensors"), real_dir)
+    blob = open(os.path.join(os.path.dirname(__file__), "golden", "tiny_en_tokenizer.bin"), "rb").read()
+    with open(os.path.join(real_dir, "tokenizer.bin"), "wb") as f:
+        f.write(blob)
+    vocab = host_ref.decode_tokenizer_bin(blob)
+    assert len(vocab) == ARCHS["tiny"].vocab
+    synth_tiny, tiny = tiny, api.Transcriber(real_dir, api.ARCH_TINY, {"vad_threshold": "0", "cross_attention": "kv"})
     lines = tiny.transcribe_without_streaming(audio)
     assert len(lines) == 1 and lines[0].is_complete
     seg = audio[:159232]
     np.testing.assert_array_equal(lines[0].audio_data, seg)
-    vocab = synthetic_vocab(ARCHS["tiny"].vocab)
     want, toks = _expected_text(engine, vocab, seg)
     assert lines[0].text_bytes == want
+    # the same ids through the synthetic vocabulary of the other tests: another spelling of the same token list
+    assert synth_tiny.transcribe_without_streaming(audio)[0].text_bytes == _expected_text(engine, synthetic_vocab(ARCHS["tiny"].vocab), seg)[0]
     assert 2 <= len(toks) <= 66
     cfg, w = ARCHS["tiny"], tiny_dir[1]
     enc = ref.encoder_forward(w, cfg, seg)
@@ -469,6 +483,8 @@ def test_config1_beckett_wav_through_the_c_api(tiny, tiny_dir, engine):
             checked += 1
     assert checked >= (len(toks) - 1) // 2
     assert [l.text_bytes for l in tiny.transcribe_without_streaming(audio)] == [want]   # deterministic
+    tiny.close()
+    shutil.rmtree(real_dir, ignore_errors=True)
 
 
 def test_cross_attention_option(tiny_dir, engine):

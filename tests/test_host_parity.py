@@ -106,6 +106,47 @@ def test_tokenizer_and_sanitize_bit_exact():
     assert lib.msh_host_tokens_to_text(b"", 0, ids.ctypes.data, 2, buf, 64) < 0
 
 
+def test_shipped_tiny_en_tokenizer_known_answers():
+    """tests/golden/tiny_en_tokenizer.bin = the reference's own language-bindings/python/.../assets/tiny-en/tokenizer.bin
+    (32,768 entries), the one model artefact its checkout holds.  Without the compiled reference (tests/test_ref_host_diff.py
+    diffs against that): the library's decoder against the oracle's on random ids, the layout SURVEY Appendix A.13 describes,
+    and the sentence test-assets/beckett.wav says as a known-answer round trip under both encodings."""
+    blob = open(os.path.join(os.path.dirname(__file__), "golden", "tiny_en_tokenizer.bin"), "rb").read()
+    vocab = host_ref.decode_tokenizer_bin(blob)
+    assert len(vocab) == 32768 and vocab[:3] == [b"<unk>", b"<s>", b"</s>"]
+    assert vocab[3:259] == [bytes([i]) for i in range(256)]
+    assert vocab[32000] == b"<<ST_0>>" and vocab[32767] == b"<<ST_767>>"
+    assert host_ref.encode_tokenizer_bin(vocab) == blob
+    lib = load_library()
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        ids = [int(t) for t in rng.integers(0, 32768, int(rng.integers(0, 60))) if t != 31353]   # 31353 is the empty entry
+        assert _tok_text(blob, ids) == host_ref.tokens_to_text(vocab, ids)
+    ids = np.asarray([5, 31353, 7], np.int32)
+    buf = C.create_string_buffer(64)
+    assert lib.msh_host_tokens_to_text(blob, len(blob), ids.ctypes.data, 3, buf, 64) < 0            # reference: "Invalid token"
+    sentence = b"Ever tried. Ever failed. No matter. Try again. Fail again. Fail better."
+    lib.msh_host_text_to_tokens.restype = C.c_int64
+    lib.msh_host_text_to_tokens.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
+    marker = "\u2581".encode()
+    got = {}
+    for bpe in (0, 1):
+        out = np.full(128, -1, np.int32)
+        n = lib.msh_host_text_to_tokens(blob, len(blob), sentence, len(sentence), marker, bpe, out.ctypes.data, out.size)
+        assert n == 19
+        ids = out[:n].tolist()
+        assert host_ref.tokens_to_text(vocab, [1] + ids + [2]) == sentence
+        assert _tok_text(blob, [1] + ids + [2]) == sentence
+        got[bpe] = ids
+    # the spellings both encoders pick (no word marker is put in front of the text; longest match takes the byte-fallback
+    # entry of a lone "E" / ".", the byte-pair replay the learned one) -- the same ids the compiled reference gives
+    pieces = [b"E", b"ver", marker + b"tried", b".", marker + b"Ever", marker + b"failed", b".", marker + b"No", marker + b"matter", b".",
+              marker + b"Try", marker + b"again", b".", marker + b"Fail", marker + b"again", b".", marker + b"Fail", marker + b"better", b"."]
+    for bpe in (0, 1):
+        assert [vocab[t] for t in got[bpe]] == pieces
+    assert got[0][:4] == [72, 369, 1898, 49] and got[1][:4] == [29923, 369, 1898, 29889]
+
+
 @pytest.mark.parametrize("in_rate,out_rate,n", [(48000, 16000, 4801), (44100, 16000, 3000), (24000, 16000, 777), (8000, 16000, 500), (11025, 16000, 333), (16000, 16000, 100)])
 def test_resampler_bit_exact(in_rate, out_rate, n):
     lib = load_library()

@@ -133,6 +133,85 @@ def test_tokenizer_decode_and_encode_identical(pair):
                     assert a == b, (vi, text, bpe)
 
 
+REAL_TOKENIZER = os.path.join(os.path.dirname(__file__), "golden", "tiny_en_tokenizer.bin")
+BECKETT = b"Ever tried. Ever failed. No matter. Try again. Fail again. Fail better."
+
+
+def test_shipped_tiny_en_tokenizer_identical(pair):
+    """The one model artefact the reference checkout holds: language-bindings/python/src/moonshine_voice/assets/tiny-en/
+    tokenizer.bin (32,768 entries: <unk> <s> </s>, the 256 byte fallbacks, learned pieces, 768 <<ST_n>> specials), committed as
+    the data fixture tests/golden/tiny_en_tokenizer.bin.  tokens_to_text over random ids incl. specials and byte fallbacks,
+    text_to_tokens (longest match AND byte-pair replay) over English, raw bytes and the marker: byte-identical to the
+    reference's bin-tokenizer.cpp (:46-66 file format, :277-404 encoders, :406-426 decoder) compiled in oracle/_ref."""
+    blob = open(REAL_TOKENIZER, "rb").read()
+    ref_copy = "/root/reference/language-bindings/python/src/moonshine_voice/assets/tiny-en/tokenizer.bin"
+    if os.path.exists(ref_copy):
+        assert open(ref_copy, "rb").read() == blob          # the fixture IS the reference's file
+    rng = np.random.default_rng(11)
+    V = 32768
+    pools = [lambda n: rng.integers(0, V, n), lambda n: rng.integers(0, 259, n), lambda n: rng.integers(31990, V, n),
+             lambda n: rng.integers(259, 32000, n)]
+    for trial in range(400):
+        ids = arr(pools[trial % 4](int(rng.integers(0, 70))), np.int32)
+        if trial % 50 == 7:
+            ids[len(ids) // 2:len(ids) // 2 + 1] = 31353     # the file's one EMPTY entry: the reference throws, both sides < 0
+        if trial % 50 == 9:
+            ids[:1] = 25299                                  # "<>": two bytes, NOT skipped as a special (needs > 2)
+
+        def mk():
+            buf = C.create_string_buffer(1 << 15)
+            return (blob, len(blob), ids.ctypes.data, len(ids), C.addressof(buf), len(buf)), lambda rc: buf.raw[:max(rc, 0)]
+
+        a, b = pair.both("tokens_to_text", mk)
+        assert a == b, ids.tolist()
+    words = (BECKETT.decode() + " the quick brown fox jumps over the lazy dog It was the best of times, it was the worst of times "
+             "Kubernetes IPv6 naïve café 東京 don't e-mail 3.14159 $100 A.I. <s> </s> <unk> <<ST_5>> <>").split(" ")
+    texts = [BECKETT, b"", b" ", b"  two  spaces ", SPACE, SPACE + b"Ever" + SPACE + b"tried.", b"\x00\x01\xff\xfe", "▁▁".encode()]
+    for trial in range(300):
+        n = int(rng.integers(1, 14))
+        t = " ".join(words[int(rng.integers(len(words)))] for _ in range(n)).encode()
+        if trial % 5 == 0:
+            t += bytes(rng.integers(0, 256, int(rng.integers(1, 6))).tolist())
+        if trial % 7 == 0:
+            t = t.replace(b" ", SPACE, 1)
+        texts.append(t)
+    for text in texts:
+        for bpe in (0, 1):
+            def mk():
+                out = np.full(1024, -7, np.int32)
+                return (blob, len(blob), text, len(text), SPACE, bpe, out.ctypes.data, out.size), lambda rc: out[:max(rc, 0)].tolist()
+
+            a, b = pair.both("text_to_tokens", mk)
+            assert (a[0] < 0) == (b[0] < 0), (text, bpe, a, b)
+            if a[0] >= 0:
+                assert a == b, (text, bpe)
+                # and back through BOTH decoders: the round trip of what the encoder produced
+                ids = arr(a[1], np.int32)
+
+                def mk2():
+                    buf = C.create_string_buffer(1 << 15)
+                    return (blob, len(blob), ids.ctypes.data, len(ids), C.addressof(buf), len(buf)), lambda rc: buf.raw[:max(rc, 0)]
+
+                x, y = pair.both("tokens_to_text", mk2)
+                assert x == y, (text, bpe)
+    # known answer: the sentence beckett.wav says (SURVEY section 8c) survives ids -> text under both encodings
+    for bpe in (0, 1):
+        def mk():
+            out = np.full(256, -7, np.int32)
+            return (blob, len(blob), BECKETT, len(BECKETT), SPACE, bpe, out.ctypes.data, out.size), lambda rc: out[:max(rc, 0)].tolist()
+
+        a, b = pair.both("text_to_tokens", mk)
+        assert a == b and a[0] > 0
+        ids = arr([1] + a[1] + [2], np.int32)               # <s> ... </s> as the greedy loop emits them
+
+        def mk2():
+            buf = C.create_string_buffer(1 << 12)
+            return (blob, len(blob), ids.ctypes.data, len(ids), C.addressof(buf), len(buf)), lambda rc: buf.raw[:max(rc, 0)]
+
+        x, y = pair.both("tokens_to_text", mk2)
+        assert x == y and x[1] == BECKETT, (bpe, x)
+
+
 def test_context_biaser_identical(pair):
     rng = np.random.default_rng(2)
     V = 300
