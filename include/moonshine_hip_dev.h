@@ -55,6 +55,14 @@ MSH_EXPORT float msh_test_cross_absorbed(const float* qt, const float* enc, int6
 MSH_EXPORT float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out,
                                   int32_t iters);
 
+/* Developer / test hook: the encoder self-attention kernels alone (k_attn.hip) on n_clips clips of T frames of uniform random
+ * q | k [R][2D] and V^T [D][R] at width D (head_dim 52).  variant 0 = block-streaming kernel, two 4-wave workgroups per
+ * (clip, head); 1 = its 7-wave shape; 2 = two query tiles per wave; 100 + abl = the LDS-resident kernel (abl 0 = as shipped,
+ * other values = ablations with garbage results).  Returns ms per launch over `iters` launches (0 = one untimed launch), < 0 on
+ * error; out (nullable) [R][D], R = n_clips * round_up(T, 8), receives the output as bf16 bit patterns. */
+MSH_EXPORT float msh_test_enc_attention(int32_t variant, int32_t n_clips, int32_t T, int32_t D, int32_t heads, int32_t iters,
+                                        uint16_t* out);
+
 #ifdef __cplusplus
 }
 #endif

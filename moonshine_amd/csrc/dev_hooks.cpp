@@ -62,6 +62,15 @@ int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const 
   }
 }
 
+float msh_test_enc_attention(int32_t variant, int32_t n_clips, int32_t T, int32_t D, int32_t heads, int32_t iters, uint16_t* out) {
+  try {
+    return msh::enc_attention_microbench(variant, n_clips, T, D, heads, iters, out);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "enc_attention: %s\n", ex.what());
+    return -1.0f;
+  }
+}
+
 float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out, int32_t iters) {
   try {
     return msh::crossq2_host(x, wq, wk, M, D, qt_out, iters);

@@ -527,7 +527,15 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
     EncLayerW& L = enc_[l];
     {
-      const std::vector<float> qkv = fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"});
+      std::vector<float> qkv = fuse({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"});
+      // The attention scale rsqrt(dh) and the exp2 domain's log2(e) are folded into the QUERY projection (hf:171-193 multiplies
+      // the scores by `scaling`; RoPE is a rotation, so scaling q before it is the same thing): the encoder attention kernels
+      // exponentiate MFMA outputs directly, 16 multiply-adds per 16 x 64 score tile less in a VALU-bound kernel (k_attn.hip).
+      // One bf16 rounding of (scale * w) instead of w: the same relative error.
+      {
+        const float qs = (1.0f / sqrtf((float)c.head_dim())) * 1.4426950408889634f;
+        for (size_t i = 0; i < (size_t)D * D; ++i) qkv[i] *= qs;
+      }
       upload_bf16(qkv, &L.wqkv);
       if (qkv_panel_supported(D, c.head_dim(), c.rot_pairs()) && !dry_run_) {
         const std::vector<float> gam = vec(p + "input_layernorm.weight", D);

@@ -11,7 +11,14 @@
 //                       ([dh][Tk] bf16, keys contiguous) with 16-byte non-temporal buffer loads: the
 //                       HBM-bound kernel that dominates batched decode (5.5 MB per clip per step at
 //                       Moonshine-base).
+#include <math.h>
 #include <stdlib.h>
+
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "kernels.h"
 
@@ -33,6 +40,16 @@ constexpr int kStreamAux = MSH_CROSS_KV_AUX;
 #define MSH_FP8_ATT_OCC 2   // minimum workgroups per CU the fp8 variant is compiled for: it lands at 114 VGPRs = 4 per CU by itself;
                           // forcing 5 (96 VGPRs, 13 spilled) measured 26.5 us per launch against 19.2
 #endif
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N)
+template <class Body, int... I>
+__device__ __forceinline__ void static_for_att_impl(Body&& body, std::integer_sequence<int, I...>) {
+  (body(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Body>
+__device__ __forceinline__ void static_for_att(Body&& body) {
+  static_for_att_impl(static_cast<Body&&>(body), std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -213,7 +230,9 @@ __global__ __launch_bounds__(64 * NW, EQT == 2 ? 3 : 2) void enc_attention_kerne
     }
   }
 
-  const float c = rsqrtf((float)DH) * kLog2e;  // scores are compared / exponentiated in the exp2 domain
+  // scores are compared / exponentiated in the exp2 domain.  Since round 6 the queries arrive PRE-SCALED (rsqrt(dh) * log2(e)
+  // is folded into the q rows of the fused QKV weight at load, Engine::load_weights): nothing is left to multiply by here
+  constexpr float c = 1.0f;
   float m_run[EQT], l_run[EQT];
   f32x4 o[EQT][4];
 #pragma unroll
@@ -340,6 +359,328 @@ __global__ __launch_bounds__(64 * NW, EQT == 2 ? 3 : 2) void enc_attention_kerne
     }
     const float inv = 1.0f / l;
     if (qi * NW + wave < tiles_per_wg && qrow[qi] < cm.rows) {
+      const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
+      bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + kg * 4;
+        if (d < DH) {
+          uint2 w = make_uint2(0u, 0u);
+          if (valid) {
+            w.x = pack_bf16x2(o[qi][dt][0] * inv, o[qi][dt][1] * inv);
+            w.y = pack_bf16x2(o[qi][dt][2] * inv, o[qi][dt][3] * inv);
+          }
+          *reinterpret_cast<uint2*>(orow + d) = w;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder attention with the keys and values of a (clip, head) RESIDENT in LDS (round 6).
+//
+// The kernel above walks the keys in 64-key blocks: fetch into registers, commit to LDS, workgroup barrier, compute -- seven
+// times per workgroup, and the two workgroups of a (clip, head) each stage every block.  PMC of that kernel and of the first
+// resident version (profiles/r6c_pmc_attn_*): one VALU instruction costs the SIMD 4.6 cycles whichever wave issues it, 109 of
+// them per (16-query tile, 64-key block) against 16 MFMAs of 16 cycles -- VALU issue is 42 % of the kernel's SIMD time, the
+// matrix pipe 19 %, and four waves per SIMD instead of two only moved 222 -> 209 us.  So the instruction count is the lever:
+//   * a 10 s clip has 415 keys: K [448][64] + V^T [64][448] bf16 is 113 KiB, which one workgroup per CU can hold.  One
+//     workgroup of NW waves per (clip, head) copies the clip's K rows and V^T rows into LDS ONCE -- every load of the thread in
+//     flight together, thread -> (key, piece) fixed so that every LDS address is one base + an immediate -- one barrier, and
+//     then every wave runs its query tiles (wave w: tiles w, w + NW, ...) over all key blocks with no barrier, no global load
+//     and no staging register in the loop;
+//   * the queries arrive PRE-SCALED: rsqrt(dh) * log2(e) is folded into the q rows of the fused QKV weight at load
+//     (Engine::load_weights; RoPE is a rotation, it commutes), so an MFMA score is already the exponent's argument;
+//   * the reference point of the online softmax rides in the ACCUMULATOR INIT of the score MFMA (C = -m per query column):
+//     the MFMA output is s - m, the 16 fused multiply-adds per tile and block are gone;
+//   * the "does the reference move?" test is per lane (any lane above kTau?): the cross-lane maximum is only formed in the
+//     rare branch that moves it;
+//   * a block is straight-line code for all of a wave's tiles (scores of every tile, ONE rarely taken branch, exponentials,
+//     P.V): the first version went tile by tile with three wave-uniform branches per tile and every tile's softmax sat in
+//     basic blocks of its own -- dependent VALU chains with nothing to interleave.
+// Per tile and block: 16 MFMAs, 8 v_max3 + 16 v_exp + 8 v_cvt_pk + 3 (was ~62 in the loop, ~109 with staging and epilogue).
+// Different rounding points from enc_attention_kernel (the reference enters the fp32 accumulation first instead of last):
+// equal to ~1e-6 in the exponent, not bit for bit.  KMAX = 448 keys (clips of up to 10.8 s); longer clips keep the
+// block-streaming kernel.  ABL (microbenchmark only, garbage results): 1 = no global loads while staging, 4 = no exp2,
+// 8 = no MFMAs, 16 = staging and epilogue only.
+// ------------------------------------------------------------------------------------------------
+template <int DH, int KMAX, int ABL = 0, int NW = 8, int EQT = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                                   long vt_ld, bf16_t* __restrict__ out,
+                                                                   const ClipMeta* __restrict__ clips, int D) {
+  static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
+  static_assert(KMAX % 128 == 64, "V^T row stride (KMAX + 8) must be 72 mod 128 elements: conflict-free ds_read_b64");
+  static_assert(NW % 4 == 0 && NW * EQT * 16 >= KMAX, "every query tile of a KMAX-frame clip needs a slot");
+  constexpr int NT = 64 * NW;
+  constexpr int PIECES = DH / 4;            // 8-byte pieces per K row
+  constexpr int VLD = KMAX + 8;             // V^T row stride in bf16
+  constexpr int VROWS = (DH + 15) / 16 * 16;
+  constexpr int VCH = KMAX / 8;             // 16-byte chunks (8 keys) per V^T row
+  constexpr bool ONES_ROW = (DH % 16) != 0;
+  constexpr float kTau = 8.0f;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KMAX * 128 + VROWS * VLD * 2];
+  unsigned char* const Ks = lds_raw;                                   // [key][8 x 16 B], chunk ^= (key >> 1) & 7
+  bf16_t* const Vt = reinterpret_cast<bf16_t*>(lds_raw + KMAX * 128);   // [d][key]
+
+  const ClipMeta cm = clips[blockIdx.z];
+  const int h = blockIdx.y;
+  const int T = cm.T;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long ld = 2L * D;   // [row][q | k]
+  const bf16_t* base = qk + (long)cm.row_start * ld + h * DH;
+  const bf16_t* vbase = vt + (long)(h * DH) * vt_ld + cm.row_start;
+  const int nkb = (T + KB - 1) / KB, nkeys = nkb * KB;   // (the host guarantees nkeys <= KMAX)
+
+  // ---- stage: every load of this thread first, then the LDS writes ----
+  {
+    // K: groups of 16 keys x PIECES pieces; thread -> (key within 32, piece) once, iteration i adds 32 keys: the swizzle term
+    // (key >> 1) & 7 does not change, the LDS address is base + 4096 i
+    constexpr int KG = NT / (16 * PIECES);          // 16-key groups per iteration
+    constexpr int KIT = (KMAX + 16 * KG - 1) / (16 * KG);
+    const int kgrp = tid / (16 * PIECES), ku = tid - kgrp * (16 * PIECES);
+    const int kkey0 = kgrp * 16 + ku / PIECES, kpiece = ku % PIECES;
+    const bool kthread = kgrp < KG;
+    // V^T: thread -> (row within VR, 16-byte chunk) once, iteration i adds VR rows
+    constexpr int VR = NT / VCH, VIT = (DH + VR - 1) / VR;
+    const int vd0 = tid / VCH, vch = tid - vd0 * VCH;
+    const bool vthread = vd0 < VR;
+    uint2 kreg[KIT];
+    uint4 vreg[VIT];
+    {
+      const bf16_t* kp = base + (long)kkey0 * ld + D + kpiece * 4;
+#pragma unroll
+      for (int i = 0; i < KIT; ++i) {
+        kreg[i] = make_uint2(0u, 0u);
+        if ((ABL & 1) == 0 && kthread && kkey0 + i * 16 * KG < T) kreg[i] = *reinterpret_cast<const uint2*>(kp + (long)i * (16 * KG) * ld);
+      }
+      const bf16_t* vp = vbase + (long)vd0 * vt_ld + vch * 8;
+#pragma unroll
+      for (int i = 0; i < VIT; ++i) {
+        vreg[i] = make_uint4(0u, 0u, 0u, 0u);
+        if ((ABL & 1) == 0 && vthread && vd0 + i * VR < DH && vch * 8 < T)   // (row_start and the chunk are multiples of 8 keys: 16-byte aligned)
+          vreg[i] = *reinterpret_cast<const uint4*>(vp + (long)i * VR * vt_ld);
+      }
+    }
+    // head-dim padding of K (pieces PIECES .. 15 of every key) and of V^T (rows DH .. VROWS - 1; row DH holds ones when it exists)
+    for (int p = tid; p < nkeys * (16 - PIECES); p += NT) {
+      const int key = p / (16 - PIECES), piece = PIECES + (p - key * (16 - PIECES));
+      *reinterpret_cast<uint2*>(Ks + key * 128 + (((piece >> 1) ^ ((key >> 1) & 7)) * 16 + (piece & 1) * 8)) = make_uint2(0u, 0u);
+    }
+    if (vthread && vch * 8 < nkeys) {
+#pragma unroll
+      for (int r = 0; r < VROWS - DH; r += VR)
+        if (r + vd0 < VROWS - DH) {
+          const unsigned fill = (ONES_ROW && r + vd0 == 0) ? 0x3f803f80u : 0u;
+          *reinterpret_cast<uint4*>(Vt + (DH + r + vd0) * VLD + vch * 8) = make_uint4(fill, fill, fill, fill);
+        }
+    }
+    // keys >= T inside the last chunk that holds a valid one: exact zeros (the clip's padding rows hold arbitrary values)
+    unsigned vmask[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nv = T - vch * 8;   // valid keys of this thread's chunk
+      vmask[e] = 2 * e + 1 < nv ? 0xffffffffu : (2 * e < nv ? 0xffffu : 0u);
+    }
+    if constexpr ((ABL & 2) != 0) {   // ablation: the loads are waited for, the kernel computes on zeros
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vmask[e] = 0u;
+#pragma unroll
+      for (int i = 0; i < KIT; ++i) kreg[i] = make_uint2(kreg[i].x & vmask[0], kreg[i].y & vmask[1]);
+    }
+    if (kthread) {
+      unsigned char* kd = Ks + kkey0 * 128 + (((kpiece >> 1) ^ ((kkey0 >> 1) & 7)) * 16 + (kpiece & 1) * 8);
+#pragma unroll
+      for (int i = 0; i < KIT; ++i)
+        if (kkey0 + i * 16 * KG < nkeys) *reinterpret_cast<uint2*>(kd + i * (16 * KG) * 128) = kreg[i];
+    }
+    if (vthread && vch * 8 < nkeys) {
+      bf16_t* vd = Vt + vd0 * VLD + vch * 8;
+#pragma unroll
+      for (int i = 0; i < VIT; ++i)
+        if (vd0 + i * VR < DH)
+          *reinterpret_cast<uint4*>(vd + i * VR * VLD) = make_uint4(vreg[i].x & vmask[0], vreg[i].y & vmask[1], vreg[i].z & vmask[2], vreg[i].w & vmask[3]);
+    }
+  }
+
+  // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
+  bool act[EQT];
+  int qrow[EQT];
+  bf16x8 qf[EQT][2];
+#pragma unroll
+  for (int qi = 0; qi < EQT; ++qi) {
+    const int tile = qi * NW + wave;
+    act[qi] = tile * 16 < T;   // wave-uniform
+    qrow[qi] = tile * 16 + li;
+    const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int d = s * 32 + kg * 8;
+      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+      if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
+      if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
+      uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
+    }
+  }
+  __syncthreads();   // the one barrier: K and V^T of the (clip, head) are in LDS
+
+  // nm[qi] = MINUS the reference point of tile qi's exponent, as the four accumulator registers the score MFMAs start from.
+  // It starts at 0 and the first block always moves it to the block's maximum (o and l are still zero then).
+  f32x4 nm[EQT];
+  float l_run[EQT];
+  f32x4 o[EQT][4];
+#pragma unroll
+  for (int qi = 0; qi < EQT; ++qi) {
+    nm[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // One key block for the wave's first NA query tiles, as a PIPELINE over the tiles: while tile i's scores go through
+  // max / (rare) reference move / exp2 / bf16 packing on the vector pipe, tile i + 1's score MFMAs run on the matrix pipe, and
+  // tile i's P.V MFMAs run beside tile i + 1's maxima.  Between two tiles there is exactly one rarely taken wave-uniform
+  // branch (does this tile's reference point move?); everything else of a tile is one basic block holding 16 MFMAs and
+  // ~36 VALU instructions for the scheduler to interleave.  (The version before this one did all score MFMAs of a block, then
+  // all maxima, one branch, all exponentials, then all P.V MFMAs: PMC showed the SIMD's VALU busy 37 % and its matrix pipe
+  // 23 % of the time with next to no overlap -- a wave alternated between phases that each use ONE of the two pipes, and two
+  // waves per SIMD are too few for chance to interleave them.)  MASKED: the block holds the clip's last valid key (compiled
+  // once more, with the -inf selects).
+  auto block = [&](int kb, auto na_c, auto masked_c) {
+    constexpr int NA = decltype(na_c)::value;
+    constexpr bool MASKED = decltype(masked_c)::value;
+    const uint4* Kb = reinterpret_cast<const uint4*>(Ks) + kb * (KB * 8);
+    const bf16_t* Vb = Vt + kb * KB;
+    uint4 kf[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = kt * 16 + li;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) kf[kt][s] = Kb[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
+    }
+    // st[kt][r] = score(q = li of the tile, key = kb*64 + kt*16 + kg*4 + r) - reference, in the exp2 domain
+    auto scores = [&](auto qc, f32x4 (&st)[4]) {
+      constexpr int qi = decltype(qc)::value;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 a = nm[qi];
+        if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[kt][s]), qf[qi][s], a, 0, 0, 0);
+        } else {
+          asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(kf[kt][0].x), "v"(kf[kt][1].w), "v"(qf[qi][0][0]));
+        }
+        st[kt] = a;
+      }
+    };
+    f32x4 sa[4], sb[4];
+    scores(std::integral_constant<int, 0>{}, sa);
+    static_for_att<NA>([&](auto qc) {
+      constexpr int qi = decltype(qc)::value;
+      f32x4(&st)[4] = (qi & 1) ? sb : sa;
+      f32x4(&sn)[4] = (qi & 1) ? sa : sb;
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kt][r] = (kb * KB + kt * 16 + kg * 4 + r >= T) ? -INFINITY : st[kt][r];
+      }
+      float m = -INFINITY;   // (this sequential form compiles to eight v_max3_f32; nested pairs came out as 21 v_max_f32 + 4 v_max3)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][r]);
+      // The reference point of a tile moves only when one of its queries found a score more than kTau above it: a few times
+      // per clip (and always in the first block).  Numerator and denominator use the same reference; p <= 2^kTau keeps bf16 /
+      // fp32 in range.
+      if (kb == 0 || __any(m > kTau)) {
+        const float delta = rows_max(m);                      // per query: the block's maximum above the old reference
+        const float alpha = __builtin_amdgcn_exp2f(-delta);   // (delta is finite: key 0 is valid for every query)
+        const float nmv = nm[qi][0] - delta;
+        nm[qi] = f32x4{nmv, nmv, nmv, nmv};
+        if (kb != 0) {   // (o and l are zero in the first block, and alpha may be 2^(+large) = inf there)
+          if constexpr (!ONES_ROW) l_run[qi] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kt][r] -= delta;
+      }
+      // ---- one basic block from here to the next tile's branch ----
+      if constexpr (qi + 1 < NA) scores(std::integral_constant<int, qi + 1>{}, sn);   // matrix pipe, independent of this tile
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr ((ABL & 4) == 0) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]);
+          if constexpr (!ONES_ROW) psum += st[kt][r];
+        }
+      if constexpr (!ONES_ROW) l_run[qi] += psum;
+      // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
+      bf16x8 pf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 pt;
+        pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
+        pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
+        pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+        pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+        pf[ks] = *reinterpret_cast<bf16x8*>(&pt);
+      }
+      // O^T += V^T P^T
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (dt * 16 >= DH) continue;
+          const bf16_t* vr = Vb + (dt * 16 + li) * VLD + ks * 32 + kg * 4;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
+          uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          if constexpr ((ABL & 8) == 0) {
+            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[ks], o[qi][dt], 0, 0, 0);
+          } else {
+            asm volatile("" : "+v"(o[qi][dt][0]), "+v"(o[qi][dt][3]) : "v"(vtf.x), "v"(vtf.w), "v"(pf[ks][0]), "v"(pf[ks][7]));
+          }
+        }
+      }
+    });
+  };
+  // the wave's active tiles are its first `nact` (tile qi * NW + wave grows with qi); whole blocks first, then the masked one
+  int nact = 0;
+#pragma unroll
+  for (int qi = 0; qi < EQT; ++qi) nact += (int)act[qi];
+  const int nfull = T / KB;
+  auto run = [&](auto na_c) {
+    for (int kb = 0; kb < nfull; ++kb) block(kb, na_c, std::false_type{});
+    if (nfull < nkb) block(nfull, na_c, std::true_type{});
+  };
+  if constexpr ((ABL & 16) == 0) {
+    switch (nact) {
+      case 4: if constexpr (EQT >= 4) run(std::integral_constant<int, 4>{}); break;
+      case 3: if constexpr (EQT >= 3) run(std::integral_constant<int, 3>{}); break;
+      case 2: if constexpr (EQT >= 2) run(std::integral_constant<int, 2>{}); break;
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      default: break;
+    }
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < EQT; ++qi) {
+    float l;
+    if constexpr (ONES_ROW) {   // row DH of O^T: tile DH / 16, lane group (DH % 16) / 4, register 0
+      l = __shfl(o[qi][DH / 16][0], ((DH % 16) / 4) * 16 + li);
+    } else {
+      l = rows_sum(l_run[qi]);
+    }
+    const float inv = 1.0f / l;
+    if (qrow[qi] < cm.rows) {
       const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
       bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
 #pragma unroll
@@ -814,13 +1155,25 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
     const char* e = dev_getenv("MSH_ENC_ATT_EQT");
     return e != nullptr && e[0] == '2';
   }();
+  // Clips of 257 .. 448 frames (a 10 s clip has 415): keys and values resident in LDS, one 8-wave workgroup per (clip, head),
+  // no barrier in the key loop (enc_attention_res_kernel; MSH_ENC_ATT_RES=0: the block-streaming kernel below)
+  static const bool resident = [] {
+    const char* e = dev_getenv("MSH_ENC_ATT_RES");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (n_clips > 65535) throw std::runtime_error("enc_attention: more than 65535 clips in one batch");
+  if (resident && max_rows > 256 && max_rows <= 448 && (dh == 52 || dh == 36)) {
+    dim3 grid(1, heads, n_clips);
+    if (dh == 52) MSH_LAUNCH((enc_attention_res_kernel<52, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
+    else MSH_LAUNCH((enc_attention_res_kernel<36, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
+    return;
+  }
   const int ntiles = (max_rows + 15) / 16;
   const bool wide = wide_wg && ntiles > 16 && ntiles <= 28;
   const int slots = wide ? 28 : (two_tiles ? 8 : 16);
   const int gx = (ntiles + slots - 1) / slots;
   const int tiles_per_wg = (ntiles + gx - 1) / gx;
   dim3 grid(gx, heads, n_clips);
-  if (n_clips > 65535) throw std::runtime_error("enc_attention: more than 65535 clips in one batch");
 #define MSH_EATT(DHV)                                                                                                       \
   case DHV:                                                                                                                 \
     if (wide)                                                                                                               \
@@ -837,6 +1190,106 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
     default: throw std::runtime_error("enc_attention: unsupported head_dim " + std::to_string(dh));
   }
 #undef MSH_EATT
+}
+
+// Microbenchmark / test hook (include/moonshine_hip_dev.h msh_test_enc_attention): n_clips clips of T frames at width D on
+// uniform random q | k / V^T; variant 0 = the block-streaming kernel (two 4-wave workgroups per (clip, head)), 1 = its 7-wave
+// shape, 2 = two query tiles per wave, 100 + abl = the LDS-resident kernel with ablation bits `abl` (0 = the product kernel).
+// Returns ms per launch; out (nullable) [R][D] receives the last launch's output as bf16 bit patterns.
+float enc_attention_microbench(int variant, int n_clips, int T, int D, int heads, int iters, uint16_t* out_host) {
+  const int dh = D / heads;
+  if (dh != 52 || T < 1 || n_clips < 1 || heads * dh != D) throw std::runtime_error("enc_attention_microbench: head_dim 52 only");
+  const int rows = (T + 7) / 8 * 8;
+  const long R = (long)rows * n_clips, vt_ld = (R + 127) / 128 * 128;
+  std::vector<ClipMeta> cm(n_clips);
+  for (int b = 0; b < n_clips; ++b) {
+    cm[b] = ClipMeta{};
+    cm[b].row_start = b * rows;
+    cm[b].rows = rows;
+    cm[b].T = T;
+  }
+  std::vector<bf16_t> qk((size_t)R * 2 * D), vtv((size_t)D * vt_ld);
+  unsigned x = 2463534242u;
+  auto rnd = [&] {
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return (float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  };
+  // q | k uniform in [-2, 2); the q half pre-scaled by rsqrt(dh) * log2(e) as the engine's weights deliver it
+  const float qscale = 1.0f / sqrtf((float)dh) * kLog2e;
+  for (size_t i = 0; i < qk.size(); ++i) qk[i] = f32_to_bf16(rnd() * 2.0f * ((int)(i % (size_t)(2 * D)) < D ? qscale : 1.0f));
+  for (auto& v : vtv) v = f32_to_bf16(rnd());
+  bf16_t *QK = nullptr, *VT = nullptr, *O = nullptr;
+  ClipMeta* CM = nullptr;
+  MSH_HIP(hipMalloc(&QK, qk.size() * 2));
+  MSH_HIP(hipMalloc(&VT, vtv.size() * 2));
+  MSH_HIP(hipMalloc(&O, (size_t)R * D * 2));
+  MSH_HIP(hipMalloc(&CM, cm.size() * sizeof(ClipMeta)));
+  MSH_HIP(hipMemcpy(QK, qk.data(), qk.size() * 2, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(VT, vtv.data(), vtv.size() * 2, hipMemcpyHostToDevice));
+  MSH_HIP(hipMemcpy(CM, cm.data(), cm.size() * sizeof(ClipMeta), hipMemcpyHostToDevice));
+  MSH_HIP(hipMemset(O, 0xff, (size_t)R * D * 2));
+  const int ntiles = (rows + 15) / 16;
+  auto run = [&] {
+    if (variant >= 100) {
+      if (rows > 448) throw std::runtime_error("enc_attention_microbench: the resident kernel holds 448 keys");
+      dim3 grid(1, heads, n_clips);
+#define MSH_RES(A)                                                                                                      \
+  case A:                                                                                                               \
+    MSH_LAUNCH((enc_attention_res_kernel<52, 448, A>), grid, dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);   \
+    break
+      switch (variant - 100) {
+        MSH_RES(0);
+        MSH_RES(1);
+        MSH_RES(2);
+        MSH_RES(4);
+        MSH_RES(5);
+        MSH_RES(8);
+        MSH_RES(9);
+        MSH_RES(13);
+        MSH_RES(16);
+        default: throw std::runtime_error("enc_attention_microbench: ablation not compiled");
+      }
+#undef MSH_RES
+      return;
+    }
+    if (variant == 50 || variant == 51) {   // the resident kernel at 12 waves x 3 tiles / 16 waves x 2 tiles
+      if (rows > 448) throw std::runtime_error("enc_attention_microbench: the resident kernel holds 448 keys");
+      dim3 grid(1, heads, n_clips);
+      if (variant == 50) MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 12, 3>), grid, dim3(768), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      else MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 16, 2>), grid, dim3(1024), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      return;
+    }
+    const int slots = variant == 1 ? 28 : variant == 2 ? 8 : 16;
+    const int gx = (ntiles + slots - 1) / slots, tpw = (ntiles + gx - 1) / gx;
+    dim3 grid(gx, heads, n_clips);
+    if (variant == 1) MSH_LAUNCH((enc_attention_kernel<52, 7>), grid, dim3(448), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
+    else if (variant == 2) MSH_LAUNCH((enc_attention_kernel<52, 4, 2>), grid, dim3(256), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
+    else MSH_LAUNCH((enc_attention_kernel<52, 4>), grid, dim3(256), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
+  };
+  run();
+  MSH_HIP(hipDeviceSynchronize());
+  float ms = 0.f;
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    MSH_HIP(hipEventCreate(&e0));
+    MSH_HIP(hipEventCreate(&e1));
+    MSH_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) run();
+    MSH_HIP(hipEventRecord(e1, 0));
+    MSH_HIP(hipEventSynchronize(e1));
+    MSH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ms /= iters;
+  }
+  if (out_host != nullptr) MSH_HIP(hipMemcpy(out_host, O, (size_t)R * D * 2, hipMemcpyDeviceToHost));
+  (void)hipFree(QK);
+  (void)hipFree(VT);
+  (void)hipFree(O);
+  (void)hipFree(CM);
+  return ms;
 }
 
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,

@@ -173,6 +173,7 @@ float qkv_panel_microbench(int R, int D, int iters, uint16_t* out_qk, uint16_t* 
 // stream rows contiguous; vt_ld >= R) -> out [R,D] bf16
 void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips,
                    int max_rows, int D, int heads, hipStream_t s);
+float enc_attention_microbench(int variant, int n_clips, int T, int D, int heads, int iters, uint16_t* out_host);
 // decode self-attention: q [M,D] f32, cache [M][H][Smax][dh] bf16, keys 0..*pos_ptr -> out [M16,D] bf16 in FM
 void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cacheV, const int* pos_ptr, int M, int D,
                         int heads, int Smax, bf16_t* out, hipStream_t s);
