@@ -101,49 +101,177 @@ __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u <<
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // ------------------------------------------------------------------------------------------------
-// Encoder attention: one workgroup per (clip, head) covers up to 64 * NW queries -- ALL queries of a 10 s clip with
-// NW = 7 (415 frames = 26 query tiles: waves 0-5 take four each, wave 6 two).
-//
-// Flash-style over 64-key LDS blocks: S^T = K Q^T and O^T = V^T P^T so that softmax statistics, P and O of a query live
-// in one lane (MFMA 16x16x32: S^T tile = 16 keys x 16 queries, lane = query li, keys kg*4 + r).  Compared with the
-// first version (128 queries per workgroup, four workgroups per (clip, head), V transposed on the way into LDS with
-// 2-byte stores):
-//   * every K / V block of a (clip, head) is staged ONCE and every LDS fragment read feeds up to four query tiles;
-//   * V arrives already transposed: the encoder's V projection is its own GEMM with the operands swapped
-//     (V^T [D][R] = Wv x Y^T: the R stream rows are its output columns), so a block's V^T tile is 52 rows of
-//     128 contiguous bytes -- one 16-byte load and one ds_write_b128 per thread instead of thirteen conflicting
-//     ds_write_b16 (PMC of the old kernel: 60 % of its LDS cycles were bank conflicts, 4.8x the algorithmic traffic).
-// fp32 online softmax in the exp2 domain, scale folded into the exponent's fma.
+// One 64-key block for the first NA query tiles of a wave -- the arithmetic BOTH encoder attention kernels below run, so
+// that a clip's output does not depend on which of them a batch's longest clip selected (identical bits).
+//   Kb   the block's K rows in LDS: [key][8 x 16 B], chunk ^= (key >> 1) & 7, head dim zero-padded to 64
+//   Vb   the block's V^T in LDS: [d][VLD], rows DH .. padded with zeros, row DH = ones when DH % 16 != 0 (the softmax
+//        denominator then comes out of the P.V MFMA as "dimension DH" of O: the same bf16 P that forms the numerator)
+//   qf   the tiles' query fragments, PRE-SCALED by rsqrt(dh) * log2(e) (folded into the q projection at load)
+//   nm   MINUS the reference point of each tile's exponent, as the accumulator the score MFMAs start from: the MFMA output
+//        is already `score - reference` in the exp2 domain, no multiply-add per score
+//   first  this is the clip's first key block: the reference (0 so far) always moves to the block's maximum
+//   keys_left  valid keys from the block's first one on (only read when MASKED: the block holds the clip's last valid key)
+// The block is a PIPELINE over the tiles: while tile i's scores go through max / (rare) reference move / exp2 / bf16 packing
+// on the vector pipe, tile i + 1's score MFMAs run on the matrix pipe, and tile i's P.V MFMAs run beside tile i + 1's
+// maxima.  Between two tiles there is exactly one rarely taken wave-uniform branch (does this tile's reference point move:
+// did a query find a score more than kTau above it?  per lane -- the cross-lane maximum is only formed inside the branch);
+// everything else of a tile is one basic block of 16 MFMAs and ~36 VALU instructions for the scheduler to interleave.
+// ABL (microbenchmark only): 4 = no exp2, 8 = no MFMAs.
 // ------------------------------------------------------------------------------------------------
-constexpr int KB = 64;        // keys per LDS block
-constexpr int VT_LD = 72;     // V^T row stride in bf16 (144 B: 16-byte aligned rows, conflict-free ds_read_b64)
-constexpr int EQT_DEFAULT = 4;        // query tiles of 16 per wave
+constexpr int KB = 64;        // keys per block
+constexpr float kAttTau = 8.0f;
 
-// EQT = query tiles per wave: 4 (232 registers: two 4-wave workgroups per CU), or 2 (fewer accumulators: three workgroups per
-// CU, twice as many workgroups stage the keys of a (clip, head) -- MSH_ENC_ATT_EQT=2)
-template <int DH, int NW, int EQT = EQT_DEFAULT>
-__global__ __launch_bounds__(64 * NW, EQT == 2 ? 3 : 2) void enc_attention_kernel(const bf16_t* __restrict__ qk,
-                                                                const bf16_t* __restrict__ vt, long vt_ld,
-                                                                bf16_t* __restrict__ out,
-                                                                const ClipMeta* __restrict__ clips, int D,
-                                                                int tiles_per_wg) {
-  static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
-  constexpr int PIECES = DH / 4;  // 8-byte pieces per K row
-  constexpr int NT = 64 * NW;
-  // head_dim is padded to a multiple of 16 rows of V^T for the MFMA: when there is a spare row, it holds ones, and the
-  // softmax denominator comes out of the P.V MFMA as "dimension DH" of O (the same bf16 P that forms the numerator)
-  // instead of 16 VALU adds per query tile and key block
+template <int DH, int VLD, int EQT, int NA, bool MASKED, int ABL = 0>
+__device__ __forceinline__ void att_key_block(const uint4* __restrict__ Kb, const bf16_t* __restrict__ Vb, bool first, int keys_left,
+                                              int li, int kg, const bf16x8 (&qf)[EQT][2], f32x4 (&nm)[EQT], f32x4 (&o)[EQT][4],
+                                              float (&l_run)[EQT]) {
   constexpr bool ONES_ROW = (DH % 16) != 0;
-  constexpr float kTau = 8.0f;
-  // two LDS buffers: block kb + 1 is fetched (into registers) while block kb is consumed and lands in the other buffer,
-  // so a workgroup that is alone on its CU (232 VGPRs) does not expose a memory round trip per key block
-  __shared__ __attribute__((aligned(16))) uint2 Ks2[2][KB * 16];        // [key][8 x 16 B], chunk ^= (key>>1)&7
-  __shared__ __attribute__((aligned(16))) bf16_t Vt2[2][64 * VT_LD];    // [d][key]
+  uint4 kf[4][2];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = kt * 16 + li;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kf[kt][s] = Kb[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
+  }
+  // st[kt][r] = score(q = li of the tile, key = kt*16 + kg*4 + r of the block) - reference, in the exp2 domain
+  auto scores = [&](auto qc, f32x4 (&st)[4]) {
+    constexpr int qi = decltype(qc)::value;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 a = nm[qi];
+      if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[kt][s]), qf[qi][s], a, 0, 0, 0);
+      } else {
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(kf[kt][0].x), "v"(kf[kt][1].w), "v"(qf[qi][0][0]));
+      }
+      st[kt] = a;
+    }
+  };
+  f32x4 sa[4], sb[4];
+  scores(std::integral_constant<int, 0>{}, sa);
+  static_for_att<NA>([&](auto qc) {
+    constexpr int qi = decltype(qc)::value;
+    f32x4(&st)[4] = (qi & 1) ? sb : sa;
+    f32x4(&sn)[4] = (qi & 1) ? sa : sb;
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] = (kt * 16 + kg * 4 + r >= keys_left) ? -INFINITY : st[kt][r];
+    }
+    float m = -INFINITY;   // (this sequential form compiles to eight v_max3_f32; nested pairs came out as 21 v_max_f32 + 4 v_max3)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][r]);
+    // The reference point moves a few times per clip (and always in the first block).  Numerator and denominator use the
+    // same reference; p <= 2^kAttTau keeps bf16 / fp32 in range.
+    if (first || __any(m > kAttTau)) {
+      const float delta = rows_max(m);                      // per query: the block's maximum above the old reference
+      const float alpha = __builtin_amdgcn_exp2f(-delta);   // (delta is finite: the block's first key is valid for every query)
+      const float nmv = nm[qi][0] - delta;
+      nm[qi] = f32x4{nmv, nmv, nmv, nmv};
+      if (!first) {   // (o and l are zero in the first block, and alpha may be 2^(+large) = inf there)
+        if constexpr (!ONES_ROW) l_run[qi] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] -= delta;
+    }
+    // ---- one basic block from here to the next tile's branch ----
+    if constexpr (qi + 1 < NA) scores(std::integral_constant<int, qi + 1>{}, sn);   // matrix pipe, independent of this tile
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr ((ABL & 4) == 0) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]);
+        if constexpr (!ONES_ROW) psum += st[kt][r];
+      }
+    if constexpr (!ONES_ROW) l_run[qi] += psum;
+    // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
+    bf16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 pt;
+      pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
+      pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
+      pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+      pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+      pf[ks] = *reinterpret_cast<bf16x8*>(&pt);
+    }
+    // O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if (dt * 16 >= DH) continue;
+        const bf16_t* vr = Vb + (dt * 16 + li) * VLD + ks * 32 + kg * 4;
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
+        uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        if constexpr ((ABL & 8) == 0) {
+          o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[ks], o[qi][dt], 0, 0, 0);
+        } else {
+          asm volatile("" : "+v"(o[qi][dt][0]), "+v"(o[qi][dt][3]) : "v"(vtf.x), "v"(vtf.w), "v"(pf[ks][0]), "v"(pf[ks][7]));
+        }
+      }
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder self-attention (modeling_moonshine.py:171-193, :283-362 with RoPE already applied by the QKV kernel; the encoder graph
+// the reference runs at core/moonshine-model.cpp:270-274): the keys and values of a (clip, head) RESIDENT in LDS.
+//
+// Rounds 1-5 walked the keys in 64-key blocks (fetch into registers, commit to LDS, workgroup barrier, compute: seven times per
+// workgroup for a 10 s clip, two workgroups per (clip, head) each staging every block) with a per-tile softmax of ~62 VALU
+// instructions per 16 x 64 score tile.  PMC of that kernel and of the first resident version (profiles/r6c_pmc_attn_*): a VALU
+// instruction costs the SIMD 4.6 cycles whichever wave issues it (v_exp_f32 8), 109 of them per tile and block with staging
+// and epilogue against 16 MFMAs of 16 cycles; VALU issue was 42 % of the kernel's SIMD time, the matrix pipe 19 %, and four
+// waves per SIMD instead of two moved nothing.  So the instruction count is the lever:
+//   * a 10 s clip has 415 keys: K [448][64] + V^T [64][448] bf16 is 113 KiB, which one workgroup per CU can hold.  One
+//     workgroup of NW waves per (clip, head, 512 queries) copies KMAX keys' K rows and V^T rows into LDS at a time -- every
+//     load of the thread in flight together, thread -> (key, piece) fixed so that every LDS address is one base + an
+//     immediate -- one barrier, and then every wave runs its query tiles (wave w: tiles w, w + NW, ...) over the chunk's key
+//     blocks with no barrier, no global load and no staging register in the loop.  A 10 s clip is ONE chunk; longer clips
+//     walk their keys in chunks of KMAX with two barriers per chunk (the online softmax state carries over);
+//   * the queries arrive PRE-SCALED, the reference point rides in the accumulator init of the score MFMA, the "does the
+//     reference move?" test is per lane, a block is a pipeline over the wave's tiles: att_key_block above.
+// Per tile and block: 16 MFMAs, 8 v_max3 + 16 v_exp + 8 v_cvt_pk + ~5 (was ~62 in the loop, ~109 with staging and epilogue):
+// 235 -> 188 us per layer at 256 x 10 s (tools/enc_attention_microbench.py, profiles/r6*_enc_att_microbench.txt).  What is
+// left is not an instruction count: the same kernel on all-zero keys and values runs in 130 us with an identical instruction
+// stream (the loads still waited for: ablation 2) -- with real operands the chip is power-limited here.
+// ABL (microbenchmark only, garbage results): 1 = no global loads while staging, 2 = loads waited for but zeroed, 4 = no exp2,
+// 8 = no MFMAs.
+// ------------------------------------------------------------------------------------------------
+// MULTI: clips of more than KMAX frames exist in the batch (the chunk loop is compiled in; it costs the kernel ~300 bytes per
+// lane of scratch, so batches of short clips run the instantiation without it -- the same att_key_block calls in the same
+// order for every clip either way: identical bits).
+template <int DH, int KMAX, int ABL = 0, int NW = 8, int EQT = 4, bool MULTI = false>
+__global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                                   long vt_ld, bf16_t* __restrict__ out,
+                                                                   const ClipMeta* __restrict__ clips, int D) {
+  static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
+  static_assert(KMAX % 128 == 64, "V^T row stride (KMAX + 8) must be 72 mod 128 elements: conflict-free ds_read_b64");
+  static_assert(NW % 4 == 0, "whole waves per SIMD");
+  constexpr int NT = 64 * NW;
+  constexpr int PIECES = DH / 4;            // 8-byte pieces per K row
+  constexpr int VLD = KMAX + 8;             // V^T row stride in bf16
+  constexpr int VROWS = (DH + 15) / 16 * 16;
+  constexpr int VCH = KMAX / 8;             // 16-byte chunks (8 keys) per V^T row
+  constexpr bool ONES_ROW = (DH % 16) != 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KMAX * 128 + VROWS * VLD * 2];
+  unsigned char* const Ks = lds_raw;                                   // [key][8 x 16 B], chunk ^= (key >> 1) & 7
+  bf16_t* const Vt = reinterpret_cast<bf16_t*>(lds_raw + KMAX * 128);   // [d][key]
 
   const ClipMeta cm = clips[blockIdx.z];
-  // this workgroup's run of 16-query tiles; its waves take them round-robin (tile0 + wave, + NW, ...), so the last,
-  // partly filled round is spread over the waves instead of leaving one wave with half the work of the others
-  const int tile0 = blockIdx.x * tiles_per_wg;
+  const int tile0 = blockIdx.x * (NW * EQT);   // this workgroup's run of 16-query tiles
   if (tile0 * 16 >= cm.rows) return;
   const int h = blockIdx.y;
   const int T = cm.T;
@@ -151,324 +279,27 @@ __global__ __launch_bounds__(64 * NW, EQT == 2 ? 3 : 2) void enc_attention_kerne
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long ld = 2L * D;   // [row][q | k]
   const bf16_t* base = qk + (long)cm.row_start * ld + h * DH;
-  const bf16_t* vbase = vt + (long)(h * DH) * vt_ld + cm.row_start;   // V^T [D][R]: row d, the clip's keys from row_start on
-
-  // zero the head-dim padding once (never overwritten by the staging loop)
-  for (int b2 = 0; b2 < 2; ++b2) {
-    for (int p = tid; p < KB * 16; p += NT) {
-      const int key = p >> 4, piece = p & 15;
-      if (piece >= PIECES) Ks2[b2][(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = make_uint2(0u, 0u);
-    }
-    for (int p = tid; p < (64 - DH) * VT_LD; p += NT) Vt2[b2][DH * VT_LD + p] = (ONES_ROW && p < VT_LD) ? 0x3f80 : 0;
-  }
-  constexpr int KP = (KB * PIECES + NT - 1) / NT, VP = (DH * 8 + NT - 1) / NT;   // staged pieces per thread and block
-  uint2 kreg[KP];
-  uint4 vreg[VP];
-  auto fetch = [&](int kb) {   // K rows: 8-byte pieces (104 contiguous bytes per key); V^T rows: 16-byte chunks of 8 keys
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const int p = tid + i * NT;
-      const int key = p / PIECES, piece = p - key * PIECES;
-      const int t = kb * KB + key;
-      kreg[i] = make_uint2(0u, 0u);
-      if (p < KB * PIECES && t < T) kreg[i] = *reinterpret_cast<const uint2*>(base + (long)t * ld + D + piece * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int p = tid + i * NT;
-      const int d = p >> 3, ch = p & 7;
-      const int key0 = kb * KB + ch * 8;
-      vreg[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (p < DH * 8 && key0 < T) {   // (row_start and key0 are multiples of 8: 16-byte aligned)
-        uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)d * vt_ld + key0);
-        if (key0 + 8 > T) {           // the clip's padding rows hold arbitrary values: exact zeros for keys >= T
-          const int nv = T - key0;    // 1..7 valid keys
-          unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (2 * e >= nv) w[e] = 0u;
-            else if (2 * e + 1 >= nv) w[e] &= 0xffffu;
-          }
-          v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        vreg[i] = v;
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const int p = tid + i * NT;
-      const int key = p / PIECES, piece = p - key * PIECES;
-      if (p < KB * PIECES) Ks2[buf][(key * 8 + ((piece >> 1) ^ ((key >> 1) & 7))) * 2 + (piece & 1)] = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int p = tid + i * NT;
-      if (p < DH * 8) *reinterpret_cast<uint4*>(&Vt2[buf][(p >> 3) * VT_LD + (p & 7) * 8]) = vreg[i];
-    }
-  };
-
-  // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
-  bool act[EQT];
-  int qrow[EQT];
-  bf16x8 qf[EQT][2];
-#pragma unroll
-  for (int qi = 0; qi < EQT; ++qi) {
-    const int tile = qi * NW + wave;   // within the workgroup's run
-    act[qi] = tile < tiles_per_wg && (tile0 + tile) * 16 < T;   // wave-uniform
-    qrow[qi] = (tile0 + tile) * 16 + li;
-    const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int d = s * 32 + kg * 8;
-      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-      if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
-      if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
-      uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
-    }
-  }
-
-  // scores are compared / exponentiated in the exp2 domain.  Since round 6 the queries arrive PRE-SCALED (rsqrt(dh) * log2(e)
-  // is folded into the q rows of the fused QKV weight at load, Engine::load_weights): nothing is left to multiply by here
-  constexpr float c = 1.0f;
-  float m_run[EQT], l_run[EQT];
-  f32x4 o[EQT][4];
-#pragma unroll
-  for (int qi = 0; qi < EQT; ++qi) {
-    m_run[qi] = -INFINITY;
-    l_run[qi] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  const int nkb = (T + KB - 1) / KB;
-  fetch(0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int buf = kb & 1;
-    commit(buf);
-    __syncthreads();  // block kb is in LDS; every wave has finished block kb - 1 (it committed after computing it)
-    if (kb + 1 < nkb) fetch(kb + 1);   // in flight during the MFMAs below
-    const uint2* Ks = Ks2[buf];
-    const bf16_t* Vt = Vt2[buf];
-
-    // S^T tiles: rows = keys, cols = queries.  st[kt][r] = score(q = li of tile qi, key = kb*64 + kt*16 + kg*4 + r).
-    // The block's K fragments are read once (32 registers) and one query tile at a time goes through scores -> softmax ->
-    // P fragments, so only 16 score registers are live instead of 16 per tile.
-    uint4 kf[4][2];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int key = kt * 16 + li;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) kf[kt][s] = reinterpret_cast<const uint4*>(Ks)[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
-    }
-    // (a tile that does no work keeps zero P fragments: the P.V product below runs over all EQT tiles without a branch per
-    // MFMA -- guarded one by one, each of its 32 MFMAs per key block sat in a basic block of its own)
-    bf16x8 pf[EQT][2];
-#pragma unroll
-    for (int qi = 0; qi < EQT; ++qi) {
-      if (!act[qi]) {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        pf[qi][0] = *reinterpret_cast<const bf16x8*>(&z);
-        pf[qi][1] = *reinterpret_cast<const bf16x8*>(&z);
-        continue;
-      }
-      f32x4 st[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[kt][s]), qf[qi][s], a, 0, 0, 0);
-        st[kt] = a;
-      }
-      // the softmax is VALU-bound (16 exp2 per lane per tile): keep the per-score work to max, one fma and the
-      // exp2 -- the scale is folded into the fma (c > 0, so the max of the raw scores is the max), and keys past
-      // the clip's length are masked only in the block that contains them
-      if (kb * KB + KB > T) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kb * KB + kt * 16 + kg * 4 + r >= T) st[kt][r] = -INFINITY;
-      }
-      float mloc = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[kt][r]);
-      const float cand = rows_max(mloc) * c;
-      // The reference point of the exponent moves only when some query of the tile found a score more than kTau above
-      // it (wave-uniform test): the accumulators are rescaled a few times per clip instead of once per block.  Numerator
-      // and denominator use the same reference, so the quotient is unchanged; p <= 2^kTau keeps bf16 / fp32 in range.
-      if (__any(cand > m_run[qi] + kTau)) {
-        const float m_new = fmaxf(m_run[qi], cand);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-        m_run[qi] = m_new;
-        if constexpr (!ONES_ROW) l_run[qi] *= alpha;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
-      }
-      const float m_ref = m_run[qi];
-      float psum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c, -m_ref));
-          if constexpr (!ONES_ROW) psum += st[kt][r];
-        }
-      if constexpr (!ONES_ROW) l_run[qi] += psum;
-      // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        uint4 pt;
-        pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
-        pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
-        pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-        pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-        pf[qi][ks] = *reinterpret_cast<bf16x8*>(&pt);
-      }
-    }
-
-    // O^T += V^T P^T: every V^T fragment read from LDS feeds up to EQT query tiles
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        if (dt * 16 >= DH) continue;
-        const bf16_t* vr = Vt + (dt * 16 + li) * VT_LD + ks * 32 + kg * 4;
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
-        uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
-#pragma unroll
-        for (int qi = 0; qi < EQT; ++qi)
-          o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[qi][ks], o[qi][dt], 0, 0, 0);
-      }
-    }
-  }
-
-#pragma unroll
-  for (int qi = 0; qi < EQT; ++qi) {
-    float l;
-    if constexpr (ONES_ROW) {   // row DH of O^T: tile DH / 16, lane group (DH % 16) / 4, register 0
-      l = __shfl(o[qi][DH / 16][0], ((DH % 16) / 4) * 16 + li);
-    } else {
-      l = rows_sum(l_run[qi]);
-    }
-    const float inv = 1.0f / l;
-    if (qi * NW + wave < tiles_per_wg && qrow[qi] < cm.rows) {
-      const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
-      bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int d = dt * 16 + kg * 4;
-        if (d < DH) {
-          uint2 w = make_uint2(0u, 0u);
-          if (valid) {
-            w.x = pack_bf16x2(o[qi][dt][0] * inv, o[qi][dt][1] * inv);
-            w.y = pack_bf16x2(o[qi][dt][2] * inv, o[qi][dt][3] * inv);
-          }
-          *reinterpret_cast<uint2*>(orow + d) = w;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Encoder attention with the keys and values of a (clip, head) RESIDENT in LDS (round 6).
-//
-// The kernel above walks the keys in 64-key blocks: fetch into registers, commit to LDS, workgroup barrier, compute -- seven
-// times per workgroup, and the two workgroups of a (clip, head) each stage every block.  PMC of that kernel and of the first
-// resident version (profiles/r6c_pmc_attn_*): one VALU instruction costs the SIMD 4.6 cycles whichever wave issues it, 109 of
-// them per (16-query tile, 64-key block) against 16 MFMAs of 16 cycles -- VALU issue is 42 % of the kernel's SIMD time, the
-// matrix pipe 19 %, and four waves per SIMD instead of two only moved 222 -> 209 us.  So the instruction count is the lever:
-//   * a 10 s clip has 415 keys: K [448][64] + V^T [64][448] bf16 is 113 KiB, which one workgroup per CU can hold.  One
-//     workgroup of NW waves per (clip, head) copies the clip's K rows and V^T rows into LDS ONCE -- every load of the thread in
-//     flight together, thread -> (key, piece) fixed so that every LDS address is one base + an immediate -- one barrier, and
-//     then every wave runs its query tiles (wave w: tiles w, w + NW, ...) over all key blocks with no barrier, no global load
-//     and no staging register in the loop;
-//   * the queries arrive PRE-SCALED: rsqrt(dh) * log2(e) is folded into the q rows of the fused QKV weight at load
-//     (Engine::load_weights; RoPE is a rotation, it commutes), so an MFMA score is already the exponent's argument;
-//   * the reference point of the online softmax rides in the ACCUMULATOR INIT of the score MFMA (C = -m per query column):
-//     the MFMA output is s - m, the 16 fused multiply-adds per tile and block are gone;
-//   * the "does the reference move?" test is per lane (any lane above kTau?): the cross-lane maximum is only formed in the
-//     rare branch that moves it;
-//   * a block is straight-line code for all of a wave's tiles (scores of every tile, ONE rarely taken branch, exponentials,
-//     P.V): the first version went tile by tile with three wave-uniform branches per tile and every tile's softmax sat in
-//     basic blocks of its own -- dependent VALU chains with nothing to interleave.
-// Per tile and block: 16 MFMAs, 8 v_max3 + 16 v_exp + 8 v_cvt_pk + 3 (was ~62 in the loop, ~109 with staging and epilogue).
-// Different rounding points from enc_attention_kernel (the reference enters the fp32 accumulation first instead of last):
-// equal to ~1e-6 in the exponent, not bit for bit.  KMAX = 448 keys (clips of up to 10.8 s); longer clips keep the
-// block-streaming kernel.  ABL (microbenchmark only, garbage results): 1 = no global loads while staging, 4 = no exp2,
-// 8 = no MFMAs, 16 = staging and epilogue only.
-// ------------------------------------------------------------------------------------------------
-template <int DH, int KMAX, int ABL = 0, int NW = 8, int EQT = 4>
-__global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                                   long vt_ld, bf16_t* __restrict__ out,
-                                                                   const ClipMeta* __restrict__ clips, int D) {
-  static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
-  static_assert(KMAX % 128 == 64, "V^T row stride (KMAX + 8) must be 72 mod 128 elements: conflict-free ds_read_b64");
-  static_assert(NW % 4 == 0 && NW * EQT * 16 >= KMAX, "every query tile of a KMAX-frame clip needs a slot");
-  constexpr int NT = 64 * NW;
-  constexpr int PIECES = DH / 4;            // 8-byte pieces per K row
-  constexpr int VLD = KMAX + 8;             // V^T row stride in bf16
-  constexpr int VROWS = (DH + 15) / 16 * 16;
-  constexpr int VCH = KMAX / 8;             // 16-byte chunks (8 keys) per V^T row
-  constexpr bool ONES_ROW = (DH % 16) != 0;
-  constexpr float kTau = 8.0f;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KMAX * 128 + VROWS * VLD * 2];
-  unsigned char* const Ks = lds_raw;                                   // [key][8 x 16 B], chunk ^= (key >> 1) & 7
-  bf16_t* const Vt = reinterpret_cast<bf16_t*>(lds_raw + KMAX * 128);   // [d][key]
-
-  const ClipMeta cm = clips[blockIdx.z];
-  const int h = blockIdx.y;
-  const int T = cm.T;
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long ld = 2L * D;   // [row][q | k]
-  const bf16_t* base = qk + (long)cm.row_start * ld + h * DH;
   const bf16_t* vbase = vt + (long)(h * DH) * vt_ld + cm.row_start;
-  const int nkb = (T + KB - 1) / KB, nkeys = nkb * KB;   // (the host guarantees nkeys <= KMAX)
+  const int nchunks = (T + KMAX - 1) / KMAX;
 
-  // ---- stage: every load of this thread first, then the LDS writes ----
+  // thread -> staging slots.  K: groups of 16 keys x PIECES pieces; iteration i adds 16 KG keys: the swizzle term
+  // (key >> 1) & 7 does not change, the LDS address is base + 2048 KG i.  V^T: (row within VR, 16-byte chunk); iteration i
+  // adds VR rows.
+  constexpr int KG = NT / (16 * PIECES);          // 16-key groups per iteration
+  constexpr int KIT = (KMAX + 16 * KG - 1) / (16 * KG);
+  constexpr int VR = NT / VCH, VIT = (DH + VR - 1) / VR;
+
+  // head-dim padding of K (pieces PIECES .. 15 of every key) and of V^T (rows DH .. VROWS - 1; row DH holds ones when it exists):
+  // written once, the chunks' staging never touches it
   {
-    // K: groups of 16 keys x PIECES pieces; thread -> (key within 32, piece) once, iteration i adds 32 keys: the swizzle term
-    // (key >> 1) & 7 does not change, the LDS address is base + 4096 i
-    constexpr int KG = NT / (16 * PIECES);          // 16-key groups per iteration
-    constexpr int KIT = (KMAX + 16 * KG - 1) / (16 * KG);
-    const int kgrp = tid / (16 * PIECES), ku = tid - kgrp * (16 * PIECES);
-    const int kkey0 = kgrp * 16 + ku / PIECES, kpiece = ku % PIECES;
-    const bool kthread = kgrp < KG;
-    // V^T: thread -> (row within VR, 16-byte chunk) once, iteration i adds VR rows
-    constexpr int VR = NT / VCH, VIT = (DH + VR - 1) / VR;
     const int vd0 = tid / VCH, vch = tid - vd0 * VCH;
     const bool vthread = vd0 < VR;
-    uint2 kreg[KIT];
-    uint4 vreg[VIT];
-    {
-      const bf16_t* kp = base + (long)kkey0 * ld + D + kpiece * 4;
-#pragma unroll
-      for (int i = 0; i < KIT; ++i) {
-        kreg[i] = make_uint2(0u, 0u);
-        if ((ABL & 1) == 0 && kthread && kkey0 + i * 16 * KG < T) kreg[i] = *reinterpret_cast<const uint2*>(kp + (long)i * (16 * KG) * ld);
-      }
-      const bf16_t* vp = vbase + (long)vd0 * vt_ld + vch * 8;
-#pragma unroll
-      for (int i = 0; i < VIT; ++i) {
-        vreg[i] = make_uint4(0u, 0u, 0u, 0u);
-        if ((ABL & 1) == 0 && vthread && vd0 + i * VR < DH && vch * 8 < T)   // (row_start and the chunk are multiples of 8 keys: 16-byte aligned)
-          vreg[i] = *reinterpret_cast<const uint4*>(vp + (long)i * VR * vt_ld);
-      }
-    }
-    // head-dim padding of K (pieces PIECES .. 15 of every key) and of V^T (rows DH .. VROWS - 1; row DH holds ones when it exists)
-    for (int p = tid; p < nkeys * (16 - PIECES); p += NT) {
+    const int npad = nchunks > 1 ? KMAX : (T + KB - 1) / KB * KB;
+    for (int p = tid; p < npad * (16 - PIECES); p += NT) {
       const int key = p / (16 - PIECES), piece = PIECES + (p - key * (16 - PIECES));
       *reinterpret_cast<uint2*>(Ks + key * 128 + (((piece >> 1) ^ ((key >> 1) & 7)) * 16 + (piece & 1) * 8)) = make_uint2(0u, 0u);
     }
-    if (vthread && vch * 8 < nkeys) {
+    if (vthread && vch * 8 < npad) {
 #pragma unroll
       for (int r = 0; r < VROWS - DH; r += VR)
         if (r + vd0 < VROWS - DH) {
@@ -476,44 +307,80 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
           *reinterpret_cast<uint4*>(Vt + (DH + r + vd0) * VLD + vch * 8) = make_uint4(fill, fill, fill, fill);
         }
     }
-    // keys >= T inside the last chunk that holds a valid one: exact zeros (the clip's padding rows hold arbitrary values)
-    unsigned vmask[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int nv = T - vch * 8;   // valid keys of this thread's chunk
-      vmask[e] = 2 * e + 1 < nv ? 0xffffffffu : (2 * e < nv ? 0xffffu : 0u);
-    }
-    if constexpr ((ABL & 2) != 0) {   // ablation: the loads are waited for, the kernel computes on zeros
-#pragma unroll
-      for (int e = 0; e < 4; ++e) vmask[e] = 0u;
-#pragma unroll
-      for (int i = 0; i < KIT; ++i) kreg[i] = make_uint2(kreg[i].x & vmask[0], kreg[i].y & vmask[1]);
-    }
-    if (kthread) {
-      unsigned char* kd = Ks + kkey0 * 128 + (((kpiece >> 1) ^ ((kkey0 >> 1) & 7)) * 16 + (kpiece & 1) * 8);
-#pragma unroll
-      for (int i = 0; i < KIT; ++i)
-        if (kkey0 + i * 16 * KG < nkeys) *reinterpret_cast<uint2*>(kd + i * (16 * KG) * 128) = kreg[i];
-    }
-    if (vthread && vch * 8 < nkeys) {
-      bf16_t* vd = Vt + vd0 * VLD + vch * 8;
-#pragma unroll
-      for (int i = 0; i < VIT; ++i)
-        if (vd0 + i * VR < DH)
-          *reinterpret_cast<uint4*>(vd + i * VR * VLD) = make_uint4(vreg[i].x & vmask[0], vreg[i].y & vmask[1], vreg[i].z & vmask[2], vreg[i].w & vmask[3]);
-    }
   }
 
+  // One chunk of KMAX keys: stage (every load of this thread first, then the LDS writes) ...
+  auto stage = [&](int ch) {
+    const int c0 = ch * KMAX;                       // first key of the chunk
+    const int Tc = T - c0 < KMAX ? T - c0 : KMAX;   // valid keys in it
+    const int nkeys = (Tc + KB - 1) / KB * KB;
+    {
+      // (the thread's slots are re-derived from an opaque copy of the thread index in every chunk: hoisted out of the chunk
+      // loop they stayed live through the key blocks and pushed the kernel 324 bytes per lane into scratch)
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));
+      const int kgrp = t2 / (16 * PIECES), ku = t2 - kgrp * (16 * PIECES);
+      const int kkey0 = kgrp * 16 + ku / PIECES, kpiece = ku % PIECES;
+      const bool kthread = kgrp < KG;
+      const int vd0 = t2 / VCH, vch = t2 - vd0 * VCH;
+      const bool vthread = vd0 < VR;
+      uint2 kreg[KIT];
+      uint4 vreg[VIT];
+      {
+        const bf16_t* kp = base + (long)(c0 + kkey0) * ld + D + kpiece * 4;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+          kreg[i] = make_uint2(0u, 0u);
+          if ((ABL & 1) == 0 && kthread && kkey0 + i * 16 * KG < Tc) kreg[i] = *reinterpret_cast<const uint2*>(kp + (long)i * (16 * KG) * ld);
+        }
+        const bf16_t* vp = vbase + (long)vd0 * vt_ld + c0 + vch * 8;
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+          vreg[i] = make_uint4(0u, 0u, 0u, 0u);
+          if ((ABL & 1) == 0 && vthread && vd0 + i * VR < DH && vch * 8 < Tc)   // (row_start, c0 and the chunk are multiples of 8 keys: 16-byte aligned)
+            vreg[i] = *reinterpret_cast<const uint4*>(vp + (long)i * VR * vt_ld);
+        }
+      }
+      // keys >= T inside the last chunk of 8 that holds a valid one: exact zeros (the clip's padding rows hold arbitrary values)
+      unsigned vmask[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nv = Tc - vch * 8;   // valid keys of this thread's chunk
+        vmask[e] = 2 * e + 1 < nv ? 0xffffffffu : (2 * e < nv ? 0xffffu : 0u);
+      }
+      if constexpr ((ABL & 2) != 0) {   // ablation: the loads are waited for, the kernel computes on zeros
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vmask[e] = 0u;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) kreg[i] = make_uint2(kreg[i].x & vmask[0], kreg[i].y & vmask[1]);
+      }
+      if (ch > 0) __syncthreads();   // every wave has finished the previous chunk's blocks
+      if (kthread) {
+        unsigned char* kd = Ks + kkey0 * 128 + (((kpiece >> 1) ^ ((kkey0 >> 1) & 7)) * 16 + (kpiece & 1) * 8);
+#pragma unroll
+        for (int i = 0; i < KIT; ++i)
+          if (kkey0 + i * 16 * KG < nkeys) *reinterpret_cast<uint2*>(kd + i * (16 * KG) * 128) = kreg[i];
+      }
+      if (vthread && vch * 8 < nkeys) {
+        bf16_t* vd = Vt + vd0 * VLD + vch * 8;
+#pragma unroll
+        for (int i = 0; i < VIT; ++i)
+          if (vd0 + i * VR < DH)
+            *reinterpret_cast<uint4*>(vd + i * VR * VLD) = make_uint4(vreg[i].x & vmask[0], vreg[i].y & vmask[1], vreg[i].z & vmask[2], vreg[i].w & vmask[3]);
+      }
+    }
+  };
+  stage(0);   // (before the queries and the accumulators exist: the 52 staging registers of a 10 s clip's one chunk are free then)
+
   // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
-  bool act[EQT];
-  int qrow[EQT];
   bf16x8 qf[EQT][2];
+  int nact = 0;   // the wave's active tiles are its first `nact` (the tile index grows with qi)
 #pragma unroll
   for (int qi = 0; qi < EQT; ++qi) {
-    const int tile = qi * NW + wave;
-    act[qi] = tile * 16 < T;   // wave-uniform
-    qrow[qi] = tile * 16 + li;
-    const int qrow_ld = qrow[qi] < cm.rows ? qrow[qi] : cm.rows - 1;
+    const int tile = tile0 + qi * NW + wave;
+    nact += (int)(tile * 16 < T);   // wave-uniform
+    const int qrow = tile * 16 + li;
+    const int qrow_ld = qrow < cm.rows ? qrow : cm.rows - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int d = s * 32 + kg * 8;
@@ -524,10 +391,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
       qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
     }
   }
-  __syncthreads();   // the one barrier: K and V^T of the (clip, head) are in LDS
-
-  // nm[qi] = MINUS the reference point of tile qi's exponent, as the four accumulator registers the score MFMAs start from.
-  // It starts at 0 and the first block always moves it to the block's maximum (o and l are still zero then).
+  // nm[qi] = MINUS the reference point of tile qi's exponent (att_key_block): 0 until the first block moves it
   f32x4 nm[EQT];
   float l_run[EQT];
   f32x4 o[EQT][4];
@@ -539,135 +403,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
     for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // One key block for the wave's first NA query tiles, as a PIPELINE over the tiles: while tile i's scores go through
-  // max / (rare) reference move / exp2 / bf16 packing on the vector pipe, tile i + 1's score MFMAs run on the matrix pipe, and
-  // tile i's P.V MFMAs run beside tile i + 1's maxima.  Between two tiles there is exactly one rarely taken wave-uniform
-  // branch (does this tile's reference point move?); everything else of a tile is one basic block holding 16 MFMAs and
-  // ~36 VALU instructions for the scheduler to interleave.  (The version before this one did all score MFMAs of a block, then
-  // all maxima, one branch, all exponentials, then all P.V MFMAs: PMC showed the SIMD's VALU busy 37 % and its matrix pipe
-  // 23 % of the time with next to no overlap -- a wave alternated between phases that each use ONE of the two pipes, and two
-  // waves per SIMD are too few for chance to interleave them.)  MASKED: the block holds the clip's last valid key (compiled
-  // once more, with the -inf selects).
-  auto block = [&](int kb, auto na_c, auto masked_c) {
-    constexpr int NA = decltype(na_c)::value;
-    constexpr bool MASKED = decltype(masked_c)::value;
-    const uint4* Kb = reinterpret_cast<const uint4*>(Ks) + kb * (KB * 8);
-    const bf16_t* Vb = Vt + kb * KB;
-    uint4 kf[4][2];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int key = kt * 16 + li;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) kf[kt][s] = Kb[key * 8 + ((s * 4 + kg) ^ ((key >> 1) & 7))];
-    }
-    // st[kt][r] = score(q = li of the tile, key = kb*64 + kt*16 + kg*4 + r) - reference, in the exp2 domain
-    auto scores = [&](auto qc, f32x4 (&st)[4]) {
-      constexpr int qi = decltype(qc)::value;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        f32x4 a = nm[qi];
-        if constexpr ((ABL & 8) == 0) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&kf[kt][s]), qf[qi][s], a, 0, 0, 0);
-        } else {
-          asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(kf[kt][0].x), "v"(kf[kt][1].w), "v"(qf[qi][0][0]));
-        }
-        st[kt] = a;
-      }
+  // ... and compute: whole blocks first, then the one that holds the clip's last valid key
+  auto compute = [&](int ch) {
+    const int c0 = ch * KMAX;
+    const int Tc = T - c0 < KMAX ? T - c0 : KMAX;
+    const int nkb = (Tc + KB - 1) / KB, nfull = Tc / KB;
+
+    // whole blocks first, then the one that holds the clip's last valid key
+    auto run = [&](auto na_c) {
+      constexpr int NA = decltype(na_c)::value;
+      const uint4* K4 = reinterpret_cast<const uint4*>(Ks);
+      for (int kb = 0; kb < nfull; ++kb)
+        att_key_block<DH, VLD, EQT, NA, false, ABL>(K4 + kb * (KB * 8), Vt + kb * KB, ch == 0 && kb == 0, 0, li, kg, qf, nm, o, l_run);
+      if (nfull < nkb)
+        att_key_block<DH, VLD, EQT, NA, true, ABL>(K4 + nfull * (KB * 8), Vt + nfull * KB, ch == 0 && nfull == 0, Tc - nfull * KB, li, kg, qf, nm, o, l_run);
     };
-    f32x4 sa[4], sb[4];
-    scores(std::integral_constant<int, 0>{}, sa);
-    static_for_att<NA>([&](auto qc) {
-      constexpr int qi = decltype(qc)::value;
-      f32x4(&st)[4] = (qi & 1) ? sb : sa;
-      f32x4(&sn)[4] = (qi & 1) ? sa : sb;
-      if constexpr (MASKED) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[kt][r] = (kb * KB + kt * 16 + kg * 4 + r >= T) ? -INFINITY : st[kt][r];
-      }
-      float m = -INFINITY;   // (this sequential form compiles to eight v_max3_f32; nested pairs came out as 21 v_max_f32 + 4 v_max3)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][r]);
-      // The reference point of a tile moves only when one of its queries found a score more than kTau above it: a few times
-      // per clip (and always in the first block).  Numerator and denominator use the same reference; p <= 2^kTau keeps bf16 /
-      // fp32 in range.
-      if (kb == 0 || __any(m > kTau)) {
-        const float delta = rows_max(m);                      // per query: the block's maximum above the old reference
-        const float alpha = __builtin_amdgcn_exp2f(-delta);   // (delta is finite: key 0 is valid for every query)
-        const float nmv = nm[qi][0] - delta;
-        nm[qi] = f32x4{nmv, nmv, nmv, nmv};
-        if (kb != 0) {   // (o and l are zero in the first block, and alpha may be 2^(+large) = inf there)
-          if constexpr (!ONES_ROW) l_run[qi] *= alpha;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[kt][r] -= delta;
-      }
-      // ---- one basic block from here to the next tile's branch ----
-      if constexpr (qi + 1 < NA) scores(std::integral_constant<int, qi + 1>{}, sn);   // matrix pipe, independent of this tile
-      float psum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr ((ABL & 4) == 0) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]);
-          if constexpr (!ONES_ROW) psum += st[kt][r];
-        }
-      if constexpr (!ONES_ROW) l_run[qi] += psum;
-      // P^T fragments.  MFMA k-slot (kg, e): e < 4 -> key ks*32 + kg*4 + e, e >= 4 -> key ks*32 + 16 + kg*4 + e-4
-      bf16x8 pf[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        uint4 pt;
-        pt.x = pack_bf16x2(st[2 * ks][0], st[2 * ks][1]);
-        pt.y = pack_bf16x2(st[2 * ks][2], st[2 * ks][3]);
-        pt.z = pack_bf16x2(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-        pt.w = pack_bf16x2(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-        pf[ks] = *reinterpret_cast<bf16x8*>(&pt);
-      }
-      // O^T += V^T P^T
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          if (dt * 16 >= DH) continue;
-          const bf16_t* vr = Vb + (dt * 16 + li) * VLD + ks * 32 + kg * 4;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
-          uint4 vtf = make_uint4(v0.x, v0.y, v1.x, v1.y);
-          if constexpr ((ABL & 8) == 0) {
-            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vtf), pf[ks], o[qi][dt], 0, 0, 0);
-          } else {
-            asm volatile("" : "+v"(o[qi][dt][0]), "+v"(o[qi][dt][3]) : "v"(vtf.x), "v"(vtf.w), "v"(pf[ks][0]), "v"(pf[ks][7]));
-          }
-        }
-      }
-    });
-  };
-  // the wave's active tiles are its first `nact` (tile qi * NW + wave grows with qi); whole blocks first, then the masked one
-  int nact = 0;
-#pragma unroll
-  for (int qi = 0; qi < EQT; ++qi) nact += (int)act[qi];
-  const int nfull = T / KB;
-  auto run = [&](auto na_c) {
-    for (int kb = 0; kb < nfull; ++kb) block(kb, na_c, std::false_type{});
-    if (nfull < nkb) block(nfull, na_c, std::true_type{});
-  };
-  if constexpr ((ABL & 16) == 0) {
     switch (nact) {
       case 4: if constexpr (EQT >= 4) run(std::integral_constant<int, 4>{}); break;
       case 3: if constexpr (EQT >= 3) run(std::integral_constant<int, 3>{}); break;
       case 2: if constexpr (EQT >= 2) run(std::integral_constant<int, 2>{}); break;
       case 1: run(std::integral_constant<int, 1>{}); break;
       default: break;
+    }
+  };
+  __syncthreads();   // the first chunk's K and V^T are in LDS
+  compute(0);
+  if constexpr (MULTI) {
+    for (int ch = 1; ch < nchunks; ++ch) {   // clips of more than KMAX frames (10.8 s)
+      stage(ch);
+      __syncthreads();
+      compute(ch);
     }
   }
 
@@ -680,9 +445,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
       l = rows_sum(l_run[qi]);
     }
     const float inv = 1.0f / l;
-    if (qrow[qi] < cm.rows) {
-      const bool valid = qrow[qi] < T;   // padding rows of the clip are written as zeros
-      bf16_t* orow = out + (long)(cm.row_start + qrow[qi]) * D + h * DH;
+    const int qrow = (tile0 + qi * NW + wave) * 16 + li;
+    if (qrow < cm.rows) {
+      const bool valid = qrow < T;   // padding rows of the clip are written as zeros
+      bf16_t* orow = out + (long)(cm.row_start + qrow) * D + h * DH;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int d = dt * 16 + kg * 4;
@@ -1144,44 +910,16 @@ void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta*
 void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows,
                    int D, int heads, hipStream_t s) {
   const int dh = D / heads;
-  // 16-query tiles, four per wave at most.  Long clips (a 10 s clip is 415 frames = 26 tiles): two workgroups of 4 waves
-  // per (clip, head), 13 tiles each -- two of them share a CU (232 VGPRs), so one's barriers and prologue are covered by
-  // the other; MSH_ENC_ATT_WIDE=1 selects the earlier shape, one workgroup of 7 waves (28 tile slots) alone on its CU.
-  static const bool wide_wg = [] {
-    const char* e = dev_getenv("MSH_ENC_ATT_WIDE");
-    return e != nullptr && e[0] == '1';
-  }();
-  static const bool two_tiles = [] {
-    const char* e = dev_getenv("MSH_ENC_ATT_EQT");
-    return e != nullptr && e[0] == '2';
-  }();
-  // Clips of 257 .. 448 frames (a 10 s clip has 415): keys and values resident in LDS, one 8-wave workgroup per (clip, head),
-  // no barrier in the key loop (enc_attention_res_kernel; MSH_ENC_ATT_RES=0: the block-streaming kernel below)
-  static const bool resident = [] {
-    const char* e = dev_getenv("MSH_ENC_ATT_RES");
-    return !(e != nullptr && e[0] == '0');
-  }();
+  // One 8-wave workgroup per (clip, head, 512 queries): a 10 s clip (415 frames = 26 tiles of 16 queries) is one workgroup
+  // and one chunk of keys; longer clips get more workgroups along x, each walking all keys in chunks of 448.
   if (n_clips > 65535) throw std::runtime_error("enc_attention: more than 65535 clips in one batch");
-  if (resident && max_rows > 256 && max_rows <= 448 && (dh == 52 || dh == 36)) {
-    dim3 grid(1, heads, n_clips);
-    if (dh == 52) MSH_LAUNCH((enc_attention_res_kernel<52, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
-    else MSH_LAUNCH((enc_attention_res_kernel<36, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
-    return;
-  }
   const int ntiles = (max_rows + 15) / 16;
-  const bool wide = wide_wg && ntiles > 16 && ntiles <= 28;
-  const int slots = wide ? 28 : (two_tiles ? 8 : 16);
-  const int gx = (ntiles + slots - 1) / slots;
-  const int tiles_per_wg = (ntiles + gx - 1) / gx;
-  dim3 grid(gx, heads, n_clips);
-#define MSH_EATT(DHV)                                                                                                       \
-  case DHV:                                                                                                                 \
-    if (wide)                                                                                                               \
-      MSH_LAUNCH((enc_attention_kernel<DHV, 7>), grid, dim3(448), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
-    else if (two_tiles)                                                                                                     \
-      MSH_LAUNCH((enc_attention_kernel<DHV, 4, 2>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);    \
-    else                                                                                                                    \
-      MSH_LAUNCH((enc_attention_kernel<DHV, 4>), grid, dim3(256), 0, s, qk, vt, vt_ld, out, clips, D, tiles_per_wg);       \
+  dim3 grid((ntiles + 31) / 32, heads, n_clips);
+  const bool multi = max_rows > 448;   // (rows >= frames: no clip of the batch has more than one chunk of keys otherwise)
+#define MSH_EATT(DHV)                                                                                                                  \
+  case DHV:                                                                                                                            \
+    if (multi) MSH_LAUNCH((enc_attention_res_kernel<DHV, 448, 0, 8, 4, true>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);   \
+    else MSH_LAUNCH((enc_attention_res_kernel<DHV, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);                        \
     break
   switch (dh) {
     MSH_EATT(52);
@@ -1193,9 +931,10 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
 }
 
 // Microbenchmark / test hook (include/moonshine_hip_dev.h msh_test_enc_attention): n_clips clips of T frames at width D on
-// uniform random q | k / V^T; variant 0 = the block-streaming kernel (two 4-wave workgroups per (clip, head)), 1 = its 7-wave
-// shape, 2 = two query tiles per wave, 100 + abl = the LDS-resident kernel with ablation bits `abl` (0 = the product kernel).
-// Returns ms per launch; out (nullable) [R][D] receives the last launch's output as bf16 bit patterns.
+// uniform random q | k / V^T; variant 0 = the product kernel (8 waves x 4 tiles, clips of up to 448 frames), 1 = its
+// instantiation with the chunk loop (any length), 50 / 51 = 12 waves x 3 tiles / 16 waves x 2 tiles, 100 + abl = the product
+// shape with ablation bits `abl`.  Returns ms per launch; out (nullable) [R][D] receives the
+// last launch's output as bf16 bit patterns.
 float enc_attention_microbench(int variant, int n_clips, int T, int D, int heads, int iters, uint16_t* out_host) {
   const int dh = D / heads;
   if (dh != 52 || T < 1 || n_clips < 1 || heads * dh != D) throw std::runtime_error("enc_attention_microbench: head_dim 52 only");
@@ -1232,41 +971,35 @@ float enc_attention_microbench(int variant, int n_clips, int T, int D, int heads
   MSH_HIP(hipMemset(O, 0xff, (size_t)R * D * 2));
   const int ntiles = (rows + 15) / 16;
   auto run = [&] {
-    if (variant >= 100) {
-      if (rows > 448) throw std::runtime_error("enc_attention_microbench: the resident kernel holds 448 keys");
-      dim3 grid(1, heads, n_clips);
+    dim3 grid((ntiles + 31) / 32, heads, n_clips);
 #define MSH_RES(A)                                                                                                      \
   case A:                                                                                                               \
     MSH_LAUNCH((enc_attention_res_kernel<52, 448, A>), grid, dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);   \
     break
-      switch (variant - 100) {
-        MSH_RES(0);
-        MSH_RES(1);
-        MSH_RES(2);
-        MSH_RES(4);
-        MSH_RES(5);
-        MSH_RES(8);
-        MSH_RES(9);
-        MSH_RES(13);
-        MSH_RES(16);
-        default: throw std::runtime_error("enc_attention_microbench: ablation not compiled");
-      }
+    if (variant == 50) {
+      dim3 g2((ntiles + 35) / 36, heads, n_clips);
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 12, 3>), g2, dim3(768), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      return;
+    }
+    if (variant == 51) {
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 16, 2>), grid, dim3(1024), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      return;
+    }
+    if (variant == 1) {   // the instantiation with the chunk loop (any clip length)
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 4, true>), grid, dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      return;
+    }
+    if (variant != 1 && rows > 448) throw std::runtime_error("enc_attention_microbench: only variant 1 walks more than 448 keys");
+    switch (variant >= 100 ? variant - 100 : variant) {
+      MSH_RES(0);
+      MSH_RES(1);
+      MSH_RES(2);
+      MSH_RES(4);
+      MSH_RES(8);
+      MSH_RES(12);
+      default: throw std::runtime_error("enc_attention_microbench: variant / ablation not compiled");
+    }
 #undef MSH_RES
-      return;
-    }
-    if (variant == 50 || variant == 51) {   // the resident kernel at 12 waves x 3 tiles / 16 waves x 2 tiles
-      if (rows > 448) throw std::runtime_error("enc_attention_microbench: the resident kernel holds 448 keys");
-      dim3 grid(1, heads, n_clips);
-      if (variant == 50) MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 12, 3>), grid, dim3(768), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
-      else MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 16, 2>), grid, dim3(1024), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
-      return;
-    }
-    const int slots = variant == 1 ? 28 : variant == 2 ? 8 : 16;
-    const int gx = (ntiles + slots - 1) / slots, tpw = (ntiles + gx - 1) / gx;
-    dim3 grid(gx, heads, n_clips);
-    if (variant == 1) MSH_LAUNCH((enc_attention_kernel<52, 7>), grid, dim3(448), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
-    else if (variant == 2) MSH_LAUNCH((enc_attention_kernel<52, 4, 2>), grid, dim3(256), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
-    else MSH_LAUNCH((enc_attention_kernel<52, 4>), grid, dim3(256), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D, tpw);
   };
   run();
   MSH_HIP(hipDeviceSynchronize());
