@@ -167,12 +167,6 @@ MSH_EXPORT int64_t msh_submit_transcribe_tokens(msh_engine* e, const float* cons
 /* Block until that batch is done; returns its status (msh_last_error has the message).  One wait per ticket. */
 MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
 
-/* Test hook: copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
- * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]; "cross_k", "cross_v": K^T / V^T of the last
- * msh_encode, [layers][hidden * keys] at 2 bytes (bf16) or 1 byte (fp8) per key) to host memory; returns the buffer's
- * size in bytes, -1 on error.  "graph_captures" (dst unused) returns the number of decode-step hipGraphs this engine has
- * instantiated so far (captured steps are cached per batch shape).  No reference counterpart (ORT owns these tensors there). */
-MSH_EXPORT int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
 /* Form of the decoder's cross-attention (additive; the reference's graphs always project K and V).  ONE form per engine,
  * whatever the batch size -- a clip's token ids never depend on how many clips share its batch:
  *   1 (and 0, the default) = the projected K^T / V^T stream, the reference's form;

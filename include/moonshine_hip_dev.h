@@ -63,6 +63,13 @@ MSH_EXPORT float msh_test_crossq2(const float* x, const float* wq, const float* 
 MSH_EXPORT float msh_test_enc_attention(int32_t variant, int32_t n_clips, int32_t T, int32_t D, int32_t heads, int32_t iters,
                                         uint16_t* out);
 
+/* Test hook (an engine created through THIS library): copy min(bytes, size) bytes of a named decode buffer of the last msh_decode call ("cache_k", "cache_v":
+ * bf16 [layers][clips][heads][Smax][head_dim]; "resid": fp32 [clips][hidden]; "cross_k", "cross_v": K^T / V^T of the last
+ * msh_encode, [layers][hidden * keys] at 2 bytes (bf16) or 1 byte (fp8) per key) to host memory; returns the buffer's
+ * size in bytes, -1 on error.  "graph_captures" (dst unused) returns the number of decode-step hipGraphs this engine has
+ * instantiated so far (captured steps are cached per batch shape).  No reference counterpart (ORT owns these tensors there). */
+MSH_EXPORT int64_t msh_test_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

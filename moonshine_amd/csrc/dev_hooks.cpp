@@ -62,6 +62,10 @@ int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const 
   }
 }
 
+extern "C" int64_t msh_internal_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes);   // msh_api.cpp, not exported
+
+int64_t msh_test_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) { return msh_internal_debug_read(e, name, dst, bytes); }
+
 float msh_test_enc_attention(int32_t variant, int32_t n_clips, int32_t T, int32_t D, int32_t heads, int32_t iters, uint16_t* out) {
   try {
     return msh::enc_attention_microbench(variant, n_clips, T, D, heads, iters, out);

@@ -328,7 +328,8 @@ int64_t msh_get_cross_attention(msh_engine* e, uint32_t clip, float* out, uint64
   return (int64_t)d[0] * d[1] * d[2];
 }
 
-int64_t msh_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) {
+// (not exported: the development library's msh_test_debug_read, dev_hooks.cpp, reads decode buffers through this)
+int64_t msh_internal_debug_read(msh_engine* e, const char* name, void* dst, uint64_t bytes) {
   int64_t v = -1;
   guarded(e, [&] { v = (int64_t)e->eng->debug_read(name ? name : "", dst, bytes); });
   return v;

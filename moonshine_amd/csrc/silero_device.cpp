@@ -137,6 +137,17 @@ void SileroDevice::release_audio() {
   for (const Slot& sl : slots_) busy |= sl.busy;
   if (busy || next_collect_ != next_ticket_) abandon();
   arena_used_ = 0, arena_live_bytes_ = 0;
+  // Keep what a typical call needs warm (kArenaKeep bytes of buffers, reused by the next call) and give the rest back: one
+  // 2048-clip call otherwise left up to kArenaBudget = 8 GiB allocated for the transcriber's lifetime beside the engines'
+  // workspaces.  (Nothing of the arena is in flight here: every ticket was collected or abandoned above.)
+  size_t kept = 0;
+  size_t keep_n = 0;
+  for (; keep_n < arena_.size(); ++keep_n) {
+    if (kept + arena_[keep_n]->cap > kArenaKeep) break;
+    kept += arena_[keep_n]->cap;
+  }
+  for (size_t i = keep_n; i < arena_.size(); ++i) arena_[i]->release();   // (takes the device's structure lock itself)
+  arena_.resize(keep_n);
 }
 
 void SileroDevice::abandon() {
@@ -232,8 +243,16 @@ int64_t SileroDevice::submit_any(const float* const* pcm, const int16_t* const* 
   DevBuf* abuf = &sl.audio;
   if (keep_audio && arena_live_bytes_ + bytes <= kArenaBudget) {
     if (arena_used_ == arena_.size()) arena_.emplace_back(new DevBuf());
-    abuf = arena_[arena_used_++].get();
-    arena_live_bytes_ += bytes;
+    DevBuf* kept = arena_[arena_used_].get();
+    try {   // no device memory for a buffer of its own is "no residency for this chunk" (the engine uploads its segments from
+            // the host), not a failure of the device VAD
+      kept->reserve(bytes + 4096);
+      abuf = kept;
+      ++arena_used_;
+      arena_live_bytes_ += bytes;
+    } catch (const std::exception&) {
+      (void)hipGetLastError();
+    }
   }
   // buffers only this slot's work touches (it was collected: nothing of it is in flight)
   abuf->reserve(bytes + 4096);   // (the last hop's reflect padding reads inside its own 576 samples: no over-read)
@@ -292,12 +311,15 @@ void SileroDevice::collect(int64_t ticket, std::vector<float>* probs, std::vecto
   Slot& sl = slots_[ticket % kSlots];
   if (!sl.busy || sl.ticket != ticket) throw std::invalid_argument("device VAD: unknown ticket " + std::to_string(ticket));
   if (ticket != next_collect_) throw std::invalid_argument("device VAD: tickets are collected in the order they were given");
-  ++next_collect_;
-  sl.busy = false;
   probs->clear();
   if (resident != nullptr) resident->assign(sl.nc, nullptr);
+  // the slot only counts as collected once its work is known to be done: if the wait throws, the slot stays busy (a following
+  // submit must not free or reuse its pinned block and device buffers under an upload / read-back still in flight) and the
+  // caller's failure path (abandon) drains the stream
+  if (sl.hops != 0) MSH_HIP(hipEventSynchronize(sl.done));
+  ++next_collect_;
+  sl.busy = false;
   if (sl.hops == 0) return;
-  MSH_HIP(hipEventSynchronize(sl.done));
   static const bool timing = getenv("MSH_HOST_TIMING") != nullptr;
   if (timing)
     MSH_LOGF("device VAD: %zu clips, %.0f MB gathered into pinned memory in %.2f ms, upload + network + read-back done %.2f ms after "

@@ -46,6 +46,7 @@ class SileroDevice {
   // (submissions never collected -- a caller that gave up half-way -- are waited for and forgotten)
   void release_audio();
   static constexpr size_t kArenaBudget = (size_t)8 << 30;
+  static constexpr size_t kArenaKeep = (size_t)2 << 30;   // kept-audio buffers that survive release_audio() for the next call
 
  private:
   void upload_weights(const msh_host::SileroWeights& w);

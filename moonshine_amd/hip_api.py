@@ -78,7 +78,6 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_profile_event_overhead_ms": (C.c_double, [vp, i32]),
         "msh_profile_cross_attention_ms": (C.c_double, [vp, i32]),
         "msh_profile_decode_chain": (i32, [vp, i32]),
-        "msh_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
         "msh_set_capture_cross_attention": (i32, [vp, i32]),
         "msh_get_cross_attention": (C.c_int64, [vp, C.c_uint32, vp, C.c_uint64, vp]),
         "msh_set_batches_in_flight": (i32, [vp, i32]),
@@ -137,9 +136,10 @@ def load_dev_library() -> C.CDLL:
     p = os.path.join(os.path.dirname(LIB_PATH), "libmoonshine_dev.so")
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not found: run `python -m moonshine_amd.build`")
-    lib = C.CDLL(p)
+    lib = load_library(p)    # (every product prototype: the development library exports the whole product API too)
     vp, i32 = C.c_void_p, C.c_int32
     protos = {
+        "msh_test_debug_read": (C.c_int64, [vp, C.c_char_p, vp, C.c_uint64]),
         "msh_test_device_alloc": (i32, []),
         "msh_test_gemm_microbench": (C.c_float, [i32, i32, i32, C.c_int64, i32, i32, i32]),
         "msh_test_mlp_microbench": (C.c_float, [i32, i32, i32, i32, i32]),
@@ -158,14 +158,14 @@ def load_dev_library() -> C.CDLL:
     return lib
 
 
-DEV_SYMBOLS = ["msh_test_device_alloc", "msh_test_gemm_microbench", "msh_test_mlp_microbench", "msh_test_mlp_run",
+DEV_SYMBOLS = ["msh_test_debug_read", "msh_test_device_alloc", "msh_test_gemm_microbench", "msh_test_mlp_microbench", "msh_test_mlp_run",
                "msh_test_mlp_oproj_run", "msh_test_qkv_panel", "msh_test_cross_absorbed", "msh_test_crossq2", "msh_test_enc_attention"]
 
 DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",
     "msh_load_weights_memory", "msh_model_info_get", "msh_encode", "msh_decode", "msh_transcribe_tokens",
     "msh_max_decode_steps", "msh_clip_frames", "msh_set_keep_encoder_output", "msh_get_encoder_output", "msh_set_kv_dtype",
-    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_profile_decode_chain", "msh_debug_read",
+    "msh_profile_enable", "msh_profile_reset", "msh_profile_count", "msh_profile_get", "msh_synchronize", "msh_profile_event_overhead_ms", "msh_profile_cross_attention_ms", "msh_profile_decode_chain",
     "msh_set_batches_in_flight", "msh_submit_transcribe_tokens", "msh_wait", "msh_set_capture_cross_attention", "msh_get_cross_attention",
     "msh_host_tokens_to_text", "msh_host_sanitize_utf8", "msh_host_resample", "msh_host_text_to_tokens",
     "msh_host_biaser_bonuses", "msh_host_context_terms", "msh_host_dtw", "msh_host_median_filter", "msh_host_align_words", "msh_host_load_wav", "msh_host_save_wav", "msh_set_hw_queues", "msh_host_silero_probabilities", "msh_host_vad_segments", "msh_stream_create", "msh_stream_create_from_memory", "msh_stream_destroy",
@@ -181,8 +181,11 @@ DECLARED_SYMBOLS = [
 class Engine:
     """One MI355X engine (one GPU, one stream).  Thin, typed wrapper; no arithmetic here."""
 
-    def __init__(self, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, dev: bool = False):
+        """dev = True: the engine lives in libmoonshine_dev.so (same objects + the msh_test_* hooks), which is what debug_read /
+        graph_captures need -- the product library exports no test hook."""
+        self.lib = load_dev_library() if dev else load_library()
+        self.dev = dev
         h = C.c_void_p()
         rc = self.lib.msh_create(device, C.byref(h))
         if rc != 0:
@@ -261,7 +264,12 @@ class Engine:
 
     def graph_captures(self) -> int:
         """Decode-step hipGraphs instantiated so far (captured steps are cached per batch shape)."""
-        return int(self.lib.msh_debug_read(self.h, b"graph_captures", None, 0))
+        return int(self._debug_read_fn()(self.h, b"graph_captures", None, 0))
+
+    def _debug_read_fn(self):
+        if not self.dev:
+            raise MshError(-1, "debug_read / graph_captures need Engine(dev=True): the product library exports no test hook")
+        return self.lib.msh_test_debug_read
 
     def cross_absorbed(self) -> bool:
         return bool(self.lib.msh_cross_absorbed(self.h))
@@ -381,11 +389,12 @@ class Engine:
 
     def debug_read(self, name: str) -> np.ndarray:
         """Raw bytes of a decode buffer of the last decode() ("cache_k", "cache_v", "resid") -- test hook."""
-        size = int(self.lib.msh_debug_read(self.h, name.encode(), None, 0))
+        fn = self._debug_read_fn()
+        size = int(fn(self.h, name.encode(), None, 0))
         if size < 0:
             raise MshError(-1, (self.lib.msh_last_error(self.h) or b"").decode())
         out = np.empty(size, np.uint8)
-        self.lib.msh_debug_read(self.h, name.encode(), out.ctypes.data, size)
+        fn(self.h, name.encode(), out.ctypes.data, size)
         return out
 
 

@@ -135,7 +135,7 @@ def test_cross_kv_on_the_panel_kernel_vs_oracle(tmp_path_factory, monkeypatch, a
     from test_gpu_parity import LOGIT_MAXABS, _engine, _teacher_logit_check
 
     monkeypatch.setenv("MSH_ENC_CROSS_KV_PANEL", "2")     # (read at load as well: the packed weight is only uploaded on request)
-    e, w, cfg = _engine(tmp_path_factory, arch, 5)
+    e, w, cfg = _engine(tmp_path_factory, arch, 5, dev=True)   # (debug_read: the development library's hook)
     if kv == "fp8":
         e.set_kv_dtype("fp8")
     clips = [make_audio(90 + i, n) for i, n in enumerate([160000, 52000, 159744, 3000, 100000])]

@@ -25,7 +25,8 @@ LOGIT_MAXABS = 5e-2
 MARGIN = 0.1
 
 
-def _engine(tmp_path_factory, arch, seed=0, weights=None):
+def _engine(tmp_path_factory, arch, seed=0, weights=None, dev=False):
+    """dev = True: an engine of the development library (debug_read / graph_captures are hooks of that library only)."""
     from moonshine_amd.hip_api import Engine
 
     cfg = ARCHS[arch]
@@ -33,7 +34,7 @@ def _engine(tmp_path_factory, arch, seed=0, weights=None):
     d = tmp_path_factory.mktemp(f"w_{arch}_{seed}")
     path = os.path.join(d, "model.safetensors")
     save_safetensors(path, w, {"arch": cfg.name, "heads": str(cfg.heads)})
-    e = Engine(0)
+    e = Engine(0, dev=dev)
     e.load_weights_file(path)
     os.remove(path)
     return e, w, cfg

@@ -286,7 +286,7 @@ def test_decode_graphs_are_cached_per_shape(tmp_path_factory):
     """Captured decode steps are kept per batch shape in a small LRU (engine.cpp DecodeGroup::graphs): alternating between
     shapes the engine has seen costs no further capture, a changing step budget inside one capacity bucket is the SAME
     shape, and the multi-step graph of a new shape is only built when the shape comes back."""
-    e, w, cfg = tp._engine(tmp_path_factory, "tiny", 4)
+    e, w, cfg = tp._engine(tmp_path_factory, "tiny", 4, dev=True)   # (graph_captures: the development library's hook)
     a = [make_audio(500 + i, 32000) for i in range(6)]
     b = [make_audio(520 + i, 36000 + 640 * i) for i in range(9)]
     tb = e.transcribe_tokens(b, forced_steps=20)      # the larger shape first: the workspaces settle (a grown workspace

@@ -19,7 +19,7 @@ from moonshine_amd.synth import ARCHS, make_audio, make_weights, save_safetensor
 cfg = ARCHS["base"]; w = make_weights(cfg, 0)
 d = tempfile.mkdtemp(); p = os.path.join(d, "model.safetensors")
 save_safetensors(p, w, {"arch": cfg.name, "heads": str(cfg.heads)})
-e = Engine(0); e.load_weights_file(p)
+e = Engine(0, dev=True); e.load_weights_file(p)
 rng = np.random.default_rng(0)
 shapes = [(256, 160000), (192, 120000), (224, 96000), (256, 64000), (128, 144000), (160, 80000)]
 pool = {n: make_audio(7, n) for _, n in shapes}
