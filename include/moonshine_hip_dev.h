@@ -34,6 +34,14 @@ MSH_EXPORT int32_t msh_test_mlp_run(float* h, int32_t R, int32_t D, int32_t F, c
 MSH_EXPORT int32_t msh_test_mlp_oproj_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
                                           const float* b1, const float* w2, const float* b2, const float* ao, const float* wo);
 
+/* Test hook: msh_test_mlp_oproj_run that also returns what the kernel hands the next layer's QKV projection (round 6):
+ * y_fm [ceil(R / 128) * 128][D] bf16 bit patterns = LayerNorm (no scale, eps 1e-5) of the new rows in fragment-major order --
+ * element e of lane l of k-step s of 32-row block w (at ((w * D / 16 + s) * 64 + l) * 8 + e) is row 32 w + (l & 31), column
+ * 16 s + 8 (l >> 5) + e. */
+MSH_EXPORT int32_t msh_test_mlp_oproj_y_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma,
+                                            const float* b1, const float* w2, const float* b2, const float* ao, const float* wo,
+                                            uint16_t* y_fm);
+
 /* Developer / test hook: the encoder QKV panel kernel (LayerNorm + q | k with RoPE + V transposed, k_panel.hip) on R rows
  * (R % 8 == 0) of synthetic data at width D (416 or 288); returns ms per launch (< 0 on error).  Non-null outputs receive the
  * last launch's results as bf16 bit patterns (qk [R][2D], vt [D][R]) and the inputs used (h [R][D], w [3D][D] fp32, pos [R],

@@ -75,6 +75,17 @@ float msh_test_enc_attention(int32_t variant, int32_t n_clips, int32_t T, int32_
   }
 }
 
+int32_t msh_test_mlp_oproj_y_run(float* h, int32_t R, int32_t D, int32_t F, const float* w1, const float* gamma, const float* b1,
+                                 const float* w2, const float* b2, const float* ao, const float* wo, uint16_t* y_fm) {
+  try {
+    msh::mlp_fused_host(h, R, D, F, w1, gamma, b1, w2, b2, ao, wo, y_fm);
+    return MSH_OK;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "mlp_oproj_y_run: %s\n", ex.what());
+    return MSH_ERR_UNKNOWN;
+  }
+}
+
 float msh_test_crossq2(const float* x, const float* wq, const float* wk, int32_t M, int32_t D, float* qt_out, int32_t iters) {
   try {
     return msh::crossq2_host(x, wq, wk, M, D, qt_out, iters);

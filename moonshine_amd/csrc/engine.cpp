@@ -918,8 +918,8 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= x1_.reserve((6 * R + 16) * D * sizeof(bf16_t));
   moved |= x2_.reserve((2 * R + 8) * 2 * D * sizeof(bf16_t));
   moved |= H_.reserve(R * D * sizeof(float));
-  moved |= Y_.reserve(R * D * sizeof(bf16_t));
   const size_t Rp = (R + 127) / 128 * 128;   // the panel kernel (k_panel.hip) stores whole 128-row panels: rows past R are padding
+  moved |= Y_.reserve(Rp * D * sizeof(bf16_t));   // (whole panels: the fused MLP hands the next layer's QKV its operand here)
   moved |= QKV_.reserve(Rp * 2 * D * sizeof(bf16_t));                // q | k rows of the current encoder layer
   moved |= VTe_.reserve(((size_t)D * Rp + 64) * sizeof(bf16_t));         // its V^T [D][Rp]: keys contiguous
   moved |= AO_.reserve(R * D * sizeof(bf16_t));
@@ -1033,6 +1033,12 @@ void Engine::run_encoder() {
   const char* mlp_env = dev_getenv("MSH_ENC_MLP");
   const int fused_mlp = mlp_env == nullptr ? 1 : (mlp_env[0] == '0' ? 0 : mlp_env[0] == '2' ? 2 : 1);
   const long mlp_min_rows = (mlp_env != nullptr && mlp_env[0] == '3') ? 1 : 128 * 256;
+  // Layer l's fused o-proj + MLP kernel hands layer l + 1's QKV panel kernel its operand -- LayerNorm of the rows it just
+  // produced, bf16, fragment-major (k_mlp.hip YOUT, k_panel.hip AM = 2) -- whenever both layers run on those kernels
+  // (MSH_ENC_LN_HANDOVER=0: the panel kernel fetches and normalises the fp32 rows itself, as before round 6)
+  const char* hand_env = dev_getenv("MSH_ENC_LN_HANDOVER");
+  const bool hand_over_on = !(hand_env != nullptr && hand_env[0] == '0');
+  bool y_handed = false;   // Y_ holds the current layer's normalised rows in fragment-major order
 
   {
     ProfScope p(this, "pack_audio", 0, sN * 4 + 384.0 * R * 2);
@@ -1107,7 +1113,12 @@ void Engine::run_encoder() {
       // panel per CU the tiled GEMMs, whose tiles are smaller, fill the chip better
       ProfScope p(this, "enc_qkv_panel", 2.0 * sT * D * 3 * D, sT * D * (4 + 6));
       vt_ld = (long)((R + 127) / 128 * 128);
-      qkv_panel(H_.as<float>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s, enc_store_nt(shared_gpu_));
+      const bool take = y_handed;
+      y_handed = false;
+      if (take)
+        qkv_panel_prenorm(Y_.as<bf16_t>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s, enc_store_nt(shared_gpu_));
+      else
+        qkv_panel(H_.as<float>(), W.qkv_panel, (int)R, D, row_pos_.as<int>(), rp, QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, s, enc_store_nt(shared_gpu_));
     } else {
       {
         ProfScope p(this, "enc_layernorm", 0, sT * D * 6);
@@ -1135,7 +1146,10 @@ void Engine::run_encoder() {
       // o-proj + residual + LayerNorm + fc1 + GELU + fc2 + residual in ONE kernel: H is read once and written once per layer
       // for both blocks, the [R][F] intermediate never exists (k_mlp.hip)
       ProfScope p(this, "enc_oproj_mlp_fused", 2.0 * sT * D * D + 4.0 * sT * D * F, sT * D * (2 + 8));
-      mlp_fused_oproj(H_.as<float>(), AO_.as<bf16_t>(), W.mlp, W.b2, R, D, F, s, enc_store_nt(shared_gpu_));
+      // (the next layer takes the hand-over iff it runs the panel kernel: the same test as at the top of this loop)
+      const bool next_panel = l + 1 < cfg_.enc_layers && qkv_panel_on && enc_[l + 1].qkv_panel != nullptr && R >= qkv_panel_min_rows && (R & 7) == 0;
+      y_handed = hand_over_on && next_panel;
+      mlp_fused_oproj(H_.as<float>(), AO_.as<bf16_t>(), W.mlp, W.b2, R, D, F, s, enc_store_nt(shared_gpu_), y_handed ? Y_.as<bf16_t>() : nullptr);
       continue;
     }
     {

@@ -71,10 +71,15 @@ __device__ __forceinline__ void static_for(Body&& body) {
 // (NOP extra stages of two 32-column tiles each at the head of Wp, AO [R][D] bf16 as their B operand), LayerNorm is then
 // taken from those registers, and H is read ONCE and written once per layer for o-proj + MLP together.
 // NTS: the residual stream is written back with non-temporal stores (see mlp_fused_oproj)
-template <int D, int ABL = 0, bool OP = false, bool NTS = false>
+// YOUT (round 6): the epilogue also hands the NEXT layer's QKV projection its operand: LayerNorm (no scale: gamma is folded
+// into that projection's weights) of the rows it just produced, taken from the accumulators, as bf16 in the fragment-major
+// order panel_gemm_kernel consumes (Yfm: per 32-row wave block, D/16 k-steps of 64 lanes x 8 values = one contiguous KiB per
+// wave-level load).  The QKV panel kernel then starts with D/16 coalesced loads instead of fetching the fp32 rows twice
+// through LDS and normalising them again: a third of its time (profiles/rd5_final_qkv_panel_ablations.txt, ablation 8).
+template <int D, int ABL = 0, bool OP = false, bool NTS = false, bool YOUT = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H, const bf16_t* __restrict__ Wp,
                                                            const float* __restrict__ b2, int R, int NC,
-                                                           const bf16_t* __restrict__ AO) {
+                                                           const bf16_t* __restrict__ AO, bf16_t* __restrict__ Yfm) {
   using G = MlpGeom<D>;
   constexpr int KS = G::KS, CT = G::CT, WP = G::WP, PIECES = G::PIECES, NST = G::NST, PMAX = G::PMAX, NG = G::NG;
   constexpr int NOP = OP ? (CT + 1) / 2 : 0;   // o-proj stages
@@ -420,36 +425,99 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(float* __restrict__ H
   }
 
   // ---- epilogue: H[row][c] = acc + b2, accumulator rows are output columns c = 32t + 8q + 4hh + e ----
-  if (row < R) {
-    float* op = H + (long)row * D + hh * 4;
+  {
     const float* bp = b2 + hh * 4;
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + t * 32 + q * 8);
+        oacc[t][4 * q] += b.x;
+        oacc[t][4 * q + 1] += b.y;
+        oacc[t][4 * q + 2] += b.z;
+        oacc[t][4 * q + 3] += b.w;
+      }
+  }
+  if (row < R) {
+    float* op = H + (long)row * D + hh * 4;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
         const int c = t * 32 + q * 8;
-        const float4 b = *reinterpret_cast<const float4*>(bp + c);
         typedef float f32x4_native __attribute__((ext_vector_type(4)));
-        const f32x4_native v = {oacc[t][4 * q] + b.x, oacc[t][4 * q + 1] + b.y, oacc[t][4 * q + 2] + b.z, oacc[t][4 * q + 3] + b.w};
+        const f32x4_native v = {oacc[t][4 * q], oacc[t][4 * q + 1], oacc[t][4 * q + 2], oacc[t][4 * q + 3]};
         if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_native*>(op + c));
         else *reinterpret_cast<f32x4_native*>(op + c) = v;
       }
+  }
+  if constexpr (YOUT) {
+    // LayerNorm of the new rows from the accumulators (this lane holds half a row: columns 32t + 8q + 4hh + e), shifted
+    // moments per lane half merged with the partner lane's (Chan) as in the prologue, then back to the operand layout
+    // (columns 16s + 8hh + 0..7: the swap is its own inverse) and out as one KiB per k-step and wave.  Rows beyond R are
+    // written too (garbage, inside the buffer's padding to whole panels): nobody reads them as valid rows.
+    const float k0 = oacc[0][0];
+    float s1 = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = oacc[t][r] - k0;
+        s1 += d;
+        s2v += d * d;
+      }
+    constexpr float kHalf = D / 2;
+    const float mean_l = k0 + s1 * (1.0f / kHalf), m2_l = s2v - s1 * s1 * (1.0f / kHalf);
+    const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2_l, 32, 64);
+    const float mean = 0.5f * (mean_l + mean_o), dm = mean_l - mean_o;
+    const float var = (m2_l + m2_o + dm * dm * (0.5f * kHalf)) * (1.0f / D);
+    const float rstd = rsqrtf(var + 1e-5f);
+    uint4* yp = reinterpret_cast<uint4*>(Yfm) + ((long)(blockIdx.x * 4 + wave) * KS) * 64 + lane;
+    static_for<KS>([&](auto sc) {
+      constexpr int s3 = decltype(sc)::value, t = s3 >> 1, q0 = 2 * (s3 & 1);
+      float a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = oacc[t][4 * q0 + e];
+        b[e] = oacc[t][4 * (q0 + 1) + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
+      uint4 p;
+      p.x = pack_bf16x2((a[0] - mean) * rstd, (a[1] - mean) * rstd);
+      p.y = pack_bf16x2((a[2] - mean) * rstd, (a[3] - mean) * rstd);
+      p.z = pack_bf16x2((b[0] - mean) * rstd, (b[1] - mean) * rstd);
+      p.w = pack_bf16x2((b[2] - mean) * rstd, (b[3] - mean) * rstd);
+      yp[s3 * 64] = p;
+    });
   }
 }
 
 template <int D, int ABL = 0>
 void launch_mlp(float* H, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s) {
-  MSH_LAUNCH((mlp_fused_kernel<D, ABL, false>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, (const bf16_t*)nullptr);
+  MSH_LAUNCH((mlp_fused_kernel<D, ABL, false>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, (const bf16_t*)nullptr,
+             (bf16_t*)nullptr);
 }
 template <int D>
-void launch_mlp_o(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s, bool store_nt) {
+void launch_mlp_o(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int F, hipStream_t s, bool store_nt, bf16_t* yfm) {
+  const dim3 grid((R + 127) / 128);
+  if (yfm != nullptr) {
+    if constexpr (D == 416) {
+      if (store_nt) {
+        MSH_LAUNCH((mlp_fused_kernel<D, 0, true, true, true>), grid, dim3(256), 0, s, H, Wp, b2, R, F / 32, AO, yfm);
+        return;
+      }
+    }
+    MSH_LAUNCH((mlp_fused_kernel<D, 0, true, false, true>), grid, dim3(256), 0, s, H, Wp, b2, R, F / 32, AO, yfm);
+    return;
+  }
   if constexpr (D == 416) {
     if (store_nt) {
-      MSH_LAUNCH((mlp_fused_kernel<D, 0, true, true>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, AO);
+      MSH_LAUNCH((mlp_fused_kernel<D, 0, true, true>), grid, dim3(256), 0, s, H, Wp, b2, R, F / 32, AO, yfm);
       return;
     }
   }
-  MSH_LAUNCH((mlp_fused_kernel<D, 0, true>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, b2, R, F / 32, AO);
+  MSH_LAUNCH((mlp_fused_kernel<D, 0, true>), grid, dim3(256), 0, s, H, Wp, b2, R, F / 32, AO, yfm);
 }
 
 }  // namespace
@@ -507,12 +575,15 @@ void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, cons
   }
 }
 
-void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s, bool store_nt) {
+// yfm (nullable): [ceil(R / 128) * 128][D] bf16, receives LayerNorm (no scale) of the new rows in fragment-major order, the
+// operand of the next layer's qkv_panel_prenorm
+void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s, bool store_nt,
+                     bf16_t* yfm) {
   if (R <= 0) return;
   switch (D) {
-    case 416: return launch_mlp_o<416>(H, AO, Wp, b2, R, F, s, store_nt);
-    case 288: return launch_mlp_o<288>(H, AO, Wp, b2, R, F, s, false);
-    case 64: return launch_mlp_o<64>(H, AO, Wp, b2, R, F, s, false);
+    case 416: return launch_mlp_o<416>(H, AO, Wp, b2, R, F, s, store_nt, yfm);
+    case 288: return launch_mlp_o<288>(H, AO, Wp, b2, R, F, s, false, yfm);
+    case 64: return launch_mlp_o<64>(H, AO, Wp, b2, R, F, s, false, yfm);
     default: throw std::runtime_error("mlp_fused_oproj: unsupported hidden size");
   }
 }
@@ -529,7 +600,7 @@ void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F,
 
 // Test hook (tests/test_gpu_mlp.py): packs the weights and runs the kernel once on h [R][D] (host, in / out).
 void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
-                    const float* b2, const float* ao, const float* wo) {
+                    const float* b2, const float* ao, const float* wo, uint16_t* y_fm) {
   if (!mlp_fused_supported(D, F)) throw std::runtime_error("mlp_fused: unsupported shape");
   const bool op = ao != nullptr && wo != nullptr;
   std::vector<bf16_t> packed(mlp_packed_elems(D, F, op));
@@ -548,10 +619,20 @@ void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float*
   MSH_HIP(hipMemcpy(H, h, (size_t)R * D * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(B2, b2, (size_t)D * 4, hipMemcpyHostToDevice));
   MSH_HIP(hipMemcpy(Wp, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
-  if (op) mlp_fused_oproj(H, AOd, Wp, B2, R, D, F, 0);
+  bf16_t* Yd = nullptr;
+  const size_t ybytes = (size_t)((R + 127) / 128 * 128) * D * 2;
+  if (y_fm != nullptr) {
+    if (!op) throw std::runtime_error("mlp_fused: the fragment-major LayerNorm output rides on the o-proj form");
+    MSH_HIP(hipMalloc(&Yd, ybytes));
+  }
+  if (op) mlp_fused_oproj(H, AOd, Wp, B2, R, D, F, 0, false, Yd);
   else mlp_fused(H, Wp, B2, R, D, F, 0);
   MSH_HIP(hipDeviceSynchronize());
   MSH_HIP(hipMemcpy(h, H, (size_t)R * D * 4, hipMemcpyDeviceToHost));
+  if (Yd != nullptr) {
+    MSH_HIP(hipMemcpy(y_fm, Yd, ybytes, hipMemcpyDeviceToHost));
+    (void)hipFree(Yd);
+  }
   if (AOd != nullptr) (void)hipFree(AOd);
   (void)hipFree(H);
   (void)hipFree(B2);

@@ -278,11 +278,13 @@ struct EpiCrossKvPanel {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// rows [128 blockIdx.x, +128) of A; Wp: NC chunks of KS KiB (pack_panel_weights).  LN: A is the fp32 residual stream and
-// LayerNorm (no bias, eps 1e-5; gamma folded into W) is computed here; else A is bf16 [R][D].
+// rows [128 blockIdx.x, +128) of A; Wp: NC chunks of KS KiB (pack_panel_weights).  AM = how the activation block arrives:
+// 1 = A is the fp32 residual stream and LayerNorm (no bias, eps 1e-5; gamma folded into W) is computed here; 0 = A is bf16
+// [R][D]; 2 (round 6) = A is bf16 in FRAGMENT-MAJOR order, already normalised by the kernel that produced the rows
+// (mlp_fused_kernel YOUT): the B operand is KS coalesced 1-KiB loads, no LDS staging, no arithmetic.
 // ABL (microbenchmark ablations, MSH_PANEL_ABL; results are garbage): 1 = no stores, 2 = no finish arithmetic, 4 = no DMA
 // after the first two stages, 8 = no activation loads / LayerNorm, 16 = no per-row epilogue context (RoPE factors)
-template <int D, bool LN, class Epi, int ABL = 0>
+template <int D, int AM, class Epi, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restrict__ Aptr, const bf16_t* __restrict__ Wp,
                                                             Epi epi, int R, int n0, int n1) {
   using G = PanelGeom<D>;
@@ -311,7 +313,11 @@ __global__ __launch_bounds__(256, 2) void panel_gemm_kernel(const void* __restri
       const uint4 p = make_uint4(0x3f803f80u + lane, 0x3f803f80u, 0x3f003f80u, 0x3f803f00u + s);
       yf[s] = frag_of(p);
     }
-  } else if constexpr (LN) {
+  } else if constexpr (AM == 2) {
+    const uint4* yp = reinterpret_cast<const uint4*>(Aptr) + ((long)(blockIdx.x * 4 + wave) * KS) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) yf[s] = frag_of(yp[s * 64]);
+  } else if constexpr (AM == 1) {
     // the wave's rows through LDS (panel_rows.h), twice: moments (shifted by the lane's first value, the two half rows merged
     // with Chan's formula: no cancellation whatever the row's mean), then -- the block comes from L2 now -- the operand
     using RV = RowsViaLds<D, (D >= 416 ? 4 : 3)>;
@@ -491,7 +497,7 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
   if constexpr (D == 416) {
     if (store_nt) {
       EpiQkvPanel<D, DH, RP, true> e2{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
-      MSH_LAUNCH((panel_gemm_kernel<D, true, EpiQkvPanel<D, DH, RP, true>>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, e2, R, 2, 1);
+      MSH_LAUNCH((panel_gemm_kernel<D, 1, EpiQkvPanel<D, DH, RP, true>>), dim3((R + 127) / 128), dim3(256), 0, s, H, Wp, e2, R, 2, 1);
       return;
     }
   }
@@ -505,13 +511,29 @@ void launch_qkv_panel(const float* H, const bf16_t* Wp, int R, const int* row_po
   if constexpr (D == 416) {
     switch (abl) {
       case 0: break;
-#define MSH_PABL(A) case A: MSH_LAUNCH((panel_gemm_kernel<D, true, E, A>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1); return;
+#define MSH_PABL(A) case A: MSH_LAUNCH((panel_gemm_kernel<D, 1, E, A>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1); return;
       MSH_PABL(1) MSH_PABL(2) MSH_PABL(3) MSH_PABL(4) MSH_PABL(8) MSH_PABL(16) MSH_PABL(32)
 #undef MSH_PABL
       default: throw std::runtime_error("qkv_panel: ablation not compiled");
     }
   }
-  MSH_LAUNCH((panel_gemm_kernel<D, true, E>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1);
+  MSH_LAUNCH((panel_gemm_kernel<D, 1, E>), grid, dim3(256), 0, s, H, Wp, epi, R, 2, 1);
+}
+
+template <int D, int DH, int RP>
+void launch_qkv_panel_prenorm(const bf16_t* Yfm, const bf16_t* Wp, int R, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
+                              long vt_ld, hipStream_t s, bool store_nt) {
+  if (rp.rot_pairs != RP || rp.head_dim != DH) throw std::runtime_error("qkv_panel: rotary layout not compiled");
+  const dim3 grid((R + 127) / 128);
+  if constexpr (D == 416) {
+    if (store_nt) {
+      EpiQkvPanel<D, DH, RP, true> e2{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
+      MSH_LAUNCH((panel_gemm_kernel<D, 2, EpiQkvPanel<D, DH, RP, true>>), grid, dim3(256), 0, s, Yfm, Wp, e2, R, 2, 1);
+      return;
+    }
+  }
+  EpiQkvPanel<D, DH, RP> epi{qk, vt, vt_ld, row_pos, rp.cos, rp.sin};
+  MSH_LAUNCH((panel_gemm_kernel<D, 2, EpiQkvPanel<D, DH, RP>>), grid, dim3(256), 0, s, Yfm, Wp, epi, R, 2, 1);
 }
 
 template <int D, bool FP8>
@@ -519,7 +541,7 @@ void launch_cross_kv_panel(const bf16_t* A, const bf16_t* Wp, int R, int L, cons
                            long layer_stride, const float* qscale, void* KT, void* VT, hipStream_t s) {
   using E = EpiCrossKvPanel<D, FP8>;
   E epi{KT, VT, row_clip, clips, layer_stride, qscale};
-  MSH_LAUNCH((panel_gemm_kernel<D, false, E>), dim3((R + 127) / 128), dim3(256), 0, s, A, Wp, epi, R, 0, 2 * L);
+  MSH_LAUNCH((panel_gemm_kernel<D, 0, E>), dim3((R + 127) / 128), dim3(256), 0, s, A, Wp, epi, R, 0, 2 * L);
 }
 
 }  // namespace
@@ -570,6 +592,18 @@ void qkv_panel(const float* H, const bf16_t* Wp, int R, int D, const int* row_po
   switch (D) {
     case 416: return launch_qkv_panel<416, 52, 23>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s, store_nt);
     case 288: return launch_qkv_panel<288, 36, 16>(H, Wp, R, row_pos, rp, qk, vt, vt_ld, s, false);
+    default: throw std::runtime_error("qkv_panel: unsupported width");
+  }
+}
+
+// The same projection on rows that arrive normalised and in fragment-major order (mlp_fused_oproj's yfm output)
+void qkv_panel_prenorm(const bf16_t* Yfm, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
+                       long vt_ld, hipStream_t s, bool store_nt) {
+  if (R <= 0) return;
+  if ((R & 7) != 0) throw std::runtime_error("qkv_panel: the row count must be a multiple of 8");
+  switch (D) {
+    case 416: return launch_qkv_panel_prenorm<416, 52, 23>(Yfm, Wp, R, row_pos, rp, qk, vt, vt_ld, s, store_nt);
+    case 288: return launch_qkv_panel_prenorm<288, 36, 16>(Yfm, Wp, R, row_pos, rp, qk, vt, vt_ld, s, false);
     default: throw std::runtime_error("qkv_panel: unsupported width");
   }
 }

@@ -146,10 +146,11 @@ void pack_mlp_weights(const float* w1, const float* gamma, const float* b1, cons
 void mlp_fused(float* H, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s);
 // the same with the attention output projection in front: H += AO Wo^T first (AO [R][D] bf16, Wp packed with wo), then the
 // MLP block on the result -- replaces gemm_resid_f32 (o-proj) + mlp_fused
-void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s, bool store_nt = false);
+void mlp_fused_oproj(float* H, const bf16_t* AO, const bf16_t* Wp, const float* b2, int R, int D, int F, hipStream_t s, bool store_nt = false,
+                     bf16_t* yfm = nullptr);
 float mlp_microbench(int R, int D, int F, int iters, int abl);
 void mlp_fused_host(float* h, int R, int D, int F, const float* w1, const float* gamma, const float* b1, const float* w2,
-                    const float* b2, const float* ao = nullptr, const float* wo = nullptr);
+                    const float* b2, const float* ao = nullptr, const float* wo = nullptr, uint16_t* y_fm = nullptr);
 
 // ---------------- A-stationary panel GEMMs of the encoder (k_panel.hip) ----------------
 // Weights packed at load by pack_panel_weights (chunks of 32 output columns, MFMA-fragment order; gamma folded in when given).
@@ -160,6 +161,9 @@ void pack_panel_weights(const float* w, const float* gamma, int N, int D, bf16_t
 bool qkv_panel_supported(int D, int head_dim, int rot_pairs);
 void qkv_panel(const float* H, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
                long vt_ld, hipStream_t s, bool store_nt = false);
+// the same with the rows already normalised, bf16, in fragment-major order ([ceil(R / 128) * 128][D]; mlp_fused_oproj yfm)
+void qkv_panel_prenorm(const bf16_t* Yfm, const bf16_t* Wp, int R, int D, const int* row_pos, RopeParams rp, bf16_t* qk, bf16_t* vt,
+                       long vt_ld, hipStream_t s, bool store_nt = false);
 // cross-attention K^T / V^T of all L decoder layers on the same kernel: A = encoder output [R][D] bf16, Wp packed from the
 // fused [L * 2 * D][D] weight (no gamma); qscale non-null = e4m3 bytes (value * qscale[column]), layer_stride in bytes then.
 // Replaces gemm_cross_kv / gemm_cross_kv_fp8 at large batches.

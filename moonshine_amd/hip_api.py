@@ -146,6 +146,7 @@ def load_dev_library() -> C.CDLL:
         "msh_test_mlp_run": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
         "msh_test_mlp_oproj_run": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "msh_test_qkv_panel": (C.c_float, [i32, i32, i32, vp, vp, vp, vp, vp]),
+        "msh_test_mlp_oproj_y_run": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "msh_test_cross_absorbed": (C.c_float, [vp, vp, C.c_int64, vp, vp, i32, i32, vp, i32]),
         "msh_test_crossq2": (C.c_float, [vp, vp, vp, i32, i32, vp, i32]),
         "msh_test_enc_attention": (C.c_float, [i32, i32, i32, i32, i32, i32, vp]),
@@ -159,7 +160,7 @@ def load_dev_library() -> C.CDLL:
 
 
 DEV_SYMBOLS = ["msh_test_debug_read", "msh_test_device_alloc", "msh_test_gemm_microbench", "msh_test_mlp_microbench", "msh_test_mlp_run",
-               "msh_test_mlp_oproj_run", "msh_test_qkv_panel", "msh_test_cross_absorbed", "msh_test_crossq2", "msh_test_enc_attention"]
+               "msh_test_mlp_oproj_run", "msh_test_mlp_oproj_y_run", "msh_test_qkv_panel", "msh_test_cross_absorbed", "msh_test_crossq2", "msh_test_enc_attention"]
 
 DECLARED_SYMBOLS = [
     "msh_device_count", "msh_version", "msh_create", "msh_destroy", "msh_last_error", "msh_load_weights_file",

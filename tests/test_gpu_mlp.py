@@ -89,3 +89,40 @@ def test_fused_oproj_mlp_block_vs_oracle(D, F, R):
     assert relrms <= 6e-3, relrms
     assert float(np.abs(err).max()) <= 8e-2     # two bf16 GEMM chains in a row
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("D,F,R", [(64, 256, 129), (288, 1152, 300), (416, 1664, 424), (416, 64, 33)])
+def test_fused_block_hands_the_next_layers_layernorm_over(D, F, R):
+    """Round 6: the kernel's second output -- LayerNorm (no scale, eps 1e-5) of the rows it just produced, bf16, in the
+    fragment-major order the next layer's QKV panel kernel loads as its MFMA operand (k_mlp.hip YOUT, k_panel.hip AM = 2;
+    hf modeling_moonshine.py:382-411: the next layer's input_layernorm on this layer's output).  Checked against LayerNorm of
+    the kernel's OWN fp32 output (same values the panel kernel used to re-read), de-interleaved by the documented layout."""
+    rng = np.random.default_rng(11 * D + F + R)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    wo = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (rng.standard_normal(F) * 0.1).astype(np.float32)
+    b2 = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    h = rng.standard_normal((R, D)).astype(np.float32) * 2.0
+    h[:: 7] += 300.0
+    ao = rng.standard_normal((R, D)).astype(np.float32)
+    lib = load_library()
+    fp = C.POINTER(C.c_float)
+    out = h.copy()
+    Rp = (R + 127) // 128 * 128
+    y = np.zeros(Rp * D, np.uint16)
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (w1, g, b1, w2, b2, ao, wo)]
+    rc = lib.msh_test_mlp_oproj_y_run(out.ctypes.data, R, D, F, *[a.ctypes.data for a in arrs], y.ctypes.data)
+    assert rc == 0
+    np.testing.assert_array_equal(out, _run_o(h, w1, g, b1, w2, b2, ao, wo))     # the residual stream itself: unchanged bits
+    KS = D // 16
+    yf = (y.astype(np.uint32) << 16).view(np.float32).reshape(Rp // 32, KS, 64, 8)
+    rows = np.empty((Rp, D), np.float32)
+    for lane in range(64):
+        for s in range(KS):
+            rows[np.arange(Rp // 32) * 32 + (lane & 31), 16 * s + 8 * (lane >> 5):16 * s + 8 * (lane >> 5) + 8] = yf[:, s, lane, :]
+    want = ref.layer_norm_nobias(out.astype(np.float64), np.ones(D)).astype(np.float32)
+    err = np.abs(rows[:R] - want)
+    assert float(err.max()) <= 2e-2, float(err.max())          # bf16 of O(1) normalised values (<= 4 sigma: 2^-6 steps)
+    assert float(np.sqrt((err ** 2).mean())) <= 3e-3
