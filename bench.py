@@ -339,6 +339,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # several ranks on one node: every rank keeps its host threads (lanes, pinned staging) on its own share of the CPUs, the ones
+    # of its GPU's NUMA node where sysfs says which those are -- before the engine (and its threads) exist
+    rank_cpu_list = msd.pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rank, world = msd.init_from_env("nccl", dev)  # "nccl" is RCCL on ROCm

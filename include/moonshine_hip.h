@@ -197,6 +197,10 @@ MSH_EXPORT int64_t msh_host_tokens_to_text(const uint8_t* tokenizer_bin, uint64_
                                            uint64_t n_ids, char* out, uint64_t out_cap);
 MSH_EXPORT int64_t msh_host_sanitize_utf8(const char* text, uint64_t n, char* out, uint64_t out_cap);
 MSH_EXPORT int32_t msh_host_effective_cpus(void);
+/* A sysfs CPU list ("0-63,128-191") as integers: the parser behind the NUMA pinning of the lanes' host threads when one
+ * process drives several GPUs (csrc/host_utils.h pin_thread_to_gpu_node).  Returns the number of CPUs named; writes
+ * min(that, cap) of them. */
+MSH_EXPORT int64_t msh_host_parse_cpu_list(const char* text, int32_t* out, uint64_t cap);
 MSH_EXPORT int64_t msh_host_resample(const float* in, uint64_t n, float in_rate, float out_rate, float* out,
                                      uint64_t out_cap);
 /* msh_host_text_to_tokens : BinTokenizer::text_to_tokens (reference core/bin-tokenizer/bin-tokenizer.cpp:277-402);

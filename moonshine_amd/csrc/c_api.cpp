@@ -535,6 +535,11 @@ int64_t msh_host_rolling_plan(const uint64_t* lens, const uint64_t* piece_sizes,
 }
 
 int32_t msh_host_effective_cpus(void) { return (int32_t)msh_host::effective_cpus(); }
+int64_t msh_host_parse_cpu_list(const char* text, int32_t* out, uint64_t cap) {
+  const std::vector<int> v = msh_host::parse_cpu_list(text != nullptr ? text : "");
+  for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+  return (int64_t)v.size();
+}
 
 int64_t msh_host_vad_segments(const uint8_t* weights, uint64_t weights_size, float threshold, int32_t window, int32_t hop,
                               uint64_t look_behind, uint64_t max_segment, uint64_t hard_cap, const float* audio,

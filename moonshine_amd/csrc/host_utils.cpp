@@ -1,5 +1,9 @@
 #include "host_utils.h"
 
+#include <ctype.h>
+#include <pthread.h>
+#include <sched.h>
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -232,6 +236,60 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out) {
   if (n < 0) return false;
   out->resize((size_t)n);
   return std::fread(out->data(), 1, (size_t)n, file.f) == (size_t)n;
+}
+
+std::vector<int> parse_cpu_list(const std::string& text) {
+  std::vector<int> out;
+  size_t i = 0;
+  while (i < text.size()) {
+    while (i < text.size() && !isdigit((unsigned char)text[i])) ++i;
+    if (i >= text.size()) break;
+    int a = 0;
+    while (i < text.size() && isdigit((unsigned char)text[i])) a = a * 10 + (text[i++] - '0');
+    int b = a;
+    if (i < text.size() && text[i] == '-') {
+      ++i;
+      b = 0;
+      while (i < text.size() && isdigit((unsigned char)text[i])) b = b * 10 + (text[i++] - '0');
+    }
+    for (int c = a; c <= b && c < 4096; ++c) out.push_back(c);
+  }
+  return out;
+}
+
+bool pin_thread_to_gpu_node(const char* pci_bus_id) {
+  const char* off = getenv("MSH_PIN_CPUS");
+  if (off != nullptr && off[0] == '0') return false;
+  if (pci_bus_id == nullptr || pci_bus_id[0] == 0) return false;
+  std::string id(pci_bus_id);
+  for (char& c : id) c = (char)tolower((unsigned char)c);
+  auto slurp = [](const std::string& path, std::string* out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (f == nullptr) return false;
+    char buf[4096];
+    const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    *out = buf;
+    return got > 0;
+  };
+  std::string text;
+  if (!slurp("/sys/bus/pci/devices/" + id + "/numa_node", &text)) return false;
+  const int node = atoi(text.c_str());
+  if (node < 0) return false;
+  if (!slurp("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", &text)) return false;
+  cpu_set_t cur, want;
+  CPU_ZERO(&cur);
+  CPU_ZERO(&want);
+  if (pthread_getaffinity_np(pthread_self(), sizeof(cur), &cur) != 0) return false;
+  int n = 0;
+  for (int c : parse_cpu_list(text))
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &cur)) {
+      CPU_SET(c, &want);
+      ++n;
+    }
+  if (n == 0) return false;
+  return pthread_setaffinity_np(pthread_self(), sizeof(want), &want) == 0;
 }
 
 unsigned effective_cpus() {

@@ -49,5 +49,13 @@ void parallel_for(size_t n, const std::function<void(size_t)>& fn, unsigned max_
 // more threads than that only buy throttling (measured on the benchmark box: the host VAD peaks at 2x the quota and
 // loses half its rate at 8x).
 unsigned effective_cpus();
+// Several GPUs in one process (load options num_gpus / devices): the calling thread is restricted to the CPUs of the NUMA node
+// the GPU with PCI bus id `pci_bus_id` ("0000:c1:00.0") hangs off, intersected with the thread's current mask -- the lanes'
+// host threads and the pinned staging blocks they first-touch then sit next to their GPU instead of wherever the scheduler
+// put them (an 8-GPU host moves 20-40 GB/s of PCM through those blocks).  No-op (returns false) when sysfs does not name a
+// node, the intersection is empty or MSH_PIN_CPUS=0.
+bool pin_thread_to_gpu_node(const char* pci_bus_id);
+// the CPU list of "/sys/devices/system/node/node<N>/cpulist" syntax ("0-63,128-191") as a vector (exposed for the CPU test)
+std::vector<int> parse_cpu_list(const std::string& text);
 
 }  // namespace msh_host

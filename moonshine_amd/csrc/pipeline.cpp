@@ -74,6 +74,13 @@ void BatchPipeline::wait(int64_t ticket) {
 
 void BatchPipeline::worker(int lane) {
   Engine& eng = *lanes_[lane];
+  // more than one GPU in this process: the lane's host thread stays on its GPU's NUMA node (host_utils.h)
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) == hipSuccess && visible > 1) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_) == hipSuccess) (void)msh_host::pin_thread_to_gpu_node(bus);
+    (void)hipGetLastError();
+  }
   for (;;) {
     std::shared_ptr<Job> j;
     {

@@ -41,6 +41,65 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
     return rank, world
 
 
+def rank_cpus(local_rank: int, local_world: int, allowed: list[int] | None = None, gpu_numa_node: int | None = None,
+              node_cpus: dict[int, list[int]] | None = None) -> list[int]:
+    """The CPUs one rank of an N-rank node should keep its host threads on (the engine's lane threads, the device VAD's gather
+    threads and the pinned staging blocks they first-touch all inherit the process's affinity mask).  Preference: the CPUs of
+    the NUMA node the rank's GPU hangs off (sysfs), shared evenly between the ranks whose GPUs sit on that node; without
+    topology information an even contiguous split of the allowed CPUs (on the usual two-socket boxes GPUs 0..N/2-1 and the
+    lower half of the CPU numbering share a socket).  Pure function of its arguments: tested on the CPU."""
+    cpus = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    if local_world <= 1 or not cpus:
+        return cpus
+    if gpu_numa_node is not None and node_cpus and gpu_numa_node in node_cpus:
+        mine = [c for c in sorted(node_cpus[gpu_numa_node]) if c in set(cpus)]
+        if mine:
+            # ranks are dealt to nodes in order: the ranks sharing this node split its CPUs by their order among themselves
+            per_node = max(1, local_world // max(1, len(node_cpus)))
+            k = local_rank % per_node
+            lo, hi = k * len(mine) // per_node, (k + 1) * len(mine) // per_node
+            return mine[lo:hi] or mine
+    lo, hi = local_rank * len(cpus) // local_world, (local_rank + 1) * len(cpus) // local_world
+    return cpus[lo:hi] or cpus
+
+
+def _sysfs_topology(local_rank: int) -> tuple[int | None, dict[int, list[int]] | None]:
+    """(NUMA node of GPU `local_rank`, {node: cpus}) from sysfs, or (None, None) where the box does not say."""
+    try:
+        nodes: dict[int, list[int]] = {}
+        base = "/sys/devices/system/node"
+        for d in os.listdir(base):
+            if d.startswith("node") and d[4:].isdigit():
+                cl: list[int] = []
+                for part in open(os.path.join(base, d, "cpulist")).read().strip().split(","):
+                    if part:
+                        a, _, b = part.partition("-")
+                        cl.extend(range(int(a), int(b or a) + 1))
+                nodes[int(d[4:])] = cl
+        cards = sorted((c for c in os.listdir("/sys/class/drm") if c.startswith("card") and c[4:].isdigit()), key=lambda c: int(c[4:]))
+        gpus = [c for c in cards if os.path.exists(f"/sys/class/drm/{c}/device/numa_node")]
+        if local_rank < len(gpus):
+            n = int(open(f"/sys/class/drm/{gpus[local_rank]}/device/numa_node").read().strip())
+            return (n if n >= 0 else None), (nodes or None)
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
+def pin_rank_cpus(local_rank: int, local_world: int) -> list[int]:
+    """Restrict this process (and every thread it starts from now on) to rank_cpus(...).  Called by bench.py before the engine
+    exists when several ranks share the node (MSH_PIN_CPUS=0: leave the affinity alone).  Returns the CPU list in force."""
+    if local_world <= 1 or os.environ.get("MSH_PIN_CPUS", "1") == "0":
+        return sorted(os.sched_getaffinity(0))
+    node, node_cpus = _sysfs_topology(local_rank)
+    cpus = rank_cpus(local_rank, local_world, None, node, node_cpus)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    return sorted(os.sched_getaffinity(0))
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous split; the first (n_items % world) ranks take one extra item."""
     base, extra = divmod(n_items, world)

@@ -165,3 +165,36 @@ def test_shard_bounds_cover_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_2048_clip_plan_gives_eight_ranks_the_same_audio():
+    """BASELINE config 4 (2,048 clips utterance-sharded over 8 GPUs): the snake deal of the length-sorted list gives every rank
+    256 clips whose total audio differs by less than ONE clip between any two ranks -- on equal clips and on a realistic mix of
+    lengths (VAD segments: many short, a third at the 10 s cap)."""
+    rng = np.random.default_rng(8)
+    mixes = [[160000] * 2048,
+             (rng.gamma(2.0, 30000.0, 2048).clip(8000, 160000)).astype(int).tolist(),
+             [160000] * 700 + rng.integers(8000, 159000, 1348).tolist()]
+    for lens in mixes:
+        plan = msd.shard_plan(lens, 8)
+        assert [len(p) for p in plan] == [256] * 8
+        tot = [sum(lens[i] for i in p) for p in plan]
+        assert max(tot) - min(tot) < max(lens), (max(tot) - min(tot), max(lens))
+        assert (max(tot) - min(tot)) / (sum(tot) / 8) < 1e-2      # ... which is under 1 % of a rank's share
+
+
+def test_rank_cpu_shares_partition_the_node():
+    """moonshine_amd/dist.py rank_cpus: the ranks of a node keep their host threads on disjoint CPU shares that cover the allowed
+    set; with topology information a rank stays on its GPU's NUMA node."""
+    allowed = list(range(0, 96)) + list(range(128, 224))     # a cgroup-restricted 192-CPU view of a 256-CPU box
+    for world in (1, 2, 4, 8):
+        shares = [msd.rank_cpus(r, world, allowed) for r in range(world)]
+        assert sorted(c for s in shares for c in s) == sorted(allowed)
+        assert all(len(s) >= len(allowed) // world for s in shares)
+    nodes = {0: list(range(0, 128)), 1: list(range(128, 256))}
+    for r in range(8):
+        got = msd.rank_cpus(r, 8, allowed, gpu_numa_node=r // 4, node_cpus=nodes)
+        assert got and set(got) <= set(nodes[r // 4]) & set(allowed)
+    on0 = [msd.rank_cpus(r, 8, allowed, 0, nodes) for r in range(4)]
+    assert sorted(c for s in on0 for c in s) == [c for c in allowed if c < 128]     # the four ranks of a node split it
+    assert msd.rank_cpus(3, 8, [5]) == [5]                                            # fewer CPUs than ranks: shared

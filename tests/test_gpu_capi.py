@@ -385,7 +385,8 @@ def test_default_options_batch_call_rolls_segments_into_sub_batches(tiny_dir, tm
     texts_r = [t for c in rolling for t, _, _ in c]
     texts_w = [t for c in waves for t, _, _ in c]
     same = sum(a == b for a, b in zip(texts_r, texts_w))
-    assert same >= 0.8 * len(texts_r), (same, len(texts_r))
+    print(f"rolling vs wave pipeline: {same} of {len(texts_r)} texts equal")
+    assert same >= 0.8 * len(texts_r), (same, len(texts_r))   # (near-tie flips on fan-in-scaled random weights: tests/test_gpu_batch_invariance.py measures the rate on a sharpened checkpoint)
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"devices": "0,0"})) == spans(rolling)
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"vad_device": "0"})) == spans(rolling)
     assert spans(run({})) == spans(rolling)     # the default chunking (one chunk here)

@@ -45,6 +45,18 @@ def test_library_exports_every_declared_symbol():
     assert set(api.C_API_SYMBOLS) <= set(declared)
 
 
+def test_sysfs_cpu_list_parser():
+    """host_utils.cpp parse_cpu_list: what pins a lane's host thread to its GPU's NUMA node when one process drives several GPUs
+    (options num_gpus / devices)."""
+    lib = load_library()
+    lib.msh_host_parse_cpu_list.restype = C.c_int64
+    lib.msh_host_parse_cpu_list.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+    for text, want in [(b"0-3,8-9\n", [0, 1, 2, 3, 8, 9]), (b"5", [5]), (b"", []), (b"0-63,128-191", list(range(64)) + list(range(128, 192)))]:
+        out = np.full(256, -1, np.int32)
+        n = lib.msh_host_parse_cpu_list(text, out.ctypes.data, out.size)
+        assert n == len(want) and out[:n].tolist() == want
+
+
 def test_struct_layout_matches_reference_abi(tmp_path):
     """sizeof / offsetof of the public structs as gcc sees include/moonshine-c-api.h must equal the
     ctypes mirror (which pins the sizes the reference binding pins: 24 / 40 / 88 / 16)."""
