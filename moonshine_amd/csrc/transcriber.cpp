@@ -161,7 +161,13 @@ int MoonshineModel::rolling_begin() {
   {
     const char* f = msh::dev_getenv("MSH_ROLLING_SHORT_FRAC");
     const char* nr = msh::dev_getenv("MSH_ROLLING_NARROW_RUNS");
-    r->plan.reset(new RollingPlanner(batch_clips, f != nullptr ? atof(f) : 0.15, nr == nullptr || atoi(nr) != 0));
+    // (the last cut balanced over one device's lanes -- MSH_ROLLING_BALANCE=0: the plain equal-audio cut; the plan does not
+    // depend on the NUMBER of devices: ids(N devices) == ids(1))
+    const char* bal = msh::dev_getenv("MSH_ROLLING_BALANCE");
+    const int lanes = (bal != nullptr && bal[0] == '0') ? 1 : std::max(1, batches_in_flight);
+    r->plan.reset(new RollingPlanner(batch_clips, f != nullptr ? atof(f) : 0.15, nr == nullptr || atoi(nr) != 0, lanes,
+                                     (double)max_tokens_per_second));
+    if (bal != nullptr && bal[0] == '1') r->plan->extra_runs_ = false;   // (A/B: only round the plain count up)
   }
   if (msh_set_capture_cross_attention(engine, 0) != MSH_OK) return 1;
   for (DeviceShard& d : devices)
@@ -180,8 +186,33 @@ int MoonshineModel::rolling_submit(const RollingClip* c, uint32_t m) {
   Rolling& r = *rolling_;
   r.subs.emplace_back();
   RollingSub& sb = r.subs.back();
-  sb.dev = r.next_dev;
-  r.next_dev = (r.next_dev + 1) % devices.size();
+  // Which device: the one with the least estimated work so far, a sub-batch whose clips all sit in the device VAD's kept audio
+  // counting its PCIe upload on every OTHER device.  (Plain round-robin gave long-clip and short-clip sub-batches alternately to
+  // the same devices -- their costs differ by the decode steps of the longest clip -- and sent (N - 1) / N of the resident
+  // sub-batches to devices that had to upload the PCM again.)  Estimate, from the 256 x 10 s batch: encoder 4 us per audio
+  // second, a decode step 0.45 ms at 6.5 steps per second of the LONGEST clip, upload 2.6 us per audio second.  The sub-batches
+  // themselves do not depend on the device list (ids(N devices) == ids(1)).
+  {
+    double audio_s = 0.0, longest_s = 0.0;
+    bool resident = true;
+    for (uint32_t i = 0; i < m; ++i) {
+      audio_s += (double)c[i].n / 16000.0;
+      longest_s = std::max(longest_s, (double)c[i].n / 16000.0);
+      resident = resident && c[i].dev != nullptr;
+    }
+    const double cost = 0.004 * audio_s + 0.45 * (double)max_tokens_per_second * longest_s, upload = 0.0026 * audio_s;
+    if (r.assigned_ms.size() != devices.size()) r.assigned_ms.assign(devices.size(), 0.0);
+    size_t best = r.next_dev % devices.size();
+    double best_t = 1e300;
+    for (size_t k = 0; k < devices.size(); ++k) {
+      const size_t dv = (r.next_dev + k) % devices.size();   // ties: the round-robin order
+      const double t = r.assigned_ms[dv] + cost + ((resident && devices[dv].device == r.device_audio_gpu) ? 0.0 : upload);
+      if (t < best_t) best_t = t, best = dv;
+    }
+    sb.dev = best;
+    r.assigned_ms[best] = best_t;
+    r.next_dev = (best + 1) % devices.size();
+  }
   DeviceShard& d = devices[sb.dev];
   bool on_device = d.device == r.device_audio_gpu;
   for (uint32_t i = 0; i < m && on_device; ++i) on_device = c[i].dev != nullptr;

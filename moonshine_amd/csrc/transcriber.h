@@ -101,7 +101,8 @@ struct MoonshineModel {
     std::unique_ptr<RollingPlanner> plan;   // which waiting clips go out when (rolling_plan.h)
     std::vector<RollingClip> clips;         // every clip handed over so far, by index
     std::deque<RollingSub> subs;            // submitted sub-batches (their arrays are written by the lanes: addresses must not move)
-    size_t next_dev = 0;
+    size_t next_dev = 0;                    // tie-break of the device choice (rolling_submit)
+    std::vector<double> assigned_ms;        // estimated GPU time handed to each device so far
     int device_audio_gpu = -1;
     bool failed = false;
   };
