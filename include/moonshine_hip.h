@@ -300,11 +300,6 @@ MSH_EXPORT int64_t msh_host_vad_segments_from_probs(const uint8_t* weights, uint
 MSH_EXPORT int64_t msh_host_rolling_plan(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces, int32_t batch_clips,
                                          float short_frac, int32_t narrow_runs, int32_t* sub_of_clip, int32_t* piece_of_sub,
                                          int32_t* first_of_sub, uint64_t max_subs);
-/* The same with the last cut balanced over `lanes` lanes (what the batch call runs with lanes = batches_in_flight): the sorted
- * rest goes out as a multiple of `lanes` consecutive runs of about equal estimated GPU time instead of equal audio. */
-MSH_EXPORT int64_t msh_host_rolling_plan_lanes(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces,
-                                               int32_t batch_clips, float short_frac, int32_t narrow_runs, int32_t lanes,
-                                               int32_t* sub_of_clip, int32_t* piece_of_sub, int32_t* first_of_sub, uint64_t max_subs);
 MSH_EXPORT int64_t msh_host_biaser_bonuses(const int32_t* flat_tokens, const int32_t* seq_lens, uint64_t n_seqs,
                                            float boost, const int32_t* prefix, uint64_t n_prefix, float* out,
                                            uint64_t vocab);

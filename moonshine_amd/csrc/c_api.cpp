@@ -510,16 +510,9 @@ int64_t msh_host_silero_probabilities(const uint8_t* weights, uint64_t weights_s
 int64_t msh_host_rolling_plan(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces, int32_t batch_clips,
                               float short_frac, int32_t narrow_runs, int32_t* sub_of_clip, int32_t* piece_of_sub,
                               int32_t* first_of_sub, uint64_t max_subs) {
-  return msh_host_rolling_plan_lanes(lens, piece_sizes, n_pieces, batch_clips, short_frac, narrow_runs, 1, sub_of_clip, piece_of_sub,
-                                     first_of_sub, max_subs);
-}
-
-int64_t msh_host_rolling_plan_lanes(const uint64_t* lens, const uint64_t* piece_sizes, uint64_t n_pieces, int32_t batch_clips,
-                                    float short_frac, int32_t narrow_runs, int32_t lanes, int32_t* sub_of_clip,
-                                    int32_t* piece_of_sub, int32_t* first_of_sub, uint64_t max_subs) {
   try {
     if ((lens == nullptr || piece_sizes == nullptr) && n_pieces > 0) return MSH_ERR_INVALID_ARGUMENT;
-    RollingPlanner plan(batch_clips, short_frac, narrow_runs != 0, lanes);
+    RollingPlanner plan(batch_clips, short_frac, narrow_runs != 0);
     uint64_t off = 0, subs = 0;
     for (uint64_t p = 0; p < n_pieces; ++p) {
       for (const std::vector<uint32_t>& ids : plan.add(lens + off, (size_t)piece_sizes[p], p + 1 == n_pieces)) {

@@ -16,12 +16,6 @@
 //     347 / 342 / 383 / 374 ms per call) -- in full sub-batches: few decode steps each, and whatever short clips there
 //     are while nothing has been submitted yet, so that the GPU starts at once;
 // everything else waits for the last piece and is cut sorted, longest first, like a whole batch.
-// Round 6, `lanes` > 1: that last cut is BALANCED -- the sorted rest is still cut into consecutive runs, but their number is
-// rounded up to a multiple of the lanes that will take them and their boundaries are placed so that every run has about the
-// same estimated GPU time (encoder ~ its audio, decode ~ the steps of its longest clip), within the same caps -- as few runs as
-// bring the costliest within 25 % of the mean (a run of long clips is cut short of the audio cap: its decode is what costs).  The plain
-// cut gives equal AUDIO: a run of 10 s clips then costs more than twice a run of 2 s clips, ten runs on four lanes leave two
-// lanes idle for the length of the last run, and the call ended with ~60 of ~290 ms of lane imbalance.
 #pragma once
 
 #include <stddef.h>
@@ -33,13 +27,7 @@ namespace msh_host {
 
 class RollingPlanner {
  public:
-  explicit RollingPlanner(int batch_clips, double short_frac = 0.15, bool narrow_runs = true, int lanes = 1,
-                          double steps_per_second = 6.5);
-  // estimated GPU milliseconds of a sub-batch (the 256 x 10 s batch's numbers: encoder 4 us per audio second, a decode step
-  // 0.45 ms at steps_per_second steps per second of the longest clip)
-  double cost_ms(uint64_t audio_samples, uint64_t longest_samples) const {
-    return 0.004 * (double)audio_samples / 16000.0 + 0.45 * steps_ * (double)longest_samples / 16000.0;
-  }
+  explicit RollingPlanner(int batch_clips, double short_frac = 0.15, bool narrow_runs = true);
   // `count` more clips of n[i] samples (16 kHz); their indices continue from the previous call.  Returns the sub-batches
   // to submit now, in submission order, each a list of clip indices, longest clip first.  last: nothing may stay behind.
   std::vector<std::vector<uint32_t>> add(const uint64_t* n, size_t count, bool last);
@@ -54,16 +42,12 @@ class RollingPlanner {
     uint64_t n;
   };
   uint32_t cut_at(size_t lo, uint64_t* sum) const;   // the cut run_shard makes at position lo of the sorted pool
-  std::vector<uint32_t> balanced_sizes() const;       // the balanced last cut of the whole pool: sizes of its consecutive runs
   std::vector<uint32_t> take(size_t lo, uint32_t m);
   std::vector<Clip> pool_;   // waiting clips, longest first
   uint32_t bc_, clip_cap_, next_idx_ = 0;
   uint64_t audio_cap_, short_len_ = 0;
-  double short_frac_, steps_ = 6.5;
-  int lanes_ = 1;
+  double short_frac_;
   bool narrow_runs_, submitted_any_ = false;
- public:
-  bool extra_runs_ = true;   // the balanced cut may use more runs than the plain one rounded up (MSH_ROLLING_BALANCE=1: it may not)
 };
 
 }  // namespace msh_host

@@ -161,13 +161,7 @@ int MoonshineModel::rolling_begin() {
   {
     const char* f = msh::dev_getenv("MSH_ROLLING_SHORT_FRAC");
     const char* nr = msh::dev_getenv("MSH_ROLLING_NARROW_RUNS");
-    // (the last cut balanced over one device's lanes -- MSH_ROLLING_BALANCE=0: the plain equal-audio cut; the plan does not
-    // depend on the NUMBER of devices: ids(N devices) == ids(1))
-    const char* bal = msh::dev_getenv("MSH_ROLLING_BALANCE");
-    const int lanes = (bal != nullptr && bal[0] == '0') ? 1 : std::max(1, batches_in_flight);
-    r->plan.reset(new RollingPlanner(batch_clips, f != nullptr ? atof(f) : 0.15, nr == nullptr || atoi(nr) != 0, lanes,
-                                     (double)max_tokens_per_second));
-    if (bal != nullptr && bal[0] == '1') r->plan->extra_runs_ = false;   // (A/B: only round the plain count up)
+    r->plan.reset(new RollingPlanner(batch_clips, f != nullptr ? atof(f) : 0.15, nr == nullptr || atoi(nr) != 0));
   }
   if (msh_set_capture_cross_attention(engine, 0) != MSH_OK) return 1;
   for (DeviceShard& d : devices)

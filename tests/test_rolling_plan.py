@@ -141,67 +141,3 @@ def test_switches_and_edge_cases():
     assert plan(np.asarray([20000], np.uint64), [0, 1, 0], bc)[0] == 1
     assert plan(np.zeros(0, np.uint64), [], bc)[0] == 0
     assert plan(np.zeros(0, np.uint64), [0, 0], bc)[0] == 0
-
-
-def plan_lanes(lens, pieces, batch_clips, lanes, short_frac=0.15, narrow=1):
-    lib = load_library()
-    f = lib.msh_host_rolling_plan_lanes
-    f.restype = C.c_int64
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
-    lens = np.ascontiguousarray(lens, np.uint64)
-    pieces = np.ascontiguousarray(pieces, np.uint64)
-    sub_of = np.full(len(lens), -1, np.int32)
-    cap = len(lens) + 4
-    piece_of = np.full(cap, -1, np.int32)
-    first_of = np.full(cap, -1, np.int32)
-    n = f(lens.ctypes.data, pieces.ctypes.data, len(pieces), batch_clips, short_frac, narrow, lanes, sub_of.ctypes.data,
-          piece_of.ctypes.data, first_of.ctypes.data, cap)
-    assert n >= 0, n
-    return int(n), sub_of, piece_of[:n], first_of[:n]
-
-
-def _cost_ms(lens, members):
-    audio = float(lens[members].sum()) / 16000.0
-    return 0.004 * audio + 0.45 * 6.5 * float(lens[members].max()) / 16000.0
-
-
-def test_last_cut_balanced_over_the_lanes():
-    """Round 6: with lanes > 1 the sorted rest of a call goes out as a multiple of `lanes` consecutive runs of about equal
-    ESTIMATED GPU TIME (encoder ~ audio, decode ~ the steps of the run's longest clip) instead of equal audio: every clip exactly
-    once, the caps of the plain cut still hold, runs stay consecutive in the sorted order, their number is a multiple of the
-    lanes, the costliest run is cheaper than the plain cut's costliest, and lanes = 1 is the plain cut."""
-    rng = np.random.default_rng(21)
-    lens = segment_mix(rng, 2048)
-    bc = 256
-    for pieces in ([len(lens)], [len(lens) // 3, len(lens) - len(lens) // 3]):
-        n1, sub1, piece1, _ = plan(lens, pieces, bc)
-        n4, sub4, piece4, first4 = plan_lanes(lens, pieces, bc, 4)
-        assert (sub4 >= 0).all() and sorted(set(sub4.tolist())) == list(range(n4))
-        lastp = len(pieces) - 1
-        late1 = [s for s in range(n1) if piece1[s] == lastp]
-        late4 = [s for s in range(n4) if piece4[s] == lastp]
-        assert len(late4) % 4 == 0 and len(late4) >= len(late1)
-        # the early sub-batches are the same whatever the lanes (the balance only touches the last cut)
-        early = [s for s in range(n4) if piece4[s] != lastp]
-        assert [sorted(np.nonzero(sub4 == s)[0].tolist()) for s in early] == [sorted(np.nonzero(sub1 == s)[0].tolist()) for s in range(n1) if piece1[s] != lastp]
-        costs4, costs1 = [], []
-        prev_shortest = None
-        for s in late4:
-            m = np.nonzero(sub4 == s)[0]
-            assert len(m) <= min(4 * bc, 1024)
-            if len(m) > bc:
-                assert int(lens[m].sum()) <= bc * 160000 + int(lens[m].max())
-            assert int(first4[s]) in m.tolist() and lens[first4[s]] == lens[m].max()
-            if prev_shortest is not None:
-                assert lens[m].max() <= prev_shortest          # consecutive runs of the sorted list
-            prev_shortest = lens[m].min()
-            costs4.append(_cost_ms(lens, m))
-        for s in late1:
-            costs1.append(_cost_ms(lens, np.nonzero(sub1 == s)[0]))
-        assert max(costs4) < max(costs1)
-        assert max(costs4) <= 1.3 * (sum(costs4) / len(costs4))        # balanced: no run far above the mean
-        assert len(late4) <= 2 * len(late1) + 4                        # ... without doubling the number of decode chains
-        print(f"last cut: plain {len(costs1)} runs, {min(costs1):.1f} .. {max(costs1):.1f} ms; balanced {len(costs4)} runs, {min(costs4):.1f} .. {max(costs4):.1f} ms")
-    nA, subA, _, _ = plan(lens, [len(lens)], bc)
-    nB, subB, _, _ = plan_lanes(lens, [len(lens)], bc, 1)
-    assert nA == nB and (subA == subB).all()
