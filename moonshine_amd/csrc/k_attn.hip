@@ -310,7 +310,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
   }
 
   // One chunk of KMAX keys: stage (every load of this thread first, then the LDS writes) ...
-  auto stage = [&](int ch) {
+  // `between` runs after the chunk's loads are issued and before they are waited for: the first chunk issues the query loads
+  // there, so that keys, values and queries arrive in ONE memory round trip (two dependent ones before; for a 1 s clip that
+  // second round trip was a quarter of the workgroup's life)
+  auto stage = [&](int ch, auto&& between) {
     const int c0 = ch * KMAX;                       // first key of the chunk
     const int Tc = T - c0 < KMAX ? T - c0 : KMAX;   // valid keys in it
     const int nkeys = (Tc + KB - 1) / KB * KB;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
             vreg[i] = *reinterpret_cast<const uint4*>(vp + (long)i * VR * vt_ld);
         }
       }
+      between();
       // keys >= T inside the last chunk of 8 that holds a valid one: exact zeros (the clip's padding rows hold arbitrary values)
       unsigned vmask[4];
 #pragma unroll
@@ -370,27 +374,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
       }
     }
   };
-  stage(0);   // (before the queries and the accumulators exist: the 52 staging registers of a 10 s clip's one chunk are free then)
-
   // this wave's query tiles; a tile that starts at or beyond the clip's last valid frame does no work
   bf16x8 qf[EQT][2];
   int nact = 0;   // the wave's active tiles are its first `nact` (the tile index grows with qi)
+  auto load_queries = [&] {
 #pragma unroll
-  for (int qi = 0; qi < EQT; ++qi) {
-    const int tile = tile0 + qi * NW + wave;
-    nact += (int)(tile * 16 < T);   // wave-uniform
-    const int qrow = tile * 16 + li;
-    const int qrow_ld = qrow < cm.rows ? qrow : cm.rows - 1;
+    for (int qi = 0; qi < EQT; ++qi) {
+      const int tile = tile0 + qi * NW + wave;
+      nact += (int)(tile * 16 < T);   // wave-uniform
+      const int qrow = tile * 16 + li;
+      const int qrow_ld = qrow < cm.rows ? qrow : cm.rows - 1;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int d = s * 32 + kg * 8;
-      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-      if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
-      if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
-      uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
+      for (int s = 0; s < 2; ++s) {
+        const int d = s * 32 + kg * 8;
+        uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+        if (d + 4 <= DH) lo = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d);
+        if (d + 8 <= DH) hi = *reinterpret_cast<const uint2*>(base + (long)qrow_ld * ld + d + 4);
+        uint4 t = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        qf[qi][s] = *reinterpret_cast<bf16x8*>(&t);
+      }
     }
-  }
+  };
+  stage(0, load_queries);   // (before the accumulators exist: the 52 staging registers of a 10 s clip's one chunk are free then)
+
   // nm[qi] = MINUS the reference point of tile qi's exponent (att_key_block): 0 until the first block moves it
   f32x4 nm[EQT];
   float l_run[EQT];
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
   compute(0);
   if constexpr (MULTI) {
     for (int ch = 1; ch < nchunks; ++ch) {   // clips of more than KMAX frames (10.8 s)
-      stage(ch);
+      stage(ch, [] {});
       __syncthreads();
       compute(ch);
     }
