@@ -81,7 +81,7 @@ GROUPS = {  # bench.py kernel group -> kernel-name pattern
     "dec_cross_attention": r"dec_cross_absorbed_kernel|dec_cross_attention_kernel", "dec_self_attention": r"dec_self_attention_kernel",
     "dec_crossq_gemm": r"dec_crossq2_kernel|EpiQtFrag", "dec_ctx_resid_gemm": r"gemm_dec_kernel<(104|72), ",
     "dec_fc2_resid_gemm": r"gemm_dec_kernel<(52|36), \d+, false, .*EpiDecResidFm<true>", "dec_proj_resid_gemm": r"gemm_dec_kernel<(13|9), \d+, false, .*EpiDecResidFm<false>",
-    "enc_attention": r"enc_attention_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
+    "enc_attention": r"enc_attention_res_kernel", "dec_qkv_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiDecQkv",
     "dec_fc1_swiglu_gemm": r"gemm_dec_kernel<\d+, \d+, true, .*EpiSwiGLU", "conv2_gelu_gemm": r"EpiGnBiasGeluBf16", "enc_fc1_gelu_gemm": r"gemm_astat_kernel.*EpiBiasGeluBf16",
     "enc_oproj_mlp_fused": r"mlp_fused_kernel", "enc_qkv_panel": r"panel_gemm_kernel", "cross_kv_gemm": r"EpiCrossKV",
 }
