@@ -321,6 +321,9 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamSynchronize(stream_);
   groups_.clear();
   if (enc_done_) (void)hipEventDestroy(enc_done_);
+  if (enc_fork_) (void)hipEventDestroy(enc_fork_);
+  if (enc_join_) (void)hipEventDestroy(enc_join_);
+  if (enc_stream2_) (void)hipStreamDestroy(enc_stream2_);
   {
     std::lock_guard<std::mutex> structure_lock(device_structure_mutex());
     if (stream_probe_) device_free(stream_probe_);
@@ -1070,7 +1073,62 @@ void Engine::run_encoder() {
   const char* small_env = dev_getenv("MSH_ENC_SMALL_ROWS");
   const long small_rows = small_env != nullptr ? atol(small_env) : 1024;
   const bool small_gemms = R <= small_rows && (R & 3) == 0 && qkv_env == nullptr && mlp_env == nullptr;   // (a developer switch that names a kernel gets that kernel)
-  for (int l = 0; l < cfg_.enc_layers; ++l) {
+  // Two halves side by side.  A layer of a large batch is three chip-filling kernels whose grids end in a partly filled round
+  // (848 panels of 128 rows on 256 CUs = 3.31 rounds for 256 x 10 s: the fused MLP takes the time of 4).  Every kernel of the
+  // layer loop works row by row or clip by clip, so the batch is cut at a clip boundary on a panel boundary and the two halves
+  // run as two chains on two streams: one half's kernels take the CUs the other half's last round leaves idle.  Same bits.
+  // Only when the engine has the GPU to itself (serial 39.3 -> 38.6 ms per 256 x 10 s batch): with batches in flight the
+  // other lanes already fill those CUs and the second stream is one more queue to arbitrate (93.7 -> 92.5-93.2 k audio-s/s).
+  // MSH_ENC_SPLIT=0 / 1: never / also with lanes.
+  const char* split_env = dev_getenv("MSH_ENC_SPLIT");
+  const bool split_on = split_env != nullptr ? split_env[0] == '1' : !shared_gpu_;
+  int c_split = -1;
+  if (split_on && !prof_on_ && !small_gemms && qkv_panel_on && fused_mlp == 1 && (R & 7) == 0) {
+    long best = -1;
+    for (uint32_t c = 1; c < n_clips_; ++c) {
+      const long rs = clips_h_[c].row_start;
+      if (rs % 128 != 0) continue;
+      if (best < 0 || std::labs(rs - R / 2) < std::labs(best - R / 2)) best = rs, c_split = (int)c;
+    }
+    const long need = std::max(qkv_panel_min_rows, mlp_min_rows);
+    if (c_split > 0 && (best < need || R - best < need)) c_split = -1;
+    for (int l = 0; l < cfg_.enc_layers && c_split > 0; ++l)
+      if (enc_[l].qkv_panel == nullptr || enc_[l].mlp == nullptr) c_split = -1;
+  }
+  if (c_split > 0) {
+    if (enc_stream2_ == nullptr) {
+      MSH_HIP(hipStreamCreateWithFlags(&enc_stream2_, hipStreamNonBlocking));
+      MSH_HIP(hipEventCreateWithFlags(&enc_fork_, hipEventDisableTiming));
+      MSH_HIP(hipEventCreateWithFlags(&enc_join_, hipEventDisableTiming));
+    }
+    MSH_HIP(hipEventRecord(enc_fork_, s));
+    MSH_HIP(hipStreamWaitEvent(enc_stream2_, enc_fork_, 0));
+    const long vt_ld = (long)((R + 127) / 128 * 128);
+    const long r_cut = clips_h_[c_split].row_start;
+    const bool nt = enc_store_nt(shared_gpu_);
+    for (int l = 0; l < cfg_.enc_layers; ++l) {
+      const EncLayerW& W = enc_[l];
+      for (int h = 0; h < 2; ++h) {
+        hipStream_t hs = h == 0 ? s : enc_stream2_;
+        const long r0 = h == 0 ? 0 : r_cut, Rn = h == 0 ? r_cut : R - r_cut;
+        const int c0 = h == 0 ? 0 : c_split, nc = h == 0 ? c_split : (int)n_clips_ - c_split;
+        float* Hh_ = H_.as<float>() + r0 * D;
+        bf16_t* Yh = Y_.as<bf16_t>() + r0 * D;
+        bf16_t* QKVh = QKV_.as<bf16_t>() + r0 * 2 * D;
+        bf16_t* AOh = AO_.as<bf16_t>() + r0 * D;
+        if (l > 0 && hand_over_on)
+          qkv_panel_prenorm(Yh, W.qkv_panel, (int)Rn, D, row_pos_.as<int>() + r0, rp, QKVh, VTe_.as<bf16_t>() + r0, vt_ld, hs, nt);
+        else
+          qkv_panel(Hh_, W.qkv_panel, (int)Rn, D, row_pos_.as<int>() + r0, rp, QKVh, VTe_.as<bf16_t>() + r0, vt_ld, hs, nt);
+        enc_attention(QKV_.as<bf16_t>(), VTe_.as<bf16_t>(), vt_ld, AO_.as<bf16_t>(), clips + c0, nc, max_rows_, D, Hh, hs);
+        const bool hand = hand_over_on && l + 1 < cfg_.enc_layers;
+        mlp_fused_oproj(Hh_, AOh, W.mlp, W.b2, Rn, D, F, hs, nt, hand ? Yh : nullptr);
+      }
+    }
+    MSH_HIP(hipEventRecord(enc_join_, enc_stream2_));
+    MSH_HIP(hipStreamWaitEvent(s, enc_join_, 0));
+  }
+  for (int l = 0; l < cfg_.enc_layers && c_split <= 0; ++l) {
     const EncLayerW& W = enc_[l];
     long vt_ld = (long)R;
     if (small_gemms) {

@@ -163,6 +163,9 @@ class Engine {
 
   int device_;
   hipStream_t stream_ = nullptr;
+  // second stream of the encoder's layer loop when the batch runs as two halves side by side (run_encoder)
+  hipStream_t enc_stream2_ = nullptr;
+  hipEvent_t enc_fork_ = nullptr, enc_join_ = nullptr;
   void* stream_probe_ = nullptr;
   struct DryRun {};
   explicit Engine(DryRun);   // no device: only load_weights' validation runs

@@ -257,6 +257,31 @@ def test_base_full_size_batch_properties(base):
         assert len(t_ref) == 66 or t_ref[-1] == cfg.eos
 
 
+@pytest.mark.parametrize("shape", ["uniform", "ragged"])
+def test_encoder_layer_loop_in_two_halves_is_bit_identical(base, monkeypatch, shape):
+    """A large batch's encoder layers run as two halves (cut at a clip boundary on a 128-row panel boundary) on two HIP
+    streams when the engine has the GPU to itself (engine.cpp run_encoder): every kernel of the loop works row by row or
+    clip by clip, so encoder outputs and ids must equal those of the single chain (MSH_ENC_SPLIT=0), for a uniform batch
+    (256 x 10 s, the cut in the middle) and a ragged one (the cut wherever a clip starts on a panel boundary)."""
+    e, _, cfg = base
+    clips = ([make_audio(100 + i, 160000) for i in range(256)] if shape == "uniform"
+             else [make_audio(900 + i, 160000 - 1280 * (i % 40)) for i in range(256)])
+    e.set_cross_mode("absorbed")
+    e.set_keep_encoder_output(True)
+    try:
+        outs = []
+        for sp in ("0", "1"):
+            monkeypatch.setenv("MSH_ENC_SPLIT", sp)
+            ids = e.transcribe_tokens(clips, forced_steps=8)
+            outs.append((ids, [e.encoder_output(c) for c in (0, 100, 127, 128, 129, 200, 255)]))
+        assert outs[0][0] == outs[1][0]
+        for a_, b_ in zip(outs[0][1], outs[1][1]):
+            assert np.isfinite(a_).all() and np.array_equal(a_, b_)
+    finally:
+        e.set_keep_encoder_output(False)
+        e.set_cross_mode("kv")
+
+
 def test_decode_groups_match_single_stream(tmp_path_factory, monkeypatch, micro):
     """The multi-stream decode split (MSH_DEC_GROUPS) must not change a single token: ragged micro batch,
     reference EOS semantics, 3 uneven groups vs the default single group."""
