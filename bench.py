@@ -312,7 +312,9 @@ def roofline_entry(p):
     intensity = flops_per / bytes_per if bytes_per > 0 else float("inf")
     ridge = PEAK_TFLOPS_BF16 * 1e12 / (PEAK_HBM_GBS * 1e9)
     # the LDS-tiled GEMMs / attention are matrix-core work by construction; everything else is a stream
+    # (the streaming encoder's window attention sees <= 21 keys per query: 10 flop per byte, a stream even on the matrix pipe)
     mfma_kernel = (p["name"].startswith(("conv", "enc_", "senc_")) and p["name"].endswith(("_gemm", "attention", "_fused", "_panel"))
+                   and p["name"] != "senc_window_attention"
                    or p["name"] in ("cross_kv_gemm", "cross_kv_panel", "stream_frontend", "stream_adapter_cross_kv") or p["name"].startswith("sver_") and "cross" not in p["name"])
     if flops_per > 0 and (mfma_kernel or intensity >= ridge):
         ach = flops_per / (ms_per * 1e-3) / 1e12

@@ -120,6 +120,149 @@ __global__ __launch_bounds__(256) void enc_window_attention_kernel(const bf16_t*
   }
 }
 
+// The same attention on the matrix pipe: one wave per (tile of 16 consecutive rows of ONE stream, head).  The tile's queries
+// see keys [r0 - past, r0 + 15 + future] = NK = 32 KT key slots (36 -> 64 for the (16, 4) layers, 32 for (16, 0)):
+//   S^T [key x query]   = K_tile (A: rows = keys, 16-byte loads along the head dim) x Q^T (B), DHP = 32 KS dims zero-padded;
+//   softmax per query column in fp32 (exp2 domain), window / stream bounds as -inf, the four lane groups of a column meet
+//   with the two row swaps; the S^T accumulator layout IS the B operand of the second product (slot 8 g + i of a 32-key
+//   step = key 4 g + i of its first 16-key tile, slot 8 g + 4 + i of its second);
+//   O^T [dim x query]   = V^T (A: the same slot order, gathered by 2-byte reads from the wave's row-major LDS copy of the
+//   V rows, row stride DHP + 8: the four lane groups land 16 banks apart) x P^T.
+// Tiles start at the stream's first row of the call (tile_row0, built by the host), so a query's key slots -- and with them
+// the summation order inside the MFMAs -- depend on the stream alone: its rows do not change with what else is in the batch.
+template <int KS, int KT>
+__global__ __launch_bounds__(256) void enc_window_attention_mfma_kernel(const bf16_t* __restrict__ qkv,
+                                                                        const int* __restrict__ tile_row0, int n_tiles,
+                                                                        const int* __restrict__ row_lo,
+                                                                        const int* __restrict__ row_hi, int R, int D, int heads,
+                                                                        int dh, int past, int future, bf16_t* __restrict__ out) {
+  constexpr int DHP = 32 * KS, NK = 32 * KT, VLD = DHP + 8, DT = DHP / 16, CH = DHP / 8;
+  __shared__ __attribute__((aligned(16))) bf16_t vs[4][NK * VLD];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= n_tiles * heads) return;
+  const int tile = item / heads, head = item - tile * heads;
+  const int r0 = tile_row0[tile];
+  const int lo = row_lo[r0], hi = row_hi[r0];
+  const int kb = r0 - past;
+  const long ld = 3L * D;
+  const bf16_t* base = qkv + head * dh;
+  union Frag {
+    uint4 u;
+    bf16x8 v;
+    uint32_t w[4];
+    bf16_t h[8];
+  };
+  // the V rows of the tile's key range, row-major, dims beyond dh zero
+  bf16_t* vw = vs[w];
+#pragma unroll
+  for (int c0 = 0; c0 < NK * CH; c0 += 64) {
+    const int c = c0 + lane, kk = c / CH, d8 = (c - kk * CH) * 8;
+    int row = kb + kk;
+    row = row < 0 ? 0 : (row >= R ? R - 1 : row);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (d8 < dh) v = *reinterpret_cast<const uint4*>(base + row * ld + 2 * D + d8);
+    *reinterpret_cast<uint4*>(vw + kk * VLD + d8) = v;
+  }
+  Frag qf[KS];
+  {
+    int row = r0 + n;
+    row = row >= R ? R - 1 : row;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = 32 * ks + 8 * g;
+      qf[ks].u = d < dh ? *reinterpret_cast<const uint4*>(base + row * ld + d) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  f32x4 st[2 * KT];
+#pragma unroll
+  for (int kt = 0; kt < 2 * KT; ++kt) {
+    int row = kb + 16 * kt + n;
+    row = row < 0 ? 0 : (row >= R ? R - 1 : row);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = 32 * ks + 8 * g;
+      Frag kf;
+      kf.u = d < dh ? *reinterpret_cast<const uint4*>(base + row * ld + D + d) : make_uint4(0u, 0u, 0u, 0u);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[ks].v, acc, 0, 0, 0);
+    }
+    st[kt] = acc;
+  }
+  const int q = r0 + n;
+  int jlo = q - past, jhi = q + future;
+  jlo = jlo < lo ? lo : jlo;
+  jhi = jhi > hi - 1 ? hi - 1 : jhi;
+  const float c = rsqrtf((float)dh) * 1.4426950408889634f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 2 * KT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = kb + 16 * kt + 4 * g + i;
+      const float t = (j >= jlo && j <= jhi) ? st[kt][i] * c : -INFINITY;
+      st[kt][i] = t;
+      mx = fmaxf(mx, t);
+    }
+  {  // the column's four lane groups (lanes n, n + 16, n + 32, n + 48)
+    const unsigned u = __float_as_uint(mx);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const unsigned u2 = __float_as_uint(mx);
+    auto r2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    mx = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+  }
+  if (mx == -INFINITY) mx = 0.f;   // (a column past the stream's last row: nothing is stored for it)
+  float sum = 0.f;
+  Frag pf[KT];
+#pragma unroll
+  for (int s = 0; s < KT; ++s) {
+    float p0[4], p1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p0[i] = exp2f(st[2 * s][i] - mx);
+      p1[i] = exp2f(st[2 * s + 1][i] - mx);
+      sum += p0[i] + p1[i];
+    }
+    pf[s].w[0] = pack_bf16x2(p0[0], p0[1]);
+    pf[s].w[1] = pack_bf16x2(p0[2], p0[3]);
+    pf[s].w[2] = pack_bf16x2(p1[0], p1[1]);
+    pf[s].w[3] = pack_bf16x2(p1[2], p1[3]);
+  }
+  {
+    const unsigned u = __float_as_uint(sum);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned u2 = __float_as_uint(sum);
+    auto r2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    sum = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+  }
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  __builtin_amdgcn_wave_barrier();   // (the wave's own LDS writes are ordered before its reads; this pins the compiler)
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    if (16 * dt >= dh) break;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+      Frag vf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vf.h[i] = vw[(32 * s + 4 * g + i) * VLD + 16 * dt + n];
+        vf.h[4 + i] = vw[(32 * s + 16 + 4 * g + i) * VLD + 16 * dt + n];
+      }
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[s].v, o, 0, 0, 0);
+    }
+    const int d = 16 * dt + 4 * g;
+    if (q < hi && d < dh) {
+      uint2 pk;
+      pk.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+      pk.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+      *reinterpret_cast<uint2*>(out + (long)q * D + head * dh + d) = pk;
+    }
+  }
+}
+
 __global__ void adapter_in_kernel(const float* __restrict__ y32, const int* __restrict__ rows,
                                   const int* __restrict__ pos, int D, const float* __restrict__ pos_emb,
                                   bf16_t* __restrict__ out16, float* __restrict__ out32) {
@@ -1018,11 +1161,28 @@ void copy_segments(const StreamSeg* segs, int n, hipStream_t s) {
   MSH_LAUNCH(copy_segments_kernel, dim3(n, 4), dim3(256), 0, s, segs);
 }
 void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_hi, int R, int D, int heads, int past,
-                          int future, bf16_t* out, hipStream_t s) {
+                          int future, bf16_t* out, hipStream_t s, const int* tile_row0, int n_tiles) {
   const int dh = D / heads;
   if (past + future + 1 > 64 || dh > 128 || (dh & 3) != 0)
     throw std::runtime_error("stream_enc_attention: window wider than 64 keys or unsupported head_dim");
   if (R <= 0) return;
+  static const bool no_mfma = [] {   // A/B switch: MSH_STREAM_WINDOW_VALU=1 keeps the one-wave-per-(row, head) VALU kernel
+    const char* e = dev_getenv("MSH_STREAM_WINDOW_VALU");
+    return e != nullptr && e[0] == '1';
+  }();
+  const int ks = (dh + 31) / 32, kt = (past + future + 16 + 31) / 32;
+  if (!no_mfma && tile_row0 != nullptr && n_tiles > 0 && (dh & 7) == 0 && (D & 7) == 0 && ks <= 4 && kt <= 3) {
+    const dim3 grid((n_tiles * heads + 3) / 4);
+#define MSH_WATT(KSV, KTV)                                                                                                       \
+  if (ks == KSV && kt == KTV) {                                                                                                  \
+    MSH_LAUNCH((enc_window_attention_mfma_kernel<KSV, KTV>), grid, dim3(256), 0, s, qkv, tile_row0, n_tiles, row_lo, row_hi, R, D, \
+               heads, dh, past, future, out);                                                                                    \
+    return;                                                                                                                      \
+  }
+    MSH_WATT(1, 1) MSH_WATT(1, 2) MSH_WATT(1, 3) MSH_WATT(2, 1) MSH_WATT(2, 2) MSH_WATT(2, 3)
+    MSH_WATT(3, 1) MSH_WATT(3, 2) MSH_WATT(3, 3) MSH_WATT(4, 1) MSH_WATT(4, 2) MSH_WATT(4, 3)
+#undef MSH_WATT
+  }
   MSH_LAUNCH(enc_window_attention_kernel, dim3((R * heads + 3) / 4), dim3(256), 0, s, qkv, row_lo, row_hi, R,
                      D, heads, past, future, out);
 }

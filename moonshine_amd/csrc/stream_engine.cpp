@@ -93,7 +93,7 @@ StreamingEngine::~StreamingEngine() {
   DevBuf* bufs[] = {&audio_, &frames_, &hidden_, &c1out_, &feat_pk_, &segs_, &jobs_, &H_, &Y_, &Y32_, &QKV_, &AO_,
                     &Z_, &Q_, &rowlo_, &rowhi_, &newrows_, &newpos_, &newslot_, &newidx_, &adp16_, &adp32_, &mem16_,
                     &mem32_, &crosstmp_, &rowslot_, &rowpos_, &tokens_, &logits_, &pred_, &draft_, &decjobs_, &stepH_,
-                    &steppos_, &probs_, &runs_, &pval_, &pidx_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
+                    &steppos_, &probs_, &runs_, &pval_, &pidx_, &tiles_, &bias_off_, &bias_tok_, &bias_node_, &bias_depth_, &bias_bonus_, &bias_prefix_};
   for (DevBuf* b : bufs) b->release();
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -634,7 +634,7 @@ void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, i
   mem32_.reserve((size_t)Nn * Dd * 4);
   crosstmp_.reserve((size_t)Nn * L * 2 * Dd * 2);
   std::vector<StreamSeg> gather, memseg;
-  std::vector<int> lo(R), hi(R), nrow(Nn), npos(Nn), nslot(Nn), nidx(Nn);
+  std::vector<int> lo(R), hi(R), nrow(Nn), npos(Nn), nslot(Nn), nidx(Nn), tiles;
   std::vector<int4> upd;
   float* H = H_.as<float>();
   int k = 0;
@@ -646,6 +646,7 @@ void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, i
       lo[j.r0 + r] = j.r0;
       hi[j.r0 + r] = j.r0 + W;
     }
+    for (int t0 = 0; t0 < W; t0 += 16) tiles.push_back(j.r0 + t0);   // window attention: 16-row tiles from the stream's first row
     memseg.push_back({mem32_.as<float>() + (size_t)k * Dd, memory_ + ((size_t)j.slot * Mcap_ + h.mem_len) * Dd,
                       (long)j.fresh * Dd * 4});
     for (int i = 0; i < j.fresh; ++i, ++k) {
@@ -664,6 +665,7 @@ void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, i
   const StreamSeg* segs_d = stage(segs_, all);
   const int* lo_d = stage(rowlo_, lo);
   const int* hi_d = stage(rowhi_, hi);
+  const int* tiles_d = stage(tiles_, tiles);
   const int* nrow_d = stage(newrows_, nrow);
   const int* npos_d = stage(newpos_, npos);
   const int* nslot_d = stage(newslot_, nslot);
@@ -691,7 +693,7 @@ void StreamingEngine::encode(int n, const int* slots, const uint8_t* is_final, i
       const double keys = cfg_.windows[l].first + cfg_.windows[l].second + 1;
       Sc sc(&prof_, stream_, "senc_window_attention", 4.0 * rd * keys, rd * 2 * 4);
       stream_enc_attention(QKV, lo_d, hi_d, R, De, cfg_.encoder_heads, cfg_.windows[l].first, cfg_.windows[l].second, AO,
-                           stream_);
+                           stream_, tiles_d, (int)tiles.size());
     }
     {
       Sc sc(&prof_, stream_, "senc_oproj_gemm", 2.0 * rd * De, rd * (2 + 8) + 2.0 * De * De);

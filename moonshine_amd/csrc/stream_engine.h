@@ -181,7 +181,7 @@ class StreamingEngine {
   DevBuf audio_, frames_, hidden_, c1out_, feat_pk_, segs_, jobs_, H_, Y_, Y32_, QKV_, AO_, Z_, Q_, rowlo_, rowhi_,
       newrows_, newpos_, newslot_, newidx_, adp16_, adp32_, mem16_, mem32_, crosstmp_, rowslot_, rowpos_, tokens_, jobmem_,
       logits_, pred_, draft_, decjobs_, stepH_, steppos_;
-  DevBuf runs_, pval_, pidx_;
+  DevBuf runs_, pval_, pidx_, tiles_;
   DevBuf bias_off_, bias_tok_, bias_node_, bias_depth_, bias_bonus_, bias_prefix_;
   BiasTrie bias_{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 };

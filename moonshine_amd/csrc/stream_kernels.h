@@ -52,8 +52,10 @@ void stream_frames(const float* audio, const FrameJob* jobs, int n_jobs, int max
 void copy_segments(const StreamSeg* segs, int n, hipStream_t s);
 // sliding-window encoder self-attention (no RoPE): row i attends rows [max(i-past, lo_i), min(i+future, hi_i-1)]
 // of the packed stream (lora/export.py:113-127: both bounds inclusive); qkv [R,3D] bf16 -> out [R,D] bf16
+// tile_row0 / n_tiles (optional): the first rows of the call's tiles of <= 16 consecutive rows of one stream, counted from
+// each stream's first row -- with them (and head_dim % 8 == 0) the MFMA kernel runs, one wave per (tile, head)
 void stream_enc_attention(const bf16_t* qkv, const int* row_lo, const int* row_hi, int R, int D, int heads, int past,
-                          int future, bf16_t* out, hipStream_t s);
+                          int future, bf16_t* out, hipStream_t s, const int* tile_row0 = nullptr, int n_tiles = 0);
 // adapter input: out[i] = y32[rows[i]] + pos_emb[pos[i]]  (lora/export.py:141-144), as bf16 and fp32
 void stream_adapter_in(const float* y32, const int* rows, const int* pos, int n, int D, const float* pos_emb,
                        bf16_t* out16, float* out32, hipStream_t s);
