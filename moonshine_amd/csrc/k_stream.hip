@@ -783,6 +783,197 @@ __global__ __launch_bounds__(256, 2) void cross_attention_runs_kernel(const bf16
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-attention of a LONG run of rows of one stream (the verify pass: BOS + draft = up to 66 rows over one memory) on the
+// matrix pipe: one 8-wave workgroup per (run of <= 128 rows, head), wave w owns query tile w (16 rows); the stream's K^T / V^T
+// pass through LDS ONCE per head, in chunks of 64 keys (the runs kernel above re-reads them for every four rows).
+//   staging: every thread fetches 16-byte pieces (8 keys of one head-dim row) of the NEXT chunk into registers while the
+//     current one is computed; keys >= nk and padding dims arrive as zeros.  V^T goes to LDS as it is ([dim][72]); K^T is
+//     written in MFMA-fragment order (a piece = 8 two-byte writes) so that every wave reads an A fragment with one
+//     ds_read_b128 -- the transposition is done once per workgroup, not once per wave;
+//   S^T [key x query] = K (A) x Q^T (B: 16-byte loads from the row-major q rows, kept in registers for all chunks);
+//   fp32 online softmax per query column in the exp2 domain; the S^T accumulator layout IS the B operand of
+//   O^T [dim x query] += V^T (A: two ds_read_b64 per fragment, the slot order of the accumulators) x P^T.
+// P is rounded to bf16 (as in every MFMA attention of this library); the one-row kernels keep it in fp32 -- the wide pass
+// and the auto-regressive steps already round differently elsewhere (tiled vs split-K GEMMs).
+template <int KS, int DT>
+__global__ __launch_bounds__(512) void cross_attention_wide_kernel(const bf16_t* __restrict__ q, const int* __restrict__ row_slot,
+                                                                   const RowRun* __restrict__ runs,
+                                                                   const SlotDev* __restrict__ slots, int D, int heads, int dh,
+                                                                   int layer, int L, int Mcap,
+                                                                   const bf16_t* __restrict__ crossKT,
+                                                                   const bf16_t* __restrict__ crossVT, bf16_t* __restrict__ out) {
+  constexpr int KC = 64, VLD = 72, DHP = 32 * KS, VR = 16 * DT;
+  constexpr int KPIECES = DHP * (KC / 8), VPIECES = VR * (KC / 8);   // 16-byte pieces per chunk
+  constexpr int KPT = (KPIECES + 511) / 512, VPT = (VPIECES + 511) / 512;
+  __shared__ __attribute__((aligned(16))) bf16_t kfm[(KC / 16) * KS * 512];   // [key tile][k-step][lane][8]
+  __shared__ __attribute__((aligned(16))) bf16_t vimg[VR * VLD];
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, g = lane >> 4;
+  const RowRun run = runs[blockIdx.x];
+  const int h = blockIdx.y;
+  const int slot = row_slot[run.row0];
+  const int nk = slots[slot].mem_len;
+  const long base = (((long)slot * L + layer) * D + h * dh) * Mcap;
+  const bf16_t* kt_g = crossKT + base;
+  const bf16_t* vt_g = crossVT + base;
+  union Frag {
+    uint4 u;
+    bf16x8 v;
+    uint32_t w[4];
+    bf16_t h[8];
+    uint2 d[2];
+  };
+  // the wave's query tile as B fragments
+  const bool active = 16 * w < run.n;
+  const int qrow = run.row0 + 16 * w + n;
+  const bool qok = 16 * w + n < run.n;
+  Frag qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d = 32 * ks + 8 * g;
+    qf[ks].u = (qok && d < dh) ? *reinterpret_cast<const uint4*>(q + (long)qrow * D + h * dh + d) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  uint4 kreg[KPT], vreg[VPT];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int p = tid + 512 * i, d = p >> 3, key = k0 + 8 * (p & 7);
+      kreg[i] = (p < KPIECES && d < dh && key < nk) ? *reinterpret_cast<const uint4*>(kt_g + (long)d * Mcap + key) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int p = tid + 512 * i, d = p >> 3, key = k0 + 8 * (p & 7);
+      vreg[i] = (p < VPIECES && d < dh && key < nk) ? *reinterpret_cast<const uint4*>(vt_g + (long)d * Mcap + key) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  // nk % 8 == 0 is not guaranteed: a piece that straddles nk brings keys >= nk with it -- they are masked in the scores
+  // (-inf -> p = 0) and their V values, finite numbers of an earlier, longer memory or zeros of the allocation, meet p = 0
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int p = tid + 512 * i;
+      if (p < KPIECES) {
+        const int d = p >> 3, kk0 = 8 * (p & 7);
+        Frag f;
+        f.u = kreg[i];
+        const int ks = d >> 5, gg = (d & 31) >> 3, e = d & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = kk0 + j;
+          kfm[(((kk >> 4) * KS + ks) * 64 + (kk & 15) + 16 * gg) * 8 + e] = f.h[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int p = tid + 512 * i;
+      if (p < VPIECES) *reinterpret_cast<uint4*>(vimg + (p >> 3) * VLD + 8 * (p & 7)) = vreg[i];
+    }
+  };
+  const float c = rsqrtf((float)dh) * 1.4426950408889634f;
+  float m_run = -INFINITY, l_part = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+#pragma unroll 1
+  for (int k0 = 0; k0 < nk; k0 += KC) {
+    if (k0 > 0) __syncthreads();   // every wave is done with the previous chunk's images
+    stash();
+    __syncthreads();
+    if (k0 + KC < nk) fetch(k0 + KC);
+    if (active) {
+      f32x4 st[KC / 16];
+#pragma unroll
+      for (int kt = 0; kt < KC / 16; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Frag kf;
+          kf.u = *reinterpret_cast<const uint4*>(kfm + ((kt * KS + ks) * 64 + lane) * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[ks].v, acc, 0, 0, 0);
+        }
+        st[kt] = acc;
+      }
+      float cm = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KC / 16; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = k0 + 16 * kt + 4 * g + i;
+          const float t = key < nk ? st[kt][i] * c : -INFINITY;
+          st[kt][i] = t;
+          cm = fmaxf(cm, t);
+        }
+      {
+        const unsigned u = __float_as_uint(cm);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        cm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        const unsigned u2 = __float_as_uint(cm);
+        auto r2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+        cm = fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+      }
+      const float m_new = fmaxf(m_run, cm);   // (finite: key k0 of the chunk is < nk)
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      Frag pf[KC / 32];
+      float psum = 0.f;
+#pragma unroll
+      for (int s = 0; s < KC / 32; ++s) {
+        float p0[4], p1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          p0[i] = exp2f(st[2 * s][i] - m_new);
+          p1[i] = exp2f(st[2 * s + 1][i] - m_new);
+          psum += p0[i] + p1[i];
+        }
+        pf[s].w[0] = pack_bf16x2(p0[0], p0[1]);
+        pf[s].w[1] = pack_bf16x2(p0[2], p0[3]);
+        pf[s].w[2] = pack_bf16x2(p1[0], p1[1]);
+        pf[s].w[3] = pack_bf16x2(p1[2], p1[3]);
+      }
+      l_part = l_part * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 acc = o[dt];
+        acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+#pragma unroll
+        for (int s = 0; s < KC / 32; ++s) {
+          Frag vf;
+          const bf16_t* vrow = vimg + (16 * dt + n) * VLD + 32 * s + 4 * g;
+          vf.d[0] = *reinterpret_cast<const uint2*>(vrow);
+          vf.d[1] = *reinterpret_cast<const uint2*>(vrow + 16);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[s].v, acc, 0, 0, 0);
+        }
+        o[dt] = acc;
+      }
+    }
+  }
+  if (!active) return;
+  float l = l_part;
+  {
+    const unsigned u = __float_as_uint(l);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    l = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned u2 = __float_as_uint(l);
+    auto r2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    l = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+  }
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (qok) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = 16 * dt + 4 * g;
+      if (d < dh) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+        pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+        *reinterpret_cast<uint2*>(out + (long)qrow * D + h * dh + d) = pk;
+      }
+    }
+  }
+}
+
 // Any other head_dim (multiple of 4, <= 128): plain two-pass kernel over the same transposed layouts.
 __global__ __launch_bounds__(256) void cross_attention_generic_kernel(const bf16_t* __restrict__ q,
                                                                       const int* __restrict__ row_slot,
@@ -1317,6 +1508,26 @@ void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int
     default: throw std::runtime_error("stream_cross_attention_runs: unsupported head_dim");
   }
 #undef MSH_XRUN
+}
+bool stream_cross_attention_wide_supported(int D, int heads, int Mcap) {
+  const int dh = D / heads;
+  return (dh & 7) == 0 && dh >= 16 && dh <= 96 && (D & 7) == 0 && (Mcap & 7) == 0;
+}
+void stream_cross_attention_wide(const bf16_t* q, const int* row_slot, const int2* runs, int n_runs, const SlotDev* slots, int D,
+                                 int heads, int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
+                                 hipStream_t s) {
+  if (n_runs <= 0) return;
+  const RowRun* rr = reinterpret_cast<const RowRun*>(runs);
+  const int dh = D / heads, ks = (dh + 31) / 32, dt = (dh + 15) / 16;
+#define MSH_XWIDE(KSV, DTV)                                                                                                     \
+  if (ks == KSV && dt == DTV) {                                                                                                 \
+    MSH_LAUNCH((cross_attention_wide_kernel<KSV, DTV>), dim3(n_runs, heads), dim3(512), 0, s, q, row_slot, rr, slots, D, heads, \
+               dh, layer, L, Mcap, crossK, crossV, out);                                                                        \
+    return;                                                                                                                     \
+  }
+  MSH_XWIDE(1, 1) MSH_XWIDE(1, 2) MSH_XWIDE(2, 3) MSH_XWIDE(2, 4) MSH_XWIDE(3, 5) MSH_XWIDE(3, 6)
+#undef MSH_XWIDE
+  throw std::runtime_error("stream_cross_attention_wide: unsupported head_dim");
 }
 bool stream_cross_attention_runs_supported(int D, int heads, int Mcap) {
   const int dh = D / heads;

@@ -751,12 +751,31 @@ const int2* StreamingEngine::stage_runs(const std::vector<int>& rs, int* n_runs)
     const char* e = dev_getenv("MSH_NO_CROSS_RUNS");
     return e != nullptr && e[0] == '1';
   }();
-  if (off || !stream_cross_attention_runs_supported(cfg_.decoder_dim, cfg_.nheads, Mcap_)) return nullptr;
+  runs_wide_ = false;
+  if (off) return nullptr;
+  // a stream with 8 or more consecutive rows in the pass (a verify pass): whole runs of up to 128 rows for the MFMA kernel
+  // (MSH_STREAM_XWIDE=0: the four-row runs kernel for every pass)
+  static const bool wide_off = [] {
+    const char* e = dev_getenv("MSH_STREAM_XWIDE");
+    return e != nullptr && e[0] == '0';
+  }();
+  size_t longest = 0;
+  for (size_t r = 0; r < rs.size();) {
+    size_t e = r + 1;
+    while (e < rs.size() && rs[e] == rs[r]) ++e;
+    longest = std::max(longest, e - r);
+    r = e;
+  }
+  const bool wide = !wide_off && longest >= 8 && capture_probs_ == nullptr &&
+                    stream_cross_attention_wide_supported(cfg_.decoder_dim, cfg_.nheads, Mcap_);
+  if (!wide && !stream_cross_attention_runs_supported(cfg_.decoder_dim, cfg_.nheads, Mcap_)) return nullptr;
+  const size_t cap = wide ? (size_t)kCrossWideRows : (size_t)kCrossRunRows;
+  runs_wide_ = wide;
   std::vector<int2> runs;
   bool any_long = false;
   for (size_t r = 0; r < rs.size();) {
     size_t e = r + 1;
-    while (e < rs.size() && rs[e] == rs[r] && e - r < (size_t)kCrossRunRows) ++e;
+    while (e < rs.size() && rs[e] == rs[r] && e - r < cap) ++e;
     runs.push_back(make_int2((int)r, (int)(e - r)));
     any_long |= e - r > 1;
     r = e;
@@ -835,7 +854,9 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       stream_cross_probs(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, capture_ecap_, capture_probs_, stream_);
     {
       Sc sc(&prof_, stream_, nm("sdec_cross_attention", "sver_cross_attention"), 0, pass_cross_bytes_ / L + md * 4);
-      if (runs_d != nullptr)
+      if (runs_d != nullptr && runs_wide_)
+        stream_cross_attention_wide(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
+      else if (runs_d != nullptr)
         stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
       else
         stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_, fm,

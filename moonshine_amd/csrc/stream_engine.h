@@ -112,6 +112,7 @@ class StreamingEngine {
   // rows of `rs` (slot per row) -> runs of <= kCrossRunRows consecutive rows with the same slot, staged on the device;
   // nullptr when the pass has no run longer than one row (the auto-regressive steps) or the kernel does not cover the shape
   const int2* stage_runs(const std::vector<int>& rs, int* n_runs);
+  bool runs_wide_ = false;   // the staged runs are whole runs of <= kCrossWideRows rows for the MFMA cross-attention
   void push_slot_state(int slot);
 
   struct EncW {

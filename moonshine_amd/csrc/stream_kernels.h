@@ -88,6 +88,13 @@ void stream_cross_attention_runs(const bf16_t* q, const int* row_slot, const int
                                  int heads, int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
                                  hipStream_t s);
 bool stream_cross_attention_runs_supported(int D, int heads, int Mcap);
+// Long runs (the verify pass: up to kCrossWideRows consecutive rows of one stream per run) on the matrix pipe: one workgroup per
+// (run, head) streams the stream's K / V once.  P is rounded to bf16: results equal the kernels above to rounding, not bit for bit.
+constexpr int kCrossWideRows = 128;
+void stream_cross_attention_wide(const bf16_t* q, const int* row_slot, const int2* runs, int n_runs, const SlotDev* slots, int D,
+                                 int heads, int layer, int L, int Mcap, const bf16_t* crossK, const bf16_t* crossV, bf16_t* out,
+                                 hipStream_t s);
+bool stream_cross_attention_wide_supported(int D, int heads, int Mcap);
 // first-max argmax of every logits row (moonshine-streaming-model.cpp:1222-1232)
 void stream_argmax(const float* logits, int M, int V, int* pred, hipStream_t s);
 // speculative verify (moonshine-streaming-model.cpp:1304-1366): longest agreeing draft prefix, rollback of the

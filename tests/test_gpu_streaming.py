@@ -510,7 +510,7 @@ with tempfile.TemporaryDirectory() as d:
     outs = []
     for flag in ("0", "1"):
         o = str(tmp_path / f"logits_{flag}.npz")
-        env = dict(os.environ, MSH_NO_CROSS_RUNS=flag)
+        env = dict(os.environ, MSH_NO_CROSS_RUNS=flag, MSH_STREAM_XWIDE="0")   # (runs of >= 8 rows would take the MFMA kernel)
         r = subprocess.run([sys.executable, "-c", code, o], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -520,6 +520,58 @@ with tempfile.TemporaryDirectory() as d:
         a, b = outs[0][k], outs[1][k]
         assert a.shape == b.shape and np.isfinite(a).all()
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("arch", ["micro_streaming", "tiny_streaming", "medium_streaming"])
+def test_wide_pass_cross_attention_on_mfma_matches_the_per_row_kernel(tmp_path, arch):
+    """Runs of 8 or more rows of one stream (a verify pass) take cross_attention_wide_kernel: the stream's K / V through
+    LDS once per head, both products on MFMA, P rounded to bf16.  Against the one-row-per-workgroup kernel
+    (MSH_NO_CROSS_RUNS=1, read once per process: two child processes) the logits of a teacher-forced pass agree to
+    rounding: runs of 9, 40, 3 (below the threshold, rides along), 66 and 131 rows (two workgroups), memories of
+    different lengths with the last chunk of keys partly filled."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ".")
+sys.path.insert(0, "./tests")
+from tests.test_gpu_streaming import make_engine, feed
+from moonshine_amd.synth import make_audio
+import pathlib, tempfile
+out, arch = sys.argv[1], sys.argv[2]
+lens = [9, 40, 3, 66, 131]
+with tempfile.TemporaryDirectory() as d:
+    eng, cfg, w = make_engine(pathlib.Path(d), arch, 7, max_slots=5, max_frames=320)
+    slots = [eng.open() for _ in lens]
+    for i, s in enumerate(slots):
+        feed(eng, s, make_audio(170 + i, 1280 * (11 + 9 * i)), 5)
+    toks = [[cfg.bos] + [(41 * (i + 1) * (t + 3)) % cfg.vocab for t in range(n - 1)] for i, n in enumerate(lens)]
+    eng.decoder_reset(slots)
+    lg = eng.decode_tokens(slots, toks)
+    np.savez(out, *[np.asarray(x) for x in lg])
+    eng.close()
+'''
+    outs = []
+    for flag in ("0", "1"):
+        o = str(tmp_path / f"logits_{flag}.npz")
+        env = dict(os.environ, MSH_NO_CROSS_RUNS=flag)
+        env.pop("MSH_STREAM_XWIDE", None)
+        r = subprocess.run([sys.executable, "-c", code, o, arch], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(o))
+    assert len(outs[0].files) == 5
+    worst = 0.0
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all()
+        worst = max(worst, float(np.abs(a - b).max()))
+        # (bf16 P in every layer's cross-attention: 1-2e-3 on the 2- and 6-layer models, 4e-3 after the 12 layers of the medium dims)
+        assert relrms(a, b) < 8e-3, (k, relrms(a, b))
+    assert 0.0 < worst < 8e-2, worst   # (not the same kernel: equal logits would mean the switch did nothing)
+    print(f"wide-pass cross-attention on MFMA vs per-row kernel ({arch}): logits max-abs {worst:.3e}")
 
 
 @pytest.mark.parametrize("arch,n_streams,chunks", [("micro_streaming", 5, 30), ("tiny_streaming", 20, 40), ("medium_streaming", 40, 24)])
