@@ -590,9 +590,30 @@ void launch_tiled_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, 
 // Tile choice: TN = 13 (208 columns) divides every base-model width; widths that are multiples of 144
 // (tiny, D = 288) use TN = 9; anything else falls back to TN = 4 with column predication.  TM = 4
 // (256 rows, 208 accumulator registers, one workgroup per CU) once the grid still fills the chip.
+// Epilogues that also exist on 64-row tiles (the GEMMs of a streaming verify pass: a few thousand rows x 640 .. 1920 columns
+// are 60 .. 130 tiles of 128 x 208 on 256 CUs; 64 x 80 / 64 x 160 tiles give 256 .. 400 workgroups, two to four per CU).
+// The k-slices and the MFMA order per output element are those of the large tile: the same bits.
+template <class Epi> constexpr bool kMidTiles = false;
+template <> constexpr bool kMidTiles<EpiResidF32> = true;
+template <> constexpr bool kMidTiles<EpiAct> = true;
+template <> constexpr bool kMidTiles<EpiQkvRopeBf16> = true;
+template <> constexpr bool kMidTiles<EpiSwiGLU> = true;
+
 template <bool SWAP, class Epi>
 void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((K & 31) != 0 || (N & 3) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_tiled: unsupported shape");
+  if constexpr (kMidTiles<Epi>) {
+    static const bool mid_off = [] {   // A/B switch: MSH_GEMM_MID_TILES=0
+      const char* e = dev_getenv("MSH_GEMM_MID_TILES");
+      return e != nullptr && e[0] == '0';
+    }();
+    const long grid128 = (long)((M + 127) / 128) * ((N + 207) / 208);
+    if (!mid_off && gemm_mode() == 2 && grid128 < 192 && M >= 64) {
+      const long ntm = (M + 63) / 64;
+      if (N % 160 == 0 && ntm * (N / 160) >= 192) return launch_tiled_dma_cfg<4, 1, 10, 3, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+      if (N % 80 == 0) return launch_tiled_dma_cfg<4, 1, 5, 3, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    }
+  }
   const bool big = (long)((M + 255) / 256) * ((N + 207) / 208) >= 512;
   if (N % 208 == 0 || (N % 144 != 0 && N >= 416)) {  // ragged last column tile (e.g. the 32768-wide LM head) is predicated
     const int mode = gemm_mode();
