@@ -533,7 +533,9 @@ __device__ __forceinline__ float s_hi(unsigned u) { return __uint_as_float(u & 0
 // 3c: keep what is read once per step out of the memory-side cache, so that it keeps the weights) on the streaming decoder,
 // whose weights (~240 MB at the medium dims) are what every step re-reads: config 5 931-934 -> 954-958 audio-s/s
 // (profiles/r5x_*).  Default for head_dim 80; MSH_STREAM_XATTN_NT=0 switches it off.
-template <int DH, bool NT = false>
+// ABL (probe, 0 in the product): 1 = no K / V loads (the arithmetic on zeros), 2 = the loads alone (their values OR-ed into the
+// output so that they stay)
+template <int DH, bool NT = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* __restrict__ q,
                                                                  const int* __restrict__ row_slot,
                                                                  const SlotDev* __restrict__ slots, int D, int heads,
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
 #pragma unroll 1
   for (int k0 = 0; k0 < nk; k0 += 512) {
     const int key = k0 + lane * 8;
-    const bool in = key < nk;  // nk <= Mcap and Mcap % 8 == 0: an "in" lane's 8 keys are inside the row
+    const bool in = key < nk && ABL != 1;  // nk <= Mcap and Mcap % 8 == 0: an "in" lane's 8 keys are inside the row
     // K and V rows of the chunk are requested together: one memory round trip per chunk (2 x DQ 16-byte loads in flight)
     su32x4 kr[DQ], vr[DQ];
 #pragma unroll
@@ -577,6 +579,14 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const bf16_t* _
       if constexpr (NT) vr[d] = in ? __builtin_nontemporal_load(reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key)) : su32x4{0u, 0u, 0u, 0u};
       else vr[d] = in ? *reinterpret_cast<const su32x4*>(vt + (long)d * Mcap + key) : su32x4{0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ABL == 2) {
+      unsigned acc = 0;
+#pragma unroll
+      for (int d = 0; d < DQ; ++d) acc |= kr[d].x | kr[d].y | kr[d].z | kr[d].w | vr[d].x | vr[d].y | vr[d].z | vr[d].w;
+      opart[0] += __uint_as_float(acc & 0x3f800000u);
+      l_part = 1.f;
+      continue;
+    }
     float sc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) sc[e] = 0.f;
@@ -1454,8 +1464,19 @@ void stream_cross_attention(const bf16_t* q, const int* row_slot, const SlotDev*
     return !(e != nullptr && e[0] == '0');
   }();
   if (nt && dh == 80) {
-    MSH_LAUNCH((cross_attention_kernel<80, true>), dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
-               crossK, crossV, out, fmi, row_mem);
+    static const int abl = [] {
+      const char* e = dev_getenv("MSH_STREAM_XATTN_ABL");
+      return e != nullptr ? atoi(e) : 0;
+    }();
+    if (abl == 1)
+      MSH_LAUNCH((cross_attention_kernel<80, true, 1>), dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+                 crossK, crossV, out, fmi, row_mem);
+    else if (abl == 2)
+      MSH_LAUNCH((cross_attention_kernel<80, true, 2>), dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+                 crossK, crossV, out, fmi, row_mem);
+    else
+      MSH_LAUNCH((cross_attention_kernel<80, true>), dim3(M, heads), dim3(256), 0, s, q, row_slot, slots, D, heads, layer, L, Mcap,
+                 crossK, crossV, out, fmi, row_mem);
     return;
   }
 #define MSH_XATT(DHV)                                                                                                  \

@@ -811,6 +811,14 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
   bf16_t* Z = Z_.as<bf16_t>();
   const RopeParams rp{rope_cos_, rope_sin_, rot_pairs_, cfg_.head_dim, Dd};
   const bool small = M <= 256;  // split-K decode kernel (16-row tiles) instead of 128-row MFMA tiles
+  // developer probe (tools/gpu_stream_chain.sh): MSH_STREAM_AR_MASK = bit mask of the kernel groups an FM auto-regressive step
+  // enqueues (bit 0 LN + QKV, 1 self-attention, 2 o-proj, 3 LN + cross-q, 4 cross-attention, 5 cross-o, 6 LN + fc1, 7 fc2,
+  // 8 final LN + LM head); the replayed graph then times that chain alone.  Tokens are garbage under a partial mask.
+  static const unsigned ar_mask = [] {
+    const char* e = dev_getenv("MSH_STREAM_AR_MASK");
+    return e != nullptr ? (unsigned)strtoul(e, nullptr, 0) : 0xffffffffu;
+  }();
+  auto on = [&](int bit) { return !fm || ((ar_mask >> bit) & 1u) != 0; };
   // profiler groups: "sdec_*" for the one-row-per-stream AR steps (weight-streaming: bytes = the weights), "sver_*" for
   // the wide verify pass (many rows per stream)
   using Sc = ScopeProfiler::Scope;
@@ -823,10 +831,11 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     {
       Sc sc(&prof_, stream_, nm("sdec_qkv_self_attention", "sver_qkv_self_attention"), 2.0 * md * 3 * Dd, 3 * wdd + md * 12);
       if (fm) {
-        if (!stream_fm_qkv(H, W.wqkv_fm, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_))
+        if (on(0) && !stream_fm_qkv(H, W.wqkv_fm, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_))
           throw std::logic_error("decoder_pass: FM qkv width not compiled");
-        stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, true,
-                                     ar_keys_bound_);
+        if (on(1))
+          stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, true,
+                                       ar_keys_bound_);
       } else if (small && small_ln_gemm_stream_qkv(H, W.wqkv_f, M, Dd, Q, selfK_, selfV_, row_slot, row_pos, rp, l, L, Scap_, stream_)) {
         stream_self_attention_cached(Q, row_slot, row_pos, M, Dd, cfg_.nheads, l, L, Scap_, selfK_, selfV_, AO, stream_, false,
                                      wide ? 0 : ar_keys_bound_);
@@ -839,7 +848,8 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     {
       Sc sc(&prof_, stream_, nm("sdec_proj_gemms", "sver_proj_gemms"), 2.0 * md * Dd * 2, 2 * wdd + md * 16);
       if (fm) {
-        if (!stream_fm_resid(AO, W.wo_fm, nullptr, M, Dd, Dd, H, stream_) || !stream_fm_ln_bf16(H, W.wq_c_fm, M, Dd, Dd, Q, stream_))
+        if ((on(2) && !stream_fm_resid(AO, W.wo_fm, nullptr, M, Dd, Dd, H, stream_)) ||
+            (on(3) && !stream_fm_ln_bf16(H, W.wq_c_fm, M, Dd, Dd, Q, stream_)))
           throw std::logic_error("decoder_pass: FM projection width not compiled");
       } else {
         if (!(small && small_gemm_resid_f32(AO, Dd, W.wo, nullptr, M, Dd, Dd, H, stream_)))
@@ -858,7 +868,7 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
         stream_cross_attention_wide(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
       else if (runs_d != nullptr)
         stream_cross_attention_runs(Q, row_slot, runs_d, n_runs, slots_d_, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_);
-      else
+      else if (on(4))
         stream_cross_attention(Q, row_slot, slots_d_, M, Dd, cfg_.nheads, l, L, Mcap_, crossK_, crossV_, AO, stream_, fm,
                                ar_row_mem_d_);
     }
@@ -866,8 +876,9 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
       Sc sc(&prof_, stream_, nm("sdec_crosso_mlp_gemms", "sver_crosso_mlp_gemms"), 2.0 * md * (Dd + 3.0 * Fd),
             wdd + 6.0 * Dd * Fd + md * 16);
       if (fm) {
-        if (!stream_fm_resid(AO, W.wo_c_fm, nullptr, M, Dd, Dd, H, stream_) ||
-            !stream_fm_ln_swiglu(H, W.fc1_fm, W.b1, M, Fd, Dd, Z, stream_) || !stream_fm_resid(Z, W.fc2_fm, W.b2, M, Dd, Fd, H, stream_))
+        if ((on(5) && !stream_fm_resid(AO, W.wo_c_fm, nullptr, M, Dd, Dd, H, stream_)) ||
+            (on(6) && !stream_fm_ln_swiglu(H, W.fc1_fm, W.b1, M, Fd, Dd, Z, stream_)) ||
+            (on(7) && !stream_fm_resid(Z, W.fc2_fm, W.b2, M, Dd, Fd, H, stream_)))
           throw std::logic_error("decoder_pass: FM MLP width not compiled");
       } else {
         if (!(small && small_gemm_resid_f32(AO, Dd, W.wo_c, nullptr, M, Dd, Dd, H, stream_)))
@@ -882,6 +893,7 @@ void StreamingEngine::decoder_pass(int M, const int* row_slot, const int* row_po
     }
   }
   // (an LN-fused head would redo the LayerNorm in each of its V / 64 column tiles: measured 46 vs 28 + 5 us)
+  if (!on(8)) return;
   Sc sc(&prof_, stream_, nm("sdec_lm_head", "sver_lm_head"), 2.0 * md * V, 2.0 * V * Dd + (pval != nullptr ? 0.0 : 4.0 * M * V));
   if (fm) dec_final_layernorm(H, dec_ln_, M, Dd, Y, stream_);   // FM in, row-major out (the LM head's A operand)
   else layernorm_bf16(H, dec_ln_, M, Dd, Y, nullptr, stream_);
