@@ -478,7 +478,9 @@ static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int
 static int wide_k_tn() {   // developer knob: column tiles per workgroup of the wide-K residual GEMM (1 or 2)
   static const int v = [] {
     const char* e = dev_getenv("MSH_XATTN_G2_TN");
-    return e != nullptr && e[0] == '2' ? 2 : 1;   // measured at M = 256: 6.6 us (416 workgroups) against 7.4 (208)
+    // round 6, M = 256 in a replayed graph: 5.2 us with two column tiles per workgroup (208 workgroups, half the A re-reads
+    // through L2) against 5.9 with one (416) -- round 4 had measured the opposite on the kernel of that time
+    return e != nullptr && e[0] == '1' ? 1 : 2;
   }();
   return v;
 }
