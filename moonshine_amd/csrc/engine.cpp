@@ -1416,6 +1416,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
   double sT = 0;
   for (int b = 0; b < M; ++b) sT += clips_h_[g.first + b].T;
   const double w_dd = 2.0 * D * D;  // bytes of a [D, D] bf16 weight
+  dec_gemm_prefer_throughput(shared_gpu_ && M >= 192);
   // chain profiling (profile_decode_chain): enqueue only the kernel group `step_only_`
   auto on = [&](int id) { return step_mask_ != 0 ? ((step_mask_ >> id) & 1u) != 0 : (step_only_ < 0 || step_only_ == id); };
   for (int l = 0; l < cfg_.dec_layers; ++l) {

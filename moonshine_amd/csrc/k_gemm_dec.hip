@@ -396,6 +396,21 @@ static bool few_tiles(int M, int N) {
   }();
   return ((M + 15) / 16) * ((N + 31) / 32) < thr;
 }
+// Throughput shapes.  The tile shapes below were chosen for the LATENCY of a decode step that has the GPU to itself: about one
+// round of ~200 workgroups.  Beside other lanes the step is not alone, and what a launch costs the others is the operand traffic
+// it pulls through L2 and the CUs it holds: 32-row workgroups (half the W re-reads, half the workgroups) measure -3 % serial and
+// +1.8 % with four batches in flight at 256 clips (93.8 -> 95.5 k audio-s/s).  The engine says which regime a step is enqueued
+// for (dec_gemm_prefer_throughput, per host thread: every lane enqueues and captures on its own); the summation order per
+// output element does not depend on the shape, so ids are the same either way.  MSH_DEC_FAT_TILES=0 / 1 forces it.
+static thread_local bool t_dec_fat_tiles = false;
+void dec_gemm_prefer_throughput(bool on) { t_dec_fat_tiles = on; }
+static bool dec_fat_tiles() {
+  static const int forced = [] {
+    const char* e = dev_getenv("MSH_DEC_FAT_TILES");
+    return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0);
+  }();
+  return forced >= 0 ? forced == 1 : t_dec_fat_tiles;
+}
 // One row tile (M <= 16, the single-clip latency case): 16-column tiles double the workgroups that share a GEMM's weight
 // stream (o-proj 13 -> 26, qkv 39 -> 78, fc1 104 -> 208); measured p50 of a 10 s clip 20.8 -> 19.0 ms (decode 19.4 -> 17.6).
 static bool narrow_small_batch(int M) {
@@ -413,7 +428,10 @@ void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s) {
   EpiDecQkv epi{q, cacheK, cacheV, pos_ptr, rp, Smax};
   // (timeline, M = 256: 96-column tiles = 208 workgroups, one round on 256 CUs, finish 0.4 us before 64-column tiles)
-  if (M >= 192 && (3 * D) % 96 == 0)
+  const bool qkv_tm2 = dec_fat_tiles();   // 32 x 96 tiles beside other lanes
+  if (M >= 192 && (3 * D) % 96 == 0 && qkv_tm2)
+    launch_fm<6, true, EpiDecQkv, 2>(H, W, M, 3 * D, D, epi, s);
+  else if (M >= 192 && (3 * D) % 96 == 0)
     launch_fm<6, true>(H, W, M, 3 * D, D, epi, s);
   else if (M >= 96)  // wide column tiles (64) halve the per-row-tile LayerNorm / A reloads of the big-N GEMMs
     launch_fm<4, true>(H, W, M, 3 * D, D, epi, s);
@@ -459,17 +477,17 @@ void dec_gemm_ln_swiglu(const float* H, const bf16_t* W, const float* bias, int 
 }
 // K = heads * D (the context of the absorbed cross-attention, k_xattn.hip): 72 / 104 k-steps, split over EIGHT waves so that a
 // wave's up-front load phase stays at 13 k-steps of W and A (the 4-wave form would hold 26 x (TN + 1) fragments in registers).
-template <int TN, class Epi>
+template <int TN, class Epi, int TM = 1>
 static void launch_fm_wide_k(const bf16_t* A, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((N & 15) != 0) throw std::runtime_error("gemm_dec (FM, wide K): N must be a multiple of 16");
-  const int m_tiles = (M + 15) / 16, n_tiles = (N + 16 * TN - 1) / (16 * TN);
+  const int m_tiles = (M + 16 * TM - 1) / (16 * TM), n_tiles = (N + 16 * TN - 1) / (16 * TN);
   switch (K) {
     case 3328:
-      MSH_LAUNCH((gemm_dec_kernel<104, TN, false, Epi, 1, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
+      MSH_LAUNCH((gemm_dec_kernel<104, TN, false, Epi, TM, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
                  (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);
       return;
     case 2304:
-      MSH_LAUNCH((gemm_dec_kernel<72, TN, false, Epi, 1, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
+      MSH_LAUNCH((gemm_dec_kernel<72, TN, false, Epi, TM, true, 8>), dim3(dec_grid(m_tiles, n_tiles)), dim3(512), 0, s, (const void*)A,
                  (long)0, (const float*)nullptr, W, M, N, dec_ntiles_arg(n_tiles), epi);
       return;
     default: throw std::runtime_error("gemm_dec (FM, wide K): unsupported K " + std::to_string(K));
@@ -489,12 +507,26 @@ static void dec_gemm_resid_t(const bf16_t* A, const bf16_t* W, const float* bias
                              hipStream_t s) {
   EpiDecResidFm<BIAS> epi{H, N / 32, bias};
   if (K == 3328 || K == 2304) {
+    // 32-row workgroups from 64 rows on: x 16 columns for a lone engine (4.9 us in the decode graph at 256 clips; 16 x 16:
+    // 5.9, 16 x 32: 5.2), x 32 columns beside other lanes (5.8 us alone, but half the operand re-reads through L2)
+    static const int wide_tm = [] {   // MSH_XATTN_G2_TM=1: the 16-row shapes of round 4 (MSH_XATTN_G2_TN columns tiles)
+      const char* e = dev_getenv("MSH_XATTN_G2_TM");
+      return e != nullptr && e[0] == '1' ? 1 : 2;
+    }();
+    if (wide_tm == 2 && M >= 64) {
+      if (!dec_fat_tiles()) launch_fm_wide_k<1, EpiDecResidFm<BIAS>, 2>(A, W, M, N, K, epi, s);
+      else launch_fm_wide_k<2, EpiDecResidFm<BIAS>, 2>(A, W, M, N, K, epi, s);
+      return;
+    }
     if (wide_k_tn() == 1 || few_tiles(M, N)) launch_fm_wide_k<1>(A, W, M, N, K, epi, s);
     else launch_fm_wide_k<2>(A, W, M, N, K, epi, s);
     return;
   }
+  const bool resid_tm2 = dec_fat_tiles();   // 32 x 32 tiles at large batches (o-proj, fc2) beside other lanes
   if (narrow_small_batch(M) || few_tiles(M, N))
     launch_fm<1, false>(A, W, M, N, K, epi, s);
+  else if (resid_tm2 && M >= 192)
+    launch_fm<2, false, EpiDecResidFm<BIAS>, 2>(A, W, M, N, K, epi, s);
   else
     launch_fm<2, false>(A, W, M, N, K, epi, s);
 }

@@ -74,6 +74,9 @@ void gemm_cross_kv_fp8(const bf16_t* A, long lda, const bf16_t* W, int M, int N,
 // the self-attention cache keep their row-major layouts.
 // q/k/v for one decoder layer: q_f32[M,D] (rope), k (rope) / v appended to the self cache
 // [M][H][Smax][dh] at position *pos_ptr.
+// tile shapes of the decode GEMMs enqueued by THIS host thread from now on: true = fewer, fatter workgroups (a step that
+// shares the GPU with other lanes), false = the latency shapes (k_gemm_dec.hip "Throughput shapes")
+void dec_gemm_prefer_throughput(bool on);
 void dec_gemm_qkv(const float* H, const bf16_t* W, int M, int D, const int* pos_ptr, RopeParams rp, float* q,
                   bf16_t* cacheK, bf16_t* cacheV, int Smax, hipStream_t s);
 // out_f32[M,N] = LN(H) * W^T
