@@ -2,7 +2,7 @@ set -u
 export MSH_DEV_KNOBS=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 for rep in 1 2; do
-for E in "MSH_XATTN_G2_TM=2 MSH_XATTN_G2_TN=1" "MSH_XATTN_G2_TM=2 MSH_XATTN_G2_TN=1 MSH_DEC_RESID_TM=2" "MSH_XATTN_G2_TM=2 MSH_XATTN_G2_TN=1 MSH_DEC_QKV_TM=2" "MSH_XATTN_G2_TM=2 MSH_XATTN_G2_TN=2 MSH_DEC_RESID_TM=2 MSH_DEC_QKV_TM=2"; do
+for E in "X=0" "MSH_LMHEAD_TALL=1"; do
   env $E timeout 600 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-latency --no-streaming --no-pcie --no-typical --no-c-api --no-fp8 > gpurun_out/r6ab.json 2> gpurun_out/r6ab.err
   python - <<PY
 import json
