@@ -125,3 +125,6 @@ timeout 300 python tools/latency_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out
 timeout 300 python tools/chain_probe.py 1 2 4 8 16 32 63 2>&1 | grep "^B=" > gpurun_out/${TAG}_small_batch_chain_costs.txt
 [ -x tools/build/mfma_peak ] && timeout 120 tools/build/mfma_peak > gpurun_out/${TAG}_mfma_issue_ceiling_with_clock.txt 2>&1
 cp gpurun_out/parity_margins.json gpurun_out/${TAG}_parity_margins.json 2>/dev/null
+# round 6: the MFMA + LDS-DMA loop at one and two waves per SIMD, and the streaming AR step kernel group by kernel group
+[ -x tools/build/mfma_dma_overlap ] && timeout 120 tools/build/mfma_dma_overlap > gpurun_out/${TAG}_mfma_dma_overlap.txt 2>&1
+MASKS="0x3ff 0x1 0x2 0x4 0x8 0x10 0x20 0x40 0x80 0x100 0x0" bash tools/gpu_stream_chain.sh ${TAG} > /dev/null 2>&1; cat gpurun_out/${TAG}_stream_chain_costs.txt | cut -c1-120
