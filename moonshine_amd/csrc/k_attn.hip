@@ -513,7 +513,8 @@ struct SelfAttnCfg {
 };
 
 // NT: the K / V cache stream with the non-temporal policy (see dec_self_attention)
-template <int DH, bool NT = false>
+// ABL (probe, 0 in the product): 1 = no K / V copies (the arithmetic on whatever the LDS holds), 2 = the copies alone
+template <int DH, bool NT = false, int ABL = 0>
 __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __restrict__ q,
                                                                  const bf16_t* __restrict__ cacheK,
                                                                  const bf16_t* __restrict__ cacheV,
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const long off = base + i * 1024 + lane * 16;
-      if (i * 1024 + lane * 16 < C::TILE_BYTES && off < run_bytes) {
+      if (ABL != 1 && i * 1024 + lane * 16 < C::TILE_BYTES && off < run_bytes) {
         lds_dma16<NT>(kp + off, kt + i * 1024);
         lds_dma16<NT>(vp + off, vt + i * 1024);
       }
@@ -566,6 +567,11 @@ __global__ __launch_bounds__(256) void dec_self_attention_kernel(const float* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     const int nk = S - k0 < KB ? S - k0 : KB;
+    if constexpr (ABL == 2) {
+      acc.x += Kl[lane] == 0x7fc1 ? 1.f : 0.f;
+      l_run = 1.f;
+      continue;
+    }
     // scores: lane = key (and key + 64 for the block's tail)
     float s0 = -INFINITY, s1 = -INFINITY;
     if (lane < nk) {
@@ -1043,6 +1049,15 @@ void dec_self_attention(const float* q, const bf16_t* cacheK, const bf16_t* cach
     const char* e = dev_getenv("MSH_SELF_NT");
     return !(e != nullptr && e[0] == '0');
   }();
+  static const int abl = [] {
+    const char* e = dev_getenv("MSH_SELF_ABL");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  if (abl != 0 && dh == 52) {
+    if (abl == 1) MSH_LAUNCH((dec_self_attention_kernel<52, true, 1>), grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out);
+    else MSH_LAUNCH((dec_self_attention_kernel<52, true, 2>), grid, dim3(256), 0, s, q, cacheK, cacheV, pos_ptr, M, D, heads, Smax, out);
+    return;
+  }
 #define MSH_SELF(DHV)                                                                                                              \
   case DHV:                                                                                                                        \
     if (nt)                                                                                                                        \
