@@ -928,6 +928,20 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
   const int ntiles = (max_rows + 15) / 16;
   dim3 grid((ntiles + 31) / 32, heads, n_clips);
   const bool multi = max_rows > 448;   // (rows >= frames: no clip of the batch has more than one chunk of keys otherwise)
+  // A few clips (the latency case): (clip, head) workgroups are 8 per clip on 256 CUs, each walking 26 query tiles.  One tile per
+  // wave instead of four gives four workgroups per (clip, head) -- each stages the clip's keys and values again, which nobody
+  // else needs the CU for -- and the same bits (a query tile's arithmetic does not depend on its neighbours): 18.6 -> 11.7 us per
+  // launch (event scope) at one 10 s clip, encode 0.655 -> 0.60 ms.  MSH_ENC_ATT_FEW=0: off.
+  static const bool few_off = [] {
+    const char* e = dev_getenv("MSH_ENC_ATT_FEW");
+    return e != nullptr && e[0] == '0';
+  }();
+  if (!few_off && dh == 52 && (long)n_clips * heads * ((ntiles + 31) / 32) <= 64) {
+    dim3 g1((ntiles + 7) / 8, heads, n_clips);
+    if (multi) MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, true>), g1, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
+    else MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, false>), g1, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
+    return;
+  }
 #define MSH_EATT(DHV)                                                                                                                  \
   case DHV:                                                                                                                            \
     if (multi) MSH_LAUNCH((enc_attention_res_kernel<DHV, 448, 0, 8, 4, true>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);   \
