@@ -353,6 +353,29 @@ def test_batches_in_flight_match_synchronous_calls(base):
         e.submit_transcribe_tokens(batches[0])
 
 
+@pytest.mark.parametrize("arch", ["tiny", "base"])
+def test_decode_tile_shapes_of_the_two_regimes_give_the_same_ids(tmp_path_factory, arch):
+    """A decode step enqueued beside other lanes takes throughput tile shapes (32-row workgroups in the QKV / o-proj / fc2 /
+    context GEMMs, k_gemm_dec.hip dec_gemm_prefer_throughput), a lone engine the latency shapes.  The summation order per output
+    element does not depend on the shape: 224 ragged clips (>= 192: the throughput shapes apply) on two lanes must give exactly
+    the ids of the synchronous call, in both cross-attention forms, at both widths (K = 288 and K = 416 instantiations)."""
+    e, _, cfg = _engine(tmp_path_factory, arch, 3)
+    clips = [make_audio(4000 + i, 16000 + 1531 * ((5 * i) % 29)) for i in range(224)]
+    for form in ("absorbed", "kv"):
+        e.set_cross_mode(form)
+        want = e.transcribe_tokens(clips, forced_steps=12)
+        e.set_batches_in_flight(2)
+        try:
+            t1 = e.submit_transcribe_tokens(clips, forced_steps=12)
+            t2 = e.submit_transcribe_tokens(clips[::-1], forced_steps=12)
+            assert e.wait_tokens(t1) == want
+            assert e.wait_tokens(t2) == want[::-1]
+        finally:
+            e.set_batches_in_flight(0)
+    e.set_cross_mode("kv")
+    assert len({tuple(t) for t in want}) > 100   # the clips do decode to different things
+
+
 # stated tolerance for cross-attention probabilities (softmax outputs in [0, 1]; bf16 GEMM operands upstream, bf16 K,
 # fp32 scores and softmax): max-abs 5e-3 (observed 2.0e-3 on 22-frame clips, where single probabilities reach 0.13)
 ATT_MAXABS = 5e-3
