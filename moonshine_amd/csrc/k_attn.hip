@@ -247,6 +247,10 @@ __device__ __forceinline__ void att_key_block(const uint4* __restrict__ Kb, cons
 // 235 -> 188 us per layer at 256 x 10 s (tools/enc_attention_microbench.py, profiles/r6*_enc_att_microbench.txt).  What is
 // left is not an instruction count: the same kernel on all-zero keys and values runs in 130 us with an identical instruction
 // stream (the loads still waited for: ablation 2) -- with real operands the chip is power-limited here.
+// The staging phase is not a latency to hide either: touching the NEXT item's lines from inside the key loop (one dword per
+// 128-byte line, LDS-DMA into a sink, so that the next workgroup's staging hits the XCD's L2) made the kernel slower, and the
+// same touches added to the "no global loads" ablation cost it 33 us = the 271 MB of q | k | v at the HBM rate -- bytes moved
+// cost time here whenever they move (HISTORY.md, round 6).  What helps is moving fewer of them: the XCD-aware item order below.
 // ABL (microbenchmark only, garbage results): 1 = no global loads while staging, 2 = loads waited for but zeroed, 4 = no exp2,
 // 8 = no MFMAs.
 // ------------------------------------------------------------------------------------------------
@@ -256,7 +260,8 @@ __device__ __forceinline__ void att_key_block(const uint4* __restrict__ Kb, cons
 template <int DH, int KMAX, int ABL = 0, int NW = 8, int EQT = 4, bool MULTI = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                                    long vt_ld, bf16_t* __restrict__ out,
-                                                                   const ClipMeta* __restrict__ clips, int D) {
+                                                                   const ClipMeta* __restrict__ clips, int n_clips, int gx,
+                                                                   int D) {
   static_assert(DH % 4 == 0 && DH <= 64, "head_dim must be a multiple of 4, at most 64");
   static_assert(KMAX % 128 == 64, "V^T row stride (KMAX + 8) must be 72 mod 128 elements: conflict-free ds_read_b64");
   static_assert(NW % 4 == 0, "whole waves per SIMD");
@@ -270,10 +275,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void enc_attention_res_kernel(cons
   unsigned char* const Ks = lds_raw;                                   // [key][8 x 16 B], chunk ^= (key >> 1) & 7
   bf16_t* const Vt = reinterpret_cast<bf16_t*>(lds_raw + KMAX * 128);   // [d][key]
 
-  const ClipMeta cm = clips[blockIdx.z];
-  const int tile0 = blockIdx.x * (NW * EQT);   // this workgroup's run of 16-query tiles
+  // Workgroup b runs on XCD b % 8 (observed placement, used for speed only).  A head's K and Q slices are 104 of the 1664 bytes
+  // of a q | k row: 128-byte lines are shared between neighbouring heads, so the heads of a clip belong on ONE XCD -- its L2
+  // then fetches every line once (PMC, 256 x 10 s: 572 MB read per layer with head h on XCD h against 271 MB of q | k | v).
+  // The 1-D grid (a multiple of 8, att_grid1) is dealt so that every XCD takes a contiguous run of (clip, query block, head).
+  const int heads = D / DH, per = gridDim.x >> 3, vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= n_clips * gx * heads) return;
+  const int clip = vb / (gx * heads), rr = vb - clip * (gx * heads), qx = rr / heads, h = rr - qx * heads;
+  const ClipMeta cm = clips[clip];
+  const int tile0 = qx * (NW * EQT);   // this workgroup's run of 16-query tiles
   if (tile0 * 16 >= cm.rows) return;
-  const int h = blockIdx.y;
   const int T = cm.T;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -919,6 +930,9 @@ void dec_cross_attention_probs(const float* q, const bf16_t* KT, const ClipMeta*
                      layers, layer, Smax, Tcap, out);
 }
 
+// (query blocks, heads, clips) -> the 1-D grid of enc_attention_res_kernel, padded to a multiple of 8 (its XCD-aware item order)
+static inline dim3 att_grid1(dim3 g) { return dim3((g.x * g.y * g.z + 7) / 8 * 8); }
+
 void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, const ClipMeta* clips, int n_clips, int max_rows,
                    int D, int heads, hipStream_t s) {
   const int dh = D / heads;
@@ -938,14 +952,14 @@ void enc_attention(const bf16_t* qk, const bf16_t* vt, long vt_ld, bf16_t* out, 
   }();
   if (!few_off && dh == 52 && (long)n_clips * heads * ((ntiles + 31) / 32) <= 64) {
     dim3 g1((ntiles + 7) / 8, heads, n_clips);
-    if (multi) MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, true>), g1, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
-    else MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, false>), g1, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);
+    if (multi) MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, true>), att_grid1(g1), dim3(512), 0, s, qk, vt, vt_ld, out, clips, (int)g1.z, (int)g1.x, D);
+    else MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 1, false>), att_grid1(g1), dim3(512), 0, s, qk, vt, vt_ld, out, clips, (int)g1.z, (int)g1.x, D);
     return;
   }
 #define MSH_EATT(DHV)                                                                                                                  \
   case DHV:                                                                                                                            \
-    if (multi) MSH_LAUNCH((enc_attention_res_kernel<DHV, 448, 0, 8, 4, true>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);   \
-    else MSH_LAUNCH((enc_attention_res_kernel<DHV, 448>), grid, dim3(512), 0, s, qk, vt, vt_ld, out, clips, D);                        \
+    if (multi) MSH_LAUNCH((enc_attention_res_kernel<DHV, 448, 0, 8, 4, true>), att_grid1(grid), dim3(512), 0, s, qk, vt, vt_ld, out, clips, (int)grid.z, (int)grid.x, D);   \
+    else MSH_LAUNCH((enc_attention_res_kernel<DHV, 448>), att_grid1(grid), dim3(512), 0, s, qk, vt, vt_ld, out, clips, (int)grid.z, (int)grid.x, D);                        \
     break
   switch (dh) {
     MSH_EATT(52);
@@ -1000,19 +1014,19 @@ float enc_attention_microbench(int variant, int n_clips, int T, int D, int heads
     dim3 grid((ntiles + 31) / 32, heads, n_clips);
 #define MSH_RES(A)                                                                                                      \
   case A:                                                                                                               \
-    MSH_LAUNCH((enc_attention_res_kernel<52, 448, A>), grid, dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);   \
+    MSH_LAUNCH((enc_attention_res_kernel<52, 448, A>), att_grid1(grid), dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, (int)grid.z, (int)grid.x, D);   \
     break
     if (variant == 50) {
       dim3 g2((ntiles + 35) / 36, heads, n_clips);
-      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 12, 3>), g2, dim3(768), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 12, 3>), att_grid1(g2), dim3(768), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, (int)g2.z, (int)g2.x, D);
       return;
     }
     if (variant == 51) {
-      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 16, 2>), grid, dim3(1024), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 16, 2>), att_grid1(grid), dim3(1024), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, (int)grid.z, (int)grid.x, D);
       return;
     }
     if (variant == 1) {   // the instantiation with the chunk loop (any clip length)
-      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 4, true>), grid, dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, D);
+      MSH_LAUNCH((enc_attention_res_kernel<52, 448, 0, 8, 4, true>), att_grid1(grid), dim3(512), 0, (hipStream_t)0, QK, VT, vt_ld, O, CM, (int)grid.z, (int)grid.x, D);
       return;
     }
     if (variant != 1 && rows > 448) throw std::runtime_error("enc_attention_microbench: only variant 1 walks more than 448 keys");
