@@ -1096,6 +1096,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   MSH_HIP(hipMemsetAsync(n_active_d_, 0, sizeof(int32_t), stream_));
   for (hipEvent_t& ev : stat_ev_)
     if (ev == nullptr) MSH_HIP(hipEventCreate(&ev));
+  const double us_staged = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
   MSH_HIP(hipEventRecord(stat_ev_[0], stream_));
   stream_embed(tok_d, M, embed_f32_, Dd, stepH_.as<float>(), stream_);
   const int2* prefix_d = bias_.n_nodes > 0 ? stage(bias_prefix_, prefix) : nullptr;
@@ -1194,8 +1195,10 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(now() - t).count(); };
   if (timing) {
+    const double us_enq = us_since(t_call);
     MSH_HIP(hipStreamSynchronize(stream_));
-    fprintf(stderr, "[moonshine] decode_full: %d streams, %d rows: staging + verify pass %.0f us\n", J, M, us_since(t_call));
+    fprintf(stderr, "[moonshine] decode_full: %d streams, %d rows: staging %.0f us, verify pass enqueued at %.0f us, done at %.0f us\n", J, M,
+            us_staged, us_enq, us_since(t_call));
   }
   const auto t_ar = now();
   MSH_HIP(hipEventRecord(stat_ev_[1], stream_));
@@ -1238,6 +1241,7 @@ void StreamingEngine::decode_full(int n, const int* slots, const int32_t* const*
       stat_ar_passes_ += steps_run;
     }
   }
+  if (timing) fprintf(stderr, "[moonshine] decode_full: results on the host %.0f us after the call\n", us_since(t_call));
   for (int j = 0; j < J; ++j) {
     const int i = job_index[j];
     const SlotDev& r = sd[jobs[j].slot];

@@ -93,9 +93,11 @@ def pin_rank_cpus(local_rank: int, local_world: int) -> list[int]:
         return sorted(os.sched_getaffinity(0))
     node, node_cpus = _sysfs_topology(local_rank)
     cpus = rank_cpus(local_rank, local_world, None, node, node_cpus)
+    if len(cpus) < 4:   # a share too small for the lanes' host threads (a CPU-starved container): sharing beats pinning
+        return sorted(os.sched_getaffinity(0))
     try:
         os.sched_setaffinity(0, cpus)
-    except OSError:
+    except (OSError, ValueError):
         pass
     return sorted(os.sched_getaffinity(0))
 
