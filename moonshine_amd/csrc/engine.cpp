@@ -336,7 +336,7 @@ Engine::~Engine() {
     (void)hipEventDestroy(r.b);
   }
   DevBuf* bufs[] = {&clips_d_, &clip_ptrs_d_, &pcm_stage_, &audio_bf16_, &row_pos_, &row_clip_, &x1_, &x2_, &H_,
-                    &Y_, &QKV_, &VTe_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
+                    &Y_, &QKV_, &VTe_, &AO_, &Z_, &ENC_, &ENC32_, &gn_part_, &gn_rows_, &gn_stats_, &gn_table_, &KT_, &VT_, &cross_probs_};
   for (DevBuf* b : bufs) b->release();
   if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -414,6 +414,8 @@ void Engine::upload_bf16_fm(const std::vector<float>& src, int rows, int K, bf16
 //   conv1  [D,1,127]   -> [D][128] (tap 127 = 0)                  GEMM over the raw sample stream, lda = 64
 //   conv2  [2D,D,7]    -> [2D][7][D]  (tap-major, channel-minor)  matches the channels-last window
 //   conv3  [D,2D,3]    -> [D][3][2D]
+//          both then re-ordered along K to [C/32][taps][32]: the order in which the conv GEMMs walk their k-slices
+//          (conv_k_offset, gemm_common.h: the two uses of an input byte three slices apart instead of 13 .. 39)
 //   q,k,v  3 x [D,D]   -> [3D][D] fused
 //   cross k,v of all decoder layers -> [L*2D][D] (one GEMM per batch)
 //   decoder fc1 [2F,D] -> rows interleaved (value_j, gate_j) so SwiGLU pairs sit in one lane
@@ -422,6 +424,7 @@ void Engine::share_weights_from(const Engine& o) {
   if (!o.loaded_ || o.device_ != device_) throw std::runtime_error("share_weights_from: owner not loaded / other device");
   cfg_ = o.cfg_;
   conv1_w_ = o.conv1_w_, conv2_w_ = o.conv2_w_, conv3_w_ = o.conv3_w_;
+  conv_kperm_ = o.conv_kperm_;
   conv2_s1_ = o.conv2_s1_, conv2_b2_ = o.conv2_b2_, conv3_b_ = o.conv3_b_, enc_ln_ = o.enc_ln_;
   enc_ = o.enc_;
   dec_ = o.dec_;
@@ -434,6 +437,18 @@ void Engine::share_weights_from(const Engine& o) {
   rope_cos_ = o.rope_cos_, rope_sin_ = o.rope_sin_;
   rope_max_pos_ = o.rope_max_pos_;
   loaded_ = true;  // weight_allocs_ stays empty: the owner frees
+}
+
+// [N][taps][C] (the window's order in memory) -> [N][C/32][taps][32] (the k-slice order of conv_k_offset)
+static std::vector<float> conv_tap_inner(const std::vector<float>& w, int N, int taps, int C) {
+  std::vector<float> r(w.size());
+  const int cbs = C / 32;
+  for (int n = 0; n < N; ++n)
+    for (int cb = 0; cb < cbs; ++cb)
+      for (int t = 0; t < taps; ++t)
+        for (int e = 0; e < 32; ++e)
+          r[(((size_t)n * cbs + cb) * taps + t) * 32 + e] = w[((size_t)n * taps + t) * C + cb * 32 + e];
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,6 +517,12 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
         s1[n] = (float)a1;
         s2[n] = (float)(a2 + b2[n]);
       }
+      conv_kperm_ = [] {   // MSH_CONV_KORDER=0: the tap-major k-order of rounds 1-5 (A/B switch)
+        const char* e = dev_getenv("MSH_CONV_KORDER");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+      }();
+      if (D % 32 != 0) conv_kperm_ = 0;
+      if (conv_kperm_) r = conv_tap_inner(r, 2 * D, 7, D);
       upload_bf16(r, &conv2_w_);
       upload(s1, &conv2_s1_);
       upload(s2, &conv2_b2_);
@@ -512,6 +533,7 @@ void Engine::load_weights(const SafeTensors& st, int expect_arch) {
     for (int n = 0; n < D; ++n)
       for (int ch = 0; ch < 2 * D; ++ch)
         for (int k = 0; k < 3; ++k) r[((size_t)n * 3 + k) * 2 * D + ch] = w[((size_t)n * 2 * D + ch) * 3 + k];
+    if (conv_kperm_) r = conv_tap_inner(r, D, 3, 2 * D);
     upload_bf16(r, &conv3_w_);
     upload(vec("model.encoder.conv3.bias", D), &conv3_b_);
     upload(vec("model.encoder.layer_norm.weight", D), &enc_ln_);
@@ -930,6 +952,7 @@ void Engine::encode(const float* const* pcm, const uint64_t* n_samples, uint32_t
   moved |= ENC_.reserve(R * D * sizeof(bf16_t));
   if (keep_enc_f32_) moved |= ENC32_.reserve(R * D * sizeof(float));
   moved |= gn_part_.reserve((size_t)count * 64 * sizeof(float2));
+  moved |= gn_rows_.reserve((size_t)6 * R * gemm_max_col_tiles(D) * sizeof(float2));   // conv1's row sums (GroupNorm statistics)
   moved |= gn_stats_.reserve(count * sizeof(float2));
   moved |= gn_table_.reserve((size_t)count * 2 * D * sizeof(float));
   // Cross-attention form of this batch (k_xattn.hip): absorbed = the decode steps attend over ENC_ itself and no K^T / V^T
@@ -1048,23 +1071,30 @@ void Engine::run_encoder() {
     pack_audio(clip_ptrs_d_.as<const float*>(), clips, (int)n_clips_, audio_bf16_.as<bf16_t>(), 0, s);
     build_row_meta(clips, (int)n_clips_, row_pos_.as<int>(), row_clip_.as<int>(), s);
   }
+  const char* gn_env = dev_getenv("MSH_GN_ROWSUMS");   // (per call, like the switches above)
+  const bool gn_rowsums = !(gn_env != nullptr && gn_env[0] == '0');
+  int gn_ntn = 0;
   {  // conv1 (k127, s64, no bias) + tanh: GEMM over the sample stream, row t = samples [64t, 64t+128)
     ProfScope p(this, "conv1_tanh_gemm", 2.0 * sL1 * D * 127, sN * 2 + sL1 * D * 2);
-    gemm_tanh_bf16(audio_bf16_.as<bf16_t>(), 64, conv1_w_, 6 * R, D, 128, x1_.as<bf16_t>(), s);
+    // (its epilogue leaves the row sums of what it stores: the GroupNorm statistics never read the 532 MB back;
+    //  MSH_GN_ROWSUMS=0: the statistics pass over the output, as before round 6)
+    gn_ntn = gemm_tanh_bf16(audio_bf16_.as<bf16_t>(), 64, conv1_w_, 6 * R, D, 128, x1_.as<bf16_t>(),
+                            gn_rowsums ? gn_rows_.as<float2>() : nullptr, s);
   }
   {  // GroupNorm(1 group): only the per-clip statistics are computed; the affine map is folded into conv2
-    ProfScope p(this, "groupnorm_stats", 0, sL1 * D * 2);
-    groupnorm_stats(x1_.as<bf16_t>(), clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
+    ProfScope p(this, "groupnorm_stats", 0, gn_rowsums ? sL1 * gn_ntn * 8.0 : sL1 * D * 2);
+    if (gn_rowsums) groupnorm_stats_rows(gn_rows_.as<float2>(), gn_ntn, clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
+    else groupnorm_stats(x1_.as<bf16_t>(), clips, (int)n_clips_, D, gn_part_.as<float>(), gn_stats_.as<float2>(), s);
     gn_fold_table(gn_stats_.as<float2>(), conv2_s1_, conv2_b2_, (int)n_clips_, 2 * D, gn_table_.as<float>(), s);
   }
   {  // conv2 (k7, s3) + GroupNorm fold + GELU: window of 7 channels-last frames is contiguous -> lda = 3D, K = 7D
     ProfScope p(this, "conv2_gelu_gemm", 2.0 * sL2 * 2 * D * 7 * D, sL1 * D * 2 + sL2 * 2 * D * 2);
     gemm_gn_bias_gelu_bf16(x1_.as<bf16_t>(), 3L * D, conv2_w_, gn_table_.as<float>(), gn_stats_.as<float2>(),
-                           row_clip_.as<int>(), 2 * R, 2 * D, 7 * D, x2_.as<bf16_t>(), s);
+                           row_clip_.as<int>(), 2 * R, 2 * D, 7 * D, x2_.as<bf16_t>(), conv_kperm_, s);
   }
   {  // conv3 (k3, s2) + GELU -> residual stream H [R, D] fp32
     ProfScope p(this, "conv3_gelu_gemm", 2.0 * sT * D * 6 * D, sL2 * 2 * D * 2 + sT * D * 4);
-    gemm_bias_gelu_f32(x2_.as<bf16_t>(), 4L * D, conv3_w_, conv3_b_, R, D, 6 * D, H_.as<float>(), s);
+    gemm_bias_gelu_f32(x2_.as<bf16_t>(), 4L * D, conv3_w_, conv3_b_, R, D, 6 * D, H_.as<float>(), conv_kperm_, s);
   }
   // A few clips (the latency case; one 10 s clip = 424 rows): the tiled kernel's 128 x 208 tiles give a layer's GEMMs 8 .. 32
   // workgroups on 256 CUs, each walking K alone (fc2: 52 slices, 35 us at one clip).  The split-K decode GEMM (16 x 32 tiles,
@@ -1368,6 +1398,12 @@ size_t Engine::debug_read(const std::string& name, void* dst, size_t bytes) {
     const size_t size = (size_t)cfg_.dec_layers * cfg_.hidden * kv_keys_ * kv_bytes();
     MSH_HIP(hipStreamSynchronize(stream_));
     if (dst != nullptr && bytes > 0) copy_blocking(dst, name == "cross_k" ? KT_.p : VT_.p, std::min(bytes, size), hipMemcpyDeviceToHost);
+    return size;
+  }
+  if (name == "gn_stats") {   // GroupNorm {mean, rstd} per clip of the last encode()
+    const size_t size = (size_t)n_clips_ * sizeof(float2);
+    MSH_HIP(hipStreamSynchronize(stream_));
+    if (dst != nullptr && bytes > 0) copy_blocking(dst, gn_stats_.p, std::min(bytes, size), hipMemcpyDeviceToHost);
     return size;
   }
   if (name == "graph_captures") {   // decode-step graphs instantiated so far (the LRU of DecodeGroup::graphs at work)

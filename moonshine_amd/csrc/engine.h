@@ -178,6 +178,7 @@ class Engine {
 
   // weights
   bf16_t *conv1_w_ = nullptr, *conv2_w_ = nullptr, *conv3_w_ = nullptr;
+  int conv_kperm_ = 0;   // 1: conv2_w_ / conv3_w_ are stored in the tap-inner k-order (conv_k_offset, gemm_common.h)
   float *conv2_s1_ = nullptr, *conv2_b2_ = nullptr, *conv3_b_ = nullptr, *enc_ln_ = nullptr;  // conv2_s1 / _b2: GroupNorm fold
   std::vector<EncLayerW> enc_;
   std::vector<DecLayerW> dec_;
@@ -214,7 +215,7 @@ class Engine {
   void* pcm_pinned_ = nullptr;  // host staging for clips handed over in pageable memory (see encode())
   size_t pcm_pinned_cap_ = 0;
   DevBuf clips_d_, clip_ptrs_d_, pcm_stage_, audio_bf16_, row_pos_, row_clip_, x1_, x2_, H_, Y_, QKV_, VTe_, AO_, Z_,
-      ENC_, ENC32_, gn_part_, gn_stats_, gn_table_, KT_, VT_;
+      ENC_, ENC32_, gn_part_, gn_rows_, gn_stats_, gn_table_, KT_, VT_;
   int Smax_ = 0;
 
   // decode groups (own stream + buffers + captured step graph each); group 0 runs on stream_

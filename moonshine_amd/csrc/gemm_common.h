@@ -49,9 +49,14 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // conv1: tanh(acc) as bf16 (the GroupNorm that follows is folded into conv2, see EpiGnBiasGeluBf16)
 struct EpiTanhBf16 {
   static constexpr bool kStagedBf16 = true;
+  static constexpr bool kRowSums = true;
   bf16_t* out;
   long ldc;
   int nt = 0;   // 1: the output goes out with the non-temporal policy (staged_store_tile; MSH_STEM_STORE_NT)
+  // GroupNorm statistics without a pass over the output: every (row, column tile) leaves the sum and the sum of squares of
+  // the bf16 values it stored -- [M][column tiles] -- and groupnorm_stats_rows (k_misc.hip) adds up each clip's valid rows
+  // in a fixed order (10 MB instead of the 532 MB of conv1 output per 256 clips).  null: no sums.
+  float2* rowsum = nullptr;
   struct RowCtx {};
   struct ColCtx {};
   __device__ RowCtx row_ctx(int) const { return RowCtx{}; }
@@ -75,12 +80,14 @@ struct EpiTanhBf16 {
 // materialised.  Row m of the conv2 output belongs to the clip of stream row m / 2.
 struct EpiGnBiasGeluBf16 {
   static constexpr bool kStagedBf16 = true;
+  static constexpr int kTaps = 7;   // conv2: K = 7 taps x C channels (conv_k_offset below)
   bf16_t* out;
   long ldc;
   const float* table;   // [clips][N]: S2[n] + bias[n] - mean_b * rstd_b * S1[n]   (gn_fold_table, once per batch)
   const float2* stats;  // per clip {mean, rstd}
   const int* row_clip;  // per stream row
   int nt = 0;           // 1: non-temporal output stores (see EpiTanhBf16)
+  int kperm = 0;        // 1: W is stored in the tap-inner k-order
   struct RowCtx {
     float rstd;
     const float* trow;
@@ -127,15 +134,43 @@ struct EpiBiasGeluBf16 {
 };
 
 struct EpiBiasGeluF32 {
+  static constexpr int kTaps = 3;   // conv3: K = 3 taps x C channels
   float* out;
   long ldc;
   const float* bias;
+  int kperm = 0;        // 1: W is stored in the tap-inner k-order
   __device__ void n4(int m, int n, f32x4 v) const {
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     float4 o = make_float4(gelu_sig(v[0] + b.x), gelu_sig(v[1] + b.y), gelu_sig(v[2] + b.z), gelu_sig(v[3] + b.w));
     *reinterpret_cast<float4*>(out + (long)m * ldc + n) = o;
   }
 };
+
+// k-ORDER OF THE CONV GEMMS.  A stride-s convolution of k taps over channels-last rows is a GEMM whose A row m is the
+// contiguous window of k * C elements that starts at input row s * m: element (m, tap t, channel c) IS element (m + 1, tap
+// t - s, channel c).  Walking K tap-major (t outer, c inner -- the order of the window in memory) puts 13 .. 39 k-slices between
+// the two uses of a byte: with 16 row tiles of 323 KB resident per XCD the L2 has dropped it by then, and conv2 fetched 3.1 x
+// its algorithmic bytes (PMC).  Walking K channel-block-major (32 channels outer, taps inner) puts THREE
+// slices between them.  Only the order of the k-slices changes: slice kt reads A at (kt % TAPS) * C + (kt / TAPS) * 32 instead
+// of 32 kt, and W is stored in that order at load (Engine::load_weights), so its slices stay contiguous.  Epilogues that
+// belong to a conv name their tap count (kTaps) and carry the switch (kperm; MSH_CONV_KORDER=0 at load: tap-major as before).
+template <class E, class = void>
+struct epi_taps : std::integral_constant<int, 1> {};
+template <class E>
+struct epi_taps<E, std::void_t<decltype(E::kTaps)>> : std::integral_constant<int, E::kTaps> {};
+template <class Epi>
+__device__ __forceinline__ int epi_kperm(const Epi& e) {
+  if constexpr (epi_taps<Epi>::value > 1) return e.kperm;
+  else return 0;
+}
+// element offset of k-slice kt inside an A row; kc = channels per tap
+template <int TAPS>
+__device__ __forceinline__ int conv_k_offset(int kt, int kc, int kperm) {
+  if constexpr (TAPS > 1) {
+    if (kperm) return (kt % TAPS) * kc + (kt / TAPS) * 32;
+  }
+  return kt << 5;
+}
 
 // rotate the two (even, odd) pairs held in v for head-dim offsets d, d+2
 __device__ __forceinline__ void rope4(f32x4& v, int d, int pos, const RopeParams& rp) {
@@ -704,9 +739,30 @@ template <class E>
 struct has_nt_flag<E, std::void_t<decltype(std::declval<const E&>().nt)>> : std::true_type {};
 typedef unsigned int u32x4_native __attribute__((ext_vector_type(4)));
 
+// epilogues that leave per-(row, column tile) sums of what they stored (EpiTanhBf16::rowsum)
+template <class E, class = void>
+struct has_row_sums : std::false_type {};
+template <class E>
+struct has_row_sums<E, std::void_t<decltype(E::kRowSums)>> : std::true_type {};
+// the four bf16 values of a packed group, as stored, into a row's running sums
+__device__ __forceinline__ void row_sums_add(uint2 pk, float& s, float& q) {
+  const float a = __uint_as_float(pk.x << 16), b = __uint_as_float(pk.x & 0xffff0000u);
+  const float c = __uint_as_float(pk.y << 16), d = __uint_as_float(pk.y & 0xffff0000u);
+  s += (a + b) + (c + d);
+  q += (a * a + b * b) + (c * c + d * d);
+}
+// the four lane groups (kg = lane >> 4) of a row hold its partial sums: fixed-order exchange, every lane ends with the total
+__device__ __forceinline__ void row_sums_reduce(float& s, float& q) {
+  s += __shfl_xor(s, 16, 64);
+  q += __shfl_xor(q, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+}
+
 template <int TN, class Epi>
 __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restrict__ stg, const f32x4 (&acc)[TN],
-                                                  int mbase, int n0, int M, int N, int lane, float* rowtab = nullptr) {
+                                                  int mbase, int n0, int M, int N, int lane, float* rowtab = nullptr,
+                                                  int ntn = 0, int tile_n = 0) {
   constexpr int ROWP = StagedRow<TN>::ROWP;
   const int li = lane & 15, kg = lane >> 4;
   auto ctx = epi.row_ctx(mbase + li < M ? mbase + li : M - 1);  // per-row inputs, fetched once per tile
@@ -720,14 +776,25 @@ __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restr
   // per-column inputs advance by 16 columns per accumulator: no integer division inside the loop (the two runtime
   // modulos per group that RoPE needs cost more than its arithmetic: ~100 us of the 300 us QKV kernel)
   auto col = epi.col_ctx(n0 + kg * 4);
+  [[maybe_unused]] float rs_s = 0.f, rs_q = 0.f;   // row sums of what this lane packs (has_row_sums epilogues)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     // a column group beyond N (ragged last tile, e.g. N = 3072 on 208-wide tiles) is dropped by the stores below, but
     // pack4 READS per-column inputs (bias, folded GroupNorm table): it gets the last valid group's address instead of one
     // up to 188 bytes past the end of a 1-D parameter -- a GPU memory fault when that parameter ends on a mapping boundary
     const int n = n0 + j * 16 + kg * 4;
-    stg[li * ROWP + j * 4 + kg] = epi.pack4(ctx, col, n < N ? n : N - 4, acc[j]);
+    const uint2 pk = epi.pack4(ctx, col, n < N ? n : N - 4, acc[j]);
+    stg[li * ROWP + j * 4 + kg] = pk;
+    if constexpr (has_row_sums<Epi>::value) {
+      if (n < N) row_sums_add(pk, rs_s, rs_q);
+    }
     epi.col_next16(col);
+  }
+  if constexpr (has_row_sums<Epi>::value) {
+    if (epi.rowsum != nullptr) {   // (wave-uniform)
+      row_sums_reduce(rs_s, rs_q);
+      if (kg == 0 && mbase + li < M) epi.rowsum[(long)(mbase + li) * ntn + tile_n] = make_float2(rs_s, rs_q);
+    }
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -750,6 +817,31 @@ __device__ __forceinline__ void staged_store_tile(const Epi& epi, uint2* __restr
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// The unstaged n4 epilogue of an epilogue with row sums (EpiTanhBf16): what its n4 stores, plus the sums.  mwave0 = first row
+// of this wave's TM 16-row tiles; the shuffles run on every lane (rows >= M contribute zeros and store nothing).
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void store_rows_with_sums(const Epi& epi, const f32x4 (&acc)[TM][TN], int mwave0, int n0, int M, int N,
+                                                     int ntn, int tile_n, int li, int kg) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mwave0 + i * 16 + li;
+    float rs = 0.f, rq = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + j * 16 + kg * 4;
+      if (m < M && n < N) {
+        const uint2 pk = epi.pack4(typename Epi::RowCtx{}, typename Epi::ColCtx{}, n, acc[i][j]);
+        *reinterpret_cast<uint2*>(epi.out + (long)m * epi.ldc + n) = pk;
+        row_sums_add(pk, rs, rq);
+      }
+    }
+    if (epi.rowsum != nullptr) {   // (wave-uniform)
+      row_sums_reduce(rs, rq);
+      if (kg == 0 && m < M) epi.rowsum[(long)m * ntn + tile_n] = make_float2(rs, rq);
+    }
+  }
 }
 
 // XOR swizzle of the 16-B k-chunk position inside a 64-B row of an LDS k-slice (conflict-free

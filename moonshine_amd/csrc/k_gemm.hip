@@ -77,10 +77,11 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
     const int row = srow + 64 * i;                                                    \
     if (row < BN) lds[buf][BM * 4 + row * 4 + (sch ^ swz(row))] = rb##i;              \
   }
-#define MSH_GLOAD(k0)                                                                 \
+#define MSH_GLOAD(kt_)                                                                \
   {                                                                                   \
-    MSH_LDA(0, k0) MSH_LDA(1, k0) MSH_LDA(2, k0) MSH_LDA(3, k0)                       \
-    MSH_LDB(0, k0) MSH_LDB(1, k0) MSH_LDB(2, k0) MSH_LDB(3, k0)                       \
+    const int ka_ = conv_k_offset<TAPS>(kt_, kc, kperm), kw_ = (kt_) << 5;            \
+    MSH_LDA(0, ka_) MSH_LDA(1, ka_) MSH_LDA(2, ka_) MSH_LDA(3, ka_)                   \
+    MSH_LDB(0, kw_) MSH_LDB(1, kw_) MSH_LDB(2, kw_) MSH_LDB(3, kw_)                   \
   }
 #define MSH_SSTORE(buf)                                                               \
   {                                                                                   \
@@ -95,12 +96,14 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K >> 5;
+  constexpr int TAPS = epi_taps<Epi>::value;   // conv GEMMs may walk K channel-block-major (conv_k_offset, gemm_common.h)
+  const int kc = K / TAPS, kperm = epi_kperm(epi);
   MSH_GLOAD(0);
   MSH_SSTORE(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) MSH_GLOAD((kt + 1) << 5);  // next k-slice in flight during the MFMAs
+    if (kt + 1 < nk) MSH_GLOAD(kt + 1);  // next k-slice in flight during the MFMAs
     bf16x8 af[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -131,6 +134,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const bf16_t* __restric
 #undef MSH_STA
 #undef MSH_STB
 
+  if constexpr (SWAP && has_row_sums<Epi>::value) {   // conv1: the stored values' row sums go out with them (GroupNorm statistics)
+    store_rows_with_sums<TM, TN>(epi, acc, m0 + wave * 16 * TM, n0, M, N, ntn, n0 / BN, li, kg);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -206,16 +213,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) v
     }
     dst[i] = lds_base + (unsigned)p * 1024u;   // piece p starts at slot 64*p (A pieces first, then W)
   }
+  constexpr int TAPS = epi_taps<Epi>::value;   // conv GEMMs may walk K channel-block-major (conv_k_offset, gemm_common.h)
+  const int kc = K / TAPS, kperm = epi_kperm(epi);
   auto issue = [&](int kt) {
     const unsigned sb = (unsigned)(kt % NSTAGE) * (STAGE_SLOTS * 16u);
+    const int ka = conv_k_offset<TAPS>(kt, kc, kperm), kw = kt << 5;   // A slices may be permuted, W slices are stored in order
 #pragma unroll
     for (int i = 0; i < PMAX; ++i)
       if (i < my_pieces) {
+        const int ko = (TAPS > 1 && wave + NW * i < PA) ? ka : kw;
         if constexpr ((ABL & 32) != 0) {   // W pieces with the non-temporal policy (a weight read once per launch: the LM head)
-          if (wave + NW * i >= PA) dma16_nt(src[i] + (kt << 5), dst[i] + sb);
-          else dma16(src[i] + (kt << 5), dst[i] + sb);
+          if (wave + NW * i >= PA) dma16_nt(src[i] + ko, dst[i] + sb);
+          else dma16(src[i] + ko, dst[i] + sb);
         } else {
-          dma16(src[i] + (kt << 5), dst[i] + sb);
+          dma16(src[i] + ko, dst[i] + sb);
         }
       }
   };
@@ -342,7 +353,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) v
     float* rowtab = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + STG_BYTES) + wave * (TAB_BYTES / 4);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      staged_store_tile<TN>(epi, stg, acc[i], m0 + wave * 16 * TM + i * 16, n0, M, N, lane, rowtab);
+      staged_store_tile<TN>(epi, stg, acc[i], m0 + wave * 16 * TM + i * 16, n0, M, N, lane, rowtab, ntn, n0 / BN);
+    return;
+  }
+  if constexpr (SWAP && has_row_sums<Epi>::value) {   // (the direct-store ablation of an epilogue with row sums)
+    store_rows_with_sums<TM, TN>(epi, acc, m0 + wave * 16 * TM, n0, M, N, ntn, n0 / BN, li, kg);
     return;
   }
 #pragma unroll
@@ -361,12 +376,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && TM * TN * 4 <= 104) ? 2 : 1) v
 }
 
 template <int NW, int TM, int TN, int NSTAGE, bool SWAP, class Epi, int ABL = 0>
-void launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+int launch_tiled_dma_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   constexpr int BM = 16 * NW * TM, BN = 16 * TN;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   const int nblocks = ntm * ntn;
   MSH_LAUNCH((gemm_tiled_dma_kernel<NW, TM, TN, NSTAGE, SWAP, Epi, ABL>), dim3(nblocks), dim3(64 * NW), 0, s, A, lda,
                      W, M, N, K, ntn, nblocks, epi);
+  return ntn;   // column tiles (the row-sum layout of EpiTanhBf16)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,12 +574,13 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const bf16_t* __rest
 }
 
 template <int KS, int TN, int NST, bool SWAP, class Epi>
-void launch_astat_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, Epi epi, hipStream_t s) {
+int launch_astat_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, Epi epi, hipStream_t s) {
   const int ntm = (M + 127) / 128, ntn = (N + 16 * TN - 1) / (16 * TN);
   int nsplit = ntm >= 1024 ? 1 : (1024 + ntm - 1) / ntm;
   if (nsplit > ntn) nsplit = ntn;
   MSH_LAUNCH((gemm_astat_kernel<KS, TN, NST, SWAP, Epi>), dim3(ntm * nsplit), dim3(256), 0, s, A, lda, W, M, N,
                      ntn, nsplit, epi);
+  return ntn;
 }
 
 // MSH_GEMM_MODE (debug / A-B switch): 0 = register-staged double buffer; 1 = LDS-DMA, 256x208 tile, 4 waves,
@@ -579,12 +596,13 @@ inline int gemm_mode() {
 }
 
 template <int TM, int TN, bool SWAP, class Epi>
-void launch_tiled_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+int launch_tiled_cfg(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   const int nblocks = ntm * ntn;
   MSH_LAUNCH((gemm_tiled_kernel<TM, TN, SWAP, Epi>), dim3(nblocks), dim3(256), 0, s, A, lda, W, M, N, K, ntn,
                      nblocks, epi);
+  return ntn;
 }
 
 // Tile choice: TN = 13 (208 columns) divides every base-model width; widths that are multiples of 144
@@ -600,7 +618,7 @@ template <> constexpr bool kMidTiles<EpiQkvRopeBf16> = true;
 template <> constexpr bool kMidTiles<EpiSwiGLU> = true;
 
 template <bool SWAP, class Epi>
-void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
+int launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, Epi epi, hipStream_t s) {
   if ((K & 31) != 0 || (N & 3) != 0 || (lda & 7) != 0) throw std::runtime_error("gemm_tiled: unsupported shape");
   if constexpr (kMidTiles<Epi>) {
     static const bool mid_off = [] {   // A/B switch: MSH_GEMM_MID_TILES=0
@@ -619,24 +637,24 @@ void launch_tiled(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int 
     const int mode = gemm_mode();
     // short K with many column tiles (fc1, cross-KV): the A-stationary kernel wins (r01k: fc1 386 -> 452,
     // cross-KV 355 -> 389 TFLOP/s); with few column tiles (qkv, o-proj) its A preload is not amortised
-    if ((mode == 4 || (mode == 2 && N >= 1664)) && K == 416 && M >= 2048 && N % 208 == 0)
+    if (epi_taps<Epi>::value == 1 && !has_row_sums<Epi>::value && (mode == 4 || (mode == 2 && N >= 1664)) && K == 416 && M >= 2048 && N % 208 == 0)   // (conv GEMMs: the tiled kernels know their k-order)
       return launch_astat_cfg<13, 13, 3, SWAP, Epi>(A, lda, W, M, N, epi, s);
     if (mode == 0) {
       if (big)
-        launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+        return launch_tiled_cfg<4, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
       else
-        launch_tiled_cfg<2, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+        return launch_tiled_cfg<2, 13, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
     } else if (mode == 1 && big) {
-      launch_tiled_dma_cfg<4, 4, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+      return launch_tiled_dma_cfg<4, 4, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
     } else if (mode == 3 && big) {
-      launch_tiled_dma_cfg<8, 2, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+      return launch_tiled_dma_cfg<8, 2, 13, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
     } else {
-      launch_tiled_dma_cfg<4, 2, 13, 3, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+      return launch_tiled_dma_cfg<4, 2, 13, 3, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
     }
   } else if (N % 144 == 0) {
-    launch_tiled_cfg<2, 9, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    return launch_tiled_cfg<2, 9, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
   } else {
-    launch_tiled_cfg<1, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
+    return launch_tiled_cfg<1, 4, SWAP, Epi>(A, lda, W, M, N, K, epi, s);
   }
 }
 
@@ -652,20 +670,22 @@ static int stem_store_nt() {
   }();
   return v;
 }
-void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiTanhBf16{out, N, stem_store_nt()}, s);
+int gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, float2* rowsum, hipStream_t s) {
+  return launch_tiled<true>(A, lda, W, M, N, K, EpiTanhBf16{out, N, stem_store_nt(), rowsum}, s);
 }
 void gemm_gn_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* table, const float2* stats,
-                            const int* row_clip, int M, int N, int K, bf16_t* out, hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiGnBiasGeluBf16{out, N, table, stats, row_clip, stem_store_nt()}, s);
+                            const int* row_clip, int M, int N, int K, bf16_t* out, int kperm, hipStream_t s) {
+  if (K % (EpiGnBiasGeluBf16::kTaps * 32) != 0) throw std::runtime_error("conv2 GEMM: K must be 7 taps of a multiple of 32 channels");
+  launch_tiled<true>(A, lda, W, M, N, K, EpiGnBiasGeluBf16{out, N, table, stats, row_clip, stem_store_nt(), kperm}, s);
 }
 void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
                          bf16_t* out, hipStream_t s) {
   launch_tiled<true>(A, lda, W, M, N, K, EpiBiasGeluBf16{out, N, bias}, s);
 }
 void gemm_bias_gelu_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K, float* out,
-                        hipStream_t s) {
-  launch_tiled<true>(A, lda, W, M, N, K, EpiBiasGeluF32{out, N, bias}, s);
+                        int kperm, hipStream_t s) {
+  if (K % (EpiBiasGeluF32::kTaps * 32) != 0) throw std::runtime_error("conv3 GEMM: K must be 3 taps of a multiple of 32 channels");
+  launch_tiled<true>(A, lda, W, M, N, K, EpiBiasGeluF32{out, N, bias, kperm}, s);
 }
 void gemm_qkv_rope_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_pos,
                         RopeParams rp, bf16_t* out, hipStream_t s) {
@@ -712,9 +732,11 @@ void gemm_argmax_partials(const bf16_t* A, long lda, const bf16_t* W, int M, int
     const char* e = dev_getenv("MSH_LMHEAD_TALL");
     return !(e != nullptr && e[0] == '0');
   }();
-  if (tall && M > 128)
-    return launch_tiled_dma_cfg<4, 4, kArgmaxTN, 3, true, EpiArgmaxPartial>(A, lda, W, M, N, K,
-                                                                            EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
+  if (tall && M > 128) {
+    launch_tiled_dma_cfg<4, 4, kArgmaxTN, 3, true, EpiArgmaxPartial>(A, lda, W, M, N, K,
+                                                                     EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);
+    return;
+  }
   if (w_nt)
     launch_tiled_dma_cfg<4, 2, kArgmaxTN, 3, true, EpiArgmaxPartial, 32>(A, lda, W, M, N, K,
                                                                          EpiArgmaxPartial{pval, pidx, gemm_argmax_tiles(N)}, s);

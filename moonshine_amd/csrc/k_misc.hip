@@ -77,6 +77,37 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const bf16_t* __
   }
 }
 
+// The same partial sums from the row sums conv1's epilogue left (EpiTanhBf16::rowsum, [6 R][ntn] {sum, sum of squares}): a clip's
+// valid rows are one contiguous run of L1 * ntn entries.  80 KB per 10 s clip instead of 4 MB of bf16 values.
+__global__ __launch_bounds__(256) void groupnorm_rows_partial_kernel(const float2* __restrict__ rowsum, int ntn,
+                                                                     const ClipMeta* __restrict__ clips,
+                                                                     float2* __restrict__ partials) {
+  __shared__ float2 red[4];
+  const ClipMeta cm = clips[blockIdx.y];
+  const long n = (long)cm.L1 * ntn;
+  const float2* p = rowsum + 6L * cm.row_start * ntn;
+  const long per = (n + GN_CHUNKS - 1) / GN_CHUNKS;
+  const long lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  float s = 0.f, ss = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float2 v = p[i];
+    s += v.x;
+    ss += v.y;
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(s, ss);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float2 a = red[0];
+    for (int i = 1; i < 4; ++i) {
+      a.x += red[i].x;
+      a.y += red[i].y;
+    }
+    partials[blockIdx.y * GN_CHUNKS + blockIdx.x] = a;
+  }
+}
+
 __global__ void gn_fold_table_kernel(const float2* __restrict__ stats, const float* __restrict__ s1,
                                      const float* __restrict__ b2, int N, float* __restrict__ table) {
   const float2 st = stats[blockIdx.x];
@@ -305,6 +336,14 @@ void groupnorm_stats(const bf16_t* x1, const ClipMeta* clips, int n_clips, int D
                      hipStream_t s) {
   if ((D & 7) != 0) throw std::runtime_error("groupnorm_stats: width must be a multiple of 8");
   MSH_LAUNCH(groupnorm_partial_kernel, dim3(GN_CHUNKS, n_clips), dim3(256), 0, s, x1, clips, D,
+                     reinterpret_cast<float2*>(partials));
+  MSH_LAUNCH(groupnorm_final_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, s,
+                     reinterpret_cast<const float2*>(partials), clips, n_clips, D, stats);
+}
+
+void groupnorm_stats_rows(const float2* rowsum, int ntn, const ClipMeta* clips, int n_clips, int D, float* partials,
+                          float2* stats, hipStream_t s) {
+  MSH_LAUNCH(groupnorm_rows_partial_kernel, dim3(GN_CHUNKS, n_clips), dim3(256), 0, s, rowsum, ntn, clips,
                      reinterpret_cast<float2*>(partials));
   MSH_LAUNCH(groupnorm_final_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, s,
                      reinterpret_cast<const float2*>(partials), clips, n_clips, D, stats);

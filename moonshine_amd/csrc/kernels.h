@@ -35,21 +35,25 @@ __host__ __device__ inline long fm32(int r, int k, int ksteps) {
 }
 
 // ---------------- tiled MFMA GEMM (large M): C = A[M,K](lda) * W[N,K]^T ----------------
-// conv1: out_bf16[M,N] = tanh(acc)
-void gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, hipStream_t s);
+// conv1: out_bf16[M,N] = tanh(acc).  rowsum (optional): [M][column tiles] {sum, sum of squares} of the bf16 values every
+// (row, column tile) stored -- the GroupNorm statistics without a pass over the output (groupnorm_stats_rows).  Returns the
+// number of column tiles of the kernel it ran (the second dimension of rowsum; at most gemm_max_col_tiles(N)).
+int gemm_tanh_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, bf16_t* out, float2* rowsum, hipStream_t s);
+inline int gemm_max_col_tiles(int N) { return (N + 63) / 64; }   // the narrowest tile of the tiled family is 64 columns
 // conv2 with the GroupNorm folded in (see EpiGnBiasGeluBf16): W = conv2 weight * gamma; table [clips][N] from
 // gn_fold_table; stats per clip {mean, rstd}; row m belongs to the clip of stream row m / 2
+// kperm = 1: W is stored in the tap-inner k-order (32 channels outer, the 7 taps inner: conv_k_offset, gemm_common.h)
 void gemm_gn_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* table, const float2* stats,
-                            const int* row_clip, int M, int N, int K, bf16_t* out, hipStream_t s);
+                            const int* row_clip, int M, int N, int K, bf16_t* out, int kperm, hipStream_t s);
 // table[b][n] = b2[n] - mean_b * rstd_b * s1[n]
 void gn_fold_table(const float2* stats, const float* s1, const float* b2, int n_clips, int N, float* table,
                    hipStream_t s);
 // out_bf16[M,N] = gelu(acc + bias)
 void gemm_bias_gelu_bf16(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
                          bf16_t* out, hipStream_t s);
-// out_f32[M,N] = gelu(acc + bias)
+// conv3: out_f32[M,N] = gelu(acc + bias); kperm as above with 3 taps
 void gemm_bias_gelu_f32(const bf16_t* A, long lda, const bf16_t* W, const float* bias, int M, int N, int K,
-                        float* out, hipStream_t s);
+                        float* out, int kperm, hipStream_t s);
 // encoder QKV: out_bf16[M,3D] = rope(acc) (q,k parts), position from row_pos[m] (junk rows: pos<0 -> 0)
 void gemm_qkv_rope_bf16(const bf16_t* A, long lda, const bf16_t* W, int M, int N, int K, const int* row_pos,
                         RopeParams rp, bf16_t* out, hipStream_t s);
@@ -251,6 +255,9 @@ void build_row_meta(const ClipMeta* clips, int n_clips, int* row_pos, int* row_c
 // GroupNorm(1 group) statistics per clip over the valid [L1, D] block of x1 (bf16) -> stats[b] = {mean, rstd}
 void groupnorm_stats(const bf16_t* x1, const ClipMeta* clips, int n_clips, int D, float* partials, float2* stats,
                      hipStream_t s);
+// the same statistics from the row sums conv1 left beside its output (gemm_tanh_bf16's rowsum, ntn column tiles per row)
+void groupnorm_stats_rows(const float2* rowsum, int ntn, const ClipMeta* clips, int n_clips, int D, float* partials,
+                          float2* stats, hipStream_t s);
 // y_bf16[r,:] = LayerNorm(x[r,:]) * gamma   (no bias, eps 1e-5); optional fp32 copy
 void layernorm_bf16(const float* x, const float* gamma, int rows, int D, bf16_t* y, float* y_f32, hipStream_t s);
 // decode bookkeeping after the logits of one step: first-max argmax per row, EOS / budget

@@ -222,11 +222,14 @@ def test_log_ort_run_option_reports_kernel_groups(tiny_dir, capfd):
     t.close()
 
 
-def test_audio_longer_than_the_engine_capacity_is_cut_not_refused(tiny_dir, engine):
+def test_audio_longer_than_the_engine_capacity_is_cut_not_refused(tiny_dir, engine, monkeypatch):
     """with vad_threshold=0 the reference's fade never ends a segment, so a long file
     reached the engine as ONE clip and failed on its 504-step budget -- on every later call too.  The detector now gets
     the engine's capacity (504 steps / max_tokens_per_second) as a hard cap: 100 s at 6.5 tok/s = two lines, the second
     starting where the first ended, each transcribed like a clip of its own."""
+    # (the second line is 22.5 s = 938 rows: alone it would take the split-K encoder GEMMs, beside the first line the tiled ones;
+    #  the texts are compared byte for byte, so one set of encoder GEMMs, like the other byte-equality tests of this file)
+    monkeypatch.setenv("MSH_ENC_SMALL_ROWS", "0")
     vocab = synthetic_vocab(ARCHS["tiny"].vocab)
     t = api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "vad_max_segment_duration": "100000"})
     audio = make_audio(21, 100 * 16000)

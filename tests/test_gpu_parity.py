@@ -89,6 +89,52 @@ def test_micro_encoder_ragged_batch(micro):
         np.testing.assert_array_equal(e.encoder_output(0), outs[i])
 
 
+@pytest.mark.parametrize("arch", ["tiny", "base"])
+def test_conv_k_order_tap_inner_vs_tap_major(tmp_path_factory, monkeypatch, arch):
+    """The conv GEMMs walk K channel-block-major (gemm_common.h conv_k_offset; weights re-ordered at load).  The order the
+    window lies in memory (MSH_CONV_KORDER=0, rounds 1-5) is the same sum in another order: both against the oracle, and
+    against each other inside the tolerance.  tiny takes the register-staged tiled kernel, base the LDS-DMA one."""
+    monkeypatch.setenv("MSH_DEV_KNOBS", "1")
+    clips = [make_audio(70 + i, n) for i, n in enumerate([16000, 31000, 9000])]
+    outs = {}
+    for order in ("0", "1"):
+        monkeypatch.setenv("MSH_CONV_KORDER", order)
+        e, w, cfg = _engine(tmp_path_factory, arch, 3)
+        e.set_keep_encoder_output(True)
+        e.encode(clips)
+        outs[order] = [e.encoder_output(i) for i in range(len(clips))]
+        for i, c in enumerate(clips):
+            _enc_check(outs[order][i], ref.encoder_forward(w, cfg, c))
+        e.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        d = a - b
+        assert float(np.sqrt((d**2).mean()) / np.sqrt((b**2).mean())) <= 8e-3   # (bf16 roundings of x2 that fall the other way, through every layer: inside the 1e-2 each order is held to against the oracle)
+        assert not np.array_equal(a, b) or arch == "micro"   # (a different order of the fp32 sum: equal bits would mean the switch did nothing)
+
+
+@pytest.mark.parametrize("arch", ["micro", "tiny", "base"])
+def test_groupnorm_statistics_from_conv1_row_sums(tmp_path_factory, monkeypatch, arch):
+    """conv1's epilogue leaves the row sums of what it stores and the GroupNorm statistics are summed from those (engine.cpp,
+    EpiTanhBf16::rowsum); MSH_GN_ROWSUMS=0 is the pass over the conv1 output they replace.  The same values summed in another
+    order: every clip's {mean, rstd} agrees to fp32 rounding.  Ragged clips, three tile shapes (micro / tiny run the
+    register-staged kernel on 64- / 144-column tiles, base the LDS-DMA kernel on 208-column tiles with staged stores)."""
+    monkeypatch.setenv("MSH_DEV_KNOBS", "1")
+    e, w, cfg = _engine(tmp_path_factory, arch, 5, dev=True)
+    e.set_keep_encoder_output(True)
+    clips = [make_audio(90 + i, n) for i, n in enumerate([16000, 40123, 895, 23789])]
+    stats, outs = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSH_GN_ROWSUMS", mode)
+        e.encode(clips)
+        stats[mode] = e.debug_read("gn_stats").view(np.float32).reshape(-1, 2).copy()
+        outs[mode] = [e.encoder_output(i) for i in range(len(clips))]
+    assert stats["0"].shape == (len(clips), 2) and np.all(stats["0"][:, 1] > 0)
+    np.testing.assert_allclose(stats["1"], stats["0"], rtol=2e-6, atol=2e-7)
+    for i, c in enumerate(clips):
+        _enc_check(outs["1"][i], ref.encoder_forward(w, cfg, c))
+    e.close()
+
+
 def test_micro_too_short_clip_is_an_error(micro):
     from moonshine_amd.hip_api import MshError
 

@@ -238,31 +238,38 @@ def test_base_batch256_benchmark_path_vs_oracle_absorbed(base_x):
     assert base_x[0].cross_absorbed()
 
 
-def test_one_form_per_engine_whatever_the_batch_size(tmp_path_factory):
+def test_one_form_per_engine_whatever_the_batch_size(tmp_path_factory, monkeypatch):
     """An engine holds ONE cross-attention form (msh_set_cross_mode), never one per batch: the default is the reference's
     projected form at any batch size (until round 4 mode 0 switched to the absorbed form at 192 clips, so a clip's ids
     depended on how many neighbours it had); within a form a batch's ids do not depend on which clips share it; the
     absorbed form refuses the word-timestamp capture and fp8 keys instead of silently changing form."""
     from moonshine_amd.hip_api import MshError
 
+    # (8 clips of 1 s are 448 rows: alone they would take the split-K encoder GEMMs, among 200 the tiled ones -- another
+    #  summation order, DESIGN.md section 4; this test is about the DECODER's form, so the encoder is pinned to one set)
+    monkeypatch.setenv("MSH_ENC_SMALL_ROWS", "0")
     e, w, cfg = tp._engine(tmp_path_factory, "tiny", 3)
     assert e.cross_absorbed_supported()
     clips = [make_audio(300 + i, 16000 + 37 * i) for i in range(200)]
-    e.encode(clips[:8])
+    # The "small" batch has 136 clips: the decode kernels change their summation order at 64 clips and the LM head at 128
+    # (DESIGN.md section 4), so byte-equal ids are promised between batches on the same side of those lines -- 136 and 200
+    # clips run the same kernels.  (Until round 6 this compared 8 clips with 200 and held by the luck of six steps' margins.)
+    n_small = 136
+    e.encode(clips[:n_small])
     assert not e.cross_absorbed()
     small = e.decode(forced_steps=6)[0]
     e.encode(clips)
     assert not e.cross_absorbed()            # 200 clips: still the projected form
     big = e.decode(forced_steps=6)[0]
-    assert big[:8] == small                  # a clip alone == the same clip among 200
+    assert big[:n_small] == small            # a clip among 136 == the same clip among 200
     e.set_cross_mode("absorbed")
     big_x = e.transcribe_tokens(clips, forced_steps=6)
     assert e.cross_absorbed()
-    assert e.transcribe_tokens(clips[:8], forced_steps=6) == big_x[:8]
-    assert e.cross_absorbed()                # 8 clips: still the absorbed form
-    agree = sum(a == b for a, b in zip(small, big_x[:8]))
-    assert agree >= 6, (small, big_x[:8])    # two roundings of the same function: near-ties may flip, nothing else
-    tp.margins.record(clips_with_equal_ids_across_forms=agree, clips=8, steps=6)
+    assert e.transcribe_tokens(clips[:n_small], forced_steps=6) == big_x[:n_small]
+    assert e.cross_absorbed()                # 136 clips: still the absorbed form
+    agree = sum(a == b for a, b in zip(small, big_x[:n_small]))
+    assert agree >= n_small * 3 // 4, (agree, n_small)    # two roundings of the same function: near-ties may flip, nothing else
+    tp.margins.record(clips_with_equal_ids_across_forms=agree, clips=n_small, steps=6)
     # the word-timestamp capture reads K^T, fp8 keys are projected keys: neither is available in the absorbed form
     e.lib.msh_set_capture_cross_attention(e.h, 1)
     with pytest.raises(MshError):
@@ -272,9 +279,9 @@ def test_one_form_per_engine_whatever_the_batch_size(tmp_path_factory):
     with pytest.raises(MshError):
         e.encode(clips[:4])
     e.set_kv_dtype("bf16")
-    assert e.transcribe_tokens(clips[:8], forced_steps=6) == big_x[:8]
+    assert e.transcribe_tokens(clips[:n_small], forced_steps=6) == big_x[:n_small]
     e.set_cross_mode("kv")
-    assert e.transcribe_tokens(clips[:8], forced_steps=6) == small
+    assert e.transcribe_tokens(clips[:n_small], forced_steps=6) == small
     # an architecture without the absorbed operands says so
     m, _, _ = tp._engine(tmp_path_factory, "micro", 0)
     if not m.cross_absorbed_supported():
