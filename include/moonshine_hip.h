@@ -179,6 +179,17 @@ MSH_EXPORT int32_t msh_wait(msh_engine* e, int64_t ticket);
  * absorbed operands (msh_cross_absorbed_supported), the word-timestamp capture, kv_dtype = fp8.  Applies to the next
  * msh_encode; set it before msh_set_batches_in_flight. */
 MSH_EXPORT int32_t msh_set_cross_mode(msh_engine* e, int32_t mode);
+/* Kernel set (additive).  0 (default): every call takes the kernels that are fastest at ITS size -- split-K encoder GEMMs for
+ * a call of <= 1024 rows, tiled ones below 16 k rows, the panel / fused kernels above; decode kernels by clip count (1-2, <= 4,
+ * 5..63, >= 64; LM head on the tiled kernel from 128 clips) -- so a clip's token ids can change (near-tie flips, same
+ * tolerance) with the number of clips in its call.  1: ONE kernel set, the large-batch one, for every call: a clip's ids do
+ * not depend on what shares its call -- the tail sub-batches of a batch call, one clip through a throughput deployment.
+ * Small calls then run slower (one 10 s clip: about twice the latency).  The host layer's `kernel_set=auto` switches it on at
+ * LOAD together with the absorbed cross-attention form (batch_clips / max_batch_size >= 192 passed).  Applies to the next
+ * msh_encode; set it before msh_set_batches_in_flight.  (reference: one graph per model, core/moonshine-model.cpp:270-274,
+ * :443-447 -- the reference's result for a clip never depends on other clips.) */
+MSH_EXPORT int32_t msh_set_uniform_kernels(msh_engine* e, int32_t on);
+MSH_EXPORT int32_t msh_uniform_kernels(const msh_engine* e);
 /* 1 if the batch encoded last decodes (with lanes: if the engine's batches decode) with the absorbed form, else 0. */
 MSH_EXPORT int32_t msh_cross_absorbed(const msh_engine* e);
 /* 1 if the loaded weights include the absorbed form's operands (8 heads, hidden 288 / 416), else 0. */

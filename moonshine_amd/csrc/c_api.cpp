@@ -99,6 +99,14 @@ void apply_options(const OptionList& options, TranscriberOptions* o) {
       else if (t == "absorbed") o->cross_attention = 2;
       else throw std::runtime_error("cross_attention must be auto, kv or absorbed, got '" + v + "'");
     }
+    else if (k == "kernel_set") {   // additive: auto (default) | per_call | uniform (msh_set_uniform_kernels)
+      std::string t = v;
+      for (char& ch : t) ch = (char)tolower((unsigned char)ch);
+      if (t == "auto") o->kernel_set = 0;
+      else if (t == "per_call" || t == "latency") o->kernel_set = 1;
+      else if (t == "uniform" || t == "throughput") o->kernel_set = 2;
+      else throw std::runtime_error("kernel_set must be auto, per_call or uniform, got '" + v + "'");
+    }
     else if (k == "batch_clips" || k == "max_batch_size") {   // additive (batch calls; SURVEY 8b names it max_batch_size)
       o->batch_clips = parse_int32(v);
       o->batch_clips_given = true;   // asking for large sub-batches is what switches cross_attention=auto to the absorbed form

@@ -434,6 +434,7 @@ void Engine::share_weights_from(const Engine& o) {
   kv_qscale_ = o.kv_qscale_, kv_dq_ = o.kv_dq_;
   kv_fp8_ = o.kv_fp8_;
   cross_mode_ = o.cross_mode_;
+  uniform_kernels_ = o.uniform_kernels_;
   rope_cos_ = o.rope_cos_, rope_sin_ = o.rope_sin_;
   rope_max_pos_ = o.rope_max_pos_;
   loaded_ = true;  // weight_allocs_ stays empty: the owner frees
@@ -1053,12 +1054,12 @@ void Engine::run_encoder() {
   // kernel at any batch size
   const char* qkv_env = dev_getenv("MSH_ENC_QKV_PANEL");
   const bool qkv_panel_on = !(qkv_env != nullptr && qkv_env[0] == '0');
-  const long qkv_panel_min_rows = (qkv_env != nullptr && qkv_env[0] == '2') ? 8 : 128 * 128;
+  const long qkv_panel_min_rows = ((qkv_env != nullptr && qkv_env[0] == '2') || uniform_kernels_) ? 8 : 128 * 128;   // (uniform_kernels_: the large-batch kernels for every call)
   // developer switch (per call): 0 = tiled GEMMs, 2 = the MLP block alone in the fused kernel behind a tiled o-proj,
   // 3 = o-proj + MLP fused at any batch size; default 1 = o-proj + MLP fused from 32 k rows on
   const char* mlp_env = dev_getenv("MSH_ENC_MLP");
   const int fused_mlp = mlp_env == nullptr ? 1 : (mlp_env[0] == '0' ? 0 : mlp_env[0] == '2' ? 2 : 1);
-  const long mlp_min_rows = (mlp_env != nullptr && mlp_env[0] == '3') ? 1 : 128 * 256;
+  const long mlp_min_rows = ((mlp_env != nullptr && mlp_env[0] == '3') || uniform_kernels_) ? 1 : 128 * 256;
   // Layer l's fused o-proj + MLP kernel hands layer l + 1's QKV panel kernel its operand -- LayerNorm of the rows it just
   // produced, bf16, fragment-major (k_mlp.hip YOUT, k_panel.hip AM = 2) -- whenever both layers run on those kernels
   // (MSH_ENC_LN_HANDOVER=0: the panel kernel fetches and normalises the fp32 rows itself, as before round 6)
@@ -1102,7 +1103,7 @@ void Engine::run_encoder() {
   // = largest row count that takes it (default 1024; 0 = off).  Same epilogue arithmetic, a different summation order over K.
   const char* small_env = dev_getenv("MSH_ENC_SMALL_ROWS");
   const long small_rows = small_env != nullptr ? atol(small_env) : 1024;
-  const bool small_gemms = R <= small_rows && (R & 3) == 0 && qkv_env == nullptr && mlp_env == nullptr;   // (a developer switch that names a kernel gets that kernel)
+  const bool small_gemms = !uniform_kernels_ && R <= small_rows && (R & 3) == 0 && qkv_env == nullptr && mlp_env == nullptr;   // (a developer switch that names a kernel gets that kernel)
   // Two halves side by side.  A layer of a large batch is three chip-filling kernels whose grids end in a partly filled round
   // (848 panels of 128 rows on 256 CUs = 3.31 rounds for 256 x 10 s: the fused MLP takes the time of 4).  Every kernel of the
   // layer loop works row by row or clip by clip, so the batch is cut at a clip boundary on a panel boundary and the two halves
@@ -1523,7 +1524,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
         ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
         dec_cross_looped(dH, W.wq_c_rm, KTl, VTl, clips, M, D, Hh, dao, s);
       }
-    } else if (fuse_q && D <= 512 && M < 64 && !capture_cross_) {  // latency-bound regime only (see k_attn.hip)
+    } else if (fuse_q && D <= 512 && M < 64 && !capture_cross_ && !uniform_kernels_) {  // latency-bound regime only (see k_attn.hip)
       // LayerNorm + query projection of the clip's row run inside the attention kernel
       if (on(4)) {
         ProfScope p(this, "dec_cross_attention", 4.0 * sT * D + 2.0 * M * D * D, sT * D * 2.0 * kv_bytes() + w_dd + M * D * 4.0);
@@ -1555,7 +1556,7 @@ void Engine::decode_step_enqueue(DecodeGroup& g) {
       dec_gemm_resid(dz, W.fc2, W.b2, M, D, F, dH, s);
     }
   }
-  if (M >= 128) {  // batch large enough for the LDS-tiled MFMA kernel: final LN once, then [M,D] x [V,D]^T
+  if (M >= 128 || uniform_kernels_) {  // batch large enough for the LDS-tiled MFMA kernel: final LN once, then [M,D] x [V,D]^T
     if (on(8)) {
       ProfScope p(this, "dec_final_layernorm", 0, M * D * 6.0);
       dec_final_layernorm(dH, dec_ln_, M, D, g.dy.as<bf16_t>(), s);
@@ -1780,7 +1781,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       // nobody reads the logits: the tiled LM head (from 128 clips on) reduces every 128 x 208 tile to (max, first index).
       // (The same on the split-K decode GEMM's 16 x 16 tiles was built and measured at one clip: head 6.5 against 6.4 us,
       // bookkeeping 4.85 against 4.25 -- that kernel's time is its chain of dependent accesses, not the scan; removed.)
-      g.fused_argmax = !off && logits_out == nullptr && M >= 128;
+      g.fused_argmax = !off && logits_out == nullptr && (M >= 128 || uniform_kernels_);
       g.argmax_tiles = gemm_argmax_tiles(V);
     }
     moved |= g.pval.reserve((size_t)M * g.argmax_tiles * sizeof(float));
@@ -1795,7 +1796,7 @@ int Engine::decode(int forced_steps, const int32_t* teacher, int teacher_stride,
       int tmax = 1;
       for (int b = 0; b < M; ++b) tmax = std::max(tmax, (int)clips_h_[g.first + b].T);
       const int xs = dec_cross_split_slices(tmax);
-      const bool small_ok = !absorbed_ && !capture_cross_ && !kv_fp8_ && M < 64 && dec_cross_split_supported(D, Hh);
+      const bool small_ok = !uniform_kernels_ && !absorbed_ && !capture_cross_ && !kv_fp8_ && M < 64 && dec_cross_split_supported(D, Hh);
       g.split_cross = small_ok && M <= xsplit_m;
       const char* xl = dev_getenv("MSH_XLOOP");   // 0: batches above MSH_XSPLIT_M keep k_attn.hip's one-pass kernel (A/B measurements)
       g.loop_cross = small_ok && !g.split_cross && xs <= dec_cross_looped_max_slices() && !(xl != nullptr && xl[0] == '0');

@@ -112,6 +112,19 @@ class Engine {
     }
   }
   int cross_mode() const { return cross_mode_; }
+  // Kernel set: 0 (default) = chosen per call by its size (split-K encoder GEMMs for <= 1024 rows, tiled ones below 16 k
+  // rows, panel / fused kernels above; decode kernels by clip count: 1-2 / <= 4 / 5..63 / >= 64, LM head tiled from 128) --
+  // fastest at every size, but a clip's bits change across those lines.  1 = ONE kernel set, the large-batch one, for every
+  // call: a clip's ids do not depend on how many clips share its call (the batch call's tail sub-batches, a single clip
+  // through a throughput deployment); small calls run slower.  ONE per engine like the cross-attention form; lanes take it
+  // when they are created.
+  void set_uniform_kernels(bool on) {
+    if (on != uniform_kernels_) {
+      uniform_kernels_ = on;
+      encoded_ = false;
+    }
+  }
+  bool uniform_kernels() const { return uniform_kernels_; }
   bool cross_absorbed_available() const { return !dec_.empty() && dec_[0].wvo != nullptr; }
   // this engine is one of several lanes that decode at the same time on one GPU (BatchPipeline): its once-per-launch streams
   // go with the non-temporal policy (kernels.h dec_cross_absorbed)
@@ -198,6 +211,7 @@ class Engine {
   bool capture_cross_ = false;
   bool kv_fp8_ = false;
   int cross_mode_ = 0;
+  bool uniform_kernels_ = false;
   bool shared_gpu_ = false;
   bool absorbed_ = false;   // the encoded batch decodes with the absorbed cross-attention: K^T / V^T were not written
   float *kv_qscale_ = nullptr, *kv_dq_ = nullptr;   // [L * 2D]: e4m3 scale of every cross-KV column and its inverse

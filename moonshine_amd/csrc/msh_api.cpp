@@ -239,6 +239,14 @@ int32_t msh_set_cross_mode(msh_engine* e, int32_t mode) {
   });
 }
 
+int32_t msh_set_uniform_kernels(msh_engine* e, int32_t on) {
+  return guarded(e, [&] {
+    if (e->pipe) throw std::invalid_argument("msh_set_uniform_kernels: set it before msh_set_batches_in_flight (lanes take it at creation)");
+    e->eng->set_uniform_kernels(on != 0);
+  });
+}
+int32_t msh_uniform_kernels(const msh_engine* e) { return e != nullptr && e->eng->uniform_kernels() ? 1 : 0; }
+
 int32_t msh_cross_absorbed(const msh_engine* e) {
   if (e == nullptr) return 0;
   // with lanes (msh_set_batches_in_flight) the batches are encoded by the lanes; the form is the engine's, all lanes share it

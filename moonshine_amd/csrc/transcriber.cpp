@@ -577,12 +577,18 @@ Transcriber::Transcriber(const TranscriberOptions& options) : opt_(options) {
       if (m == 0) m = (opt_.batch_clips_given && opt_.batch_clips >= 192 && !needs_keys && msh_cross_absorbed_supported(d.engine) == 1) ? 2 : 1;
       if (msh_set_cross_mode(d.engine, m) != MSH_OK)
         throw std::runtime_error(std::string("cross_attention: ") + msh_last_error(d.engine));
+      // Kernel set, fixed here like the form: a transcriber configured for large sub-batches runs EVERY call -- the tail
+      // sub-batches of a batch call, a single clip -- on the large-batch kernels, so a clip's transcript does not depend on
+      // what shared its sub-batch; a transcriber loaded without batch options keeps the per-call choice (the latency path).
+      const bool uniform = opt_.kernel_set == 2 || (opt_.kernel_set == 0 && opt_.batch_clips_given && opt_.batch_clips >= 192);
+      if (msh_set_uniform_kernels(d.engine, uniform ? 1 : 0) != MSH_OK)
+        throw std::runtime_error(std::string("kernel_set: ") + msh_last_error(d.engine));
       // (two deployments whose EFFECTIVE options are equal can still differ in this form -- `auto` looks at whether a sub-batch
       // size was asked for at all, INTEGRATION.md section A -- so the resolved form is said out loud where logging is on)
       if (opt_.log_ort_run)
-        MSH_LOGF("device %d: decoder cross-attention form = %s (option cross_attention=%s, batch_clips %s = %d)", d.device,
+        MSH_LOGF("device %d: decoder cross-attention form = %s (option cross_attention=%s, batch_clips %s = %d); kernel set = %s", d.device,
                  m == 2 ? "absorbed" : "projected K/V", mode == 0 ? "auto" : mode == 2 ? "absorbed" : "kv",
-                 opt_.batch_clips_given ? "given" : "defaulted", opt_.batch_clips);
+                 opt_.batch_clips_given ? "given" : "defaulted", opt_.batch_clips, uniform ? "uniform (large-batch kernels for every call)" : "per call");
     }
   }
 }

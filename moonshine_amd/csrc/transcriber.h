@@ -143,6 +143,7 @@ struct TranscriberOptions {  // reference core/transcriber.h:129-229 (fields thi
   int cross_attention = 0;               // additive: form of the decoder's cross-attention (msh_set_cross_mode), ONE per transcriber, fixed at load: 0 = auto (absorbed when the caller ASKED for sub-batches of >= 192 clips -- batch_clips / max_batch_size passed -- and neither word_timestamps nor kv_dtype=fp8 is on; else projected K / V, the reference's order of operations and the form with the single-clip latency path), 1 = projected K / V, 2 = absorbed (an error where it cannot be honoured)
   int batch_clips = 256;                 // additive: clips per GPU sub-batch of a batch call
   bool batch_clips_given = false;        // the option was passed (the cross_attention=auto rule reads it)
+  int kernel_set = 0;                    // additive: 0 = auto (the uniform set when the caller ASKED for sub-batches of >= 192 clips, like cross_attention=auto), 1 = per call (every call the kernels that are fastest at its size), 2 = uniform (ONE kernel set, the large-batch one: a clip's ids do not depend on what shares its call; msh_set_uniform_kernels)
   int batches_in_flight = 2;             // additive: sub-batches on the GPU at once (1 = strictly one after the other)
   bool return_audio_data = true;
   bool log_output_text = false;

@@ -68,6 +68,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "msh_get_encoder_output": (i32, [vp, u32, vp]),
         "msh_set_kv_dtype": (i32, [vp, i32]),
         "msh_set_cross_mode": (i32, [vp, i32]),
+        "msh_set_uniform_kernels": (i32, [vp, i32]),
+        "msh_uniform_kernels": (i32, [vp]),
         "msh_cross_absorbed": (i32, [vp]),
         "msh_cross_absorbed_supported": (i32, [vp]),
         "msh_profile_enable": (i32, [vp, i32]),
@@ -174,7 +176,7 @@ DECLARED_SYMBOLS = [
     "msh_stream_process_audio", "msh_stream_encode", "msh_stream_decoder_reset", "msh_stream_decode_tokens", "msh_stream_cross_attention",
     "msh_stream_decode_full", "msh_stream_set_bias", "msh_stream_query", "msh_stream_get_memory",
     "msh_stream_profile_enable", "msh_stream_profile_reset", "msh_stream_profile_count", "msh_stream_profile_get",
-    "msh_set_cross_mode", "msh_cross_absorbed", "msh_cross_absorbed_supported",
+    "msh_set_cross_mode", "msh_set_uniform_kernels", "msh_uniform_kernels", "msh_cross_absorbed", "msh_cross_absorbed_supported",
     "msh_stream_get_features",
 ]
 
@@ -259,6 +261,10 @@ class Engine:
         the reference's form and the default) or "absorbed" (one pass over the encoder output for all heads, k_xattn.hip:
         pays from ~192 clips per batch on); before set_batches_in_flight."""
         self._check(self.lib.msh_set_cross_mode(self.h, {"default": 0, "kv": 1, "absorbed": 2}[mode]))
+
+    def set_uniform_kernels(self, on: bool = True):
+        """One kernel set (the large-batch one) for every call: a clip's ids do not depend on what shares its call."""
+        self._check(self.lib.msh_set_uniform_kernels(self.h, 1 if on else 0))
 
     def cross_absorbed_supported(self) -> bool:
         return bool(self.lib.msh_cross_absorbed_supported(self.h))

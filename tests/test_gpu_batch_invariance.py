@@ -52,3 +52,37 @@ def test_id_flip_rate_across_kernel_selection_thresholds(tmp_path_factory):
     # what was measured (0-2 of 16) with room for box-to-box variation; a kernel bug (wrong tile, wrong row) differs on
     # every clip.
     assert worst <= 0.25, report
+
+
+@pytest.mark.parametrize("form", ["absorbed", "kv"])
+def test_uniform_kernel_set_makes_a_clips_ids_independent_of_its_call(tmp_path_factory, form):
+    """msh_set_uniform_kernels (host option kernel_set; on by itself in a transcriber configured for sub-batches of >= 192
+    clips): every call runs the large-batch kernels, so the SAME clip gives byte-identical encoder frames and 65 free-running ids
+    alone, among 5, 40, 72, 136 and 200 clips -- on both sides of every line the per-call choice draws (1,024 / 16 k rows;
+    4 / 64 / 128 clips).  Plain random weights on purpose: their near-ties are what a changed summation order would flip."""
+    from test_gpu_parity import _engine
+
+    e, w, cfg = _engine(tmp_path_factory, "base", 0)
+    assert e.lib.msh_uniform_kernels(e.h) == 0
+    e.set_cross_mode(form)
+    e.set_uniform_kernels(True)
+    assert e.lib.msh_uniform_kernels(e.h) == 1
+    e.set_keep_encoder_output(True)
+    steps = 65
+    lens = [160_000, 48_000, 95_123, 16_000]
+    probe = [make_audio(7000 + i, lens[i % 4]) for i in range(4)]
+    filler = [make_audio(7100 + i, 16_000 + 977 * (i % 40)) for i in range(196)]
+    alone, frames = [], []
+    for c in probe:
+        alone.append(e.transcribe_tokens([c], forced_steps=steps)[0])
+        frames.append(e.encoder_output(0))
+    for n in (5, 40, 72, 136, 200):
+        clips = probe + filler[: n - len(probe)]
+        got = e.transcribe_tokens(clips, forced_steps=steps)
+        for i in range(len(probe)):
+            np.testing.assert_array_equal(e.encoder_output(i), frames[i], err_msg=f"{n} clips, clip {i}: encoder frames")
+            assert got[i] == alone[i], (form, n, i)
+    # the per-call choice on the same engine is a different (faster at one clip) set of kernels: switching back is allowed
+    e.set_uniform_kernels(False)
+    assert len(e.transcribe_tokens(probe[:1], forced_steps=steps)[0]) == steps + 1
+    e.close()

@@ -390,6 +390,11 @@ def test_default_options_batch_call_rolls_segments_into_sub_batches(tiny_dir, tm
     same = sum(a == b for a, b in zip(texts_r, texts_w))
     print(f"rolling vs wave pipeline: {same} of {len(texts_r)} texts equal")
     assert same >= 0.8 * len(texts_r), (same, len(texts_r))   # (near-tie flips on fan-in-scaled random weights: tests/test_gpu_batch_invariance.py measures the rate on a sharpened checkpoint)
+    # kernel_set=uniform (what a transcriber configured for >= 192-clip sub-batches gets by itself): ONE kernel set for every
+    # sub-batch, so other sub-batch compositions give the same transcripts byte for byte
+    rolling_u = run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"kernel_set": "uniform"})
+    assert run({"MSH_BATCH_ROLLING": "0"}, {"kernel_set": "uniform"}) == rolling_u
+    assert spans(rolling_u) == spans(rolling)
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"devices": "0,0"})) == spans(rolling)
     assert spans(run({"MSH_BATCH_CHUNK_CLIPS": "5"}, {"vad_device": "0"})) == spans(rolling)
     assert spans(run({})) == spans(rolling)     # the default chunking (one chunk here)
@@ -517,28 +522,39 @@ def test_cross_attention_option(tiny_dir, engine):
         assert all(len(lines) == 1 for lines in got)
         return [lines[0].text_bytes for lines in got]
 
+    # The kernel set (kernel_set = auto | per_call | uniform -> msh_set_uniform_kernels) is resolved by the same rule at the
+    # same place: a transcriber configured for sub-batches of >= 192 clips runs every call on the large-batch kernels.
     want = {}
     for form in ("absorbed", "kv"):
-        engine.set_cross_mode(form)
-        try:
-            ids = engine.transcribe_tokens(clips)
-            assert engine.cross_absorbed() == (form == "absorbed")
-        finally:
-            engine.set_cross_mode("kv")
-        want[form] = [host_ref.sanitize_text(host_ref.tokens_to_text(vocab, t)) for t in ids]
-    assert texts({"cross_attention": "absorbed"}) == want["absorbed"]
-    assert texts({"cross_attention": "kv", "batch_clips": "256"}) == want["kv"]
+        for uniform in (False, True):
+            engine.set_cross_mode(form)
+            engine.set_uniform_kernels(uniform)
+            try:
+                ids = engine.transcribe_tokens(clips)
+                assert engine.cross_absorbed() == (form == "absorbed")
+            finally:
+                engine.set_cross_mode("kv")
+                engine.set_uniform_kernels(False)
+            want[form, uniform] = [host_ref.sanitize_text(host_ref.tokens_to_text(vocab, t)) for t in ids]
+    assert texts({"cross_attention": "absorbed"}) == want["absorbed", False]
+    assert texts({"cross_attention": "kv", "batch_clips": "256"}) == want["kv", True]
     # auto: by the sub-batch size the caller ASKED for, not by the 8 clips of this call; no option = the projected form
-    assert texts({}) == want["kv"]
-    assert texts({"batch_clips": "256"}) == want["absorbed"]
-    assert texts({"batch_clips": "64"}) == want["kv"]
+    assert texts({}) == want["kv", False]
+    assert texts({"batch_clips": "256"}) == want["absorbed", True]
+    assert texts({"batch_clips": "64"}) == want["kv", False]
+    assert texts({"kernel_set": "uniform"}) == want["kv", True]
+    assert texts({"batch_clips": "256", "kernel_set": "per_call"}) == want["absorbed", False]
+    with pytest.raises(Exception):
+        api.Transcriber(tiny_dir[0], api.ARCH_TINY, {"vad_threshold": "0", "kernel_set": "sometimes"})
     # word timestamps force the projected form (they read its keys); the capture also switches the small-batch decode to the
     # general cross-attention kernel (another summation order than the 64-key-slice form `want["kv"]` ran on), so the
     # expectation is an engine decode with the capture on -- the same kernels, the same bits
     engine.set_capture_cross_attention(True)
+    engine.set_uniform_kernels(True)    # (batch_clips = 256 below: the uniform kernel set)
     try:
         ids = engine.transcribe_tokens(clips)
     finally:
         engine.set_capture_cross_attention(False)
+        engine.set_uniform_kernels(False)
     want_cap = [host_ref.sanitize_text(host_ref.tokens_to_text(vocab, t)) for t in ids]
     assert texts({"batch_clips": "256", "word_timestamps": "true"}) == want_cap
