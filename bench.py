@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--workload", default="offline", choices=["offline", "streaming"],
                     help="offline = BASELINE.json configs[2] (default); streaming = configs[4] (speculative streaming decode)")
+    ap.add_argument("--capi-kernel-set", default="auto", choices=["auto", "per_call", "uniform"],
+                    help="c_api_batch sub-run: the transcribers' kernel_set option (auto = uniform with batch_clips >= 192)")
     ap.add_argument("--streams", type=int, default=64, help="streaming workload: concurrent streams per GPU")
     ap.add_argument("--stream-arch", default="medium_streaming")
     ap.add_argument("--update-ms", type=int, default=500, help="streaming workload: audio per update")
@@ -487,7 +489,8 @@ def main():
         with tempfile.TemporaryDirectory() as md:
             write_model_dir(md, cfg, seed=0, weights=w)
             tr = mapi.Transcriber(md, mapi.ARCH_BASE if args.arch == "base" else mapi.ARCH_TINY,
-                                  {"vad_threshold": "0", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank)})
+                                  {"vad_threshold": "0", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank),
+                                   "kernel_set": args.capi_kernel_set})
         reps = 8   # 2048 clips: BASELINE config 4's clip count, here on one GPU (8 sub-batches over the lanes)
         n = reps * B
         arrs = [host[i % B] for i in range(n)]
@@ -502,7 +505,7 @@ def main():
         lines = sum(int(outs[i].contents.line_count) for i in range(n))
         c_api = {"value": round(n * CLIP_SECONDS / dtc, 1), "unit": "audio-seconds/sec", "clips": n, "ms_per_call": round(dtc * 1e3, 1),
                  "lines": lines, "entry_point": "moonshine_transcribe_batch_without_streaming", "host_buffers": "pageable",
-                 "options": {"vad_threshold": 0, "batch_clips": B, "batches_in_flight": F}}
+                 "options": {"vad_threshold": 0, "batch_clips": B, "batches_in_flight": F, "kernel_set": args.capi_kernel_set}}
         tr.close()
         # ---- the same call with the reference's DEFAULT options: vad_threshold 0.5, every 32 ms hop of every clip through the
         # Silero network (synthetic Silero weights: what counts here is the cost, not where the cuts fall) ----
@@ -513,7 +516,8 @@ def main():
                 write_model_dir(md, cfg, seed=0, weights=w)
                 save_safetensors(os.path.join(md, "silero_vad.safetensors"), make_silero_weights(2))
                 trv = mapi.Transcriber(md, mapi.ARCH_BASE if args.arch == "base" else mapi.ARCH_TINY,
-                                       {"vad_threshold": "0.5", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank)})
+                                       {"vad_threshold": "0.5", "batch_clips": str(B), "batches_in_flight": str(F), "device": str(local_rank),
+                                        "kernel_set": args.capi_kernel_set})
             callv = lambda: mapi.lib().moonshine_transcribe_batch_without_streaming(trv.handle, cptrs, clens, n, 16000, 0, outs)
             assert callv() == 0
             tv = time.perf_counter()
