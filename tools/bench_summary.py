@@ -1,3 +1,4 @@
+"""One screen of a gpu_final.sh bundle: python tools/bench_summary.py <tag>  (reads gpurun_out/<tag>_*)."""
 import json, sys
 tag = sys.argv[1]
 print(open(f'gpurun_out/{tag}_pytest.log').read().strip().splitlines()[-1])

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Conv GEMMs' k-order A/B (MSH_CONV_KORDER=0 tap-major / 1 channel-block-major, read at LOAD): parity files, headline + conv2 / conv3
+# times alternating on one box, FETCH_SIZE of both kernels under each order (HISTORY.md, round 6).
 set -u
 export MSH_DEV_KNOBS=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out

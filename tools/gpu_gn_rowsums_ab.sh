@@ -1,3 +1,6 @@
+#!/bin/bash
+# GroupNorm statistics A/B (MSH_GN_ROWSUMS=0 pass over the conv1 output / 1 row sums out of conv1's epilogue): parity file, then
+# headline + conv1 / statistics times alternating on one box.
 set -u
 export MSH_DEV_KNOBS=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out

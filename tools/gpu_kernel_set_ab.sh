@@ -1,3 +1,6 @@
+#!/bin/bash
+# C-API batch call with kernel_set=per_call against auto (= uniform with batch_clips >= 192), alternating on one box, and the
+# single-clip p50 with and without msh_set_uniform_kernels.
 export MSH_DEV_KNOBS=1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 for rep in 1 2; do
