@@ -695,6 +695,21 @@ def main():
             cands[-1]["sample"] += (f"; ids equal to the GPU's free run on {cands[-1]['clips_with_ids_equal_to_gpu']} of {nb} clips with the plain "
                                     f"random weights (near-tie cascades) and on {cands[-1]['sharpened_checkpoint']['clips_with_ids_equal_to_gpu']} of {ns} "
                                     "with the sharpened checkpoint (margins of a trained model)")
+            # the same model with its Linear layers in int8 (int8 weights, dynamically quantised int8 activations: the arithmetic
+            # class of the reference's shipped .ort graphs): the closest runnable stand-in for the CPU-ORT int8 path
+            try:
+                toks_q, dtq = hf_baseline.run(cfg, w, host[:nb], args.decode_steps, per, threads, int8=True)
+                cands.append({"value": round(nb * CLIP_SECONDS / dtq, 2), "unit": "audio-seconds/sec", "cores": threads,
+                              "host_cores_visible": cores, "host_cpus_usable": usable, "kind": "port",
+                              "sample": f"{nb} clips x 10 s in batches of {per}, {args.decode_steps} forced decode steps, HuggingFace "
+                                        f"MoonshineForConditionalGeneration with every Linear in int8 (int8 weights + dynamic int8 activations, "
+                                        f"torch quantize_dynamic, {torch.backends.quantized.engine} kernels; convolutions / norms / attention "
+                                        f"products fp32), torch {threads} threads, {dtq:.1f} s of wall time; the arithmetic class of the "
+                                        "reference's int8 .ort graphs, which cannot be run here (no onnxruntime, no graphs)",
+                              "clips_with_ids_equal_to_gpu": sum(int(a == list(b)) for a, b in zip(toks_q, serial_ref[:nb])),
+                              "clips_with_ids_equal_to_fp32_cpu": sum(int(a == b) for a, b in zip(toks_q, toks_hf))})
+            except Exception as e:
+                print(f"int8 CPU baseline skipped: {e}", file=sys.stderr)
         except Exception as e:  # transformers missing / incompatible: keep the numpy port
             print(f"HF CPU baseline skipped: {e}", file=sys.stderr)
         n_clips = min(args.cpu_clips, 3)
@@ -717,6 +732,11 @@ def main():
         cands.sort(key=lambda c: -c["value"])
         cpu = dict(cands[0])
         cpu["other_cpu_baselines"] = cands[1:]
+        # (the id comparison with the GPU belongs to the fp32 run -- int8 noise flips near-ties of the random weights on almost
+        #  every clip: keep it one key away when the int8 run is the faster, hence the quoted, baseline)
+        fp32_runs = [c for c in cands if "fp32 eager" in c["sample"]]
+        if fp32_runs and "fp32 eager" not in cpu["sample"]:
+            cpu["fp32_eager_same_model"] = {k: fp32_runs[0][k] for k in ("value", "clips_with_ids_equal_to_gpu", "sharpened_checkpoint") if k in fp32_runs[0]}
         # the >= 100x target of BASELINE.json is judged against whichever CPU number was measured; a large ratio says
         # nothing about kernel quality (the roofline fraction does)
         cpu["gpu_over_cpu"] = {"overlapped": round(value / cpu["value"], 1),

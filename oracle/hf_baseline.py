@@ -7,7 +7,8 @@ the graphs are in the checkout.  HF Moonshine is the floa
 oracle (docs/models/accuracy.md:14-19), so this is "the same arithmetic in fp32 on a tuned CPU BLAS" -- slower per FLOP
 than int8 ORT kernels, which is stated next to the number wherever it is quoted.
 
-``run(cfg, weights, clips, steps, batch, threads)`` -> (token lists, seconds).  Clips of one call must have equal length
+``run(cfg, weights, clips, steps, batch, threads, int8=False)`` -> (token lists, seconds); int8 = the Linear layers with int8
+weights and dynamic int8 activations (quantize_linears_int8), the arithmetic class of the reference's shipped graphs.  Clips of one call must have equal length
 (they are batched without an attention mask, like the reference's fixed batch of one).
 """
 from __future__ import annotations
@@ -56,11 +57,27 @@ def greedy(model, cfg, clips: np.ndarray, steps: int) -> list[list[int]]:
         return torch.cat(toks, dim=1).tolist()
 
 
-def run(cfg, w, clips: list[np.ndarray], steps: int, batch: int, threads: int):
+def quantize_linears_int8(model):
+    """Every nn.Linear with int8 weights and dynamically quantised int8 activations (torch's x86 / fbgemm kernels): the closest
+    thing this image can run to what the reference ships -- ONNX Runtime graphs with int8 weights and dynamic int8 activations
+    in their MatMuls (core/ort-utils/ort-utils.cpp:256-288 loads them) -- convolutions, norms,
+    softmax and the attention products stay fp32."""
+    import warnings
+
+    import torch
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return torch.ao.quantization.quantize_dynamic(model, {torch.nn.Linear}, dtype=torch.qint8)
+
+
+def run(cfg, w, clips: list[np.ndarray], steps: int, batch: int, threads: int, int8: bool = False):
     import torch
 
     torch.set_num_threads(max(1, threads))
     model = build_hf(cfg, w)
+    if int8:
+        model = quantize_linears_int8(model)
     greedy(model, cfg, np.stack(clips[:1])[:, :32000], 2)   # warm up the thread pool / allocator
     out = []
     t0 = time.perf_counter()
