@@ -198,3 +198,16 @@ def test_rank_cpu_shares_partition_the_node():
     on0 = [msd.rank_cpus(r, 8, allowed, 0, nodes) for r in range(4)]
     assert sorted(c for s in on0 for c in s) == [c for c in allowed if c < 128]     # the four ranks of a node split it
     assert msd.rank_cpus(3, 8, [5]) == [5]                                            # fewer CPUs than ranks: shared
+
+
+def test_a_cpu_share_too_small_for_the_lanes_is_not_pinned():
+    """pin_rank_cpus: a rank whose share of the allowed CPUs is under four (a CPU-starved container: 8 ranks on 16 CPUs) keeps
+    the process's affinity -- four lanes' host threads on one or two CPUs would cost more than crossing a socket -- and a
+    single rank is never pinned."""
+    import os
+
+    before = sorted(os.sched_getaffinity(0))
+    world = max(2, len(before))            # at most one CPU per rank
+    assert msd.pin_rank_cpus(0, world) == before
+    assert sorted(os.sched_getaffinity(0)) == before
+    assert msd.pin_rank_cpus(0, 1) == before
